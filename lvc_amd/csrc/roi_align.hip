@@ -1,0 +1,163 @@
+// roi_align.hip -- ROIAlign forward for gfx950 (HBM/L2-bound gather; no matrix work).
+//
+// Replaces reference detectron2/layers/csrc/ROIAlign/ROIAlign_cuda.cu:65-139 (RoIAlignForward)
+// and its CPU twin ROIAlign_cpu.cpp:20-218, reached through detectron2/layers/roi_align.py:63-117
+// from ROIPooler.forward (detectron2/modeling/poolers.py:191-246).  Same arithmetic, same operation
+// order per output element (this file is compiled with -ffp-contract=off so that no FMA contraction
+// changes a rounding relative to the x86-64 reference build):
+//   start = x*scale - 0.5 (aligned) ; bin = roi_size/pooled ; grid g = sampling_ratio>0 ? sr : ceil(roi_size/pooled)
+//   sample (iy,ix) at start + p*bin + (i+.5)*bin/g ; outside [-1,H]x[-1,W] contributes 0 ; bilinear taps
+//   with the <=0 clamp and the top-edge clamp ; average over max(g_h*g_w,1).
+// Unlike the reference CUDA host code (ROIAlign_cuda.cu:364) nothing here synchronises the device.
+//
+// Mapping (NHWC features): one workgroup per (RoI, 256-channel slice); lane = channel, so every
+// bilinear tap is one fully coalesced 1 KiB read per wave (256 B per 64 channels) and every output
+// bin one coalesced store; tap coordinates are wave-uniform.  The same kernel serves the reference's
+// NCHW op signature through explicit strides (lane = channel is then strided; that entry point is a
+// drop-in convenience, the engine uses NHWC).
+#include "common.h"
+
+#define LVC_MAX_LEVELS 8
+
+struct RoiAlignArgs {
+  const float* feat[LVC_MAX_LEVELS];
+  int H[LVC_MAX_LEVELS], W[LVC_MAX_LEVELS];
+  float scale[LVC_MAX_LEVELS];
+  long long sb[LVC_MAX_LEVELS];  // batch stride (elements) per level
+  long long sc, sh_mul_w;        // channel stride; (unused for NHWC) -- see below
+  int nhwc;                      // 1: feature is [B,H,W,C]; 0: [B,C,H,W]
+  int C;
+  const float* rois;             // [K,5]
+  const int* levels;             // [K] or nullptr (level 0)
+  const int* num_valid;          // device int: rows >= *num_valid are zero-filled (nullptr = all valid)
+  int K, ph, pw, sampling_ratio, aligned;
+  float* out;
+  long long so_k, so_c, so_h, so_w;  // output strides (elements)
+  int* status;                   // device status word (bit 0: negative RoI size with aligned=true)
+};
+
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(RoiAlignArgs p) {
+  const int k = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const bool c_ok = c < p.C;
+  float* outk = p.out + (long long)k * p.so_k + (long long)c * p.so_c;
+  if (p.num_valid && k >= *p.num_valid) {
+    if (c_ok)
+      for (int a = 0; a < p.ph; ++a)
+        for (int b = 0; b < p.pw; ++b) outk[a * p.so_h + b * p.so_w] = 0.f;
+    return;
+  }
+  const float* r = p.rois + (long long)k * 5;
+  const int lvl = p.levels ? p.levels[k] : 0;
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float spatial_scale = p.scale[lvl];
+  const int b = (int)r[0];
+  const float offset = p.aligned ? 0.5f : 0.0f;
+  const float roi_start_w = r[1] * spatial_scale - offset;
+  const float roi_start_h = r[2] * spatial_scale - offset;
+  const float roi_end_w = r[3] * spatial_scale - offset;
+  const float roi_end_h = r[4] * spatial_scale - offset;
+  float roi_width = roi_end_w - roi_start_w;
+  float roi_height = roi_end_h - roi_start_h;
+  if (p.aligned) {
+    if (!(roi_width >= 0 && roi_height >= 0)) {
+      if (p.status && threadIdx.x == 0 && blockIdx.y == 0) atomicOr(p.status, 1);
+    }
+  } else {
+    roi_width = roi_width > 1.f ? roi_width : 1.f;
+    roi_height = roi_height > 1.f ? roi_height : 1.f;
+  }
+  const float bin_h = roi_height / (float)p.ph;
+  const float bin_w = roi_width / (float)p.pw;
+  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_height / (float)p.ph);
+  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_width / (float)p.pw);
+  const int cnt = gh * gw > 1 ? gh * gw : 1;
+  const float count = (float)cnt;
+
+  long long s_pix, s_c;
+  if (p.nhwc) { s_pix = p.C; s_c = 1; } else { s_pix = 1; s_c = (long long)H * W; }
+  const float* in = p.feat[lvl] + (long long)b * p.sb[lvl] + (long long)(c_ok ? c : 0) * s_c;
+
+  for (int ph = 0; ph < p.ph; ++ph) {
+    for (int pw = 0; pw < p.pw; ++pw) {
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int y_low = (int)y, x_low = (int)x, y_high, x_high;
+          if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+          if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+          const float ly = y - y_low, lx = x - x_low;
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const float v1 = in[(long long)(y_low * W + x_low) * s_pix];
+          const float v2 = in[(long long)(y_low * W + x_high) * s_pix];
+          const float v3 = in[(long long)(y_high * W + x_low) * s_pix];
+          const float v4 = in[(long long)(y_high * W + x_high) * s_pix];
+          acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+        }
+      }
+      if (c_ok) outk[ph * p.so_h + pw * p.so_w] = acc / count;
+    }
+  }
+}
+
+static int launch(RoiAlignArgs& a, void* stream) {
+  if (a.K == 0) return LVC_OK;
+  dim3 grid(a.K, lvc_cdiv(a.C, 256)), block(256);
+  hipLaunchKernelGGL(roi_align_fwd_kernel, grid, block, 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// Reference-shaped op: NCHW in, [K,C,ph,pw] out (csrc/vision.cpp:96 roi_align_forward).
+extern "C" int lvc_roi_align_forward_nchw(const float* input, const float* rois, float* output, int B,
+                                          int C, int H, int W, int K, int pooled_h, int pooled_w,
+                                          float spatial_scale, int sampling_ratio, int aligned,
+                                          int* d_status, void* stream) {
+  LVC_CHECK_ARG(K == 0 || (input && rois && output), "null pointer");
+  LVC_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && K >= 0, "bad shape");
+  RoiAlignArgs a;
+  memset(&a, 0, sizeof a);
+  a.feat[0] = input; a.H[0] = H; a.W[0] = W; a.scale[0] = spatial_scale;
+  a.sb[0] = (long long)C * H * W;
+  a.nhwc = 0; a.C = C; a.rois = rois; a.levels = nullptr; a.num_valid = nullptr;
+  a.K = K; a.ph = pooled_h; a.pw = pooled_w; a.sampling_ratio = sampling_ratio; a.aligned = aligned;
+  a.out = output;
+  a.so_k = (long long)C * pooled_h * pooled_w; a.so_c = (long long)pooled_h * pooled_w;
+  a.so_h = pooled_w; a.so_w = 1;
+  a.status = d_status;
+  return launch(a, stream);
+}
+
+// Engine op: L pyramid levels in NHWC, per-RoI level ids, output [K, ph, pw, C] (channels-last, the
+// layout the box-head GEMM consumes).  Replaces the per-level gather/scatter loop of
+// detectron2/modeling/poolers.py:236-246 with one launch over all RoIs.
+extern "C" int lvc_roi_align_fpn_nhwc(const float* const* feats, const int* Hs, const int* Ws,
+                                      const float* scales, int L, int B, int C, const float* rois,
+                                      const int* levels, const int* d_num_valid, int K, int pooled_h,
+                                      int pooled_w, int sampling_ratio, int aligned, float* output,
+                                      int* d_status, void* stream) {
+  LVC_CHECK_ARG(L >= 1 && L <= LVC_MAX_LEVELS, "1..8 levels");
+  LVC_CHECK_ARG(K == 0 || (feats && Hs && Ws && scales && rois && output), "null pointer");
+  LVC_CHECK_ARG(B > 0 && C > 0 && pooled_h > 0 && pooled_w > 0 && K >= 0, "bad shape");
+  LVC_CHECK_ARG(L == 1 || levels, "levels required when L > 1");
+  RoiAlignArgs a;
+  memset(&a, 0, sizeof a);
+  for (int l = 0; l < L; ++l) {
+    a.feat[l] = feats[l]; a.H[l] = Hs[l]; a.W[l] = Ws[l]; a.scale[l] = scales[l];
+    a.sb[l] = (long long)C * Hs[l] * Ws[l];
+  }
+  a.nhwc = 1; a.C = C; a.rois = rois; a.levels = levels; a.num_valid = d_num_valid;
+  a.K = K; a.ph = pooled_h; a.pw = pooled_w; a.sampling_ratio = sampling_ratio; a.aligned = aligned;
+  a.out = output;
+  a.so_k = (long long)C * pooled_h * pooled_w; a.so_c = 1;
+  a.so_h = (long long)pooled_w * C; a.so_w = C;
+  a.status = d_status;
+  return launch(a, stream);
+}

@@ -1,0 +1,208 @@
+"""Python host bindings of the gfx950 kernels (one function per C-ABI entry point of
+include/lvc_amd.h).  torch is used for device memory and streams only; all arithmetic of the
+hot path happens inside liblvc_amd.so.  Every function requires CUDA(HIP) tensors and raises if
+the native library is missing -- there is deliberately no CPU path here.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import c_double, c_float, c_int, c_longlong, c_void_p, check, ptr
+
+BK = 32  # gemm-K chunk of the implicit-GEMM kernel
+BN = 128
+
+
+def _stream(t):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("lvc_amd kernels need device tensors (got a CPU tensor); there is no CPU path")
+
+
+# --------------------------------------------------------------------------- convolution / GEMM
+class PackedConv:
+    """Weights of one conv/linear layer in the kernel's layout + folded per-channel affine.
+
+    w_packed: [Kpad, Kg] fp32, rows = out channel (zero rows up to a multiple of 128),
+              k = (r, s, c) with c fastest (mode 0) or (r, 8 pixels x 4 ch) (mode 1, the 7x7 stem).
+    scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
+    """
+
+    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode")
+
+    def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.K, self.C, self.R, self.S, self.stride, self.pad, self.Kg, self.mode = K, C, R, S, stride, pad, Kg, mode
+
+
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False):
+    """weight: [K, C, R, S] (OIHW, the reference's state_dict layout) on the target device.
+    bn: None or (weight, bias, running_mean, running_var) of a FrozenBatchNorm2d
+        (reference detectron2/layers/batch_norm.py:45-65: scale = w * rsqrt(var + eps),
+         shift = b - mean * scale).
+    stem=True packs the 3-channel 7x7 stem for the NHWC4 "row mode" of the kernel.
+    """
+    _req_cuda(weight)
+    K, C, R, S = weight.shape
+    dev = weight.device
+    w = weight.detach().float()
+    if stem:
+        assert C <= 4 and S <= 8
+        wk = torch.zeros(K, R, 8, 4, device=dev, dtype=torch.float32)
+        wk[:, :, :S, :C] = w.permute(0, 2, 3, 1)
+        Kg = R * BK
+        wk = wk.reshape(K, Kg)
+        Cphys, mode = 4, 1
+    else:
+        assert C % BK == 0, "implicit-GEMM kernel needs in_channels % 32 == 0 (got {})".format(C)
+        Kg = R * S * C
+        wk = w.permute(0, 2, 3, 1).reshape(K, Kg)
+        Cphys, mode = C, 0
+    Kpad = (K + BN - 1) // BN * BN
+    wp = torch.zeros(Kpad, Kg, device=dev, dtype=torch.float32)
+    wp[:K] = wk
+    scale = shift = None
+    if bn is not None:
+        bw, bb, rm, rv = [t.detach().float() for t in bn]
+        scale = bw * (rv + eps).rsqrt()
+        shift = bb - rm * scale
+        if bias is not None:
+            shift = shift + bias.detach().float() * scale
+    elif bias is not None:
+        shift = bias.detach().float().clone()
+    if scale is not None:
+        scale = scale.contiguous()
+    if shift is not None:
+        shift = shift.contiguous()
+    return PackedConv(wp.contiguous(), scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
+
+
+def pack_linear(weight, bias=None):
+    """weight [K_out, K_in] -> a 1x1 'conv' over M x 1 x 1 x K_in rows."""
+    return pack_conv(weight[:, :, None, None], bias=bias)
+
+
+def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
+    """x: [N,H,W,C] fp32 contiguous (NHWC).  Returns [N,Ho,Wo,K].
+    res_mode 1: residual has the output's shape; 2: residual is [N,Ho/2,Wo/2,K] and is
+    nearest-x2-upsampled on the fly (FPN top-down path, reference fpn.py:131-133)."""
+    _req_cuda(x, residual)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    N, H, W, C = x.shape
+    assert C == pc.C, "channel mismatch: tensor {} vs packed {}".format(C, pc.C)
+    Ho = (H + 2 * pc.pad - pc.R) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.S) // pc.stride + 1
+    if out is None:
+        out = torch.empty(N, Ho, Wo, pc.K, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == torch.float32
+        if res_mode == 0:
+            res_mode = 1
+    st = _lib.lib().lvc_conv2d_nhwc_f32(
+        ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+        c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
+        c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
+        c_int(out.shape[-1]), c_int(residual.shape[-1] if residual is not None else 0),
+        c_int(pc.mode), _stream(x))
+    check(st, "lvc_conv2d_nhwc_f32")
+    return out
+
+
+def linear(x, pc, relu=False):
+    """x: [M, K_in] -> [M, K_out] through the same MFMA kernel."""
+    M, Kin = x.shape
+    y = conv2d_nhwc(x.view(M, 1, 1, Kin), pc, relu=relu)
+    return y.view(M, pc.K)
+
+
+# --------------------------------------------------------------------------- ROIAlign
+def new_status(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, aligned, status=None):
+    """Reference-shaped op (csrc/vision.cpp:96): NCHW input, rois [K,5], returns [K,C,ph,pw]."""
+    _req_cuda(input, rois)
+    input = input.contiguous().float()
+    rois = rois.contiguous().float()
+    B, C, H, W = input.shape
+    K = rois.shape[0]
+    out = torch.empty(K, C, pooled_h, pooled_w, device=input.device, dtype=torch.float32)
+    st = _lib.lib().lvc_roi_align_forward_nchw(
+        ptr(input), ptr(rois), ptr(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(K),
+        c_int(pooled_h), c_int(pooled_w), c_float(spatial_scale), c_int(sampling_ratio),
+        c_int(1 if aligned else 0), ptr(status), _stream(input))
+    check(st, "lvc_roi_align_forward_nchw")
+    return out
+
+
+def roi_align_fpn_nhwc(feats, scales, rois, levels, pooled_h, pooled_w, sampling_ratio, aligned,
+                       num_valid=None, status=None):
+    """feats: list of NHWC level tensors [B,H_l,W_l,C]; rois [K,5]; levels [K] int32 (or None when one
+    level).  Returns [K, ph, pw, C]."""
+    _req_cuda(rois, *feats)
+    L = len(feats)
+    B, _, _, C = feats[0].shape
+    K = rois.shape[0]
+    rois = rois.contiguous().float()
+    out = torch.empty(K, pooled_h, pooled_w, C, device=rois.device, dtype=torch.float32)
+    FP = c_void_p * L
+    IP = c_int * L
+    FL = c_float * L
+    fp = FP(*[f.data_ptr() for f in feats])
+    hs = IP(*[f.shape[1] for f in feats])
+    ws = IP(*[f.shape[2] for f in feats])
+    sc = FL(*[float(s) for s in scales])
+    for f in feats:
+        assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[0] == B and f.shape[3] == C
+    if levels is not None:
+        assert levels.dtype == torch.int32 and levels.is_contiguous()
+    st = _lib.lib().lvc_roi_align_fpn_nhwc(
+        fp, hs, ws, sc, c_int(L), c_int(B), c_int(C), ptr(rois), ptr(levels), ptr(num_valid), c_int(K),
+        c_int(pooled_h), c_int(pooled_w), c_int(sampling_ratio), c_int(1 if aligned else 0), ptr(out),
+        ptr(status), _stream(rois))
+    check(st, "lvc_roi_align_fpn_nhwc")
+    return out
+
+
+# --------------------------------------------------------------------------- NMS
+def batched_nms_batch(boxes, scores, idxs, counts, iou_threshold, max_keep=0):
+    """boxes [B,Nmax,4], scores [B,Nmax], idxs [B,Nmax] int32 or None, counts [B] int32 device or None.
+    Returns (keep [B,Nmax] int32, num_keep [B] int32), all on device, no sync."""
+    _req_cuda(boxes, scores, idxs, counts)
+    B, Nmax = scores.shape
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    if idxs is not None:
+        idxs = idxs.contiguous()
+        assert idxs.dtype == torch.int32
+    keep = torch.empty(B, Nmax, dtype=torch.int32, device=boxes.device)
+    num_keep = torch.empty(B, dtype=torch.int32, device=boxes.device)
+    wsb = _lib.lib().lvc_batched_nms_workspace_bytes(c_int(B), c_int(Nmax))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=boxes.device)
+    st = _lib.lib().lvc_batched_nms(
+        ptr(boxes), ptr(scores), ptr(idxs), ptr(counts), c_int(B), c_int(Nmax), c_double(iou_threshold),
+        c_int(max_keep), ptr(keep), ptr(num_keep), ptr(ws), c_longlong(wsb), _stream(boxes))
+    check(st, "lvc_batched_nms")
+    return keep, num_keep
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """Drop-in for reference detectron2/layers/nms.py:10-29 (single image): int64 keep indices,
+    score-descending."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    idx32 = idxs.to(torch.int32)[None] if idxs is not None else None
+    keep, nk = batched_nms_batch(boxes[None], scores[None], idx32, None, iou_threshold)
+    return keep[0, : int(nk.item())].to(torch.int64)
+
+
+def nms(boxes, scores, iou_threshold):
+    """Drop-in for torchvision.ops.nms as imported by reference detectron2/layers/nms.py:7."""
+    return batched_nms(boxes, scores, None, iou_threshold)

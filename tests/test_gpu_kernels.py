@@ -1,0 +1,212 @@
+"""Parity of the hand-written gfx950 kernels against the CPU oracle, through the C ABI.
+GPU-only (-m gpu).  Tolerances: integer/index outputs bit-exact; fp32 conv within 2e-5 relative to
+the layer's output scale (different but equally valid fp32 summation order); ROIAlign within 1e-6
+relative (same operation order; only the reciprocal/division units differ in principle)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize(
+    "N,C,H,W,K,R,stride,pad",
+    [
+        (2, 64, 50, 84, 64, 1, 1, 0),      # res2 1x1
+        (1, 64, 40, 56, 64, 3, 1, 1),      # res2 3x3
+        (2, 256, 28, 36, 128, 1, 2, 0),    # stride-in-1x1
+        (1, 128, 25, 42, 128, 3, 1, 1),    # odd sizes, M tail
+        (1, 256, 13, 21, 256, 3, 1, 1),    # p6-like
+        (1, 256, 20, 28, 15, 1, 1, 0),     # rpn predictors: K=15 (N tail)
+        (3, 512, 7, 9, 2048, 1, 1, 0),     # wide K
+        (1, 2048, 5, 6, 256, 1, 1, 0),     # deep C (lateral5)
+    ],
+)
+def test_conv_igemm_matches_cpu(N, C, H, W, K, R, stride, pad):
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(N * 1000 + C + K + R)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    bn = (torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1,
+          torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5)
+    ref = F.conv2d(x, w, None, stride=stride, padding=pad)
+    scale = bn[0] * (bn[3] + 1e-5).rsqrt()
+    ref_bn = F.relu(ref * scale[None, :, None, None] + (bn[1] - bn[2] * scale)[None, :, None, None])
+    ref_bias = ref + b[None, :, None, None]
+    d = _dev()
+    xd = _nhwc(x).to(d)
+    pc = k.pack_conv(w.to(d), bn=[t.to(d) for t in bn], stride=stride, pad=pad)
+    y = k.conv2d_nhwc(xd, pc, relu=True).cpu().permute(0, 3, 1, 2)
+    tol = 2e-5 * float(ref_bn.abs().max())
+    assert (y - ref_bn).abs().max() <= tol
+    pc2 = k.pack_conv(w.to(d), bias=b.to(d), stride=stride, pad=pad)
+    y2 = k.conv2d_nhwc(xd, pc2).cpu().permute(0, 3, 1, 2)
+    assert (y2 - ref_bias).abs().max() <= 2e-5 * float(ref_bias.abs().max())
+
+
+def test_conv_residual_and_upsample_add():
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 20, 28, generator=g)
+    w = torch.randn(256, 64, 1, 1, generator=g) * 0.1
+    res = torch.randn(2, 256, 20, 28, generator=g)
+    top = torch.randn(2, 256, 10, 14, generator=g)
+    d = _dev()
+    pc = k.pack_conv(w.to(d))
+    ref = F.conv2d(x, w)
+    y1 = k.conv2d_nhwc(_nhwc(x).to(d), pc, relu=True, residual=_nhwc(res).to(d), res_mode=1)
+    assert (y1.cpu().permute(0, 3, 1, 2) - F.relu(ref + res)).abs().max() < 1e-4
+    y2 = k.conv2d_nhwc(_nhwc(x).to(d), pc, residual=_nhwc(top).to(d), res_mode=2)
+    up = F.interpolate(top, scale_factor=2, mode="nearest")
+    assert (y2.cpu().permute(0, 3, 1, 2) - (ref + up)).abs().max() < 1e-4
+
+
+def test_conv_stem_7x7():
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 3, 64, 96, generator=g) * 50
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    d = _dev()
+    x4 = torch.zeros(2, 64, 96, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    pc = k.pack_conv(w.to(d), stride=2, pad=3, stem=True)
+    y = k.conv2d_nhwc(x4.to(d), pc).cpu().permute(0, 3, 1, 2)
+    assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
+
+
+def test_linear_matches_cpu():
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(300, 1024, generator=g)
+    w = torch.randn(81, 1024, generator=g) * 0.03
+    b = torch.randn(81, generator=g)
+    d = _dev()
+    y = k.linear(x.to(d), k.pack_linear(w.to(d), b.to(d)), relu=False).cpu()
+    ref = F.linear(x, w, b)
+    assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
+
+
+def _rand_rois(g, n, B, Wimg, Himg, smin=2.0, smax=600.0):
+    cx = torch.rand(n, generator=g) * Wimg
+    cy = torch.rand(n, generator=g) * Himg
+    w = smin + torch.rand(n, generator=g) * (smax - smin)
+    h = smin + torch.rand(n, generator=g) * (smax - smin)
+    b = torch.randint(0, B, (n,), generator=g).float()
+    x1 = (cx - w / 2).clamp(0, Wimg)
+    y1 = (cy - h / 2).clamp(0, Himg)
+    x2 = (cx + w / 2).clamp(0, Wimg)
+    y2 = (cy + h / 2).clamp(0, Himg)
+    return torch.stack([b, x1, y1, x2, y2], 1)
+
+
+@pytest.mark.parametrize("scale,aligned,sr", [(0.25, True, 0), (0.125, True, 0), (1 / 32, True, 0),
+                                               (0.0625, False, 2), (0.25, True, 2)])
+def test_roi_align_nchw_matches_oracle(scale, aligned, sr):
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(11)
+    B, C = 2, 40
+    H, W = int(800 * scale), int(1344 * scale)
+    feat = torch.randn(B, C, H, W, generator=g)
+    rois = _rand_rois(g, 200, B, 1333, 800)
+    # degenerate / edge RoIs: zero area, full image, out of image (clipped boxes can touch the border)
+    extra = torch.tensor([[0, 10, 10, 10, 10], [1, 0, 0, 1333, 800], [0, 1300, 780, 1333, 800],
+                          [1, 0, 0, 0.5, 0.5], [0, 5, 5, 5, 300]], dtype=torch.float32)
+    rois = torch.cat([rois, extra])
+    ref = oops.roi_align_forward(feat, rois, scale, 7, 7, sr, aligned)
+    d = _dev()
+    out = k.roi_align_forward(feat.to(d), rois.to(d), scale, 7, 7, sr, aligned).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_roi_align_fpn_nhwc_matches_oracle():
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(12)
+    B, C = 2, 256
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [torch.randn(B, C, int(800 * s), int(1344 * s), generator=g) for s in scales]
+    rois = _rand_rois(g, 300, B, 1333, 800)
+    levels = torch.randint(0, 4, (300,), generator=g).int()
+    d = _dev()
+    out = k.roi_align_fpn_nhwc([_nhwc(f).to(d) for f in feats], scales, rois.to(d), levels.to(d), 7, 7, 0, True)
+    out = out.cpu().permute(0, 3, 1, 2)
+    for l in range(4):
+        sel = (levels == l).nonzero().view(-1)
+        ref = oops.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, 0, True)
+        assert (out[sel] - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
+
+
+def _nms_case(g, n, nidx, jitter):
+    base = _rand_rois(g, max(4, n // 6), 1, 1333, 800, 8, 300)[:, 1:]
+    pick = torch.randint(0, base.shape[0], (n,), generator=g)
+    boxes = base[pick] + torch.randn(n, 4, generator=g) * jitter
+    boxes[:, 2:] = torch.max(boxes[:, 2:], boxes[:, :2] + 0.5)
+    scores = torch.randn(n, generator=g)
+    idxs = torch.randint(0, nidx, (n,), generator=g)
+    return boxes, scores, idxs
+
+
+@pytest.mark.parametrize("n,nidx,thr", [(1, 1, 0.5), (63, 2, 0.7), (64, 1, 0.3), (65, 5, 0.5),
+                                         (1000, 80, 0.5), (4819, 5, 0.7), (9000, 3, 0.7)])
+def test_batched_nms_keep_indices_bit_exact(n, nidx, thr):
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(n)
+    boxes, scores, idxs = _nms_case(g, n, nidx, 4.0)
+    scores[::7] = scores[0]  # exact score ties must resolve by index like the stable CPU sort
+    ref = oops.batched_nms(boxes, scores, idxs, thr)
+    d = _dev()
+    got = k.batched_nms(boxes.to(d), scores.to(d), idxs.to(d), thr).cpu()
+    assert got.dtype == torch.int64
+    assert got.tolist() == ref.tolist()
+
+
+def test_batched_nms_batch_with_counts_and_max_keep():
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(99)
+    B, Nmax = 3, 2000
+    counts = torch.tensor([2000, 777, 0], dtype=torch.int32)
+    boxes = torch.zeros(B, Nmax, 4)
+    scores = torch.zeros(B, Nmax)
+    idxs = torch.zeros(B, Nmax, dtype=torch.int32)
+    for b in range(B):
+        bb, ss, ii = _nms_case(g, Nmax, 5, 3.0)
+        boxes[b], scores[b], idxs[b] = bb, ss, ii.int()
+    d = _dev()
+    keep, nk = k.batched_nms_batch(boxes.to(d), scores.to(d), idxs.to(d), counts.to(d), 0.7, max_keep=300)
+    keep, nk = keep.cpu(), nk.cpu()
+    for b in range(B):
+        n = int(counts[b])
+        ref = oops.batched_nms(boxes[b, :n], scores[b, :n], idxs[b, :n].long(), 0.7)[:300]
+        assert int(nk[b]) == len(ref)
+        assert keep[b, : len(ref)].tolist() == ref.tolist()
+
+
+def test_nms_empty():
+    from lvc_amd import kernels as k
+
+    d = _dev()
+    out = k.nms(torch.zeros(0, 4, device=d), torch.zeros(0, device=d), 0.5)
+    assert out.numel() == 0 and out.dtype == torch.int64
