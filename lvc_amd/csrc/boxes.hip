@@ -1,0 +1,548 @@
+// boxes.hip -- the box pipeline between the conv trunk and the heads, entirely on device, no host sync:
+//   * lvc_rpn_proposals          = RPN.predict_proposals + find_top_rpn_proposals
+//       reference detectron2/modeling/proposal_generator/rpn.py:455-508,
+//                 detectron2/modeling/proposal_generator/proposal_utils.py:13-118,
+//                 detectron2/modeling/anchor_generator.py:157-178 (grid anchors = shift + cell anchor),
+//                 detectron2/modeling/box_regression.py:73-110 (apply_deltas)
+//   * lvc_assign_levels_rois     = assign_boxes_to_levels + convert_boxes_to_pooler_format
+//       reference detectron2/modeling/poolers.py:23-59, 69-96
+//   * lvc_fast_rcnn_inference    = FastRCNNOutputs.predict_boxes/predict_probs + fast_rcnn_inference
+//       (+ optional detector_postprocess)
+//       reference lvc/modeling/roi_heads/fast_rcnn.py:95-137, 440-468; detectron2/modeling/postprocessing.py:10-79
+// Built with -ffp-contract=off: each fp32 operation of the decode/clip chain rounds once, in the
+// reference's association, so boxes entering NMS equal the CPU path's up to the exp()/log2()
+// library difference (<= 1 ulp).  All orderings that the reference defines by position
+// (level-major candidate order, row-major (roi, class) order, score-sorted keep) are reproduced by
+// ORDERED compaction (block scan), never by atomics.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+extern "C" int lvc_batched_nms(const float*, const float*, const int*, const int*, int, int, double, int,
+                               int*, int*, void*, long long, void*);
+extern "C" long long lvc_batched_nms_workspace_bytes(int, int);
+
+#define MAXL 8
+
+__device__ __forceinline__ unsigned int desc_key(float f) {
+  if (f == 0.f) f = 0.f;
+  unsigned int u = __float_as_uint(f);
+  u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+  return ~u;
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads = 16 waves); returns exclusive prefix,
+// *total gets the block sum.  `sh` must hold >= 17 ints.
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* sh, int* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(x, o);
+    if (lane >= o) x += t;
+  }
+  __syncthreads();  // protect sh from a previous use
+  if (lane == 63) sh[wave] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < 16; ++w) { int t = sh[w]; sh[w] = s; s += t; }
+    sh[16] = s;
+  }
+  __syncthreads();
+  *total = sh[16];
+  return sh[wave] + x - v;
+}
+
+template <typename T>
+__device__ __forceinline__ void bitonic_sort_lds(T* keys, int npad) {
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < npad / 2; t += blockDim.x) {
+        int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int hi = lo | j;
+        bool up = (lo & k) == 0;
+        T a = keys[lo], b = keys[hi];
+        if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// =====================================================================================
+// RPN step 1: per (image, level) top-k of the objectness logits, sorted descending (ties: lower index).
+// Radix select (4 x 8 bit) on the order-preserving key, ordered take of the threshold ties, bitonic sort.
+// =====================================================================================
+struct RpnLevels {
+  const float* logits[MAXL];  // [B, HW, ld_logit] : logit of anchor a at pixel p = base[(b*HW+p)*ld + a]
+  const float* deltas[MAXL];  // [B, HW, ld_delta] : delta c of anchor a = base[(b*HW+p)*ld + a*4 + c]
+  int ld_logit[MAXL], ld_delta[MAXL];
+  int H[MAXL], W[MAXL], stride[MAXL];
+  int cand_off[MAXL + 1];     // prefix of min(topk, H*W*A)
+  long long key_off[MAXL + 1];// prefix of H*W*A (workspace offsets, per image)
+  const float* cell_anchors[MAXL];  // [A,4]
+  int L, A;
+};
+
+#define TOPK_PAD 2048
+__global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnLevels lv, int topk, unsigned int* __restrict__ wkeys,
+                                                        float* __restrict__ cand_score,
+                                                        int* __restrict__ cand_idx, int Ntot) {
+  __shared__ u64 sortbuf[TOPK_PAD];
+  __shared__ int hist[256];
+  __shared__ int sh[20];
+  __shared__ int s_prefix_digit, s_krem, s_nlt;
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int A = lv.A, HW = lv.H[l] * lv.W[l], n = HW * A;
+  const int k = topk < n ? topk : n;
+  const int ld = lv.ld_logit[l];
+  const float* lg = lv.logits[l] + (size_t)b * HW * ld;
+  unsigned int* keys = wkeys + (size_t)b * lv.key_off[lv.L] + lv.key_off[l];
+  const int npad = k <= 1024 ? 1024 : TOPK_PAD;
+
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    int p = i / A, a = i - p * A;
+    unsigned int key = desc_key(lg[(size_t)p * ld + a]);
+    keys[i] = key;
+    atomicAdd(&hist[key >> 24], 1);
+  }
+  __syncthreads();
+  unsigned int prefix = 0, pmask = 0;
+  int krem = k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (pass > 0) {
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      for (int i = tid; i < n; i += 1024) {
+        unsigned int key = keys[i];
+        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      int cum = 0, d = 0;
+      for (; d < 256; ++d) {
+        int c = hist[d];
+        if (cum + c >= krem) break;
+        cum += c;
+      }
+      s_prefix_digit = d;
+      s_krem = krem - cum;
+    }
+    __syncthreads();
+    prefix |= (unsigned int)s_prefix_digit << shift;
+    pmask |= 255u << shift;
+    krem = s_krem;
+    __syncthreads();
+  }
+  // prefix = threshold key T; take every key < T, and the first `krem` (by index) with key == T
+  const unsigned int T = prefix;
+  const int need_eq = krem, n_lt = k - krem;
+  for (int i = tid; i < npad; i += 1024) sortbuf[i] = ~0ull;
+  if (tid == 0) s_nlt = 0;
+  __syncthreads();
+  int eq_base = 0;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + tid;
+    unsigned int key = i < n ? keys[i] : 0xFFFFFFFFu;
+    bool is_lt = i < n && key < T;
+    bool is_eq = i < n && key == T;
+    if (is_lt) {
+      int slot = atomicAdd(&s_nlt, 1);
+      sortbuf[slot] = ((u64)key << 32) | (unsigned)i;
+    }
+    if (eq_base < need_eq) {  // uniform
+      int tot;
+      int rank = eq_base + block_excl_scan_1024(is_eq ? 1 : 0, sh, &tot);
+      if (is_eq && rank < need_eq) sortbuf[n_lt + rank] = ((u64)key << 32) | (unsigned)i;
+      eq_base += tot;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_lds(sortbuf, npad);
+  for (int r = tid; r < k; r += 1024) {
+    int i = (int)(sortbuf[r] & 0xFFFFFFFFu);
+    int p = i / A, a = i - p * A;
+    cand_idx[(size_t)b * Ntot + lv.cand_off[l] + r] = i;
+    cand_score[(size_t)b * Ntot + lv.cand_off[l] + r] = lg[(size_t)p * ld + a];
+  }
+}
+
+// =====================================================================================
+// shared decode (Box2BoxTransform.apply_deltas, box_regression.py:73-110)
+// =====================================================================================
+__device__ __forceinline__ void apply_deltas(float bx1, float by1, float bx2, float by2, float d0, float d1,
+                                             float d2, float d3, float wx, float wy, float ww, float wh,
+                                             float scale_clamp, float* o) {
+  const float widths = bx2 - bx1, heights = by2 - by1;
+  const float ctr_x = bx1 + 0.5f * widths, ctr_y = by1 + 0.5f * heights;
+  const float dx = d0 / wx, dy = d1 / wy;
+  float dw = d2 / ww, dh = d3 / wh;
+  dw = dw > scale_clamp ? scale_clamp : dw;  // torch.clamp(max=): NaN stays NaN
+  dh = dh > scale_clamp ? scale_clamp : dh;
+  const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+  const float pw = expf(dw) * widths, ph = expf(dh) * heights;
+  o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
+}
+__device__ __forceinline__ float clampf(float v, float lo, float hi) {  // torch clamp_(min,max)
+  v = v < lo ? lo : v;
+  return v > hi ? hi : v;
+}
+
+// RPN step 2: decode the candidates, drop non-finite, clip, drop empty (ordered compaction)
+__global__ __launch_bounds__(1024) void rpn_decode_kernel(RpnLevels lv, const float* __restrict__ cand_score,
+                                                          const int* __restrict__ cand_idx, int Ntot,
+                                                          const int* __restrict__ image_sizes,
+                                                          float scale_clamp, float min_box_size,
+                                                          float* __restrict__ cboxes,
+                                                          float* __restrict__ cscores,
+                                                          int* __restrict__ clevels,
+                                                          int* __restrict__ ccount) {
+  __shared__ int sh[20];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float img_h = (float)image_sizes[b * 2 + 0], img_w = (float)image_sizes[b * 2 + 1];
+  int base = 0;
+  for (int c0 = 0; c0 < Ntot; c0 += 1024) {
+    const int c = c0 + tid;
+    bool ok = false;
+    float box[4] = {0, 0, 0, 0};
+    float score = 0.f;
+    int l = 0;
+    if (c < Ntot) {
+      while (l + 1 < lv.L && c >= lv.cand_off[l + 1]) ++l;
+      const int i = cand_idx[(size_t)b * Ntot + c];
+      score = cand_score[(size_t)b * Ntot + c];
+      const int A = lv.A, W = lv.W[l], HW = lv.H[l] * W;
+      const int p = i / A, a = i - p * A;
+      const int y = p / W, x = p - y * W;
+      const float sx = (float)(x * lv.stride[l]), sy = (float)(y * lv.stride[l]);
+      const float* ca = lv.cell_anchors[l] + a * 4;
+      const float ax1 = sx + ca[0], ay1 = sy + ca[1], ax2 = sx + ca[2], ay2 = sy + ca[3];
+      const float* d = lv.deltas[l] + ((size_t)b * HW + p) * lv.ld_delta[l] + a * 4;
+      apply_deltas(ax1, ay1, ax2, ay2, d[0], d[1], d[2], d[3], 1.f, 1.f, 1.f, 1.f, scale_clamp, box);
+      ok = isfinite(box[0]) && isfinite(box[1]) && isfinite(box[2]) && isfinite(box[3]) && isfinite(score);
+      box[0] = clampf(box[0], 0.f, img_w); box[1] = clampf(box[1], 0.f, img_h);
+      box[2] = clampf(box[2], 0.f, img_w); box[3] = clampf(box[3], 0.f, img_h);
+      ok = ok && (box[2] - box[0] > min_box_size) && (box[3] - box[1] > min_box_size);
+    }
+    int tot;
+    int pos = base + block_excl_scan_1024(ok ? 1 : 0, sh, &tot);
+    if (ok) {
+      float* o = cboxes + ((size_t)b * Ntot + pos) * 4;
+      o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3];
+      cscores[(size_t)b * Ntot + pos] = score;
+      clevels[(size_t)b * Ntot + pos] = l;
+    }
+    base += tot;
+  }
+  if (tid == 0) ccount[b] = base;
+}
+
+// RPN step 4: gather the kept candidates into the fixed-size proposal arrays (rows past count = 0)
+__global__ void gather_proposals_kernel(const float* __restrict__ cboxes, const float* __restrict__ cscores,
+                                        const int* __restrict__ keep, const int* __restrict__ num_keep,
+                                        int Ntot, int post_topk, float* __restrict__ pboxes,
+                                        float* __restrict__ plogits) {
+  const int b = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= post_topk) return;
+  float4 bx = {0, 0, 0, 0};
+  float s = 0.f;
+  if (r < num_keep[b]) {
+    const int i = keep[(size_t)b * Ntot + r];
+    bx = *reinterpret_cast<const float4*>(cboxes + ((size_t)b * Ntot + i) * 4);
+    s = cscores[(size_t)b * Ntot + i];
+  }
+  *reinterpret_cast<float4*>(pboxes + ((size_t)b * post_topk + r) * 4) = bx;
+  plogits[(size_t)b * post_topk + r] = s;
+}
+
+static long long align16(long long x) { return (x + 15) & ~15ll; }
+
+struct RpnPlan {
+  int Ntot;
+  long long nkeys;  // per image
+  long long off_keys, off_cscore, off_cidx, off_cboxes, off_cscores2, off_clevels, off_ccount, off_keep, off_nms, total;
+};
+static RpnPlan rpn_plan(int B, int L, int A, const int* Hs, const int* Ws, int pre_topk) {
+  RpnPlan p;
+  p.Ntot = 0; p.nkeys = 0;
+  for (int l = 0; l < L; ++l) {
+    long long n = (long long)Hs[l] * Ws[l] * A;
+    p.nkeys += n;
+    p.Ntot += (int)(n < pre_topk ? n : pre_topk);
+  }
+  long long o = 0;
+  p.off_keys = o; o = align16(o + (long long)B * p.nkeys * 4);
+  p.off_cscore = o; o = align16(o + (long long)B * p.Ntot * 4);
+  p.off_cidx = o; o = align16(o + (long long)B * p.Ntot * 4);
+  p.off_cboxes = o; o = align16(o + (long long)B * p.Ntot * 16);
+  p.off_cscores2 = o; o = align16(o + (long long)B * p.Ntot * 4);
+  p.off_clevels = o; o = align16(o + (long long)B * p.Ntot * 4);
+  p.off_ccount = o; o = align16(o + (long long)B * 4);
+  p.off_keep = o; o = align16(o + (long long)B * p.Ntot * 4);
+  p.off_nms = o; o = align16(o + lvc_batched_nms_workspace_bytes(B, p.Ntot));
+  p.total = o;
+  return p;
+}
+
+extern "C" long long lvc_rpn_proposals_workspace_bytes(int B, int L, int A, const int* Hs, const int* Ws,
+                                                       int pre_nms_topk) {
+  if (L < 1 || L > MAXL) return -1;
+  return rpn_plan(B, L, A, Hs, Ws, pre_nms_topk).total;
+}
+
+extern "C" int lvc_rpn_proposals(const float* const* logits, const int* ld_logit, const float* const* deltas,
+                                 const int* ld_delta, const float* const* cell_anchors, const int* Hs,
+                                 const int* Ws, const int* strides, int L, int A, int B,
+                                 const int* d_image_sizes, int pre_nms_topk, int post_nms_topk,
+                                 double nms_thresh, float min_box_size, float scale_clamp,
+                                 float* out_boxes, float* out_logits, int* d_out_count, void* workspace,
+                                 long long workspace_bytes, void* stream) {
+  LVC_CHECK_ARG(L >= 1 && L <= MAXL, "1..8 levels");
+  LVC_CHECK_ARG(B > 0 && A > 0, "bad B/A");
+  LVC_CHECK_ARG(pre_nms_topk > 0 && pre_nms_topk <= TOPK_PAD, "pre_nms_topk must be in 1..2048");
+  LVC_CHECK_ARG(post_nms_topk > 0, "post_nms_topk must be positive");
+  LVC_CHECK_ARG(logits && deltas && cell_anchors && Hs && Ws && strides && d_image_sizes && out_boxes &&
+                    out_logits && d_out_count && workspace, "null pointer");
+  RpnPlan p = rpn_plan(B, L, A, Hs, Ws, pre_nms_topk);
+  LVC_CHECK_ARG(workspace_bytes >= p.total, "workspace too small");
+  LVC_CHECK_ARG(p.Ntot <= 16384, "too many pre-NMS candidates per image (> 16384)");
+  RpnLevels lv;
+  memset(&lv, 0, sizeof lv);
+  lv.L = L; lv.A = A;
+  for (int l = 0; l < L; ++l) {
+    lv.logits[l] = logits[l]; lv.deltas[l] = deltas[l];
+    lv.ld_logit[l] = ld_logit[l]; lv.ld_delta[l] = ld_delta[l];
+    lv.H[l] = Hs[l]; lv.W[l] = Ws[l]; lv.stride[l] = strides[l];
+    lv.cell_anchors[l] = cell_anchors[l];
+    long long n = (long long)Hs[l] * Ws[l] * A;
+    lv.key_off[l + 1] = lv.key_off[l] + n;
+    lv.cand_off[l + 1] = lv.cand_off[l] + (int)(n < pre_nms_topk ? n : pre_nms_topk);
+  }
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned int* keys = (unsigned int*)(ws + p.off_keys);
+  float* cand_score = (float*)(ws + p.off_cscore);
+  int* cand_idx = (int*)(ws + p.off_cidx);
+  float* cboxes = (float*)(ws + p.off_cboxes);
+  float* cscores = (float*)(ws + p.off_cscores2);
+  int* clevels = (int*)(ws + p.off_clevels);
+  int* ccount = (int*)(ws + p.off_ccount);
+  int* keep = (int*)(ws + p.off_keep);
+  hipLaunchKernelGGL(rpn_topk_kernel, dim3(L, B), dim3(1024), 0, st, lv, pre_nms_topk, keys, cand_score,
+                     cand_idx, p.Ntot);
+  LVC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3(B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
+                     d_image_sizes, scale_clamp, min_box_size, cboxes, cscores, clevels, ccount);
+  LVC_CHECK_LAUNCH();
+  int rc = lvc_batched_nms(cboxes, cscores, clevels, ccount, B, p.Ntot, nms_thresh, post_nms_topk, keep,
+                           d_out_count, ws + p.off_nms, p.total - p.off_nms, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gather_proposals_kernel, dim3(lvc_cdiv(post_nms_topk, 256), B), dim3(256), 0, st, cboxes,
+                     cscores, keep, d_out_count, p.Ntot, post_nms_topk, out_boxes, out_logits);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// =====================================================================================
+// FPN level assignment + pooler-format rois
+// =====================================================================================
+__global__ void assign_levels_kernel(const float* __restrict__ boxes, int R, int B, int min_level, int max_level,
+                                     float canonical_box_size, float canonical_level, int* __restrict__ levels,
+                                     float* __restrict__ rois) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * B) return;
+  const float4 bx = *reinterpret_cast<const float4*>(boxes + (size_t)i * 4);
+  const float area = (bx.z - bx.x) * (bx.w - bx.y);
+  const float size = sqrtf(area);
+  float lvl = floorf(canonical_level + log2f(size / canonical_box_size + 1e-8f));
+  lvl = lvl < (float)min_level ? (float)min_level : lvl;
+  lvl = lvl > (float)max_level ? (float)max_level : lvl;
+  levels[i] = (int)lvl - min_level;
+  if (rois) {
+    float* r = rois + (size_t)i * 5;
+    r[0] = (float)(i / R); r[1] = bx.x; r[2] = bx.y; r[3] = bx.z; r[4] = bx.w;
+  }
+}
+
+// boxes [B,R,4] -> levels [B*R] int32 (offset from min_level) and rois [B*R,5] (batch index = image)
+extern "C" int lvc_assign_levels_rois(const float* boxes, int B, int R, int min_level, int max_level,
+                                      int canonical_box_size, int canonical_level, int* levels, float* rois,
+                                      void* stream) {
+  LVC_CHECK_ARG(B >= 0 && R >= 0, "negative size");
+  if (B * R == 0) return LVC_OK;
+  LVC_CHECK_ARG(boxes && levels, "null pointer");
+  hipLaunchKernelGGL(assign_levels_kernel, dim3(lvc_cdiv(B * R, 256)), dim3(256), 0, (hipStream_t)stream, boxes, R,
+                     B, min_level, max_level, (float)canonical_box_size, (float)canonical_level, levels, rois);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// =====================================================================================
+// Fast R-CNN inference: softmax, per-class decode, clip, threshold -> candidates (ordered) -> NMS -> top-k
+// =====================================================================================
+__global__ __launch_bounds__(1024) void det_candidates_kernel(
+    const float* __restrict__ cls_logits, int ld_cls, const float* __restrict__ deltas, int ld_delta,
+    int K, int cls_agnostic, const float* __restrict__ proposals, const int* __restrict__ prop_count, int R,
+    const int* __restrict__ image_sizes, float wx, float wy, float ww, float wh, float scale_clamp,
+    float score_thresh, int Nmax, float* __restrict__ cboxes, float* __restrict__ cscores,
+    int* __restrict__ cclass, int* __restrict__ crow, int* __restrict__ ccount, int* __restrict__ status) {
+  __shared__ int sh[20];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nrow = prop_count ? min(prop_count[b], R) : R;
+  const float img_h = (float)image_sizes[b * 2 + 0], img_w = (float)image_sizes[b * 2 + 1];
+  int base = 0;
+  for (int r0 = 0; r0 < nrow; r0 += 1024) {
+    const int r = r0 + tid;
+    int cnt = 0;
+    float mx = -INFINITY, inv = 0.f;
+    const float* lg = cls_logits + ((size_t)b * R + (r < nrow ? r : 0)) * ld_cls;
+    if (r < nrow) {
+      for (int k = 0; k <= K; ++k) { float v = lg[k]; mx = v > mx ? v : mx; }
+      float sum = 0.f;
+      for (int k = 0; k <= K; ++k) sum += expf(lg[k] - mx);
+      inv = 1.f / sum;
+      for (int k = 0; k < K; ++k) cnt += (expf(lg[k] - mx) * inv > score_thresh) ? 1 : 0;
+    }
+    int tot;
+    int pos = base + block_excl_scan_1024(cnt, sh, &tot);
+    if (r < nrow && cnt > 0) {
+      const float4 pb = *reinterpret_cast<const float4*>(proposals + ((size_t)b * R + r) * 4);
+      const float* dl = deltas + ((size_t)b * R + r) * ld_delta;
+      for (int k = 0; k < K; ++k) {
+        const float pr = expf(lg[k] - mx) * inv;
+        if (pr > score_thresh) {
+          if (pos < Nmax) {
+            const float* d = dl + (cls_agnostic ? 0 : k * 4);
+            float box[4];
+            apply_deltas(pb.x, pb.y, pb.z, pb.w, d[0], d[1], d[2], d[3], wx, wy, ww, wh, scale_clamp, box);
+            float* o = cboxes + ((size_t)b * Nmax + pos) * 4;
+            o[0] = clampf(box[0], 0.f, img_w); o[1] = clampf(box[1], 0.f, img_h);
+            o[2] = clampf(box[2], 0.f, img_w); o[3] = clampf(box[3], 0.f, img_h);
+            cscores[(size_t)b * Nmax + pos] = pr;
+            cclass[(size_t)b * Nmax + pos] = k;
+            crow[(size_t)b * Nmax + pos] = r;
+          }
+          ++pos;
+        }
+      }
+    }
+    base += tot;
+  }
+  if (tid == 0) {
+    if (base > Nmax) { atomicOr(status, 2); base = Nmax; }
+    ccount[b] = base;
+  }
+}
+
+// gather the kept detections, optionally detector_postprocess (scale, clip, drop empty; ordered)
+__global__ __launch_bounds__(256) void det_gather_kernel(
+    const float* __restrict__ cboxes, const float* __restrict__ cscores, const int* __restrict__ cclass,
+    const int* __restrict__ crow, const int* __restrict__ keep, const int* __restrict__ num_keep, int Nmax,
+    int topk, const float* __restrict__ post, float* __restrict__ oboxes, float* __restrict__ oscores,
+    int* __restrict__ oclasses, int* __restrict__ orows, int* __restrict__ ocount) {
+  __shared__ int wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int nk = min(num_keep[b], topk);
+  int base = 0;
+  for (int r0 = 0; r0 < topk; r0 += 256) {
+    const int r = r0 + tid;
+    bool ok = false;
+    float4 bx = {0, 0, 0, 0};
+    float s = 0.f; int c = 0, row = 0;
+    if (r < nk) {
+      const int i = keep[(size_t)b * Nmax + r];
+      bx = *reinterpret_cast<const float4*>(cboxes + ((size_t)b * Nmax + i) * 4);
+      s = cscores[(size_t)b * Nmax + i]; c = cclass[(size_t)b * Nmax + i]; row = crow[(size_t)b * Nmax + i];
+      ok = true;
+      if (post) {  // post[b] = (scale_x, scale_y, out_h, out_w)
+        const float sx = post[b * 4 + 0], sy = post[b * 4 + 1], oh = post[b * 4 + 2], ow = post[b * 4 + 3];
+        bx.x = clampf(bx.x * sx, 0.f, ow); bx.y = clampf(bx.y * sy, 0.f, oh);
+        bx.z = clampf(bx.z * sx, 0.f, ow); bx.w = clampf(bx.w * sy, 0.f, oh);
+        ok = (bx.z - bx.x > 0.f) && (bx.w - bx.y > 0.f);
+      }
+    }
+    const u64 bal = __ballot(ok);
+    const int lane = tid & 63, wave = tid >> 6;
+    __syncthreads();
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) wbase += wsum[w]; tot += wsum[w]; }
+    const int pos = base + wbase + __popcll(bal & ((1ull << lane) - 1ull));
+    if (ok) {
+      *reinterpret_cast<float4*>(oboxes + ((size_t)b * topk + pos) * 4) = bx;
+      oscores[(size_t)b * topk + pos] = s; oclasses[(size_t)b * topk + pos] = c; orows[(size_t)b * topk + pos] = row;
+    }
+    base += tot;
+  }
+  __syncthreads();
+  // zero-fill the tail
+  for (int r = base + tid; r < topk; r += 256) {
+    float4 z = {0, 0, 0, 0};
+    *reinterpret_cast<float4*>(oboxes + ((size_t)b * topk + r) * 4) = z;
+    oscores[(size_t)b * topk + r] = 0.f; oclasses[(size_t)b * topk + r] = 0; orows[(size_t)b * topk + r] = 0;
+  }
+  if (tid == 0) ocount[b] = base;
+}
+
+struct DetPlan { long long off_cboxes, off_cscores, off_cclass, off_crow, off_ccount, off_keep, off_nk, off_nms, total; };
+static DetPlan det_plan(int B, int Nmax) {
+  DetPlan p; long long o = 0;
+  p.off_cboxes = o; o = align16(o + (long long)B * Nmax * 16);
+  p.off_cscores = o; o = align16(o + (long long)B * Nmax * 4);
+  p.off_cclass = o; o = align16(o + (long long)B * Nmax * 4);
+  p.off_crow = o; o = align16(o + (long long)B * Nmax * 4);
+  p.off_ccount = o; o = align16(o + (long long)B * 4);
+  p.off_keep = o; o = align16(o + (long long)B * Nmax * 4);
+  p.off_nk = o; o = align16(o + (long long)B * 4);
+  p.off_nms = o; o = align16(o + lvc_batched_nms_workspace_bytes(B, Nmax));
+  p.total = o;
+  return p;
+}
+extern "C" long long lvc_fast_rcnn_inference_workspace_bytes(int B, int max_candidates) {
+  return det_plan(B, max_candidates).total;
+}
+
+// cls_logits [B*R, ld_cls] (K+1 used), deltas [B*R, ld_delta] (4K or 4 used), proposals [B,R,4],
+// d_prop_count [B] or NULL, d_image_sizes [B,2] (h,w) int32, d_post [B,4] (sx,sy,out_h,out_w) or NULL.
+// Outputs are fixed-size [B, topk, ...] with d_out_count [B]; d_status bit 1 (value 2) = candidate overflow.
+extern "C" int lvc_fast_rcnn_inference(const float* cls_logits, int ld_cls, const float* deltas, int ld_delta,
+                                       int K, int cls_agnostic, const float* proposals,
+                                       const int* d_prop_count, int B, int R, const int* d_image_sizes,
+                                       float wx, float wy, float ww, float wh, float scale_clamp,
+                                       float score_thresh, double nms_thresh, int topk, int max_candidates,
+                                       const float* d_post, float* out_boxes, float* out_scores,
+                                       int* out_classes, int* out_rows, int* d_out_count, int* d_status,
+                                       void* workspace, long long workspace_bytes, void* stream) {
+  LVC_CHECK_ARG(B > 0 && R > 0 && K > 0 && topk > 0, "bad sizes");
+  LVC_CHECK_ARG(max_candidates > 0 && max_candidates <= 16384, "max_candidates must be in 1..16384");
+  LVC_CHECK_ARG(cls_logits && deltas && proposals && d_image_sizes && out_boxes && out_scores && out_classes &&
+                    out_rows && d_out_count && d_status && workspace, "null pointer");
+  DetPlan p = det_plan(B, max_candidates);
+  LVC_CHECK_ARG(workspace_bytes >= p.total, "workspace too small");
+  char* ws = (char*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  float* cboxes = (float*)(ws + p.off_cboxes);
+  float* cscores = (float*)(ws + p.off_cscores);
+  int* cclass = (int*)(ws + p.off_cclass);
+  int* crow = (int*)(ws + p.off_crow);
+  int* ccount = (int*)(ws + p.off_ccount);
+  int* keep = (int*)(ws + p.off_keep);
+  int* nk = (int*)(ws + p.off_nk);
+  hipLaunchKernelGGL(det_candidates_kernel, dim3(B), dim3(1024), 0, st, cls_logits, ld_cls, deltas, ld_delta, K,
+                     cls_agnostic, proposals, d_prop_count, R, d_image_sizes, wx, wy, ww, wh, scale_clamp,
+                     score_thresh, max_candidates, cboxes, cscores, cclass, crow, ccount, d_status);
+  LVC_CHECK_LAUNCH();
+  int rc = lvc_batched_nms(cboxes, cscores, cclass, ccount, B, max_candidates, nms_thresh, topk, keep, nk,
+                           ws + p.off_nms, p.total - p.off_nms, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(det_gather_kernel, dim3(B), dim3(256), 0, st, cboxes, cscores, cclass, crow, keep, nk,
+                     max_candidates, topk, d_post, out_boxes, out_scores, out_classes, out_rows, d_out_count);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

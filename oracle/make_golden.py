@@ -1,0 +1,289 @@
+"""Generate tests/golden/*.npz from the IMPORTED REFERENCE (runs only in the build container, where
+/root/reference exists; the reference has no tests or golden vectors of its own -- SURVEY.md section 4).
+Each fixture holds seeded inputs and the reference's outputs; nothing of the reference's source text is
+stored.  Re-run:  python -m oracle.make_golden   (about 2 minutes on 8 cores).
+TEST INFRASTRUCTURE ONLY.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle import refshim  # noqa: E402
+
+refshim.install()
+
+from lvc_amd.utils import synthetic as syn  # noqa: E402
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %-40s %8.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def build_ref_model(yaml, opts=()):
+    from lvc.config import get_cfg, set_global_cfg
+    from lvc.modeling import build_model
+
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(refshim.REF_ROOT, "configs", yaml))
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"] + list(opts))
+    cfg.freeze()
+    set_global_cfg(cfg)
+    model = build_model(cfg).eval()
+    return cfg, model
+
+
+def gen_roi_align():
+    from detectron2 import _C
+
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(2, 8, 50, 84, generator=g)
+    n = 64
+    cx, cy = torch.rand(n, generator=g) * 1333, torch.rand(n, generator=g) * 800
+    w, h = 2 + torch.rand(n, generator=g) * 900, 2 + torch.rand(n, generator=g) * 700
+    rois = torch.stack([torch.randint(0, 2, (n,), generator=g).float(), (cx - w / 2).clamp(0, 1333),
+                        (cy - h / 2).clamp(0, 800), (cx + w / 2).clamp(0, 1333), (cy + h / 2).clamp(0, 800)], 1)
+    extra = torch.tensor([[0, 10, 10, 10, 10], [1, 0, 0, 1333, 800], [0, 1300, 780, 1333, 800],
+                          [1, 0, 0, 0.5, 0.5], [0, 5, 5, 5, 300], [1, 1332.5, 799.5, 1333, 800]])
+    rois = torch.cat([rois, extra])
+    outs = {}
+    for scale in (0.25, 0.125, 0.0625, 0.03125):
+        for aligned in (True, False):
+            for sr in (0, 2):
+                key = "out_s%g_a%d_sr%d" % (scale, aligned, sr)
+                outs[key] = _C.roi_align_forward(feat, rois, scale, 7, 7, sr, aligned)
+    save("roi_align", feat=feat, rois=rois, **outs)
+
+
+def gen_nms():
+    from detectron2.layers import batched_nms
+
+    g = torch.Generator().manual_seed(1)
+    n = 5000
+    base = torch.rand(400, 4, generator=g)
+    base = torch.stack([base[:, 0] * 1200, base[:, 1] * 700, base[:, 0] * 1200 + 8 + base[:, 2] * 300,
+                        base[:, 1] * 700 + 8 + base[:, 3] * 300], 1)
+    boxes = base[torch.randint(0, 400, (n,), generator=g)] + torch.randn(n, 4, generator=g) * 4
+    boxes[:, 2:] = torch.max(boxes[:, 2:], boxes[:, :2] + 0.5)
+    scores = torch.randn(n, generator=g)
+    lvl = torch.randint(0, 5, (n,), generator=g)
+    keep = batched_nms(boxes, scores, lvl, 0.7)
+    keep5 = batched_nms(boxes, scores, lvl, 0.5)
+    save("nms", boxes=boxes, scores=scores, idxs=lvl, keep_thr07=keep, keep_thr05=keep5)
+
+
+def gen_box_ops():
+    from detectron2.modeling.anchor_generator import DefaultAnchorGenerator
+    from detectron2.modeling.box_regression import Box2BoxTransform
+    from detectron2.modeling.poolers import assign_boxes_to_levels
+    from detectron2.structures import Boxes
+    from detectron2.layers import ShapeSpec
+
+    ag = DefaultAnchorGenerator(sizes=[[32], [64], [128], [256], [512]], aspect_ratios=[[0.5, 1.0, 2.0]],
+                                strides=[4, 8, 16, 32, 64], offset=0.0)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    anchors = ag([torch.zeros(1, 1, h, w) for h, w in shapes])
+    d = {}
+    for i, a in enumerate(anchors):
+        t = a.tensor
+        d["lvl%d_first" % i] = t[:8]
+        d["lvl%d_last" % i] = t[-8:]
+        d["lvl%d_sum" % i] = t.double().sum(0)
+        d["lvl%d_n" % i] = np.int64(len(t))
+    d["cell_anchors"] = torch.stack([b for b in ag.cell_anchors])
+    save("anchors", **d)
+
+    g = torch.Generator().manual_seed(2)
+    boxes = torch.rand(300, 4, generator=g) * 600
+    boxes[:, 2:] = boxes[:, :2] + 1 + torch.rand(300, 2, generator=g) * 500
+    deltas1 = torch.randn(300, 4, generator=g) * 0.5
+    deltas1[:5, 2:] = 9.0  # exercises the exp clamp
+    deltas80 = torch.randn(300, 320, generator=g) * 2.0
+    out1 = Box2BoxTransform(weights=(1.0, 1.0, 1.0, 1.0)).apply_deltas(deltas1, boxes)
+    out80 = Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0)).apply_deltas(deltas80, boxes)
+    small = torch.rand(300, 4, generator=g) * 100
+    small[:, 2:] = small[:, :2] + torch.rand(300, 2, generator=g).pow(3) * 1300
+    small = torch.cat([small, torch.tensor([[0, 0, 224, 224], [0, 0, 112, 112], [0, 0, 448, 448], [5, 5, 5, 5.]])])
+    lv = assign_boxes_to_levels([Boxes(small)], 2, 5, 224, 4)
+    save("box_ops", boxes=boxes, deltas1=deltas1, deltas80=deltas80, out1=out1, out80=out80, lvl_boxes=small,
+         levels=lv)
+
+
+def gen_rpn_and_det_ops():
+    from detectron2.modeling.proposal_generator.proposal_utils import find_top_rpn_proposals
+    from lvc.modeling.roi_heads.fast_rcnn import fast_rcnn_inference_single_image
+    from detectron2.modeling.postprocessing import detector_postprocess
+    from oracle import rcnn as orc
+
+    g = torch.Generator().manual_seed(3)
+    shapes = [(40, 64), (20, 32), (10, 16), (5, 8), (3, 4)]
+    strides = [4, 8, 16, 32, 64]
+    N, A = 2, 3
+    cell = [orc.generate_cell_anchors((s,), (0.5, 1.0, 2.0)) for s in (32, 64, 128, 256, 512)]
+    anchors = orc.grid_anchors(cell, shapes, strides)
+    logits = [torch.randn(N, h * w * A, generator=g) * 3 for h, w in shapes]
+    deltas = [torch.randn(N, h * w * A, 4, generator=g) * 0.4 for h, w in shapes]
+    props = [orc.apply_deltas(d.reshape(-1, 4), a.unsqueeze(0).expand(N, -1, -1).reshape(-1, 4), (1., 1., 1., 1.)).view(N, -1, 4)
+             for a, d in zip(anchors, deltas)]
+    sizes = [(160, 250), (150, 256)]
+    res = find_top_rpn_proposals(props, logits, sizes, 0.7, 300, 200, 0.0, False)
+    d = {}
+    for i in range(5):
+        d["logits%d" % i] = logits[i]
+        d["deltas%d" % i] = deltas[i]
+    for n in range(N):
+        d["out_boxes%d" % n] = res[n].proposal_boxes.tensor
+        d["out_logits%d" % n] = res[n].objectness_logits
+    save("rpn_proposals", shapes=np.array(shapes), image_sizes=np.array(sizes), **d)
+
+    R, K = 400, 20
+    pb = torch.rand(R, 4, generator=g) * 300
+    pb[:, 2:] = pb[:, :2] + 4 + torch.rand(R, 2, generator=g) * 200
+    pd = torch.randn(R, 4 * K, generator=g) * 1.5
+    cl = torch.randn(R, K + 1, generator=g) * 2.0
+    boxes = orc.apply_deltas(pd.view(-1, 4), pb.unsqueeze(1).expand(-1, K, 4).reshape(-1, 4), (10., 10., 5., 5.)).view(R, 4 * K)
+    probs = torch.softmax(cl, -1)
+    raw = boxes.clone()  # the reference clips its `boxes` argument in place (fast_rcnn.py:110-112)
+    inst, rows = fast_rcnn_inference_single_image(boxes, probs, (300, 420), 0.05, 0.5, 100)
+    post = detector_postprocess(inst, 450, 640)
+    save("fast_rcnn_inference", proposals=pb, deltas=pd, cls_logits=cl, image_size=np.array([300, 420]),
+         out_boxes=post.pred_boxes.tensor, raw_boxes=raw, probs=probs,
+         out_scores=post.scores, out_classes=post.pred_classes, kept_rows=rows, out_hw=np.array([450, 640]))
+
+
+def gen_blocks():
+    from detectron2.modeling.backbone.resnet import BottleneckBlock
+    from detectron2.layers import FrozenBatchNorm2d
+
+    torch.manual_seed(4)
+    blk = BottleneckBlock(64, 128, bottleneck_channels=32, stride=2, norm="FrozenBN", stride_in_1x1=True).eval()
+    for m in blk.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+            m.bias.copy_(torch.randn_like(m.bias) * 0.1)
+            m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
+            m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
+    x = torch.randn(2, 64, 20, 28)
+    with torch.no_grad():
+        y = blk(x)
+    save("bottleneck", x=x, y=y, **{"sd." + k: v for k, v in blk.state_dict().items()})
+
+
+def gen_e2e():
+    from detectron2.layers import FrozenBatchNorm2d
+
+    cfg, model = build_ref_model("COCO-detection/faster_rcnn_R_50_FPN_base.yaml", ["MODEL.ROI_HEADS.NUM_CLASSES", 80])
+    sd0 = syn.conditioned_state_dict(model.state_dict(), seed=0)
+    model.load_state_dict(sd0, strict=True)
+    img1 = syn.synthetic_image(1)
+    inp1 = [{"image": img1, "height": 800, "width": 1333}]
+    calib = syn.calibrate_frozen_bn_(model, lambda: model(inp1), FrozenBatchNorm2d)
+    save("r50_bn_calibration", **calib)
+    # key order + shapes of the reference state_dict: the drop-in contract for checkpoints
+    sd = model.state_dict()
+    save("r50_fpn_state_dict_keys", keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+
+    def run(inputs):
+        with torch.no_grad():
+            images = model.preprocess_image(inputs)
+            feats = model.backbone(images.tensor)
+            props, _ = model.proposal_generator(images, feats, None)
+            out = model(inputs)
+        return images, feats, props, out
+
+    img2 = syn.synthetic_image(2)
+    inputs = [{"image": img1, "height": 800, "width": 1333}, {"image": img2, "height": 800, "width": 1333}]
+    images, feats, props, out = run(inputs)
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k] = v[:, ::16, ::8, ::8].contiguous()  # sparse sample, enough to localise a diff
+        d["featstat_" + k] = torch.stack([v.mean(), v.std(), v.abs().max()])
+    for i in range(2):
+        d["prop_boxes%d" % i] = props[i].proposal_boxes.tensor
+        d["prop_logits%d" % i] = props[i].objectness_logits
+        inst = out[i]["instances"]
+        d["det_boxes%d" % i] = inst.pred_boxes.tensor
+        d["det_scores%d" % i] = inst.scores
+        d["det_classes%d" % i] = inst.pred_classes
+    save("e2e_r50_fpn_800x1333", **d)
+    for i in range(2):
+        print("  image", i, "proposals", len(props[i]), "detections", len(out[i]["instances"]),
+              "score range", float(out[i]["instances"].scores.max()), float(out[i]["instances"].scores.min()))
+
+    # small case (fast on CPU): 2 different-size images, exercises padding + output rescale
+    a = syn.synthetic_image(3, 240, 320)
+    b = syn.synthetic_image(4, 200, 352)
+    inputs = [{"image": a, "height": 480, "width": 640}, {"image": b, "height": 200, "width": 352}]
+    images, feats, props, out = run(inputs)
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k] = v[:, ::8].contiguous()
+    for i in range(2):
+        d["prop_boxes%d" % i] = props[i].proposal_boxes.tensor
+        d["prop_logits%d" % i] = props[i].objectness_logits
+        inst = out[i]["instances"]
+        d["det_boxes%d" % i] = inst.pred_boxes.tensor
+        d["det_scores%d" % i] = inst.scores
+        d["det_classes%d" % i] = inst.pred_classes
+    save("e2e_r50_fpn_small", **d)
+    for i in range(2):
+        print("  small image", i, "proposals", len(props[i]), "detections", len(out[i]["instances"]))
+
+
+def gen_knn():
+    from detectron2.structures import Instances
+    from tools.run_nearest_neighbours import get_nn_class_confirmatory, run_nearest_neighbours
+
+    g = torch.Generator().manual_seed(5)
+    S, D, C = 240, 64, 12
+    centers = torch.randn(C, D, generator=g)
+    shot_classes = torch.arange(C).repeat_interleave(S // C)
+    shots = centers[shot_classes] + 0.8 * torch.randn(S, D, generator=g) + 0.5
+    counts, descs, dcls = [], [], []
+    for i in range(50):
+        nq = int(torch.randint(0, 6, (1,), generator=g))
+        cls = torch.randint(0, C, (nq,), generator=g)
+        counts.append(nq)
+        descs.append(centers[cls] + 0.9 * torch.randn(nq, D, generator=g) + 0.5)
+        dcls.append(cls)
+
+    def make_queries():
+        qs = []
+        for d, c in zip(descs, dcls):
+            inst = Instances((10, 10))
+            inst.crop_feats = d.clone()
+            inst.gt_classes = c.clone()
+            qs.append({"instances": inst})
+        return qs
+
+    res = {}
+    for tag, cosine in (("cos", True), ("l2", False)):
+        qs = run_nearest_neighbours(shot_classes, shots, make_queries(), cosine)
+        get_nn_class_confirmatory(qs, 10)
+        res["top10_" + tag] = torch.cat([q["instances"].top10_shots.reshape(-1, 10) for q in qs])
+        res["keep_" + tag] = torch.cat([q["instances"].keep for q in qs])
+    save("knn", shots=shots, shot_classes=shot_classes, counts=np.array(counts), q_desc=torch.cat(descs),
+         q_classes=torch.cat(dcls), **res)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn"]
+    for w in which:
+        print("== ", w)
+        globals()["gen_" + w]()

@@ -48,7 +48,10 @@ def nms(boxes, scores, iou_threshold):
     n = boxes.shape[0]
     if n == 0:
         return torch.empty(0, dtype=torch.int64)
-    order = scores.sort(0, descending=True)[1].contiguous()
+    # The reference sorts with an UNSTABLE sort (torchvision nms_cpu.cpp: scores.sort(0, true)), so the
+    # order of exactly tied scores is unspecified there; the oracle (and the HIP kernels) fix it to
+    # "lower index first" = torch's stable sort.
+    order = scores.sort(dim=0, descending=True, stable=True)[1].contiguous()
     keep = torch.empty(n, dtype=torch.int64)
     nk = lib().orc_nms(_p(boxes), _p(order), ctypes.c_int64(n), ctypes.c_double(iou_threshold), _p(keep))
     return keep[:nk].clone()
