@@ -1,0 +1,83 @@
+// elementwise.hip -- the non-GEMM layers of the trunk, NHWC, float4-vectorised (HBM-bound).
+//   lvc_preprocess_nhwc4 : GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333:
+//                          (x - mean) / std per channel) + ImageList.from_tensors zero padding
+//                          (detectron2/structures/image_list.py:95-119) + CHW -> NHWC4 relayout.
+//   lvc_maxpool2d_nhwc   : F.max_pool2d of BasicStem (resnet.py:591, k3 s2 p1) and LastLevelMaxPool
+//                          (fpn.py:176, k1 s2 p0); padding behaves as -inf like ATen.
+#include "common.h"
+
+template <typename T>
+__global__ void preprocess_kernel(const T* __restrict__ img, int h, int w, float m0, float m1, float m2, float s0,
+                                  float s1, float s2, float* __restrict__ out, int Hp, int Wp) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= Wp) return;
+  float4 v = {0.f, 0.f, 0.f, 0.f};
+  if (y < h && x < w) {
+    const size_t plane = (size_t)h * w, o = (size_t)y * w + x;
+    v.x = ((float)img[o] - m0) / s0;
+    v.y = ((float)img[plane + o] - m1) / s1;
+    v.z = ((float)img[2 * plane + o] - m2) / s2;
+  }
+  *reinterpret_cast<float4*>(out + ((size_t)y * Wp + x) * 4) = v;
+}
+
+// image: CHW (3 planes) float32 (dtype 0) or uint8 (dtype 1) on device; out: this image's [Hp,Wp,4] slot.
+extern "C" int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float* mean3,
+                                    const float* std3, float* out, int Hp, int Wp, void* stream) {
+  LVC_CHECK_ARG(image && out && mean3 && std3, "null pointer");
+  LVC_CHECK_ARG(h > 0 && w > 0 && Hp >= h && Wp >= w, "bad sizes");
+  LVC_CHECK_ARG(dtype == 0 || dtype == 1, "dtype must be 0 (f32) or 1 (u8)");
+  dim3 block(256), grid(lvc_cdiv(Wp, 256), Hp);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 0)
+    hipLaunchKernelGGL(preprocess_kernel<float>, grid, block, 0, st, (const float*)image, h, w, mean3[0], mean3[1],
+                       mean3[2], std3[0], std3[1], std3[2], out, Hp, Wp);
+  else
+    hipLaunchKernelGGL(preprocess_kernel<unsigned char>, grid, block, 0, st, (const unsigned char*)image, h, w,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], out, Hp, Wp);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C4,
+                                    int Ho, int Wo, int k, int stride, int pad) {
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long p = i / C4;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int r = 0; r < k; ++r) {
+      const int hi = ho * stride - pad + r;
+      if (hi < 0 || hi >= H) continue;
+      for (int s = 0; s < k; ++s) {
+        const int wi = wo * stride - pad + s;
+        if (wi < 0 || wi >= W) continue;
+        const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + hi) * W + wi) * C4 * 4 + c * 4);
+        m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+        m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
+      }
+    }
+    *reinterpret_cast<float4*>(y + (size_t)i * 4) = m;
+  }
+}
+
+extern "C" int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
+                                  void* stream) {
+  LVC_CHECK_ARG(x && y, "null pointer");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "C must be a positive multiple of 4");
+  LVC_CHECK_ARG(k >= 1 && stride >= 1 && pad >= 0 && pad <= k / 2, "bad window");
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
+  const long long total = (long long)N * Ho * Wo * (C / 4);
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C / 4, Ho,
+                     Wo, k, stride, pad);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

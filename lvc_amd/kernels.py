@@ -206,3 +206,141 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
 def nms(boxes, scores, iou_threshold):
     """Drop-in for torchvision.ops.nms as imported by reference detectron2/layers/nms.py:7."""
     return batched_nms(boxes, scores, None, iou_threshold)
+
+
+# --------------------------------------------------------------------------- box pipeline
+SCALE_CLAMP = 4.135166556742356  # log(1000/16), reference detectron2/modeling/box_regression.py:11-12
+
+
+def _arr(ctype, vals):
+    return (ctype * len(vals))(*vals)
+
+
+def rpn_proposals(logits, deltas, cell_anchors, strides, image_sizes, pre_nms_topk, post_nms_topk,
+                  nms_thresh, min_box_size=0.0):
+    """find_top_rpn_proposals on device (reference proposal_utils.py:13-118 + rpn.py:489-508).
+
+    logits[l]: [B,H,W,ld] view whose channel a holds the objectness of anchor a (any channel stride);
+    deltas[l]: [B,H,W,ld'] view whose channel a*4+c holds delta c of anchor a.  Both may be channel
+    slices of one fused NHWC tensor (pass tensor[..., :A] and tensor[..., A:]).
+    cell_anchors[l]: [A,4] device tensors; image_sizes: [B,2] int32 device (h, w).
+    Returns (boxes [B,post,4], objectness_logits [B,post], count [B] int32); rows past count are zero.
+    """
+    L = len(logits)
+    B, A = logits[0].shape[0], cell_anchors[0].shape[0]
+    dev = logits[0].device
+    _req_cuda(*logits, *deltas, *cell_anchors, image_sizes)
+    for t in list(logits) + list(deltas):
+        assert t.dtype == torch.float32 and t.stride(-1) == 1 and t.dim() == 4
+        assert t.stride(2) == t.stride(3) * 0 + t.stride(2)  # pixel-major view
+    Hs = [t.shape[1] for t in logits]
+    Ws = [t.shape[2] for t in logits]
+    for t, h, w in zip(list(logits) + list(deltas), Hs * 2, Ws * 2):
+        # rows must be dense pixels: stride(1) == W*stride(2), stride(0) == H*W*stride(2)
+        assert t.stride(1) == w * t.stride(2) and t.stride(0) == h * w * t.stride(2), "need an NHWC channel slice"
+    VP, IP = c_void_p * L, c_int * L
+    lp = VP(*[t.data_ptr() for t in logits])
+    dp = VP(*[t.data_ptr() for t in deltas])
+    ap = VP(*[t.contiguous().data_ptr() for t in cell_anchors])
+    ldl = IP(*[t.stride(2) for t in logits])
+    ldd = IP(*[t.stride(2) for t in deltas])
+    hs, ws_, st = IP(*Hs), IP(*Ws), IP(*strides)
+    lib = _lib.lib()
+    lib.lvc_rpn_proposals_workspace_bytes.restype = c_longlong
+    nbytes = lib.lvc_rpn_proposals_workspace_bytes(c_int(B), c_int(L), c_int(A), hs, ws_, c_int(pre_nms_topk))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    boxes = torch.empty(B, post_nms_topk, 4, device=dev, dtype=torch.float32)
+    olog = torch.empty(B, post_nms_topk, device=dev, dtype=torch.float32)
+    count = torch.empty(B, dtype=torch.int32, device=dev)
+    assert image_sizes.dtype == torch.int32 and image_sizes.is_contiguous()
+    rc = lib.lvc_rpn_proposals(lp, ldl, dp, ldd, ap, hs, ws_, st, c_int(L), c_int(A), c_int(B), ptr(image_sizes),
+                               c_int(pre_nms_topk), c_int(post_nms_topk), c_double(nms_thresh),
+                               c_float(min_box_size), c_float(SCALE_CLAMP), ptr(boxes), ptr(olog), ptr(count),
+                               ptr(ws), c_longlong(nbytes), _stream(boxes))
+    check(rc, "lvc_rpn_proposals")
+    return boxes, olog, count
+
+
+def assign_levels_rois(boxes, min_level, max_level, canonical_box_size=224, canonical_level=4):
+    """boxes [B,R,4] -> (levels [B*R] int32, rois [B*R,5]) (reference poolers.py:23-59, 69-96)."""
+    _req_cuda(boxes)
+    B, R, _ = boxes.shape
+    boxes = boxes.contiguous()
+    levels = torch.empty(B * R, dtype=torch.int32, device=boxes.device)
+    rois = torch.empty(B * R, 5, dtype=torch.float32, device=boxes.device)
+    rc = _lib.lib().lvc_assign_levels_rois(ptr(boxes), c_int(B), c_int(R), c_int(min_level), c_int(max_level),
+                                           c_int(canonical_box_size), c_int(canonical_level), ptr(levels), ptr(rois),
+                                           _stream(boxes))
+    check(rc, "lvc_assign_levels_rois")
+    return levels, rois
+
+
+def fast_rcnn_inference(cls_logits, deltas, proposals, prop_count, image_sizes, num_classes, box_weights,
+                        score_thresh, nms_thresh, topk, post=None, status=None, max_candidates=16384):
+    """predict_boxes/predict_probs + fast_rcnn_inference (+ detector_postprocess when `post` is given).
+
+    cls_logits [B*R, >=K+1], deltas [B*R, 4K or 4] (row-contiguous, any row stride), proposals [B,R,4],
+    prop_count [B] int32 or None, image_sizes [B,2] int32, post [B,4] fp32 = (scale_x, scale_y, out_h, out_w).
+    Returns (boxes [B,topk,4], scores [B,topk], classes [B,topk] int32, rows [B,topk] int32, count [B] int32).
+    """
+    _req_cuda(cls_logits, deltas, proposals, prop_count, image_sizes, post)
+    B, R, _ = proposals.shape
+    K = num_classes
+    dev = proposals.device
+    assert cls_logits.stride(1) == 1 and deltas.stride(1) == 1
+    cls_agnostic = 1 if deltas.shape[1] == 4 else 0
+    if status is None:
+        status = new_status(dev)
+    lib = _lib.lib()
+    lib.lvc_fast_rcnn_inference_workspace_bytes.restype = c_longlong
+    max_candidates = min(max_candidates, max(1, R * K))
+    nbytes = lib.lvc_fast_rcnn_inference_workspace_bytes(c_int(B), c_int(max_candidates))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ob = torch.empty(B, topk, 4, device=dev, dtype=torch.float32)
+    osc = torch.empty(B, topk, device=dev, dtype=torch.float32)
+    ocl = torch.empty(B, topk, device=dev, dtype=torch.int32)
+    orow = torch.empty(B, topk, device=dev, dtype=torch.int32)
+    cnt = torch.empty(B, device=dev, dtype=torch.int32)
+    wx, wy, ww, wh = box_weights
+    rc = lib.lvc_fast_rcnn_inference(
+        ptr(cls_logits), c_int(cls_logits.stride(0)), ptr(deltas), c_int(deltas.stride(0)), c_int(K),
+        c_int(cls_agnostic), ptr(proposals.contiguous()), ptr(prop_count), c_int(B), c_int(R), ptr(image_sizes),
+        c_float(wx), c_float(wy), c_float(ww), c_float(wh), c_float(SCALE_CLAMP), c_float(score_thresh),
+        c_double(nms_thresh), c_int(topk), c_int(max_candidates), ptr(post), ptr(ob), ptr(osc), ptr(ocl), ptr(orow),
+        ptr(cnt), ptr(status), ptr(ws), c_longlong(nbytes), _stream(proposals))
+    check(rc, "lvc_fast_rcnn_inference")
+    return ob, osc, ocl, orow, cnt
+
+
+# --------------------------------------------------------------------------- trunk elementwise
+def preprocess_into(image, out_slot, mean, std):
+    """image: CHW (3,h,w) float32 or uint8 device tensor; out_slot: [Hp,Wp,4] view of the batch tensor.
+    out = (image - mean) / std, zero padded, 4th channel zero (reference rcnn.py:324-333, image_list.py:95-119)."""
+    _req_cuda(image, out_slot)
+    assert image.dim() == 3 and image.shape[0] == 3
+    if image.dtype == torch.uint8:
+        dt = 1
+    else:
+        image = image.float()
+        dt = 0
+    image = image.contiguous()
+    Hp, Wp, four = out_slot.shape
+    assert four == 4 and out_slot.is_contiguous()
+    m = (c_float * 3)(*[float(v) for v in mean])
+    s = (c_float * 3)(*[float(v) for v in std])
+    rc = _lib.lib().lvc_preprocess_nhwc4(ptr(image), c_int(dt), c_int(image.shape[1]), c_int(image.shape[2]), m, s,
+                                         ptr(out_slot), c_int(Hp), c_int(Wp), _stream(image))
+    check(rc, "lvc_preprocess_nhwc4")
+
+
+def maxpool2d_nhwc(x, k, stride, pad):
+    _req_cuda(x)
+    assert x.is_contiguous() and x.dtype == torch.float32
+    N, H, W, C = x.shape
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    y = torch.empty(N, Ho, Wo, C, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_maxpool2d_nhwc(ptr(x), ptr(y), c_int(N), c_int(H), c_int(W), c_int(C), c_int(k), c_int(stride),
+                                       c_int(pad), _stream(x))
+    check(rc, "lvc_maxpool2d_nhwc")
+    return y

@@ -1,0 +1,128 @@
+"""Box pipeline kernels vs the oracle / reference-generated golden vectors (GPU, through the C ABI).
+Index outputs are compared exactly; fp32 boxes within 1e-4 px (expf differs by <=1 ulp between libm and ocml)."""
+import pytest
+import torch
+
+from helpers import gold
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+
+
+def _nhwc_rpn(logits, deltas, shapes, A=3):
+    """[N,HWA] / [N,HWA,4] oracle layout -> fused NHWC [N,H,W,A+4A] tensor like the rpn predictor conv emits."""
+    out = []
+    for lg, dl, (h, w) in zip(logits, deltas, shapes):
+        N = lg.shape[0]
+        t = torch.cat([lg.view(N, h, w, A), dl.view(N, h, w, A * 4)], dim=3).contiguous()
+        out.append(t)
+    return out
+
+
+def test_rpn_proposals_golden():
+    from lvc_amd import kernels as k
+    from oracle import rcnn as orc
+
+    g = gold("rpn_proposals")
+    shapes = [tuple(s) for s in g["shapes"].tolist()]
+    fused = [t.to(D) for t in _nhwc_rpn([g["logits%d" % i] for i in range(5)], [g["deltas%d" % i] for i in range(5)], shapes)]
+    cell = [orc.generate_cell_anchors((s,), (0.5, 1.0, 2.0)).to(D) for s in (32, 64, 128, 256, 512)]
+    sizes = torch.tensor(g["image_sizes"].tolist(), dtype=torch.int32, device=D)
+    boxes, logits, count = k.rpn_proposals([f[..., :3] for f in fused], [f[..., 3:] for f in fused], cell,
+                                           [4, 8, 16, 32, 64], sizes, 300, 200, 0.7)
+    for n in range(2):
+        gb, gl = g["out_boxes%d" % n], g["out_logits%d" % n]
+        assert int(count[n]) == len(gb)
+        assert torch.equal(logits[n, : len(gl)].cpu(), gl)          # same candidates, same order
+        assert (boxes[n, : len(gb)].cpu() - gb).abs().max() <= 1e-4
+
+
+@pytest.mark.parametrize("seed,pre,post", [(0, 1000, 1000), (1, 2000, 500), (2, 50, 1000)])
+def test_rpn_proposals_random_vs_oracle(seed, pre, post):
+    from lvc_amd import kernels as k
+    from oracle import rcnn as orc
+
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(50, 84), (25, 42), (13, 21), (7, 11), (4, 6)]
+    N = 3
+    logits = [torch.randn(N, h * w * 3, generator=g) * 2 for h, w in shapes]
+    for lg in logits:  # exact ties in the scores: lower index must win
+        lg[:, ::5] = lg[:, :1]
+    deltas = [torch.randn(N, h * w * 3, 4, generator=g) * 0.5 for h, w in shapes]
+    sizes = [(200, 333), (190, 336), (120, 150)]
+    cell = [orc.generate_cell_anchors((s,), (0.5, 1.0, 2.0)) for s in (32, 64, 128, 256, 512)]
+    anchors = orc.grid_anchors(cell, shapes, [4, 8, 16, 32, 64])
+    ref = orc.find_top_rpn_proposals(anchors, logits, deltas, sizes, 0.7, pre, post)
+    fused = [t.to(D) for t in _nhwc_rpn(logits, deltas, shapes)]
+    boxes, olog, count = k.rpn_proposals([f[..., :3] for f in fused], [f[..., 3:] for f in fused],
+                                         [c.to(D) for c in cell], [4, 8, 16, 32, 64],
+                                         torch.tensor(sizes, dtype=torch.int32, device=D), pre, post, 0.7)
+    for n in range(N):
+        rb, rl = ref[n]
+        assert int(count[n]) == len(rb)
+        assert torch.equal(olog[n, : len(rl)].cpu(), rl)
+        assert (boxes[n, : len(rb)].cpu() - rb).abs().max() <= 1e-4
+        assert float(boxes[n, len(rb):].abs().sum()) == 0.0
+
+
+def test_assign_levels_golden():
+    from lvc_amd import kernels as k
+
+    g = gold("box_ops")
+    lv, rois = k.assign_levels_rois(g["lvl_boxes"][None].to(D), 2, 5)
+    assert lv.cpu().tolist() == g["levels"].tolist()
+    assert torch.equal(rois.cpu()[:, 1:], g["lvl_boxes"]) and float(rois[:, 0].abs().sum()) == 0
+
+
+def test_fast_rcnn_inference_golden():
+    from lvc_amd import kernels as k
+
+    g = gold("fast_rcnn_inference")
+    size = torch.tensor([g["image_size"].tolist()], dtype=torch.int32, device=D)
+    oh, ow = g["out_hw"].tolist()
+    ih, iw = g["image_size"].tolist()
+    post = torch.tensor([[ow / iw, oh / ih, oh, ow]], dtype=torch.float32, device=D)
+    b, s, c, rows, cnt = k.fast_rcnn_inference(g["cls_logits"].to(D), g["deltas"].to(D), g["proposals"][None].to(D),
+                                               None, size, 20, (10.0, 10.0, 5.0, 5.0), 0.05, 0.5, 100, post=post)
+    n = len(g["out_scores"])
+    assert int(cnt[0]) == n
+    assert c[0, :n].cpu().tolist() == g["out_classes"].tolist()
+    assert (s[0, :n].cpu() - g["out_scores"]).abs().max() <= 1e-6
+    assert (b[0, :n].cpu() - g["out_boxes"]).abs().max() <= 1e-3
+    # kept_rows in the fixture is pre-postprocess; apply the same non-empty filter the reference applies
+    from oracle import rcnn as orc
+    rb, rs, rc, rr = orc.fast_rcnn_inference_single_image(g["raw_boxes"].clone(), g["probs"],
+                                                          tuple(g["image_size"].tolist()), 0.05, 0.5, 100)
+    assert rr.tolist() == g["kept_rows"].tolist()
+    sb = rb.clone(); sb[:, 0::2] *= ow / iw; sb[:, 1::2] *= oh / ih
+    keep = orc.nonempty(orc.clip_boxes_(sb, (oh, ow)))
+    assert rows[0, :n].cpu().tolist() == rr[keep].tolist()
+
+
+def test_fast_rcnn_inference_batch_vs_oracle():
+    from lvc_amd import kernels as k
+    from oracle import rcnn as orc
+
+    g = torch.Generator().manual_seed(7)
+    B, R, K = 3, 500, 80
+    counts = [500, 321, 0]
+    props = torch.rand(B, R, 4, generator=g) * 400
+    props[..., 2:] = props[..., :2] + 4 + torch.rand(B, R, 2, generator=g) * 300
+    cls = torch.randn(B * R, K + 1, generator=g) * 2.5
+    dl = torch.randn(B * R, 4 * K, generator=g) * 1.2
+    sizes = [(480, 640), (500, 700), (300, 300)]
+    b, s, c, rows, cnt = k.fast_rcnn_inference(cls.to(D), dl.to(D), props.to(D),
+                                               torch.tensor(counts, dtype=torch.int32, device=D),
+                                               torch.tensor(sizes, dtype=torch.int32, device=D), K,
+                                               (10.0, 10.0, 5.0, 5.0), 0.05, 0.5, 100)
+    for i in range(B):
+        n = counts[i]
+        pb = orc.apply_deltas(dl[i * R: i * R + n].reshape(-1, 4),
+                              props[i, :n].unsqueeze(1).expand(-1, K, 4).reshape(-1, 4), (10.0, 10.0, 5.0, 5.0)).view(n, 4 * K)
+        pr = torch.softmax(cls[i * R: i * R + n], -1)
+        rb, rs, rc, rr = orc.fast_rcnn_inference_single_image(pb, pr, sizes[i], 0.05, 0.5, 100)
+        m = len(rs)
+        assert int(cnt[i]) == m
+        assert c[i, :m].cpu().tolist() == rc.tolist() and rows[i, :m].cpu().tolist() == rr.tolist()
+        assert m == 0 or (s[i, :m].cpu() - rs).abs().max() <= 1e-6
+        assert m == 0 or (b[i, :m].cpu() - rb).abs().max() <= 1e-3
