@@ -81,3 +81,35 @@ extern "C" int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W,
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+// Row-wise L2 normalisation: y[m,:] = (x[m,:] - mu) / den,  den = |x-mu| + eps (mode 0, the form of
+// CosineSimOutputLayers, lvc/modeling/roi_heads/fast_rcnn.py:822-833) or max(|x-mu|, eps) (mode 1, the
+// form inside F.cosine_similarity used by tools/run_nearest_neighbours.py:150-153).  One wave per row.
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                      float* __restrict__ y, int M, int D, int ldx, int ldy,
+                                                      float eps, int mode) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    float v = xr[d] - (mu ? mu[d] : 0.f);
+    ss += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  const float nrm = sqrtf(ss);
+  const float den = mode == 0 ? nrm + eps : (nrm > eps ? nrm : eps);
+  float* yr = y + (size_t)row * ldy;
+  for (int d = lane; d < D; d += 64) yr[d] = (xr[d] - (mu ? mu[d] : 0.f)) / den;
+}
+
+extern "C" int lvc_rownorm(const float* x, const float* mu, float* y, int M, int D, int ldx, int ldy, float eps,
+                           int mode, void* stream) {
+  LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
+  if (M == 0) return LVC_OK;
+  LVC_CHECK_ARG(x && y, "null pointer");
+  hipLaunchKernelGGL(rownorm_kernel, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, M, D,
+                     ldx > 0 ? ldx : D, ldy > 0 ? ldy : D, eps, mode);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

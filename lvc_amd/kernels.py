@@ -344,3 +344,16 @@ def maxpool2d_nhwc(x, k, stride, pad):
                                        c_int(pad), _stream(x))
     check(rc, "lvc_maxpool2d_nhwc")
     return y
+
+
+def rownorm(x, mu=None, eps=1e-5, mode=0, out=None):
+    """y = (x - mu) / (|x - mu| + eps)  (mode 0)   or   / max(|x - mu|, eps)  (mode 1), row-wise."""
+    _req_cuda(x, mu)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    M, D = x.shape
+    if out is None:
+        out = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_rownorm(ptr(x), ptr(mu), ptr(out), c_int(M), c_int(D), c_int(x.stride(0)), c_int(out.stride(0)),
+                                c_float(eps), c_int(mode), _stream(x))
+    check(rc, "lvc_rownorm")
+    return out

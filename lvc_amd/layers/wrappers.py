@@ -1,0 +1,110 @@
+"""Conv2d / Linear parameter owners whose forward is the gfx950 implicit-GEMM kernel.
+
+Mirrors reference detectron2/layers/wrappers.py:41-99 (Conv2d with optional `norm` and `activation`
+sub-objects; parameter names `weight`, `bias`, `norm.*`) but runs conv + FrozenBN + bias + ReLU
+(+ residual / upsample-add) as ONE launch of csrc/conv_igemm.hip.  Weights stay in the reference's
+OIHW layout in the state_dict; the packed KRSC copy is rebuilt lazily whenever a parameter changes.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import kernels as K
+from .batch_norm import FrozenBatchNorm2d
+from .layout import require_device, to_nchw_view, to_nhwc
+
+
+def cat(tensors, dim=0):
+    assert isinstance(tensors, (list, tuple))
+    if len(tensors) == 1:
+        return tensors[0]
+    return torch.cat(tensors, dim)
+
+
+def nonzero_tuple(x):
+    return x.nonzero(as_tuple=True) if x.dim() > 0 else x.unsqueeze(0).nonzero(as_tuple=True)
+
+
+class _PackedCache:
+    """Re-pack when any source tensor was modified in place or replaced (optimizer step, load_state_dict, .to())."""
+
+    def __init__(self):
+        self.key = None
+        self.value = None
+
+    def get(self, tensors, build):
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in tensors if t is not None)
+        if key != self.key:
+            self.value = build()
+            self.key = key
+        return self.value
+
+
+class Conv2d(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, norm=None,
+                 activation=None, dilation=1, groups=1):
+        super().__init__()
+        if dilation != 1 or groups != 1:
+            raise NotImplementedError("dilation/groups are not used by the shipped configs")
+        ks = kernel_size if isinstance(kernel_size, (tuple, list)) else (kernel_size, kernel_size)
+        assert ks[0] == ks[1]
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = ks, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, ks[0], ks[1]))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.norm = norm
+        self.activation = activation
+        if activation is not None and activation not in (F.relu, F.relu_):
+            raise NotImplementedError("only ReLU is fused (the only activation on the path)")
+        self._cache = _PackedCache()
+
+    def packed(self):
+        bn = None
+        srcs = [self.weight, self.bias]
+        if self.norm is not None:
+            assert isinstance(self.norm, FrozenBatchNorm2d)
+            bn = (self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var)
+            srcs += list(bn)
+        stem = self.in_channels == 3
+        return self._cache.get(srcs, lambda: K.pack_conv(self.weight, bias=self.bias, bn=bn, stride=self.stride,
+                                                         pad=self.padding, eps=self.norm.eps if bn else 1e-5, stem=stem))
+
+    def forward_nhwc(self, x, residual=None, res_mode=0, relu=None):
+        """x: [N,H,W,C] contiguous.  relu=None -> this layer's own activation."""
+        if relu is None:
+            relu = self.activation is not None
+        return K.conv2d_nhwc(x, self.packed(), relu=relu, residual=residual, res_mode=res_mode)
+
+    def forward(self, x):
+        require_device(x, "Conv2d")
+        xh = to_nhwc(x)
+        if self.in_channels == 3 and xh.shape[-1] == 3:
+            xh = F.pad(xh, (0, 1))  # generic caller: pad RGB to the 4-slot pixel the stem kernel reads
+        return to_nchw_view(self.forward_nhwc(xh))
+
+    def extra_repr(self):
+        return "{}, {}, kernel_size={}, stride={}, padding={}".format(
+            self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding)
+
+
+class Linear(nn.Module):
+    """nn.Linear-compatible parameters (`weight` [out,in], `bias`), forward on the MFMA GEMM kernel."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.zeros(out_features)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self._cache = _PackedCache()
+
+    def packed(self):
+        return self._cache.get([self.weight, self.bias], lambda: K.pack_linear(self.weight, self.bias))
+
+    def forward(self, x, relu=False):
+        require_device(x, "Linear")
+        return K.linear(x.contiguous(), self.packed(), relu=relu)
+
+    def extra_repr(self):
+        return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features, self.bias is not None)

@@ -1,0 +1,215 @@
+"""ResNet bottom-up trunk: `BasicStem`, `BottleneckBlock`, `ResNet`, `build_resnet_backbone`.
+
+Same module tree / parameter names / config keys as reference
+detectron2/modeling/backbone/resnet.py:101-211 (BottleneckBlock), :564-592 (BasicStem),
+:648-763 (ResNet), :845-941 (builder), so reference checkpoints load unchanged.  Every conv+FrozenBN
+(+ReLU, +residual add) is one launch of the fp32-MFMA implicit-GEMM kernel; activations stay NHWC in
+HBM between layers.  BasicBlock / DeepStem / Dropout / CLIP / Deform variants are not selected by any
+shipped config and are not provided (the builder raises for them).
+"""
+import torch.nn.functional as F
+from torch import nn
+
+from ... import kernels as K
+from ...layers import Conv2d, ShapeSpec, get_norm
+from ...layers.layout import require_device, to_nchw_view, to_nhwc
+from ...utils import weight_init
+from .backbone import BACKBONE_REGISTRY, Backbone
+
+
+class CNNBlockBase(nn.Module):
+    """reference detectron2/layers/blocks.py: records in/out channels + stride; `freeze()` stops grads."""
+
+    def __init__(self, in_channels, out_channels, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        return self
+
+
+class BottleneckBlock(CNNBlockBase):
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
+                 stride_in_1x1=False, dilation=1):
+        super().__init__(in_channels, out_channels, stride)
+        if num_groups != 1 or dilation != 1:
+            raise NotImplementedError("grouped / dilated bottlenecks are not used by the shipped configs")
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False,
+                            norm=get_norm(norm, bottleneck_channels), activation=F.relu_)
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3, padding=1,
+                            bias=False, norm=get_norm(norm, bottleneck_channels), activation=F.relu_)
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for layer in [self.conv1, self.conv2, self.conv3, self.shortcut]:
+            if layer is not None:
+                weight_init.c2_msra_fill(layer)
+
+    def forward_nhwc(self, x):
+        out = self.conv1.forward_nhwc(x)
+        out = self.conv2.forward_nhwc(out)
+        shortcut = self.shortcut.forward_nhwc(x) if self.shortcut is not None else x
+        # conv3 + FrozenBN + residual add + ReLU in one epilogue (reference resnet.py:205-211)
+        return self.conv3.forward_nhwc(out, residual=shortcut, res_mode=1, relu=True)
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
+
+
+class BasicStem(CNNBlockBase):
+    def __init__(self, in_channels=3, out_channels=64, norm="BN"):
+        super().__init__(in_channels, out_channels, 4)
+        self.in_channels = in_channels
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=7, stride=2, padding=3, bias=False,
+                            norm=get_norm(norm, out_channels), activation=F.relu_)
+        weight_init.c2_msra_fill(self.conv1)
+
+    def forward_nhwc(self, x4):
+        """x4: [N,H,W,4] (RGB + zero slot)."""
+        y = self.conv1.forward_nhwc(x4)
+        return K.maxpool2d_nhwc(y, 3, 2, 1)
+
+    def forward(self, x):
+        return to_nchw_view(self.forward_nhwc(_as_nhwc4(x)))
+
+
+def _as_nhwc4(x):
+    """NCHW-shaped 3-channel image batch -> [N,H,W,4] buffer; zero-copy when x is the view that
+    GeneralizedRCNN.preprocess_image hands out (storage already NHWC4)."""
+    N, C, H, W = x.shape
+    assert C == 3
+    s = x.stride()
+    if s == (H * W * 4, 1, W * 4, 4) and x.storage_offset() % 4 == 0:
+        return x.as_strided((N, H, W, 4), (H * W * 4, W * 4, 4, 1), x.storage_offset())
+    return F.pad(x.permute(0, 2, 3, 1), (0, 1)).contiguous()
+
+
+class ResNet(Backbone):
+    def __init__(self, stem, stages, num_classes=None, out_features=None):
+        super().__init__()
+        if num_classes is not None:
+            raise NotImplementedError("classification head is not on the detection path")
+        self.stem = stem
+        current_stride = self.stem.stride
+        self._out_feature_strides = {"stem": current_stride}
+        self._out_feature_channels = {"stem": self.stem.out_channels}
+        self.stages_and_names = []
+        for i, blocks in enumerate(stages):
+            assert len(blocks) > 0, len(blocks)
+            for block in blocks:
+                assert isinstance(block, CNNBlockBase), block
+            name = "res" + str(i + 2)
+            stage = nn.Sequential(*blocks)
+            self.add_module(name, stage)
+            self.stages_and_names.append((stage, name))
+            current_stride = int(current_stride * _prod([k.stride for k in blocks]))
+            self._out_feature_strides[name] = current_stride
+            self._out_feature_channels[name] = blocks[-1].out_channels
+        if out_features is None:
+            out_features = [name]
+        self._out_features = out_features
+        assert len(self._out_features)
+        children = [x[0] for x in self.named_children()]
+        for f in self._out_features:
+            assert f in children, "Available children: {}".format(", ".join(children))
+
+    def forward_nhwc(self, x4):
+        outputs = {}
+        x = self.stem.forward_nhwc(x4)
+        if "stem" in self._out_features:
+            outputs["stem"] = x
+        for stage, name in self.stages_and_names:
+            for blk in stage:
+                x = blk.forward_nhwc(x)
+            if name in self._out_features:
+                outputs[name] = x
+        return outputs
+
+    def forward(self, x):
+        require_device(x, "ResNet")
+        return {k: to_nchw_view(v) for k, v in self.forward_nhwc(_as_nhwc4(x)).items()}
+
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+                for name in self._out_features}
+
+    def freeze(self, freeze_at=0):
+        """Freeze the stem (1) and the first `freeze_at - 1` res stages (reference resnet.py:733-757)."""
+        if freeze_at >= 1:
+            self.stem.freeze()
+        for idx, (stage, _) in enumerate(self.stages_and_names, start=2):
+            if freeze_at >= idx:
+                for block in stage.children():
+                    block.freeze()
+        return self
+
+    @staticmethod
+    def make_stage(block_class, num_blocks, first_stride=None, *, in_channels, out_channels, **kwargs):
+        if first_stride is not None:
+            assert "stride" not in kwargs and "stride_per_block" not in kwargs
+            kwargs["stride_per_block"] = [first_stride] + [1] * (num_blocks - 1)
+        blocks = []
+        for i in range(num_blocks):
+            curr = {}
+            for k, v in kwargs.items():
+                if k.endswith("_per_block"):
+                    assert len(v) == num_blocks
+                    curr[k[: -len("_per_block")]] = v[i]
+                else:
+                    curr[k] = v
+            blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, **curr))
+            in_channels = out_channels
+        return blocks
+
+
+def _prod(xs):
+    p = 1
+    for x in xs:
+        p *= x
+    return p
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, input_shape):
+    R = cfg.MODEL.RESNETS
+    norm = R.NORM
+    unsupported = []
+    if R.get("D", False):
+        unsupported.append("RESNETS.D (DeepStem/CLIP blocks)")
+    if R.get("DROPOUT", 0):
+        unsupported.append("RESNETS.DROPOUT")
+    if any(R.DEFORM_ON_PER_STAGE):
+        unsupported.append("RESNETS.DEFORM_ON_PER_STAGE")
+    if R.DEPTH in (18, 34):
+        unsupported.append("BasicBlock depths 18/34")
+    if R.NUM_GROUPS != 1 or R.RES5_DILATION != 1:
+        unsupported.append("grouped/dilated res5")
+    if unsupported:
+        raise NotImplementedError("not on the path of any shipped config: " + ", ".join(unsupported))
+    stem = BasicStem(in_channels=input_shape.channels, out_channels=R.STEM_OUT_CHANNELS, norm=norm)
+    freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
+    out_features = R.OUT_FEATURES
+    bottleneck_channels = R.NUM_GROUPS * R.WIDTH_PER_GROUP
+    in_channels, out_channels = R.STEM_OUT_CHANNELS, R.RES2_OUT_CHANNELS
+    num_blocks_per_stage = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[R.DEPTH]
+    stages = []
+    max_stage_idx = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features)
+    for idx, stage_idx in enumerate(range(2, max_stage_idx + 1)):
+        first_stride = 1 if idx == 0 else 2
+        blocks = ResNet.make_stage(
+            block_class=BottleneckBlock, num_blocks=num_blocks_per_stage[idx],
+            stride_per_block=[first_stride] + [1] * (num_blocks_per_stage[idx] - 1),
+            in_channels=in_channels, out_channels=out_channels, norm=norm,
+            bottleneck_channels=bottleneck_channels, stride_in_1x1=R.STRIDE_IN_1X1, dilation=1, num_groups=1)
+        in_channels = out_channels
+        out_channels *= 2
+        bottleneck_channels *= 2
+        stages.append(blocks)
+    return ResNet(stem, stages, out_features=out_features).freeze(freeze_at)

@@ -1,0 +1,169 @@
+"""GeneralizedRCNN / ProposalNetwork (reference lvc/modeling/meta_arch/rcnn.py:25-333, 413-488).
+
+`forward(batched_inputs: list[dict]) -> list[{"instances": Instances}]` in eval mode, same input keys
+(`image`, optional `height`/`width`/`proposals`) and the same freeze switches as the reference.
+
+The inference path is one uninterrupted stream of HIP launches with fixed shapes:
+  preprocess (normalise + pad + NHWC4)  ->  ResNet/FPN (fp32 MFMA implicit GEMM, fused epilogues)
+  ->  RPN head + on-device proposal selection  ->  ROIAlign over all levels  ->  box head GEMMs
+  ->  softmax / decode / per-class NMS / top-k / detector_postprocess
+with exactly ONE device->host read at the end (per-image detection counts + the status word), where
+the reference path has >= 10 hidden syncs per image.
+"""
+import torch
+from torch import nn
+
+from ... import kernels as K
+from ...structures import Boxes, ImageList, Instances
+from ..backbone import build_backbone
+from ..postprocessing import detector_postprocess
+from ..proposal_generator import RPN, build_proposal_generator
+from ..roi_heads import StandardROIHeads, build_roi_heads
+from ..roi_heads.roi_heads import check_status, instances_from_batched
+from .build import META_ARCH_REGISTRY
+
+
+def _freeze(module):
+    for p in module.parameters():
+        p.requires_grad = False
+
+
+class _RCNNBase(nn.Module):
+    def _init_common(self, cfg):
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        assert len(cfg.MODEL.PIXEL_MEAN) == len(cfg.MODEL.PIXEL_STD)
+        self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+        assert len(self.pixel_mean) == 3, "the stem kernel is built for 3-channel images"
+
+    def preprocess_image(self, batched_inputs):
+        """Normalize, pad and batch (reference rcnn.py:324-333).  Storage is NHWC with 4 channel slots;
+        `.tensor` is the NCHW-shaped [N,3,Hp,Wp] view of it."""
+        images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
+        sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
+        buf = torch.empty(len(images), Hp, Wp, 4, device=self.device, dtype=torch.float32)
+        for i, im in enumerate(images):
+            K.preprocess_into(im, buf[i], self.pixel_mean, self.pixel_std)
+        return ImageList(buf.permute(0, 3, 1, 2)[:, :3], sizes)
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(_RCNNBase):
+    def __init__(self, cfg):
+        super().__init__()
+        self._init_common(cfg)
+        self.backbone = build_backbone(cfg)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.roi_heads = build_roi_heads(cfg, self.backbone.output_shape())
+        self.to(self.device)
+        M = cfg.MODEL
+        if M.BACKBONE.FREEZE:
+            _freeze(self.backbone)
+        if M.BACKBONE.FREEZE_BOTTOM_UP:
+            _freeze(self.backbone.bottom_up)
+        if M.PROPOSAL_GENERATOR.FREEZE and self.proposal_generator:
+            _freeze(self.proposal_generator)
+        if M.ROI_HEADS.FREEZE_FEAT:
+            _freeze(self.roi_heads.box_head)
+            if M.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG:
+                for n, p in self.roi_heads.box_predictor.named_parameters():
+                    if "bbox_pred" in n:
+                        p.requires_grad = False
+        if M.ROI_HEADS.FREEZE_BBOX_PRED:
+            for n, p in self.roi_heads.box_predictor.named_parameters():
+                if "bbox_pred" in n:
+                    p.requires_grad = False
+        if M.PROPOSAL_GENERATOR.UNFREEZE_FIN:
+            for p in self.proposal_generator.rpn_head.objectness_logits.parameters():
+                p.requires_grad = True
+            for p in self.proposal_generator.rpn_head.anchor_deltas.parameters():
+                p.requires_grad = True
+        assert not M.IMAGES_ONLY
+        self.roi_heads_name = M.ROI_HEADS.NAME
+        self.output_layer = M.ROI_HEADS.OUTPUT_LAYER
+
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        raise NotImplementedError(
+            "GeneralizedRCNN training forward is not implemented in lvc_amd round 1 "
+            "(inference path first; see DESIGN.md 'what comes next')")
+
+    # ------------------------------------------------------------------ device-side fast path
+    def inference_batched(self, batched_inputs, do_postprocess=True):
+        """Whole forward with device-resident, fixed-shape outputs and no host sync:
+        (boxes [B,topk,4], scores [B,topk], classes [B,topk] int32, count [B] int32, status [1] int32)."""
+        assert isinstance(self.proposal_generator, RPN) and isinstance(self.roi_heads, StandardROIHeads)
+        images = self.preprocess_image(batched_inputs)
+        sizes = images.image_sizes
+        dev = self.device
+        sizes_dev = torch.tensor([list(s) for s in sizes], dtype=torch.int32, device=dev)
+        N, _, Hp, Wp = images.tensor.shape
+        x4 = images.tensor.as_strided((N, Hp, Wp, 4), (Hp * Wp * 4, Wp * 4, 4, 1), images.tensor.storage_offset())
+        feats = self.backbone.forward_nhwc(x4)
+        pboxes, _plogits, pcount = self.proposal_generator.predict_proposals_batched(feats, sizes_dev)
+        post = None
+        if do_postprocess:
+            rows = []
+            for inp, (h, w) in zip(batched_inputs, sizes):
+                oh, ow = inp.get("height", h), inp.get("width", w)
+                rows.append([ow / w, oh / h, float(oh), float(ow)])
+            post = torch.tensor(rows, dtype=torch.float32, device=dev)
+        status = K.new_status(dev)
+        ob, osc, ocl, _orow, cnt = self.roi_heads.forward_batched(feats, pboxes, pcount, sizes_dev, post=post, status=status)
+        return ob, osc, ocl, cnt, status
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        """Reference rcnn.py:177-322 (the GeneralizedRCNN + RPN + StandardROIHeads branch)."""
+        assert not self.training
+        if detected_instances is not None:
+            raise NotImplementedError("forward_with_given_boxes (mask/keypoint heads) is not on the box-only path")
+        if not (isinstance(self.proposal_generator, RPN) and isinstance(self.roi_heads, StandardROIHeads)):
+            return self._inference_modular(batched_inputs, do_postprocess)
+        ob, osc, ocl, cnt, status = self.inference_batched(batched_inputs, do_postprocess)
+        out_sizes = []
+        for inp in batched_inputs:
+            h, w = int(inp["image"].shape[-2]), int(inp["image"].shape[-1])
+            out_sizes.append((inp.get("height", h), inp.get("width", w)) if do_postprocess else (h, w))
+        insts = instances_from_batched(ob, osc, ocl, cnt, out_sizes, status)
+        return [{"instances": r} for r in insts] if do_postprocess else insts
+
+    def _inference_modular(self, batched_inputs, do_postprocess):
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        if self.proposal_generator:
+            proposals, _ = self.proposal_generator(images, features, None)
+        else:
+            assert "proposals" in batched_inputs[0]
+            proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+        results, _ = self.roi_heads(images, features, proposals, None)
+        if not do_postprocess:
+            return results
+        processed = []
+        for r, inp, size in zip(results, batched_inputs, images.image_sizes):
+            processed.append({"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return processed
+
+
+@META_ARCH_REGISTRY.register()
+class ProposalNetwork(_RCNNBase):
+    """reference rcnn.py:413-488: backbone + RPN only; output key "proposals"."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self._init_common(cfg)
+        self.backbone = build_backbone(cfg)
+        self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
+        self.to(self.device)
+
+    def forward(self, batched_inputs):
+        if self.training:
+            raise NotImplementedError("ProposalNetwork training is not implemented in lvc_amd round 1")
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None)
+        processed = []
+        for r, inp, size in zip(proposals, batched_inputs, images.image_sizes):
+            processed.append({"proposals": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
+        return processed

@@ -1,0 +1,119 @@
+"""RPN: `StandardRPNHead` + `RPN` (reference detectron2/modeling/proposal_generator/rpn.py:67-139,
+142-508; `find_top_rpn_proposals` proposal_utils.py:13-118).
+
+Launch plan (inference), all on the current stream, no host sync:
+  per level: 3x3 conv + bias + ReLU (MFMA implicit GEMM), then ONE fused 1x1 conv producing
+  [B,H,W,A+4A] = objectness | deltas (the reference runs two convs);
+  then lvc_rpn_proposals: per-(image,level) radix-select top-k, decode only the selected anchors,
+  clip, drop empty, batched NMS (ballot kernels), gather top post_nms_topk.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import kernels as K
+from ...layers import Conv2d, ShapeSpec
+from ...layers.layout import require_device, to_nchw_view, to_nhwc
+from ...layers.wrappers import _PackedCache
+from ...structures import Boxes, Instances
+from ...utils.registry import Registry
+from ..anchor_generator import build_anchor_generator
+from ..box_regression import Box2BoxTransform
+from .build import PROPOSAL_GENERATOR_REGISTRY
+
+RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
+
+
+def build_rpn_head(cfg, input_shape):
+    return RPN_HEAD_REGISTRY.get(cfg.MODEL.RPN.HEAD_NAME)(cfg, input_shape)
+
+
+@RPN_HEAD_REGISTRY.register()
+class StandardRPNHead(nn.Module):
+    def __init__(self, cfg=None, input_shape=None, *, in_channels=None, num_anchors=None, box_dim=4):
+        super().__init__()
+        if cfg is not None:
+            in_channels = [s.channels for s in input_shape]
+            assert len(set(in_channels)) == 1, "Each level must have the same channel!"
+            in_channels = in_channels[0]
+            ag = build_anchor_generator(cfg, input_shape)
+            num_anchors, box_dim = ag.num_anchors, ag.box_dim
+            assert len(set(num_anchors)) == 1, "Each level must have the same number of anchors per spatial position"
+            num_anchors = num_anchors[0]
+        self.num_anchors, self.box_dim = num_anchors, box_dim
+        self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1, activation=F.relu_)
+        self.objectness_logits = Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
+        self.anchor_deltas = Conv2d(in_channels, num_anchors * box_dim, kernel_size=1, stride=1)
+        for l in [self.conv, self.objectness_logits, self.anchor_deltas]:
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+        self._fused = _PackedCache()
+
+    def fused_predictor(self):
+        o, d = self.objectness_logits, self.anchor_deltas
+        return self._fused.get(
+            [o.weight, o.bias, d.weight, d.bias],
+            lambda: K.pack_conv(torch.cat([o.weight, d.weight], 0), bias=torch.cat([o.bias, d.bias], 0)))
+
+    def forward_nhwc(self, feats):
+        """feats: list of [B,H,W,C] -> list of fused [B,H,W,A+A*box_dim] tensors."""
+        pc = self.fused_predictor()
+        return [K.conv2d_nhwc(self.conv.forward_nhwc(x), pc) for x in feats]
+
+    def forward(self, features):
+        """Reference signature: list of NCHW maps -> (list of [N,A,H,W], list of [N,A*box_dim,H,W])."""
+        fused = self.forward_nhwc([to_nhwc(f) for f in features])
+        A = self.num_anchors
+        return [to_nchw_view(t[..., :A]) for t in fused], [to_nchw_view(t[..., A:]) for t in fused]
+
+
+@PROPOSAL_GENERATOR_REGISTRY.register()
+class RPN(nn.Module):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self.in_features = cfg.MODEL.RPN.IN_FEATURES
+        shapes = [input_shape[f] for f in self.in_features]
+        self.rpn_head = build_rpn_head(cfg, shapes)
+        self.anchor_generator = build_anchor_generator(cfg, shapes)
+        self.box2box_transform = Box2BoxTransform(weights=cfg.MODEL.RPN.BBOX_REG_WEIGHTS)
+        self.batch_size_per_image = cfg.MODEL.RPN.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = cfg.MODEL.RPN.POSITIVE_FRACTION
+        self.pre_nms_topk = (cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN)
+        self.post_nms_topk = (cfg.MODEL.RPN.POST_NMS_TOPK_TEST, cfg.MODEL.RPN.POST_NMS_TOPK_TRAIN)
+        self.nms_thresh = cfg.MODEL.RPN.NMS_THRESH
+        self.min_box_size = float(cfg.MODEL.PROPOSAL_GENERATOR.MIN_SIZE)
+        self.anchor_boundary_thresh = cfg.MODEL.RPN.BOUNDARY_THRESH
+        self.loss_weight = {"loss_rpn_cls": cfg.MODEL.RPN.LOSS_WEIGHT,
+                            "loss_rpn_loc": cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT}
+        self.box_reg_loss_type = cfg.MODEL.RPN.BBOX_REG_LOSS_TYPE
+        self.smooth_l1_beta = cfg.MODEL.RPN.SMOOTH_L1_BETA
+        assert tuple(self.box2box_transform.weights) == (1.0, 1.0, 1.0, 1.0), \
+            "the fused RPN decode kernel assumes RPN.BBOX_REG_WEIGHTS == (1,1,1,1) (the default of every shipped config)"
+
+    def predict_proposals_batched(self, feats_nhwc, image_sizes_dev):
+        """feats_nhwc: dict name -> [B,H,W,C]; image_sizes_dev: [B,2] int32 device (h,w).
+        Returns (boxes [B,post,4], objectness_logits [B,post], count [B] int32) on device."""
+        feats = [feats_nhwc[f] for f in self.in_features]
+        fused = self.rpn_head.forward_nhwc(feats)
+        A = self.rpn_head.num_anchors
+        t = int(self.training)
+        return K.rpn_proposals([f[..., :A] for f in fused], [f[..., A:] for f in fused],
+                               list(self.anchor_generator.cell_anchors), self.anchor_generator.strides, image_sizes_dev,
+                               self.pre_nms_topk[t], self.post_nms_topk[t], self.nms_thresh, self.min_box_size)
+
+    def forward(self, images, features, gt_instances=None):
+        """Reference signature (rpn.py:402-451): -> (list[Instances], losses)."""
+        if self.training:
+            raise NotImplementedError("RPN losses are not implemented in lvc_amd round 1 (see DESIGN.md 'next')")
+        feats = {f: to_nhwc(features[f]) for f in self.in_features}
+        require_device(feats[self.in_features[0]], "RPN")
+        sizes = torch.tensor([list(s) for s in images.image_sizes], dtype=torch.int32, device=images.tensor.device)
+        boxes, logits, count = self.predict_proposals_batched(feats, sizes)
+        counts = count.tolist()  # the one host sync of this entry point
+        out = []
+        for i, size in enumerate(images.image_sizes):
+            inst = Instances(size)
+            inst.proposal_boxes = Boxes(boxes[i, : counts[i]])
+            inst.objectness_logits = logits[i, : counts[i]]
+            out.append(inst)
+        return out, {}

@@ -1,0 +1,100 @@
+"""Fast R-CNN output layers + inference (reference lvc/modeling/roi_heads/fast_rcnn.py):
+`FastRCNNOutputLayers` :499-598, `CosineSimOutputLayers` :721-841, `fast_rcnn_inference` :51-137,
+`FastRCNNOutputs.predict_boxes/predict_probs/inference` :440-493.
+
+Parameter names `cls_score.{weight,bias}`, `bbox_pred.{weight,bias}` (no cls bias for the cosine
+layer).  Inference = one fused GEMM for both linears (two for the cosine variant, whose inputs
+differ) + lvc_fast_rcnn_inference (softmax, per-class decode, clip, threshold, per-class NMS, top-k,
+optional detector_postprocess) on device.
+"""
+import torch
+from torch import nn
+
+from ... import kernels as K
+from ...layers import Linear, ShapeSpec
+from ...layers.wrappers import _PackedCache
+from ...utils.registry import Registry
+from ..box_regression import Box2BoxTransform
+
+ROI_HEADS_OUTPUT_REGISTRY = Registry("ROI_HEADS_OUTPUT")
+
+
+class _OutputLayersBase(nn.Module):
+    def _common(self, cfg, input_shape):
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        self.input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        self.cls_agnostic_bbox_reg = cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG
+        self.box2box_transform = Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS)
+        self.smooth_l1_beta = cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA
+        self.test_score_thresh = cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST
+        self.test_nms_thresh = cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST
+        self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+        self.box_reg_loss_type = cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE
+        self.loss_weight = {"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT}
+        self.num_bbox_reg_classes = 1 if self.cls_agnostic_bbox_reg else self.num_classes
+
+
+@ROI_HEADS_OUTPUT_REGISTRY.register()
+class FastRCNNOutputLayers(_OutputLayersBase):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self._common(cfg, input_shape)
+        self.cls_score = Linear(self.input_size, self.num_classes + 1)
+        self.bbox_pred = Linear(self.input_size, self.num_bbox_reg_classes * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in [self.cls_score, self.bbox_pred]:
+            nn.init.constant_(l.bias, 0)
+        self._fused = _PackedCache()
+
+    def forward(self, x):
+        """-> (scores [M,K+1], deltas [M,4K|4]); both are column slices of one fused GEMM output."""
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        c, b = self.cls_score, self.bbox_pred
+        pc = self._fused.get([c.weight, c.bias, b.weight, b.bias],
+                             lambda: K.pack_linear(torch.cat([c.weight, b.weight], 0), torch.cat([c.bias, b.bias], 0)))
+        y = K.linear(x.contiguous(), pc)
+        k1 = self.num_classes + 1
+        return y[:, :k1], y[:, k1:]
+
+
+@ROI_HEADS_OUTPUT_REGISTRY.register()
+class CosineSimOutputLayers(_OutputLayersBase):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        self._common(cfg, input_shape)
+        self.cls_score = Linear(self.input_size, self.num_classes + 1, bias=False)
+        self.scale = cfg.MODEL.ROI_HEADS.COSINE_SCALE
+        if self.scale == -1:
+            self.scale = nn.Parameter(torch.ones(1) * 20.0)
+        self.bbox_pred = Linear(self.input_size, self.num_bbox_reg_classes * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        nn.init.constant_(self.bbox_pred.bias, 0)
+        self._cos = _PackedCache()
+
+    def forward(self, x):
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        x = x.contiguous()
+        xn = K.rownorm(x, eps=1e-5, mode=0)
+        # the reference renormalises cls_score.weight.data IN PLACE on every call (fast_rcnn.py:830-837)
+        w = self.cls_score.weight
+        K.rownorm(w.data, eps=1e-5, mode=0, out=w.data)
+        w.data_ptr()  # noqa: B018
+        w._version  # noqa: B018
+        scale = float(self.scale) if not isinstance(self.scale, nn.Parameter) else float(self.scale.item())
+
+        def build():
+            pc = K.pack_linear(w)
+            pc.scale = torch.full((pc.K,), scale, device=w.device, dtype=torch.float32)
+            return pc
+
+        # rownorm wrote through `out=`, which does not bump torch's version counter: always rebuild
+        self._cos.key = None
+        scores = K.linear(xn, self._cos.get([w], build))
+        deltas = self.bbox_pred(x)
+        return scores, deltas
