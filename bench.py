@@ -1,0 +1,142 @@
+#!/usr/bin/env python
+"""bench.py -- img/s of the R50-FPN GeneralizedRCNN inference forward on synthetic 800x1333 batches.
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the hot path over one batch of 8 synthetic 3x800x1333 images per GPU (BASELINE.json
+configs[1]); inputs are resident in HBM before the timed region; weights are the conditioned random-init
+R50-FPN (lvc_amd/utils/synthetic.py).  Images shard data-parallel across ranks with no data-path collective
+(reference InferenceSampler semantics), so scaling is "weak" and value = all images of all ranks / max time.
+Prints ONE JSON line on rank 0 with `roofline` (the fp32-MFMA conv/GEMM kernel, measured live with HIP events
+around every launch in the timed region) and `cpu_baseline` (the CPU oracle timed on this host, rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BATCH_PER_GPU = 8
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-launch-timer", action="store_true", help="skip the per-launch HIP events (A/B their cost)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    from lvc_amd import kernels as K
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+
+    cfg = base_rcnn_fpn(depth=50, num_classes=80, device="cuda:%d" % local_rank)
+    model = build_model(cfg).eval()
+    syn.conditioned_r50_fpn_(model)
+    # the rank's shard of the (synthetic) dataset: contiguous block, like reference InferenceSampler
+    imgs = [syn.synthetic_image(1 + (rank * BATCH_PER_GPU + i) % 16).to(dev) for i in range(BATCH_PER_GPU)]
+    batch = [{"image": im, "height": 800, "width": 1333} for im in imgs]
+
+    def step():
+        with torch.no_grad():
+            return model.inference_batched(batch)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    timer = None if args.no_launch_timer else K.LaunchTimer()
+    K.CONV_TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    K.CONV_TIMER = None
+    from lvc_amd.modeling.roi_heads.roi_heads import check_status
+    check_status(int(out[4].item()))
+    n_det = out[3].tolist()
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+    total_imgs = world * BATCH_PER_GPU * args.steps
+    value = total_imgs / dt_max
+
+    roofline = None
+    if timer is not None:
+        fl, ms, nlaunch = timer.flops_and_ms()
+        achieved = fl / (ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        roofline = {"kernel": "conv_igemm_f32_kernel (all %d launches/step: trunk, RPN head, box head)" % (nlaunch // args.steps),
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_gflop_per_image": round(fl / (BATCH_PER_GPU * args.steps) / 1e9, 1),
+                    "kernel_ms_per_step": round(ms / args.steps, 3)}
+
+    cpu_baseline = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        from oracle import rcnn as orc
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        cpu_in = [{"image": imgs[0].cpu(), "height": 800, "width": 1333}]
+        with torch.no_grad():
+            orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), cpu_in)  # warm-up
+            n, t1 = 0, time.perf_counter()
+            while n < 3 or (time.perf_counter() - t1 < 10.0 and n < 8):
+                orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), cpu_in)
+                n += 1
+            cdt = time.perf_counter() - t1
+        cpu_baseline = {"value": round(n / cdt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+                        "sample": "%d x one 3x800x1333 image (bs=1) through oracle/rcnn.py (torch-CPU convs, oracle.c ROIAlign/NMS)" % n}
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": "img/s COCO 800x1333 R50-FPN inference (GeneralizedRCNN forward, 1000 proposals, 100 detections)",
+            "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "COCO-detection R50-FPN inference, bs=8 synthetic 3x800x1333 per GPU, 1000 pre/post-NMS "
+                                   "proposals per level/image, 80 classes, conditioned random-init weights",
+                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
+                       "detections_per_image": n_det},
+            "roofline": roofline, "cpu_baseline": cpu_baseline,
+        }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,23 @@ def pack_linear(weight, bias=None):
     return pack_conv(weight[:, :, None, None], bias=bias)
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event bracket for the conv/GEMM kernel (bench.py's roofline leg).
+    Events are recorded on the stream the kernel is launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []  # (algorithmic flops, start event, end event)
+
+    def flops_and_ms(self):
+        torch.cuda.synchronize()
+        fl = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return fl, ms, len(self.records)
+
+
+CONV_TIMER = None  # set to a LaunchTimer to instrument lvc_conv2d_nhwc_f32 launches
+
+
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     """x: [N,H,W,C] fp32 contiguous (NHWC).  Returns [N,Ho,Wo,K].
     res_mode 1: residual has the output's shape; 2: residual is [N,Ho/2,Wo/2,K] and is
@@ -103,6 +120,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         assert residual.is_contiguous() and residual.dtype == torch.float32
         if res_mode == 0:
             res_mode = 1
+    timer = CONV_TIMER
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     st = _lib.lib().lvc_conv2d_nhwc_f32(
         ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
         c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
@@ -110,6 +131,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         c_int(out.shape[-1]), c_int(residual.shape[-1] if residual is not None else 0),
         c_int(pc.mode), _stream(x))
     check(st, "lvc_conv2d_nhwc_f32")
+    if timer is not None:
+        e1.record()
+        c_real = 3 if pc.mode == 1 else C
+        timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1))
     return out
 
 

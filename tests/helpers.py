@@ -49,3 +49,23 @@ def match_detections(boxes, scores, classes, gboxes, gscores, gclasses, tol=1e-3
         worst = max(worst, float(d[j]))
         used.add(j)
     return True, "worst %g" % worst
+
+
+def match_fraction(boxes, scores, classes, gboxes, gscores, gclasses, box_tol, score_tol):
+    """Greedy one-to-one matching of golden detections to predictions; returns (fraction matched,
+    worst box error among matched, worst score error among matched)."""
+    used = set()
+    matched, wb, ws = 0, 0.0, 0.0
+    for i in range(len(gboxes)):
+        db = (boxes - gboxes[i]).abs().max(dim=1)[0]
+        ds = (scores - gscores[i]).abs()
+        ok = (db <= box_tol) & (ds <= score_tol) & (classes == gclasses[i])
+        for u in used:
+            ok[u] = False
+        idx = ok.nonzero().view(-1)
+        if len(idx):
+            j = int(idx[db[idx].argmin()])
+            used.add(j)
+            matched += 1
+            wb, ws = max(wb, float(db[j])), max(ws, float(ds[j]))
+    return matched / max(1, len(gboxes)), wb, ws
