@@ -108,14 +108,18 @@ def main():
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         from oracle import rcnn as orc
 
-        cores = os.cpu_count() or 1
+        # bounded sample: torch-CPU convolutions stop scaling (and regress) far below the 256 hardware threads
+        # of the GPU host, so the baseline uses 32 threads -- stated as `cores` -- and stops after ~10-30 s.
+        cores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(cores)
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         cpu_in = [{"image": imgs[0].cpu(), "height": 800, "width": 1333}]
         with torch.no_grad():
-            orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), cpu_in)  # warm-up
+            t1 = time.perf_counter()
+            orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), cpu_in)  # warm-up (also bounds the sample)
+            warm = time.perf_counter() - t1
             n, t1 = 0, time.perf_counter()
-            while n < 3 or (time.perf_counter() - t1 < 10.0 and n < 8):
+            while n < 1 or (n < 8 and (time.perf_counter() - t1) + warm < 20.0):
                 orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), cpu_in)
                 n += 1
             cdt = time.perf_counter() - t1

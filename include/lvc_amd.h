@@ -1,0 +1,158 @@
+/*
+ * lvc_amd.h -- C ABI of liblvc_amd.so: the MI355X (gfx950) kernels of the lvc hot path.
+ *
+ * The reference (prannaykaul/lvc) has no C ABI for this path: it sits behind Python registries and
+ * nn.Module call signatures, with exactly one native op of its own
+ * (detectron2/layers/csrc/vision.cpp:96-97, roi_align_forward/backward) and torchvision's nms.  This header
+ * is the drop-in boundary a maintainer binds instead (INTEGRATION.md shows the ctypes / torch.library
+ * stubs).  Conventions:
+ *   - extern "C", plain pointers and sizes; no torch types.  All data pointers are DEVICE pointers unless
+ *     marked [host]; tensors are dense fp32 / int32 / int64 as stated.
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*; NULL = default stream) and
+ *     returns immediately; nothing here synchronises the device (the reference's ROIAlign does:
+ *     ROIAlign_cuda.cu:364, a defect we do not reproduce).
+ *   - return value: 0 = LVC_OK, 1 = LVC_ERR_INVALID (bad argument), 2 = LVC_ERR_HIP (launch failed);
+ *     lvc_last_error() gives the message for the calling thread.  Data-dependent conditions that the
+ *     reference asserts on the host (negative RoI size, ROIAlign_cpu.cpp:149-152) are reported
+ *     asynchronously through a device status word (`d_status`, bit 0 = negative RoI size, bit 1 =
+ *     detection candidate overflow) which the host reads together with the results.
+ *   - ownership: the caller owns every buffer, including workspaces (sizes from the *_workspace_bytes
+ *     queries); the library allocates nothing and keeps no state between calls.
+ *   - threading: one host thread per stream; functions are re-entrant.
+ */
+#ifndef LVC_AMD_H
+#define LVC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LVC_OK 0
+#define LVC_ERR_INVALID 1
+#define LVC_ERR_HIP 2
+
+int lvc_abi_version(void);
+const char* lvc_last_error(void);
+void lvc_set_error(const char* fmt, ...);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Convolution / linear layers: NHWC fp32 implicit GEMM on v_mfma_f32_32x32x2_f32, with the per-channel
+ * affine (FrozenBN and/or bias), optional residual and ReLU fused into the epilogue.
+ * Replaces: detectron2/layers/wrappers.py:41-99 (Conv2d+norm+activation), batch_norm.py:45-65 (FrozenBN),
+ *   backbone/resnet.py:195-211 (residual add + ReLU), backbone/fpn.py:131-133 (nearest x2 upsample + add),
+ *   lvc/modeling/roi_heads/box_head.py:82-91 and fast_rcnn.py:583-598 (Linear = 1x1 conv on [M,1,1,K]).
+ *   x        [N,H,W,C]        C = physical channels (mode 0: C % 32 == 0; mode 1: C == 4, the RGB0 stem)
+ *   w_packed [Kpad,Kg]        rows = out channel, zero rows up to a multiple of 128;
+ *                             mode 0: k = (r,s,c), c fastest, Kg = R*S*C
+ *                             mode 1: k = (r, 8 pixels x 4 ch), Kg = R*32 (7x7 stem: pixel 7 / ch 3 zero)
+ *   scale, shift [K] or NULL  y = acc*scale + shift
+ *   residual                  res_mode 0 none | 1: [M,ldr] same rows as y | 2: [N,Ho/2,Wo/2,ldr], upsampled x2
+ *   y        [N*Ho*Wo, ldy]   ldy/ldr = row strides in floats (<=0: K)
+ */
+int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
+                        const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
+                        int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, int mode,
+                        void* stream);
+
+/* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
+ * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero
+ * outside h x w.  image: CHW, dtype 0 = fp32, 1 = uint8.  mean3/std3 are [host] arrays of 3 floats. */
+int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float* mean3, const float* std3,
+                         float* out, int Hp, int Wp, void* stream);
+
+/* F.max_pool2d on NHWC (BasicStem resnet.py:591: k3 s2 p1; LastLevelMaxPool fpn.py:176: k1 s2 p0). */
+int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
+                       void* stream);
+
+/* Row-wise (x - mu) / den; den = |x-mu| + eps (mode 0, CosineSimOutputLayers fast_rcnn.py:822-833) or
+ * max(|x-mu|, eps) (mode 1, F.cosine_similarity as used by tools/run_nearest_neighbours.py:150-153). */
+int lvc_rownorm(const float* x, const float* mu, float* y, int M, int D, int ldx, int ldy, float eps, int mode,
+                void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * ROIAlign forward.  Same arithmetic and operation order as ROIAlign_cpu.cpp:20-218 / ROIAlign_cuda.cu:65-139.
+ * lvc_roi_align_forward_nchw has the reference op's shape contract (csrc/vision.cpp:96):
+ *   input [B,C,H,W], rois [K,5] = (batch index, x1, y1, x2, y2), output [K,C,pooled_h,pooled_w].
+ * lvc_roi_align_fpn_nhwc is the engine form: L pyramid levels [B,H_l,W_l,C] (feats/Hs/Ws/scales are [host]
+ * arrays of L entries), per-RoI level ids [K] int32 (NULL if L == 1), output [K,pooled_h,pooled_w,C];
+ * replaces the per-level gather/ROIAlign/scatter loop of detectron2/modeling/poolers.py:236-246.
+ * d_num_valid (device int, may be NULL): rows >= *d_num_valid are zero-filled.
+ */
+int lvc_roi_align_forward_nchw(const float* input, const float* rois, float* output, int B, int C, int H, int W,
+                               int K, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                               int aligned, int* d_status, void* stream);
+int lvc_roi_align_fpn_nhwc(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int L,
+                           int B, int C, const float* rois, const int* levels, const int* d_num_valid, int K,
+                           int pooled_h, int pooled_w, int sampling_ratio, int aligned, float* output,
+                           int* d_status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Batched NMS, B images per call.  Replaces torchvision.ops.boxes.batched_nms / nms as called from
+ * detectron2/layers/nms.py:10-29 (consumers proposal_utils.py:104, lvc fast_rcnn.py:128).  Keep indices are
+ * bit-exact w.r.t. the CPU algorithm (offset trick in fp32, IoU in fp32 compared against the double
+ * threshold, score ties -> lower index).
+ *   boxes [B,Nmax,4], scores [B,Nmax], idxs [B,Nmax] int32 or NULL, d_counts [B] int32 or NULL (= Nmax)
+ *   keep [B,Nmax] int32 (indices into the image's rows, score-descending), d_num_keep [B] int32
+ *   max_keep <= 0: unlimited.  Nmax <= 16384.
+ */
+long long lvc_batched_nms_workspace_bytes(int B, int Nmax);
+int lvc_batched_nms(const float* boxes, const float* scores, const int* idxs, const int* d_counts, int B,
+                    int Nmax, double iou_threshold, int max_keep, int* keep, int* d_num_keep, void* workspace,
+                    long long workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * RPN.predict_proposals + find_top_rpn_proposals (detectron2/modeling/proposal_generator/rpn.py:455-508,
+ * proposal_utils.py:13-118, anchor_generator.py:157-178, box_regression.py:73-110), inference branch.
+ *   per level l (arrays of L [host] entries):
+ *     logits[l]  device ptr: objectness of anchor a at pixel p of image b = logits[l][(b*H*W + p)*ld_logit[l] + a]
+ *     deltas[l]  device ptr: delta c of anchor a                          = deltas[l][(b*H*W + p)*ld_delta[l] + a*4 + c]
+ *     cell_anchors[l] device ptr [A,4]; Hs, Ws, strides
+ *   d_image_sizes [B,2] int32 (h, w).  Outputs: out_boxes [B,post,4], out_logits [B,post] (zero rows past
+ *   d_out_count[b]).  pre_nms_topk <= 2048; sum over levels of min(pre_nms_topk, H*W*A) <= 16384.
+ */
+long long lvc_rpn_proposals_workspace_bytes(int B, int L, int A, const int* Hs, const int* Ws, int pre_nms_topk);
+int lvc_rpn_proposals(const float* const* logits, const int* ld_logit, const float* const* deltas,
+                      const int* ld_delta, const float* const* cell_anchors, const int* Hs, const int* Ws,
+                      const int* strides, int L, int A, int B, const int* d_image_sizes, int pre_nms_topk,
+                      int post_nms_topk, double nms_thresh, float min_box_size, float scale_clamp,
+                      float* out_boxes, float* out_logits, int* d_out_count, void* workspace,
+                      long long workspace_bytes, void* stream);
+
+/* assign_boxes_to_levels + convert_boxes_to_pooler_format (detectron2/modeling/poolers.py:23-59, 69-96).
+ * boxes [B,R,4] -> levels [B*R] int32 (offset from min_level), rois [B*R,5] (may be NULL). */
+int lvc_assign_levels_rois(const float* boxes, int B, int R, int min_level, int max_level, int canonical_box_size,
+                           int canonical_level, int* levels, float* rois, void* stream);
+
+/* FastRCNNOutputs.predict_boxes / predict_probs + fast_rcnn_inference (lvc/modeling/roi_heads/fast_rcnn.py:95-137,
+ * 440-468) + optional detector_postprocess (detectron2/modeling/postprocessing.py:10-79).
+ *   cls_logits [B*R, ld_cls] (K+1 used), deltas [B*R, ld_delta] (4K, or 4 when cls_agnostic), proposals [B,R,4],
+ *   d_prop_count [B] or NULL, d_image_sizes [B,2] (h,w), (wx,wy,ww,wh) = ROI_BOX_HEAD.BBOX_REG_WEIGHTS,
+ *   d_post [B,4] = (scale_x, scale_y, out_h, out_w) or NULL.
+ *   Outputs [B,topk,*] + d_out_count [B]; out_rows = index of the proposal each detection came from.
+ *   max_candidates <= 16384 (roi,class) pairs above score_thresh per image (overflow -> d_status bit 1).
+ */
+long long lvc_fast_rcnn_inference_workspace_bytes(int B, int max_candidates);
+int lvc_fast_rcnn_inference(const float* cls_logits, int ld_cls, const float* deltas, int ld_delta, int K,
+                            int cls_agnostic, const float* proposals, const int* d_prop_count, int B, int R,
+                            const int* d_image_sizes, float wx, float wy, float ww, float wh, float scale_clamp,
+                            float score_thresh, double nms_thresh, int topk, int max_candidates,
+                            const float* d_post, float* out_boxes, float* out_scores, int* out_classes,
+                            int* out_rows, int* d_out_count, int* d_status, void* workspace,
+                            long long workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Label-verification kNN (tools/run_nearest_neighbours.py:142-162, 214-227).
+ * lvc_colmean: mu[d] = mean_m x[m,d].  lvc_knn_topk_vote: per query row, class ids of the 10 most similar
+ * shots (ties -> lower shot index) and keep = (mode of the first kvote ids, ties -> smallest id, == detector class).
+ *   sims [Q,ld] fp32 (S columns used, S <= 4096), shot_classes [S] int64, det_classes [Q] int64 or NULL,
+ *   top_classes [Q,10] int64, keep [Q] int64 or NULL.
+ */
+int lvc_colmean(const float* x, float* mu, int M, int D, int ld, void* stream);
+int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* shot_classes,
+                      const long long* det_classes, int kvote, long long* top_classes, long long* keep,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVC_AMD_H */

@@ -382,3 +382,30 @@ def rownorm(x, mu=None, eps=1e-5, mode=0, out=None):
                                 c_float(eps), c_int(mode), _stream(x))
     check(rc, "lvc_rownorm")
     return out
+
+
+# --------------------------------------------------------------------------- label-verification kNN
+def colmean(x):
+    _req_cuda(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    mu = torch.empty(x.shape[1], device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_colmean(ptr(x), ptr(mu), c_int(x.shape[0]), c_int(x.shape[1]), c_int(x.stride(0)), _stream(x))
+    check(rc, "lvc_colmean")
+    return mu
+
+
+def knn_topk_vote(sims, num_shots, shot_classes, det_classes, k):
+    """sims [Q, >=S] fp32; shot_classes [S] int64; det_classes [Q] int64 or None.
+    Returns (top10 class ids [Q,10] int64, keep [Q] int64 or None)."""
+    _req_cuda(sims, shot_classes, det_classes)
+    Q = sims.shape[0]
+    assert sims.stride(1) == 1 and shot_classes.dtype == torch.int64 and shot_classes.is_contiguous()
+    top = torch.empty(Q, 10, dtype=torch.int64, device=sims.device)
+    keep = torch.empty(Q, dtype=torch.int64, device=sims.device) if det_classes is not None else None
+    if det_classes is not None:
+        det_classes = det_classes.contiguous()
+        assert det_classes.dtype == torch.int64
+    rc = _lib.lib().lvc_knn_topk_vote(ptr(sims), c_int(sims.stride(0)), c_int(Q), c_int(num_shots), ptr(shot_classes),
+                                      ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(sims))
+    check(rc, "lvc_knn_topk_vote")
+    return top, keep

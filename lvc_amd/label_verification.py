@@ -1,0 +1,87 @@
+"""Label verification: mean-centred cosine kNN over crop descriptors + majority vote
+(reference tools/run_nearest_neighbours.py: `assemble_tensors` :131-139, `run_nearest_neighbours`
+:142-162, `get_nn_class_confirmatory` :214-227), as one batched device sweep.
+
+`knn_sweep` is the MI355X path: all queries of all images in one [Q,D] tensor; the reference's
+per-image Python loop and its [q_i,S,D] broadcast disappear.  `run_nearest_neighbours` /
+`get_nn_class_confirmatory` keep the reference's list-of-dicts signatures on top of it.
+"""
+import torch
+
+from . import kernels as K
+
+QUERY_CHUNK = 32768  # rows of the similarity matrix materialised at once (x S x 4 bytes)
+
+
+def assemble_tensors(shot_features):
+    """reference :131-139: concatenate shot classes/descriptors, sorted by class."""
+    classes = torch.cat([x["instances"].gt_classes for x in shot_features])
+    sorter = classes.argsort()
+    desc = torch.cat([x["instances"].crop_feats for x in shot_features])
+    return classes[sorter], desc[sorter]
+
+
+def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classes=None, k=10, cosine=True):
+    """shot_descriptors [S,D], shot_classes [S] int64, query_descriptors [Q,D] (device, fp32, D % 32 == 0).
+    Returns (top10_shots [Q,10] int64 class ids, keep [Q] int64 or None)."""
+    shots = shot_descriptors.contiguous().float()
+    q = query_descriptors.contiguous().float()
+    S, D = shots.shape
+    Q = q.shape[0]
+    if D % 32 != 0:
+        raise RuntimeError("descriptor dimension must be a multiple of 32 (got {})".format(D))
+    shot_classes = shot_classes.to(torch.int64).contiguous()
+    if cosine:
+        mu = K.colmean(shots)
+        sn = K.rownorm(shots, mu=mu, eps=1e-8, mode=1)
+        pc = K.pack_linear(sn)
+    else:
+        # ranking by -cdist(q, s) == ranking by q.s - |s|^2/2 (|q| is constant per row)
+        pc = K.pack_linear(shots)
+        pc.shift = (-0.5 * (shots * shots).sum(1)).contiguous()
+    tops, keeps = [], []
+    for s0 in range(0, max(Q, 1), QUERY_CHUNK):
+        qc = q[s0: s0 + QUERY_CHUNK]
+        if qc.shape[0] == 0:
+            break
+        qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
+        sims = K.linear(qn, pc)
+        dc = detector_classes[s0: s0 + QUERY_CHUNK].to(torch.int64) if detector_classes is not None else None
+        t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
+        tops.append(t)
+        keeps.append(kp)
+    if not tops:
+        dev = q.device
+        return torch.empty(0, 10, dtype=torch.int64, device=dev), (
+            torch.empty(0, dtype=torch.int64, device=dev) if detector_classes is not None else None)
+    return torch.cat(tops), (torch.cat(keeps) if detector_classes is not None else None)
+
+
+def run_nearest_neighbours(shot_classes, shot_descriptors, query_features, cosine=True, device="cuda"):
+    """Reference signature (:142-162): sets `top10_shots` on every item's Instances."""
+    feats = [d["instances"].get("crop_feats") for d in query_features]
+    counts = [len(f) for f in feats]
+    if sum(counts):
+        allq = torch.cat(feats).to(device)
+        top, _ = knn_sweep(shot_classes.to(device), shot_descriptors.to(device), allq, None, 10, cosine)
+        top = top.to(feats[0].device)
+    else:
+        top = torch.empty(0, 10, dtype=torch.int64)
+    o = 0
+    for d, n in zip(query_features, counts):
+        d["instances"].set("top10_shots", top[o: o + n])
+        o += n
+    return query_features
+
+
+def get_nn_class_confirmatory(query_features, k):
+    """Reference signature (:214-227): keep[i] = 1 iff mode(top10_shots[i,:k]) == detector class
+    (`gt_classes` field); ties in the vote resolve to the smallest class id (torch.mode)."""
+    for d in query_features:
+        inst = d["instances"]
+        votes = inst.get("top10_shots")
+        keep = torch.zeros(len(inst), dtype=torch.int64)
+        if len(inst):
+            nn_class = torch.mode(votes[:, :k].cpu(), dim=1)[0]
+            keep = (nn_class == inst.gt_classes.cpu()).to(torch.int64)
+        inst.set("keep", keep)

@@ -1,0 +1,59 @@
+"""Label-verification kNN sweep vs golden vectors from the reference (tools/run_nearest_neighbours.py) and the
+oracle.  `keep` and the vote are integer outputs: exact.  top10 class ids: exact on the fixture (no near ties)."""
+import pytest
+import torch
+
+from helpers import gold
+
+pytestmark = pytest.mark.gpu
+D = "cuda:0"
+
+
+@pytest.mark.parametrize("tag,cosine", [("cos", True), ("l2", False)])
+def test_knn_golden(tag, cosine):
+    from lvc_amd.label_verification import knn_sweep
+
+    g = gold("knn")
+    top, keep = knn_sweep(g["shot_classes"].to(D), g["shots"].to(D), g["q_desc"].to(D), g["q_classes"].to(D), 10, cosine)
+    assert torch.equal(keep.cpu(), g["keep_" + tag])
+    assert torch.equal(top.cpu(), g["top10_" + tag])
+
+
+def test_knn_reference_signature_roundtrip():
+    from lvc_amd.label_verification import get_nn_class_confirmatory, run_nearest_neighbours
+    from lvc_amd.structures import Instances
+
+    g = gold("knn")
+    counts = g["counts"].tolist()
+    qs, o = [], 0
+    for n in counts:
+        inst = Instances((10, 10))
+        inst.crop_feats = g["q_desc"][o: o + n]
+        inst.gt_classes = g["q_classes"][o: o + n]
+        qs.append({"instances": inst})
+        o += n
+    run_nearest_neighbours(g["shot_classes"], g["shots"], qs, True)
+    get_nn_class_confirmatory(qs, 10)
+    assert torch.equal(torch.cat([q["instances"].keep for q in qs]), g["keep_cos"])
+    assert torch.equal(torch.cat([q["instances"].top10_shots.reshape(-1, 10) for q in qs]), g["top10_cos"])
+
+
+def test_knn_large_vs_oracle_dense():
+    """BASELINE config 4 shape at 1/8 scale: 15k x 2400 x 1024, 80 classes x 30 shots."""
+    from lvc_amd.label_verification import knn_sweep
+    from oracle import knn as oknn
+
+    g = torch.Generator().manual_seed(0)
+    S, Dm, Q = 2400, 1024, 15000
+    classes = torch.arange(80).repeat_interleave(30)
+    centers = torch.randn(80, Dm, generator=g)
+    shots = centers[classes] + 2.0 * torch.randn(S, Dm, generator=g) + 0.3
+    qcls = torch.randint(0, 80, (Q,), generator=g)
+    q = centers[qcls] + 2.5 * torch.randn(Q, Dm, generator=g) + 0.3
+    det = torch.where(torch.rand(Q, generator=g) < 0.7, qcls, torch.randint(0, 80, (Q,), generator=g))
+    top, keep = knn_sweep(classes.to(D), shots.to(D), q.to(D), det.to(D), 10, True)
+    ref_top = oknn.dense(classes, shots, q, True)
+    ref_keep = oknn.get_nn_class_confirmatory(ref_top, det, 10)
+    # fp32 similarity ties between two shots of different classes can swap neighbours: allow 0.1 % of rows
+    assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 1e-3
+    assert (keep.cpu() != ref_keep).float().mean() <= 1e-3

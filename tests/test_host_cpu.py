@@ -1,0 +1,287 @@
+"""CPU suite (-m "not gpu"): host logic, the drop-in surface, and the C-ABI library's symbols.  No kernel is
+launched here (no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from helpers import ROOT, gold
+
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------ C ABI
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "lvc_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lvc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lvc_amd import _lib
+
+    L = _lib.lib()
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), "liblvc_amd.so does not export " + s
+    assert L.lvc_abi_version() == 1
+
+
+def test_header_compiles_as_c():
+    src = os.path.join(ROOT, "include", "lvc_amd.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", src])
+
+
+def test_no_cpu_fallback_in_product_path():
+    from lvc_amd import kernels as K
+
+    with pytest.raises(RuntimeError):
+        K.batched_nms(torch.zeros(3, 4), torch.zeros(3), torch.zeros(3, dtype=torch.int64), 0.5)
+    with pytest.raises(RuntimeError):
+        K.roi_align_forward(torch.zeros(1, 1, 4, 4), torch.zeros(1, 5), 1.0, 7, 7, 0, True)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "lvc_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                t = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "liboracle" in t:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+# ------------------------------------------------------------------ config / registry / state_dict surface
+def test_cfgnode_semantics(tmp_path):
+    from lvc_amd.config import get_cfg
+
+    cfg = get_cfg()
+    base = tmp_path / "base.yaml"
+    base.write_text("MODEL:\n  RESNETS:\n    DEPTH: 101\n  RPN:\n    NMS_THRESH: 0.6\n")
+    child = tmp_path / "sub" / "child.yaml"
+    child.parent.mkdir()
+    child.write_text('_BASE_: "../base.yaml"\nMODEL:\n  RPN:\n    NMS_THRESH: 0.5\n  ROI_BOX_HEAD:\n    BBOX_REG_WEIGHTS: [1, 2, 3, 4]\n')
+    cfg.merge_from_file(str(child))
+    assert cfg.MODEL.RESNETS.DEPTH == 101 and cfg.MODEL.RPN.NMS_THRESH == 0.5
+    assert cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS == (1, 2, 3, 4)  # list coerced to the default's tuple type
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NUM_CLASSES", "20", "SOLVER.BASE_LR", 0.001])
+    assert cfg.MODEL.ROI_HEADS.NUM_CLASSES == 20
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("MODEL:\n  NOT_A_KEY: 1\n")
+    with pytest.raises(KeyError):
+        cfg.merge_from_file(str(bad))
+    with pytest.raises(ValueError):
+        cfg.merge_from_list(["MODEL.ROI_HEADS.NUM_CLASSES", "'many'"])
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.MODEL.DEVICE = "cpu"
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.MODEL.DEVICE = "cpu"
+    assert cfg.MODEL.DEVICE != "cpu"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_yaml_files_load_unchanged():
+    import glob
+
+    from lvc_amd.config import get_cfg
+    from lvc_amd.config.presets import base_rcnn_fpn
+
+    files = sorted(glob.glob(os.path.join(REF, "configs", "COCO-detection", "*.yaml")))
+    assert len(files) == 5
+    for f in files:
+        cfg = get_cfg()
+        cfg.merge_from_file(f)
+        assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNN"
+    # the preset used where the yaml tree is absent equals the yaml
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(REF, "configs", "COCO-detection", "faster_rcnn_R_50_FPN_base.yaml"))
+    p = base_rcnn_fpn(num_classes=60, device=cfg.MODEL.DEVICE)
+    for sec in ("BACKBONE", "RESNETS", "FPN", "ANCHOR_GENERATOR", "RPN", "ROI_HEADS", "ROI_BOX_HEAD"):
+        assert cfg.MODEL[sec] == p.MODEL[sec], sec
+    # the label-verification yaml ships with a syntax slip (DT_PATH: "('...json'"): a str where a tuple is
+    # expected; yacs raises ValueError for it and so do we (same error behaviour)
+    with pytest.raises(ValueError):
+        get_cfg().merge_from_file(os.path.join(REF, "configs", "LABEL-Verification", "dino_label_verification.yaml"))
+
+
+def _cpu_model(**over):
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+
+    cfg = base_rcnn_fpn(device="cpu")
+    for k, v in over.items():
+        node = cfg
+        parts = k.split(".")
+        for p in parts[:-1]:
+            node = node[p]
+        node[parts[-1]] = v
+    return cfg, build_model(cfg)
+
+
+def test_state_dict_keys_match_reference():
+    _, m = _cpu_model()
+    g = gold("r50_fpn_state_dict_keys")
+    mine = {k: str(tuple(v.shape)) for k, v in m.state_dict().items()}
+    assert list(mine) == g["keys"].tolist()
+    assert list(mine.values()) == g["shapes"].tolist()
+
+
+def test_freeze_switches_of_novel_finetune_config():
+    """cfg 3 (faster_rcnn_R_50_FPN_ft_novel_30shot.yaml:7-13): only box_predictor trains -> 4 tensors, 103 525 floats."""
+    _, m = _cpu_model(**{"MODEL.BACKBONE.FREEZE": True, "MODEL.PROPOSAL_GENERATOR.FREEZE": True,
+                         "MODEL.ROI_HEADS.FREEZE_FEAT": True, "MODEL.ROI_HEADS.NUM_CLASSES": 20})
+    train = [(n, p.numel()) for n, p in m.named_parameters() if p.requires_grad]
+    assert [n for n, _ in train] == ["roi_heads.box_predictor.cls_score.weight", "roi_heads.box_predictor.cls_score.bias",
+                                     "roi_heads.box_predictor.bbox_pred.weight", "roi_heads.box_predictor.bbox_pred.bias"]
+    assert sum(c for _, c in train) == 103525
+
+
+def test_registries_and_unknown_names():
+    from lvc_amd.modeling import (BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY,
+                                  ROI_BOX_HEAD_REGISTRY, ROI_HEADS_OUTPUT_REGISTRY, ROI_HEADS_REGISTRY)
+
+    for reg, names in ((META_ARCH_REGISTRY, ["GeneralizedRCNN", "ProposalNetwork"]),
+                       (BACKBONE_REGISTRY, ["build_resnet_backbone", "build_resnet_fpn_backbone"]),
+                       (PROPOSAL_GENERATOR_REGISTRY, ["RPN"]), (ROI_HEADS_REGISTRY, ["StandardROIHeads"]),
+                       (ROI_BOX_HEAD_REGISTRY, ["FastRCNNConvFCHead"]),
+                       (ROI_HEADS_OUTPUT_REGISTRY, ["FastRCNNOutputLayers", "CosineSimOutputLayers"])):
+        for n in names:
+            assert reg.get(n) is not None
+    with pytest.raises(KeyError):
+        META_ARCH_REGISTRY.get("NoSuchArch")
+    with pytest.raises(AssertionError):
+        META_ARCH_REGISTRY.register(META_ARCH_REGISTRY.get("GeneralizedRCNN"))
+
+
+def test_model_on_cpu_fails_loudly():
+    from lvc_amd.utils import synthetic as syn
+
+    _, m = _cpu_model()
+    m.eval()
+    with pytest.raises(RuntimeError):
+        m([{"image": syn.synthetic_image(1, 64, 64)}])
+
+
+# ------------------------------------------------------------------ value types
+def test_instances_and_boxes_contract():
+    from lvc_amd.structures import Boxes, ImageList, Instances, pairwise_iou
+
+    b = Boxes(torch.tensor([[0.0, 0, 10, 10], [5, 5, 5, 9], [-3, -3, 50, 50]]))
+    assert b.nonempty().tolist() == [True, False, True]
+    b.clip((20, 30))
+    assert b.tensor[2].tolist() == [0, 0, 30, 20]
+    inst = Instances((20, 30), pred_boxes=b, scores=torch.tensor([0.9, 0.8, 0.7]))
+    with pytest.raises(AssertionError):
+        inst.pred_classes = torch.zeros(2)
+    sub = inst[torch.tensor([True, False, True])]
+    assert len(sub) == 2 and sub.scores.tolist() == pytest.approx([0.9, 0.7])
+    with pytest.raises(NotImplementedError):
+        len(Instances((1, 1)))
+    both = Instances.cat([inst, sub])
+    assert len(both) == 5 and isinstance(both.pred_boxes, Boxes)
+    with pytest.raises(AssertionError):
+        Instances.cat([inst, Instances((1, 1), scores=torch.zeros(1))])
+    iou = pairwise_iou(Boxes(torch.tensor([[0.0, 0, 10, 10]])), Boxes(torch.tensor([[5.0, 5, 15, 15], [20, 20, 30, 30]])))
+    assert iou[0].tolist() == pytest.approx([25 / 175, 0.0])
+    il = ImageList.from_tensors([torch.ones(3, 5, 7), torch.ones(3, 6, 4)], 8)
+    assert il.tensor.shape == (2, 3, 8, 8) and il.image_sizes == [(5, 7), (6, 4)]
+    assert float(il.tensor[0, :, 5:].sum()) == 0 and il[1].shape == (3, 6, 4)
+
+
+def test_anchor_generator_buffers_match_golden():
+    from lvc_amd.modeling.anchor_generator import DefaultAnchorGenerator
+
+    g = gold("anchors")
+    ag = DefaultAnchorGenerator(sizes=[[32], [64], [128], [256], [512]], aspect_ratios=[[0.5, 1.0, 2.0]],
+                                strides=[4, 8, 16, 32, 64], offset=0.0)
+    assert torch.equal(torch.stack(list(ag.cell_anchors)), g["cell_anchors"])
+    anchors = ag([torch.zeros(1, 1, h, w) for h, w in [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]])
+    for i, a in enumerate(anchors):
+        assert torch.equal(a.tensor[:8], g["lvl%d_first" % i]) and torch.equal(a.tensor[-8:], g["lvl%d_last" % i])
+
+
+def test_box2box_transform_matches_golden():
+    from lvc_amd.modeling.box_regression import Box2BoxTransform
+
+    g = gold("box_ops")
+    assert torch.equal(Box2BoxTransform((10.0, 10.0, 5.0, 5.0)).apply_deltas(g["deltas80"], g["boxes"]), g["out80"])
+    t = Box2BoxTransform((10.0, 10.0, 5.0, 5.0))
+    tgt = g["boxes"] + 3.0
+    rec = t.apply_deltas(t.get_deltas(g["boxes"], tgt), g["boxes"])
+    assert (rec - tgt).abs().max() < 1e-2
+
+
+def test_pack_layouts_cpu_shapes():
+    """Weight packing is host logic: check layout math without launching anything (device-free path via meta)."""
+    from lvc_amd.kernels import BK, BN
+
+    assert BK == 32 and BN == 128
+
+
+# ------------------------------------------------------------------ distributed (gloo, world_size 2)
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from lvc_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # inference sharding: contiguous blocks, no overlap, full cover
+        r = D.shard_range(11)
+        # kNN: shots of each rank -> every rank holds all, in rank order
+        mine = torch.full((2 + rank, 4), float(rank))
+        allshots = D.all_gather_rows(mine)
+        # DDP step semantics: averaged gradient == gradient of the concatenated batch
+        torch.manual_seed(0)
+        w = torch.nn.Parameter(torch.randn(3, 5))
+        x = torch.randn(8, 5)
+        y = torch.randn(8, 3)
+        xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+        loss = ((xs @ w.t() - ys) ** 2).mean()
+        loss.backward()
+        nbytes = D.allreduce_gradients_([w])
+        w_full = torch.nn.Parameter(w.detach().clone())
+        ((x @ w_full.t() - y) ** 2).mean().backward()
+        ok = torch.allclose(w.grad, w_full.grad, atol=1e-6)
+        gathered = D.gather_rows(torch.full((1 + rank, 2), float(rank)))
+        q.put((rank, list(r), allshots[:, 0].tolist(), ok, nbytes, None if gathered is None else gathered[:, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_helpers_world_size_2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, s0, a0, ok0, nb0, g0), (r1, s1, a1, ok1, nb1, g1) = res
+    assert s0 == [0, 1, 2, 3, 4, 5] and s1 == [6, 7, 8, 9, 10]
+    assert a0 == a1 == [0.0, 0.0, 1.0, 1.0, 1.0]
+    assert ok0 and ok1 and nb0 == nb1 == 60
+    assert g0 == [0.0, 1.0, 1.0] and g1 is None
+
+
+def test_shard_range_single_process():
+    from lvc_amd.distributed import shard_range
+
+    assert list(shard_range(5, 0, 1)) == [0, 1, 2, 3, 4]
+    assert [list(shard_range(5, r, 4)) for r in range(4)] == [[0, 1], [2, 3], [4], []]
+    assert list(shard_range(0, 0, 2)) == []
