@@ -48,11 +48,15 @@ void lvc_set_error(const char* fmt, ...);
  *   scale, shift [K] or NULL  y = acc*scale + shift
  *   residual                  res_mode 0 none | 1: [M,ldr] same rows as y | 2: [N,Ho/2,Wo/2,ldr], upsampled x2
  *   y        [N*Ho*Wo, ldy]   ldy/ldr = row strides in floats (<=0: K)
+ *   workspace                 lvc_conv_workspace_bytes() bytes, zero-initialised ONCE by the caller and then
+ *                             reused by every launch on the same stream (split-tile partials + flags of the
+ *                             stream-K decomposition); launches on different streams need different workspaces
  */
+long long lvc_conv_workspace_bytes(void);
 int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                         const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
                         int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, int mode,
-                        void* stream);
+                        void* workspace, void* stream);
 
 /* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
  * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero

@@ -12,13 +12,24 @@
 //   n = output channel
 //   k = (r, s, c) with c fastest      -- a BK=32 chunk of k is 128 contiguous bytes of one input pixel
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; 64 FLOP/clk/SIMD = 157 TF chip peak).
-// The 1e-3 box/score parity bar of the path needs true fp32; bf16 MFMA would not hold it.
+// The parity bar of the path needs true fp32; bf16 MFMA would not hold it.
 //
-// Tile: 128(M) x 128(N) x 32(K) per 256-thread workgroup; 4 waves as 2x2, each wave a 64x64 sub-tile
-// = 2x2 MFMA 32x32 accumulators (64 acc VGPRs).  LDS: A and B tiles, k-contiguous rows padded to 36
-// floats (144 B) so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots; double buffered
-// (73.7 KB -> 2 workgroups per CU).  Global->LDS staging goes through registers (prefetch chunk k+1
-// before the MFMA block of chunk k, ds_write after it), one barrier per chunk.
+// Work decomposition (stream-K): the launch is a set of PERSISTENT workers (<= 2 per CU, all co-resident).
+// The (tile, k-chunk) iteration space of the layer is cut into equal contiguous ranges, one per worker, so
+// every CU gets the same number of MFMA chunks whatever the layer's tile count is (the 50x84 and 25x42
+// pyramid levels have 1.03 or 2.05 tiles per CU: a tile-per-workgroup launch leaves the chip 1/3 idle there).
+// A tile whose k-range is split over several workers is finished by the worker holding its k=0 piece: the
+// others store their 64 KB partial accumulators (their FIRST work item) and raise a flag with an agent-scope
+// release; the finisher (for whom this tile is the LAST work item) polls relaxed, acquires once, adds the
+// partials in worker order (deterministic) and runs the epilogue.  Flags are reset by their consumer.
+//
+// Tile: 128(M) x BN(N) x 32(K) per 256-thread workgroup, BN = 128 or 64; 4 waves as 2x2, each wave a
+// 64 x BN/2 sub-tile = 2 x NI MFMA 32x32 accumulators.  LDS: A and B tiles, k-contiguous rows padded to 36
+// floats (144 B) so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots; double buffered.
+// Global->LDS staging goes through registers (prefetch chunk k+1 before the MFMA block of chunk k, ds_write
+// after it), one barrier per chunk.
+// Epilogue: accumulators -> LDS (row-major C tile) -> each lane handles float4 column groups: 512-B
+// coalesced stores, residual / scale / shift read as float4 and all issued before use.
 //
 // Lane/fragment map for 32x32x2 (A: lane l holds A[i=l&31][k=l>>5]; B: B[k=l>>5][j=l&31]):
 // lane (i,h) ds_read_b128's 4 consecutive k (= 8*kk + 4*h + t, t=0..3) from row i; MFMA step t then
@@ -29,17 +40,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define BM 128
-#define BN 128
 #define BK 32
-#define LDS_STRIDE 36  // floats per tile row (BK + 4 pad)
+#define LDS_STRIDE 36   // floats per staged tile row (BK + 4 pad)
+#define SPIN_LIMIT (1 << 24)
 
 struct ConvArgs {
   const float* x;      // input  [N,H,W,C]   (C = physical channel count, multiple of 4)
-  const float* w;      // packed weights [Kpad][Kg]  (Kpad multiple of BN, Kg multiple of BK)
+  const float* w;      // packed weights [Kpad][Kg]  (Kpad multiple of 128, Kg multiple of BK)
   const float* scale;  // per out-channel multiplier or nullptr (=1)
   const float* shift;  // per out-channel addend or nullptr (=0)
   const float* res;    // residual tensor or nullptr
   float* y;            // output [M][ldy]
+  float* partials;     // [workers][256 threads][64 floats]
+  int* flags;          // [workers] (+ [workers] = error word)
   int N, H, W, C;
   int K;               // real out channels
   int R, S, stride, pad;
@@ -48,170 +61,291 @@ struct ConvArgs {
   int relu;
   int res_mode;        // 0 none | 1 same shape [M][ldr] | 2 nearest-x2-upsampled: res is [N,Ho/2,Wo/2,ldr]
   int ldy, ldr;
-  int tiles_n;
-  int mode;            // 0: chunk -> (r,s,c0) ; 1: "row mode" (stem): chunk -> r, 32 floats = 8 pixels x 4 ch
+  int tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
 };
 
-template <int MODE>
+template <int MODE, int NI>
 __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_STRIDE];
+  constexpr int BN_ = 64 * NI;
+  constexpr int STAGE_FLOATS = 2 * (BM + BN_) * LDS_STRIDE;
+  constexpr int CS_STRIDE = BN_ + 4;  // floats per C-staging row
+  constexpr int CS_FLOATS = BM * CS_STRIDE;
+  constexpr int SMEM_FLOATS = STAGE_FLOATS > CS_FLOATS ? STAGE_FLOATS : CS_FLOATS;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   float* As = smem;                          // [2][BM][LDS_STRIDE]
-  float* Bs = smem + 2 * BM * LDS_STRIDE;    // [2][BN][LDS_STRIDE]
+  float* Bs = smem + 2 * BM * LDS_STRIDE;    // [2][BN_][LDS_STRIDE]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;        // float4 slot inside a 32-float chunk
+  const int row0 = tid >> 3;    // staged rows row0 + 32*j
 
-  const int nwg = gridDim.x;
-  const int wg = lvc_xcd_remap(blockIdx.x, nwg);
-  const int tile_n = wg % p.tiles_n;
-  const int tile_m = wg / p.tiles_n;
-  const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
-
-  // ---- staging assignment: thread loads float4 q of rows (tid>>3)+32*j, j=0..3 (A and B alike)
-  const int q = tid & 7;
-  const int row0 = tid >> 3;
-
-  int a_base[4];   // element offset of pixel (n, base_h, base_w) relative to x, or <0 when row >= M
-  int a_bh[4], a_bw[4];
-  bool a_ok[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + row0 + 32 * j;
-    a_ok[j] = m < p.M;
-    int mm = a_ok[j] ? m : 0;
-    int n = mm / (p.Ho * p.Wo);
-    int rem = mm - n * (p.Ho * p.Wo);
-    int ho = rem / p.Wo;
-    int wo = rem - ho * p.Wo;
-    a_bh[j] = ho * p.stride - p.pad;
-    a_bw[j] = wo * p.stride - p.pad;
-    a_base[j] = n * p.H * p.W;  // pixel index base of image n
-  }
-  const float* wrow[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) wrow[j] = p.w + (size_t)(n0 + row0 + 32 * j) * p.Kg + q * 4;
-
-  const int nk = p.Kg / BK;
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);  // logical worker id
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
   const int cpc = (MODE == 0) ? (p.C / BK) : 1;  // chunks per (r,s)
 
-  f32x4 areg[4], breg[4];
-
-  auto load_chunk = [&](int kc) {
-    int r, s, c0;
-    if (MODE == 0) {
-      int rs = kc / cpc;
-      c0 = (kc - rs * cpc) * BK;
-      r = rs / p.S;
-      s = rs - r * p.S;
-    } else {
-      r = kc; s = 0; c0 = 0;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int hi = a_bh[j] + r;
-      int wi = a_bw[j] + s + (MODE == 1 ? q : 0);
-      bool ok = a_ok[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        size_t off = (size_t)(a_base[j] + hi * p.W + wi) * p.C + c0 + (MODE == 0 ? q * 4 : 0);
-        v = *reinterpret_cast<const f32x4*>(p.x + off);
-      }
-      areg[j] = v;
-      breg[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kc * BK);
-    }
-  };
-  auto store_chunk = [&](int buf) {
-    float* a = As + buf * BM * LDS_STRIDE;
-    float* b = Bs + buf * BN * LDS_STRIDE;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      *reinterpret_cast<f32x4*>(a + (row0 + 32 * j) * LDS_STRIDE + q * 4) = areg[j];
-      *reinterpret_cast<f32x4*>(b + (row0 + 32 * j) * LDS_STRIDE + q * 4) = breg[j];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  const int fi = lane & 31, fh = lane >> 5;
   const int a_frag_off = (wm * 64 + fi) * LDS_STRIDE + fh * 4;
-  const int b_frag_off = (wn * 64 + fi) * LDS_STRIDE + fh * 4;
+  const int b_frag_off = (wn * (BN_ / 2) + fi) * LDS_STRIDE + fh * 4;
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int kc0 = u - tile * p.nk;
+    const int kc1 = min(p.nk, kc0 + (u_end - u));
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN_;
 
-  int cur = 0;
-  for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) load_chunk(kc + 1);
-    const float* a = As + cur * BM * LDS_STRIDE + a_frag_off;
-    const float* b = Bs + cur * BN * LDS_STRIDE + b_frag_off;
+    int a_base[4], a_bh[4], a_bw[4];
+    bool a_ok[4];
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      f32x4 af0 = *reinterpret_cast<const f32x4*>(a + kk * 8);
-      f32x4 af1 = *reinterpret_cast<const f32x4*>(a + 32 * LDS_STRIDE + kk * 8);
-      f32x4 bf0 = *reinterpret_cast<const f32x4*>(b + kk * 8);
-      f32x4 bf1 = *reinterpret_cast<const f32x4*>(b + 32 * LDS_STRIDE + kk * 8);
+    for (int j = 0; j < 4; ++j) {
+      int m = m0 + row0 + 32 * j;
+      a_ok[j] = m < p.M;
+      int mm = a_ok[j] ? m : 0;
+      int n = mm / (p.Ho * p.Wo);
+      int rem = mm - n * (p.Ho * p.Wo);
+      int ho = rem / p.Wo;
+      int wo = rem - ho * p.Wo;
+      a_bh[j] = ho * p.stride - p.pad;
+      a_bw[j] = wo * p.stride - p.pad;
+      a_base[j] = n * p.H * p.W;
+    }
+    const float* wrow[NI * 2];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[t], bf0[t], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[t], bf1[t], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[t], bf0[t], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[t], bf1[t], acc[1][1], 0, 0, 0);
+    for (int j = 0; j < NI * 2; ++j) wrow[j] = p.w + (size_t)(n0 + row0 + 32 * j) * p.Kg + q * 4;
+
+    f32x4 areg[4], breg[NI * 2];
+    auto load_chunk = [&](int kc) {
+      int r, s, c0;
+      if (MODE == 0) {
+        int rs = kc / cpc;
+        c0 = (kc - rs * cpc) * BK;
+        r = rs / p.S;
+        s = rs - r * p.S;
+      } else {
+        r = kc; s = 0; c0 = 0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int hi = a_bh[j] + r;
+        int wi = a_bw[j] + s + (MODE == 1 ? q : 0);
+        bool ok = a_ok[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          size_t off = (size_t)(a_base[j] + hi * p.W + wi) * p.C + c0 + (MODE == 0 ? q * 4 : 0);
+          v = *reinterpret_cast<const f32x4*>(p.x + off);
+        }
+        areg[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < NI * 2; ++j) breg[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kc * BK);
+    };
+    auto store_chunk = [&](int buf) {
+      float* a = As + buf * BM * LDS_STRIDE;
+      float* b = Bs + buf * BN_ * LDS_STRIDE;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(a + (row0 + 32 * j) * LDS_STRIDE + q * 4) = areg[j];
+#pragma unroll
+      for (int j = 0; j < NI * 2; ++j) *reinterpret_cast<f32x4*>(b + (row0 + 32 * j) * LDS_STRIDE + q * 4) = breg[j];
+    };
+
+    f32x16 acc[2][NI];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    load_chunk(kc0);
+    store_chunk(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kc = kc0; kc < kc1; ++kc) {
+      if (kc + 1 < kc1) load_chunk(kc + 1);
+      const float* a = As + cur * BM * LDS_STRIDE + a_frag_off;
+      const float* b = Bs + cur * BN_ * LDS_STRIDE + b_frag_off;
+#pragma unroll
+      for (int kk = 0; kk < BK / 8; ++kk) {
+        f32x4 af[2], bf[NI];
+        af[0] = *reinterpret_cast<const f32x4*>(a + kk * 8);
+        af[1] = *reinterpret_cast<const f32x4*>(a + 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
+      }
+      if (kc + 1 < kc1) store_chunk(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
+    u += kc1 - kc0;
+
+    // ------------------------------------------------------------ split tiles: publish or combine partials
+    if (kc0 != 0) {
+      // not the k=0 piece: hand the accumulators to the finisher.  Layout [e4][tid] float4 -> coalesced.
+      float* dst = p.partials + (size_t)lw * (256 * 32 * NI);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * 256 + tid) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;  // the finisher owns the epilogue
+    }
+    if (kc1 < p.nk) {
+      // k=0 piece of a tile that continues in the following workers: wait for them, add in worker order
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int last_worker = last_unit / p.units_per_worker;
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (256 * 32 * NI);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * NI + ni) * 4 + e4) * 256 + tid) * 4);
+              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
+              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
+            }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    if (kc + 1 < nk) store_chunk(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
 
-  // ---- epilogue: y = act(acc*scale + shift + residual)
-  // C/D map of 32x32x2: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // ------------------------------------------------------------ epilogue: y = act(acc*scale + shift + residual)
+    // C/D map of 32x32x2: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    float* Cs = smem;  // staging tiles are dead (barrier at the end of the k loop)
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    int col = n0 + wn * 64 + ni * 32 + fi;
-    bool col_ok = col < p.K;
-    float sc = (p.scale && col_ok) ? p.scale[col] : 1.f;
-    float sh = (p.shift && col_ok) ? p.shift[col] : 0.f;
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int row = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (row < p.M && col_ok) {
-          float v = acc[mi][ni][e] * sc + sh;
-          if (p.res_mode == 1) {
-            v += p.res[(size_t)row * p.ldr + col];
-          } else if (p.res_mode == 2) {
-            int n = row / (p.Ho * p.Wo);
-            int rem = row - n * (p.Ho * p.Wo);
-            int ho = rem / p.Wo;
-            int wo = rem - ho * p.Wo;
-            size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
-            v += p.res[ro * p.ldr + col];
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int col = wn * (BN_ / 2) + ni * 32 + fi;
+          Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    constexpr int C4 = BN_ / 4;          // float4 groups per tile row
+    constexpr int RPI = 256 / C4;        // rows handled per iteration
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    const bool vec_ok = ((p.K & 3) == 0) && ((p.ldy & 3) == 0) && (p.res_mode == 0 || (p.ldr & 3) == 0);
+    if (vec_ok) {
+      if (col < p.K) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+        for (int it = 0; it < BM / RPI; ++it) {
+          const int r = it * RPI + rsub;
+          const int row = m0 + r;
+          if (row < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+            v = v * sc + sh;
+            if (p.res_mode == 1) {
+              v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+            } else if (p.res_mode == 2) {
+              int n = row / (p.Ho * p.Wo);
+              int rem = row - n * (p.Ho * p.Wo);
+              int ho = rem / p.Wo;
+              int wo = rem - ho * p.Wo;
+              size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+              v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+            }
+            if (p.relu) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
           }
+        }
+      }
+    } else {
+      for (int it = 0; it < BM / RPI; ++it) {
+        const int r = it * RPI + rsub;
+        const int row = m0 + r;
+        if (row >= p.M) continue;
+        size_t ro = 0;
+        if (p.res_mode == 2) {
+          int n = row / (p.Ho * p.Wo);
+          int rem = row - n * (p.Ho * p.Wo);
+          int ho = rem / p.Wo;
+          int wo = rem - ho * p.Wo;
+          ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+        }
+        for (int cc = 0; cc < 4; ++cc) {
+          const int c = col + cc;
+          if (c >= p.K) break;
+          float v = Cs[r * CS_STRIDE + c4 * 4 + cc] * (p.scale ? p.scale[c] : 1.f) + (p.shift ? p.shift[c] : 0.f);
+          if (p.res_mode == 1) v += p.res[(size_t)row * p.ldr + c];
+          else if (p.res_mode == 2) v += p.res[ro * p.ldr + c];
           if (p.relu) v = v > 0.f ? v : 0.f;
-          p.y[(size_t)row * p.ldy + col] = v;
+          p.y[(size_t)row * p.ldy + c] = v;
         }
       }
     }
+    __syncthreads();  // Cs is overwritten by the next work item's staging stores
   }
+}
+
+static int g_capacity = 0;  // co-resident workers (2 per CU)
+static int worker_capacity() {
+  if (g_capacity == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    g_capacity = 2 * cus;
+  }
+  return g_capacity;
+}
+#define LVC_MAX_WORKERS 1024
+
+// Persistent per-device scratch for split tiles: partial accumulators + flags (+1 error word).  Must be
+// zero-initialised once by the caller and must not be shared by launches that run concurrently on
+// different streams.
+extern "C" long long lvc_conv_workspace_bytes(void) {
+  return (long long)LVC_MAX_WORKERS * 256 * 64 * 4 + (LVC_MAX_WORKERS + 1) * 4 + 256;
 }
 
 // C ABI -- see include/lvc_amd.h for the contract of each argument.
 extern "C" int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const float* scale,
                                    const float* shift, const float* residual, float* y, int N, int H,
                                    int W, int C, int K, int R, int S, int stride, int pad, int Kg,
-                                   int relu, int res_mode, int ldy, int ldr, int mode, void* stream) {
-  LVC_CHECK_ARG(x && w_packed && y, "null pointer");
+                                   int relu, int res_mode, int ldy, int ldr, int mode, void* workspace,
+                                   void* stream) {
+  LVC_CHECK_ARG(x && w_packed && y && workspace, "null pointer");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
   LVC_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 or 1");
   LVC_CHECK_ARG(Kg % BK == 0, "Kg must be a multiple of 32");
@@ -223,6 +357,8 @@ extern "C" int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const 
   }
   LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2, "res_mode must be 0..2");
   LVC_CHECK_ARG(res_mode == 0 || residual, "residual pointer missing");
+  LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_packed & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+                "x / w_packed / workspace must be 16-byte aligned");
   int Ho = (H + 2 * pad - R) / stride + 1;
   int Wo = (W + 2 * pad - S) / stride + 1;
   LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
@@ -234,15 +370,35 @@ extern "C" int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const 
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
   a.Ho = Ho; a.Wo = Wo; a.M = (int)Mll; a.Kg = Kg; a.relu = relu; a.res_mode = res_mode;
   a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
-  a.tiles_n = lvc_cdiv(K, BN);
-  a.mode = mode;
-  int tiles_m = lvc_cdiv(a.M, BM);
-  dim3 grid(tiles_m * a.tiles_n), block(256);
+  if ((a.K & 3) == 0 && (a.ldy & 3) == 0) LVC_CHECK_ARG(((uintptr_t)y & 15) == 0, "y must be 16-byte aligned");
+  const int ni = (K <= 64) ? 1 : 2;  // BN = 64 tile for the 64-channel layers, else 128
+  const int bn = 64 * ni;
+  a.tiles_n = lvc_cdiv(K, bn);
+  const int tiles_m = lvc_cdiv(a.M, BM);
+  a.nk = Kg / BK;
+  long long units = (long long)tiles_m * a.tiles_n * a.nk;
+  LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
+  a.total_units = (int)units;
+  int cap = worker_capacity();
+  if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
+  const int min_units = 4;  // do not cut below 4 chunks per worker: the split-tile hand-off costs microseconds
+  int workers = (int)((units + min_units - 1) / min_units);
+  if (workers > cap) workers = cap;
+  if (workers < 1) workers = 1;
+  a.units_per_worker = (int)((units + workers - 1) / workers);
+  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker);
+  a.partials = (float*)workspace;
+  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 64 * 4);
+  a.err_index = LVC_MAX_WORKERS;
+  dim3 grid(a.nworkers), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 0)
-    hipLaunchKernelGGL(conv_igemm_f32_kernel<0>, grid, block, 0, st, a);
-  else
-    hipLaunchKernelGGL(conv_igemm_f32_kernel<1>, grid, block, 0, st, a);
+  if (mode == 0) {
+    if (ni == 1) hipLaunchKernelGGL((conv_igemm_f32_kernel<0, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<0, 2>), grid, block, 0, st, a);
+  } else {
+    if (ni == 1) hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 1>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_f32_kernel<1, 2>), grid, block, 0, st, a);
+  }
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

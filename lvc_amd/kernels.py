@@ -87,6 +87,27 @@ def pack_linear(weight, bias=None):
     return pack_conv(weight[:, :, None, None], bias=bias)
 
 
+_CONV_WS = {}
+
+
+def conv_workspace(device):
+    """Per-(device, stream) scratch of the stream-K conv kernel (zeroed once; see include/lvc_amd.h)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        lib = _lib.lib()
+        lib.lvc_conv_workspace_bytes.restype = c_longlong
+        ws = torch.zeros(lib.lvc_conv_workspace_bytes(), dtype=torch.uint8, device=device)
+        _CONV_WS[key] = ws
+    return ws
+
+
+def conv_error_word(device):
+    """The kernel's spin-timeout word (0 = fine); reading it synchronises."""
+    ws = conv_workspace(device)
+    return int(ws[1024 * 256 * 64 * 4 + 1024 * 4: 1024 * 256 * 64 * 4 + 1024 * 4 + 4].view(torch.int32).item())
+
+
 class LaunchTimer:
     """Optional per-launch HIP-event bracket for the conv/GEMM kernel (bench.py's roofline leg).
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
@@ -129,7 +150,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
         c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
         c_int(out.shape[-1]), c_int(residual.shape[-1] if residual is not None else 0),
-        c_int(pc.mode), _stream(x))
+        c_int(pc.mode), ptr(conv_workspace(x.device)), _stream(x))
     check(st, "lvc_conv2d_nhwc_f32")
     if timer is not None:
         e1.record()

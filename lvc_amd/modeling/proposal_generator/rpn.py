@@ -51,9 +51,16 @@ class StandardRPNHead(nn.Module):
 
     def fused_predictor(self):
         o, d = self.objectness_logits, self.anchor_deltas
-        return self._fused.get(
-            [o.weight, o.bias, d.weight, d.bias],
-            lambda: K.pack_conv(torch.cat([o.weight, d.weight], 0), bias=torch.cat([o.bias, d.bias], 0)))
+        def build():
+            w = torch.cat([o.weight, d.weight], 0)
+            b = torch.cat([o.bias, d.bias], 0)
+            padk = (-w.shape[0]) % 4  # zero output channels so rows are float4-aligned (vector epilogue)
+            if padk:
+                w = torch.cat([w, w.new_zeros((padk,) + tuple(w.shape[1:]))], 0)
+                b = torch.cat([b, b.new_zeros(padk)], 0)
+            return K.pack_conv(w, bias=b)
+
+        return self._fused.get([o.weight, o.bias, d.weight, d.bias], build)
 
     def forward_nhwc(self, feats):
         """feats: list of [B,H,W,C] -> list of fused [B,H,W,A+A*box_dim] tensors."""
@@ -63,8 +70,8 @@ class StandardRPNHead(nn.Module):
     def forward(self, features):
         """Reference signature: list of NCHW maps -> (list of [N,A,H,W], list of [N,A*box_dim,H,W])."""
         fused = self.forward_nhwc([to_nhwc(f) for f in features])
-        A = self.num_anchors
-        return [to_nchw_view(t[..., :A]) for t in fused], [to_nchw_view(t[..., A:]) for t in fused]
+        A, Bd = self.num_anchors, self.box_dim
+        return [to_nchw_view(t[..., :A]) for t in fused], [to_nchw_view(t[..., A:A + A * Bd]) for t in fused]
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
@@ -97,7 +104,7 @@ class RPN(nn.Module):
         fused = self.rpn_head.forward_nhwc(feats)
         A = self.rpn_head.num_anchors
         t = int(self.training)
-        return K.rpn_proposals([f[..., :A] for f in fused], [f[..., A:] for f in fused],
+        return K.rpn_proposals([f[..., :A] for f in fused], [f[..., A:5 * A] for f in fused],
                                list(self.anchor_generator.cell_anchors), self.anchor_generator.strides, image_sizes_dev,
                                self.pre_nms_topk[t], self.post_nms_topk[t], self.nms_thresh, self.min_box_size)
 

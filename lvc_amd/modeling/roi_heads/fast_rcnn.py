@@ -54,11 +54,18 @@ class FastRCNNOutputLayers(_OutputLayersBase):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
         c, b = self.cls_score, self.bbox_pred
-        pc = self._fused.get([c.weight, c.bias, b.weight, b.bias],
-                             lambda: K.pack_linear(torch.cat([c.weight, b.weight], 0), torch.cat([c.bias, b.bias], 0)))
-        y = K.linear(x.contiguous(), pc)
+        def build():
+            w = torch.cat([c.weight, b.weight], 0)
+            bias = torch.cat([c.bias, b.bias], 0)
+            padk = (-w.shape[0]) % 4  # float4-aligned rows for the vector epilogue
+            if padk:
+                w = torch.cat([w, w.new_zeros(padk, w.shape[1])], 0)
+                bias = torch.cat([bias, bias.new_zeros(padk)], 0)
+            return K.pack_linear(w, bias)
+
+        y = K.linear(x.contiguous(), self._fused.get([c.weight, c.bias, b.weight, b.bias], build))
         k1 = self.num_classes + 1
-        return y[:, :k1], y[:, k1:]
+        return y[:, :k1], y[:, k1:k1 + self.num_bbox_reg_classes * 4]
 
 
 @ROI_HEADS_OUTPUT_REGISTRY.register()
@@ -84,8 +91,6 @@ class CosineSimOutputLayers(_OutputLayersBase):
         # the reference renormalises cls_score.weight.data IN PLACE on every call (fast_rcnn.py:830-837)
         w = self.cls_score.weight
         K.rownorm(w.data, eps=1e-5, mode=0, out=w.data)
-        w.data_ptr()  # noqa: B018
-        w._version  # noqa: B018
         scale = float(self.scale) if not isinstance(self.scale, nn.Parameter) else float(self.scale.item())
 
         def build():
