@@ -26,8 +26,9 @@
 // Tile: 128(M) x BN(N) x 32(K) per 256-thread workgroup, BN = 128 or 64; 4 waves as 2x2, each wave a
 // 64 x BN/2 sub-tile = 2 x NI MFMA 32x32 accumulators.  LDS: A and B tiles, k-contiguous rows padded to 36
 // floats (144 B) so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots; double buffered.
-// Global->LDS staging goes through registers (prefetch chunk k+1 before the MFMA block of chunk k, ds_write
-// after it), one barrier per chunk.
+// Global->LDS staging goes through registers with a two-deep software pipeline (chunk k+1 is written to the
+// idle LDS buffer and chunk k+2 is requested while chunk k's 64 MFMAs issue); loads are branch-free
+// buffer_load_dwordx4 whose out-of-range lanes (padding taps, rows past M) return 0; one barrier per chunk.
 // Epilogue: accumulators -> LDS (row-major C tile) -> each lane handles float4 column groups: 512-B
 // coalesced stores, residual / scale / shift read as float4 and all issued before use.
 //
@@ -35,6 +36,7 @@
 // lane (i,h) ds_read_b128's 4 consecutive k (= 8*kk + 4*h + t, t=0..3) from row i; MFMA step t then
 // contracts k in {8kk+t, 8kk+4+t}; A and B use the same permutation so every k is used exactly once.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -62,6 +64,7 @@ struct ConvArgs {
   int res_mode;        // 0 none | 1 same shape [M][ldr] | 2 nearest-x2-upsampled: res is [N,Ho/2,Wo/2,ldr]
   int ldy, ldr;
   int tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
+  int x_bytes, w_bytes;
 };
 
 template <int MODE, int NI>
@@ -91,6 +94,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
   const int a_frag_off = (wm * 64 + fi) * LDS_STRIDE + fh * 4;
   const int b_frag_off = (wn * (BN_ / 2) + fi) * LDS_STRIDE + fh * 4;
 
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
   while (u < u_end) {
     const int tile = u / p.nk;
     const int kc0 = u - tile * p.nk;
@@ -100,50 +106,58 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN_;
 
-    int a_base[4], a_bh[4], a_bw[4];
-    bool a_ok[4];
+    // ---- per-row load descriptors.  A is read through a raw buffer resource: lane offsets are 32-bit and an
+    // offset >= num_records returns 0, which is how padding taps / rows past M are produced (no branches).
+    unsigned a_off[4];   // byte offset of (n, ho*stride-pad, wo*stride-pad, q*4)   [mode 1: pixel +q]
+    unsigned a_msk[4];   // bit rs set <=> tap (r,s) of this row is inside the image
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int m = m0 + row0 + 32 * j;
-      a_ok[j] = m < p.M;
-      int mm = a_ok[j] ? m : 0;
-      int n = mm / (p.Ho * p.Wo);
-      int rem = mm - n * (p.Ho * p.Wo);
-      int ho = rem / p.Wo;
-      int wo = rem - ho * p.Wo;
-      a_bh[j] = ho * p.stride - p.pad;
-      a_bw[j] = wo * p.stride - p.pad;
-      a_base[j] = n * p.H * p.W;
+      const int m = m0 + row0 + 32 * j;
+      const bool okm = m < p.M;
+      const int mm = okm ? m : 0;
+      const int n = mm / (p.Ho * p.Wo);
+      const int rem = mm - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      const int bh = ho * p.stride - p.pad, bw = wo * p.stride - p.pad;
+      a_off[j] = (unsigned)(((n * p.H + bh) * p.W + bw) * p.C + (MODE == 0 ? q * 4 : q * 4)) * 4u;
+      unsigned msk = 0;
+      if (okm) {
+        if (MODE == 0) {
+          for (int r = 0; r < p.R; ++r)
+            for (int s2 = 0; s2 < p.S; ++s2)
+              if (bh + r >= 0 && bh + r < p.H && bw + s2 >= 0 && bw + s2 < p.W) msk |= 1u << (r * p.S + s2);
+        } else {
+          for (int r = 0; r < p.R; ++r)
+            if (bh + r >= 0 && bh + r < p.H && bw + q >= 0 && bw + q < p.W) msk |= 1u << r;
+        }
+      }
+      a_msk[j] = msk;
     }
-    const float* wrow[NI * 2];
+    unsigned b_off[NI * 2];
 #pragma unroll
-    for (int j = 0; j < NI * 2; ++j) wrow[j] = p.w + (size_t)(n0 + row0 + 32 * j) * p.Kg + q * 4;
+    for (int j = 0; j < NI * 2; ++j) b_off[j] = (unsigned)((n0 + row0 + 32 * j) * p.Kg + q * 4) * 4u;
 
     f32x4 areg[4], breg[NI * 2];
     auto load_chunk = [&](int kc) {
-      int r, s, c0;
+      int rs, coff;
       if (MODE == 0) {
-        int rs = kc / cpc;
-        c0 = (kc - rs * cpc) * BK;
-        r = rs / p.S;
-        s = rs - r * p.S;
+        rs = kc / cpc;
+        const int c0 = (kc - rs * cpc) * BK;
+        const int r = rs / p.S, s2 = rs - r * p.S;
+        coff = ((r * p.W + s2) * p.C + c0) * 4;
       } else {
-        r = kc; s = 0; c0 = 0;
+        rs = kc;
+        coff = kc * p.W * p.C * 4;
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        int hi = a_bh[j] + r;
-        int wi = a_bw[j] + s + (MODE == 1 ? q : 0);
-        bool ok = a_ok[j] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          size_t off = (size_t)(a_base[j] + hi * p.W + wi) * p.C + c0 + (MODE == 0 ? q * 4 : 0);
-          v = *reinterpret_cast<const f32x4*>(p.x + off);
-        }
-        areg[j] = v;
+        const unsigned vo = ((a_msk[j] >> rs) & 1u) ? a_off[j] + (unsigned)coff : 0x80000000u;
+        areg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vo, 0, 0));
       }
 #pragma unroll
-      for (int j = 0; j < NI * 2; ++j) breg[j] = *reinterpret_cast<const f32x4*>(wrow[j] + (size_t)kc * BK);
+      for (int j = 0; j < NI * 2; ++j)
+        breg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, b_off[j], kc * (BK * 4), 0));
     };
     auto store_chunk = [&](int buf) {
       float* a = As + buf * BM * LDS_STRIDE;
@@ -162,12 +176,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+    // software pipeline: iteration kc computes chunk kc from LDS[cur]; registers hold chunk kc+1 (loaded one
+    // iteration earlier) and are written to LDS[cur^1] at the START of the iteration, then immediately
+    // refilled with chunk kc+2; every global load has a whole MFMA block (>= 4096 cycles) to land.
     load_chunk(kc0);
     store_chunk(0);
+    if (kc0 + 1 < kc1) load_chunk(kc0 + 1);
     __syncthreads();
     int cur = 0;
     for (int kc = kc0; kc < kc1; ++kc) {
-      if (kc + 1 < kc1) load_chunk(kc + 1);
       const float* a = As + cur * BM * LDS_STRIDE + a_frag_off;
       const float* b = Bs + cur * BN_ * LDS_STRIDE + b_frag_off;
 #pragma unroll
@@ -177,6 +194,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
         af[1] = *reinterpret_cast<const f32x4*>(a + 32 * LDS_STRIDE + kk * 8);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_STRIDE + kk * 8);
+        if (kk == 1 && kc + 1 < kc1) store_chunk(cur ^ 1);       // regs (chunk kc+1) -> the idle LDS buffer
+        if (kk == 2 && kc + 2 < kc1) load_chunk(kc + 2);          // refill regs with chunk kc+2
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -185,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
             for (int ni = 0; ni < NI; ++ni)
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
       }
-      if (kc + 1 < kc1) store_chunk(cur ^ 1);
       __syncthreads();
       cur ^= 1;
     }
@@ -326,7 +344,10 @@ static int worker_capacity() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    g_capacity = 2 * cus;
+    int per_cu = 2;
+    const char* e = getenv("LVC_CONV_WORKERS_PER_CU");  // tuning knob (1 or 2); 2 = the LDS/VGPR residency limit
+    if (e && e[0] == '1') per_cu = 1;
+    g_capacity = per_cu * cus;
   }
   return g_capacity;
 }
@@ -387,6 +408,11 @@ extern "C" int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const 
   if (workers < 1) workers = 1;
   a.units_per_worker = (int)((units + workers - 1) / workers);
   a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker);
+  {
+    const long long xb = (long long)N * H * W * C * 4, wb = (long long)(a.tiles_n * bn) * Kg * 4;
+    LVC_CHECK_ARG(xb < (1ll << 31) && wb < (1ll << 31), "input / weight tensor must be smaller than 2 GiB (32-bit buffer offsets)");
+    a.x_bytes = (int)xb; a.w_bytes = (int)wb;
+  }
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 64 * 4);
   a.err_index = LVC_MAX_WORKERS;
