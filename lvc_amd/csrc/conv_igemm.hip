@@ -139,17 +139,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
     for (int j = 0; j < NI * 2; ++j) b_off[j] = (unsigned)((n0 + row0 + 32 * j) * p.Kg + q * 4) * 4u;
 
     f32x4 areg[4], breg[NI * 2];
-    auto load_chunk = [&](int kc) {
-      int rs, coff;
-      if (MODE == 0) {
-        rs = kc / cpc;
-        const int c0 = (kc - rs * cpc) * BK;
-        const int r = rs / p.S, s2 = rs - r * p.S;
-        coff = ((r * p.W + s2) * p.C + c0) * 4;
-      } else {
-        rs = kc;
-        coff = kc * p.W * p.C * 4;
-      }
+    // running (r, s, c-chunk) position of the NEXT chunk to request: advanced incrementally (no divisions in
+    // the MFMA loop); requests past the work item's range re-load its last chunk (harmless, branch-free).
+    int ld_kc = kc0, ld_c, ld_r, ld_s;
+    if (MODE == 0) {
+      const int rs0 = kc0 / cpc;
+      ld_c = kc0 - rs0 * cpc;
+      ld_r = rs0 / p.S;
+      ld_s = rs0 - ld_r * p.S;
+    } else {
+      ld_c = 0; ld_r = kc0; ld_s = 0;
+    }
+    auto load_next = [&]() {
+      const int rs = (MODE == 0) ? ld_r * p.S + ld_s : ld_r;
+      const int coff = (MODE == 0) ? ((ld_r * p.W + ld_s) * p.C + ld_c * BK) * 4 : ld_r * p.W * p.C * 4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const unsigned vo = ((a_msk[j] >> rs) & 1u) ? a_off[j] + (unsigned)coff : 0x80000000u;
@@ -157,7 +160,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < NI * 2; ++j)
-        breg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, b_off[j], kc * (BK * 4), 0));
+        breg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wres, b_off[j], ld_kc * (BK * 4), 0));
+      if (ld_kc + 1 < kc1) {   // uniform scalar bookkeeping
+        ++ld_kc;
+        if (MODE == 0) {
+          if (++ld_c == cpc) { ld_c = 0; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }
+        } else {
+          ++ld_r;
+        }
+      }
     };
     auto store_chunk = [&](int buf) {
       float* a = As + buf * BM * LDS_STRIDE;
@@ -176,37 +187,80 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    // software pipeline: iteration kc computes chunk kc from LDS[cur]; registers hold chunk kc+1 (loaded one
-    // iteration earlier) and are written to LDS[cur^1] at the START of the iteration, then immediately
-    // refilled with chunk kc+2; every global load has a whole MFMA block (>= 4096 cycles) to land.
-    load_chunk(kc0);
+    // Software pipeline, one barrier per chunk, everything else issued in the shadow of the 64-cycle MFMAs:
+    //   group kk=0: ds_read frags(kk=1) | 16 MFMA(kk=0) interleaved with the 8 ds_write of chunk kc+1 (regs -> idle buffer)
+    //   group kk=1: ds_read frags(kk=2) | 16 MFMA(kk=1) interleaved with the 8 buffer_load of chunk kc+2 (-> the same regs)
+    //   group kk=2: ds_read frags(kk=3) | 16 MFMA(kk=2)
+    //   barrier (all reads of this buffer issued and waited, all writes of the other buffer visible)
+    //   group kk=3: ds_read frags(kk=0 of chunk kc+1, other buffer) | 16 MFMA(kk=3)
+    // The loop body is branch-free (loads of chunks past the range are clamped re-loads, stores past the range
+    // land in the idle buffer) so that it is ONE scheduling region and the sched_group_barrier interleave holds.
+    f32x4 fa[2][2], fb[2][NI];
+    auto read_frags = [&](int sel, const float* a, const float* b, int kk) {
+      fa[sel][0] = *reinterpret_cast<const f32x4*>(a + kk * 8);
+      fa[sel][1] = *reinterpret_cast<const f32x4*>(a + 32 * LDS_STRIDE + kk * 8);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) fb[sel][ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_STRIDE + kk * 8);
+    };
+    auto mfma_group = [&](int sel) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sel][mi][t], fb[sel][ni][t], acc[mi][ni], 0, 0, 0);
+    };
+    constexpr int NMF = 8 * NI;       // MFMAs per kk group
+    constexpr int NST = 4 + 2 * NI;   // staged float4 per thread per chunk (A: 4, B: 2*NI)
+
+    load_next();
     store_chunk(0);
-    if (kc0 + 1 < kc1) load_chunk(kc0 + 1);
+    load_next();
     __syncthreads();
     int cur = 0;
+    read_frags(0, As + a_frag_off, Bs + b_frag_off, 0);
     for (int kc = kc0; kc < kc1; ++kc) {
       const float* a = As + cur * BM * LDS_STRIDE + a_frag_off;
       const float* b = Bs + cur * BN_ * LDS_STRIDE + b_frag_off;
+      const float* an = As + (cur ^ 1) * BM * LDS_STRIDE + a_frag_off;
+      const float* bn = Bs + (cur ^ 1) * BN_ * LDS_STRIDE + b_frag_off;
+      // ---- group 0
+      read_frags(1, a, b, 1);
+      store_chunk(cur ^ 1);
+      mfma_group(0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 0);   // DS reads first
 #pragma unroll
-      for (int kk = 0; kk < BK / 8; ++kk) {
-        f32x4 af[2], bf[NI];
-        af[0] = *reinterpret_cast<const f32x4*>(a + kk * 8);
-        af[1] = *reinterpret_cast<const f32x4*>(a + 32 * LDS_STRIDE + kk * 8);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(b + ni * 32 * LDS_STRIDE + kk * 8);
-        if (kk == 1 && kc + 1 < kc1) store_chunk(cur ^ 1);       // regs (chunk kc+1) -> the idle LDS buffer
-        if (kk == 2 && kc + 2 < kc1) load_chunk(kc + 2);          // refill regs with chunk kc+2
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][t], bf[ni][t], acc[mi][ni], 0, 0, 0);
+      for (int i = 0; i < NST; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // 1 DS write
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - NST, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- group 1
+      read_frags(0, a, b, 2);
+      load_next();
+      mfma_group(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + NI, 1);
+#pragma unroll
+      for (int i = 0; i < NST; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);      // 1 VMEM read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NMF - NST, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- group 2
+      read_frags(1, a, b, 3);
+      mfma_group(0);
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
+      // ---- group 3 (frags of the next chunk come from the other buffer, complete behind these MFMAs)
+      read_frags(0, an, bn, 0);
+      mfma_group(1);
+      __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
     }
+    __syncthreads();  // the speculative frag reads / idle-buffer stores of the last iteration are done
     u += kc1 - kc0;
 
     // ------------------------------------------------------------ split tiles: publish or combine partials
@@ -357,7 +411,7 @@ static int worker_capacity() {
 // zero-initialised once by the caller and must not be shared by launches that run concurrently on
 // different streams.
 extern "C" long long lvc_conv_workspace_bytes(void) {
-  return (long long)LVC_MAX_WORKERS * 256 * 64 * 4 + (LVC_MAX_WORKERS + 1) * 4 + 256;
+  return (long long)LVC_MAX_WORKERS * 256 * 128 * 4 + (LVC_MAX_WORKERS + 1) * 4 + 256;
 }
 
 // C ABI -- see include/lvc_amd.h for the contract of each argument.
@@ -393,6 +447,7 @@ extern "C" int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const 
   a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
   if ((a.K & 3) == 0 && (a.ldy & 3) == 0) LVC_CHECK_ARG(((uintptr_t)y & 15) == 0, "y must be 16-byte aligned");
   const int ni = (K <= 64) ? 1 : 2;  // BN = 64 tile for the 64-channel layers, else 128
+  // (a 128x256 tile / 1 worker per CU was measured: 256 VGPRs + SGPR spills, 120 vs 125 TF on the p2 3x3 -> dropped)
   const int bn = 64 * ni;
   a.tiles_n = lvc_cdiv(K, bn);
   const int tiles_m = lvc_cdiv(a.M, BM);
@@ -414,7 +469,7 @@ extern "C" int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const 
     a.x_bytes = (int)xb; a.w_bytes = (int)wb;
   }
   a.partials = (float*)workspace;
-  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 64 * 4);
+  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
   dim3 grid(a.nworkers), block(256);
   hipStream_t st = (hipStream_t)stream;

@@ -105,7 +105,7 @@ def conv_workspace(device):
 def conv_error_word(device):
     """The kernel's spin-timeout word (0 = fine); reading it synchronises."""
     ws = conv_workspace(device)
-    return int(ws[1024 * 256 * 64 * 4 + 1024 * 4: 1024 * 256 * 64 * 4 + 1024 * 4 + 4].view(torch.int32).item())
+    return int(ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4].view(torch.int32).item())
 
 
 class LaunchTimer:
