@@ -43,7 +43,7 @@ void lvc_set_error(const char* fmt, ...);
  *   lvc/modeling/roi_heads/box_head.py:82-91 and fast_rcnn.py:583-598 (Linear = 1x1 conv on [M,1,1,K]).
  *   x        [N,H,W,C]        C = physical channels (mode 0: C % 32 == 0; mode 1: C == 4, the RGB0 stem)
  *   w_packed [Kpad,Kg]        rows = out channel, zero rows up to a multiple of 128;
- *                             mode 0: k = (r,s,c), c fastest, Kg = R*S*C
+ *                             mode 0: k = (c/32, r, s, c%32), Kg = R*S*C
  *                             mode 1: k = (r, 8 pixels x 4 ch), Kg = R*32 (7x7 stem: pixel 7 / ch 3 zero)
  *   scale, shift [K] or NULL  y = acc*scale + shift
  *   residual                  res_mode 0 none | 1: [M,ldr] same rows as y | 2: [N,Ho/2,Wo/2,ldr], upsampled x2

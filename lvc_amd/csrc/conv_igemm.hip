@@ -10,7 +10,8 @@
 // GEMM view:  D[m][n] = sum_k A[m][k] * B[n][k]
 //   m = output pixel (n_img, ho, wo)  -- NHWC, so m is exactly the row index of the output tensor
 //   n = output channel
-//   k = (r, s, c) with c fastest      -- a BK=32 chunk of k is 128 contiguous bytes of one input pixel
+//   k = (c/32, r, s, c%32)            -- a BK=32 chunk of k is 128 contiguous bytes of one input pixel; the 9 taps
+//                                        of a channel chunk are consecutive chunks (L2 reuse of the shifted lines)
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; 64 FLOP/clk/SIMD = 157 TF chip peak).
 // The parity bar of the path needs true fp32; bf16 MFMA would not hold it.
 //
@@ -89,7 +90,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);  // logical worker id
   int u = lw * p.units_per_worker;
   const int u_end = min(u + p.units_per_worker, p.total_units);
-  const int cpc = (MODE == 0) ? (p.C / BK) : 1;  // chunks per (r,s)
 
   const int a_frag_off = (wm * 64 + fi) * LDS_STRIDE + fh * 4;
   const int b_frag_off = (wn * (BN_ / 2) + fi) * LDS_STRIDE + fh * 4;
@@ -143,8 +143,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
     // the MFMA loop); requests past the work item's range re-load its last chunk (harmless, branch-free).
     int ld_kc = kc0, ld_c, ld_r, ld_s;
     if (MODE == 0) {
-      const int rs0 = kc0 / cpc;
-      ld_c = kc0 - rs0 * cpc;
+      // k order is (channel chunk, r, s) with s fastest: consecutive chunks of one tile re-read the same input
+      // lines shifted by one pixel / one row, so the taps hit L2 instead of going back to the fabric
+      const int RS = p.R * p.S;
+      ld_c = kc0 / RS;
+      const int rs0 = kc0 - ld_c * RS;
       ld_r = rs0 / p.S;
       ld_s = rs0 - ld_r * p.S;
     } else {
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32_kernel(ConvArgs p) {
       if (ld_kc + 1 < kc1) {   // uniform scalar bookkeeping
         ++ld_kc;
         if (MODE == 0) {
-          if (++ld_c == cpc) { ld_c = 0; if (++ld_s == p.S) { ld_s = 0; ++ld_r; } }
+          if (++ld_s == p.S) { ld_s = 0; if (++ld_r == p.R) { ld_r = 0; ++ld_c; } }
         } else {
           ++ld_r;
         }

@@ -29,7 +29,7 @@ class PackedConv:
     """Weights of one conv/linear layer in the kernel's layout + folded per-channel affine.
 
     w_packed: [Kpad, Kg] fp32, rows = out channel (zero rows up to a multiple of 128),
-              k = (r, s, c) with c fastest (mode 0) or (r, 8 pixels x 4 ch) (mode 1, the 7x7 stem).
+              k = (c//32, r, s, c%32) (mode 0) or (r, 8 pixels x 4 ch) (mode 1, the 7x7 stem).
     scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
     """
 
@@ -61,7 +61,8 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False)
     else:
         assert C % BK == 0, "implicit-GEMM kernel needs in_channels % 32 == 0 (got {})".format(C)
         Kg = R * S * C
-        wk = w.permute(0, 2, 3, 1).reshape(K, Kg)
+        # k = (c // 32, r, s, c % 32): the taps of one 32-channel chunk are consecutive gemm-k chunks
+        wk = w.view(K, C // BK, BK, R, S).permute(0, 1, 3, 4, 2).reshape(K, Kg)
         Cphys, mode = C, 0
     Kpad = (K + BN - 1) // BN * BN
     wp = torch.zeros(Kpad, Kg, device=dev, dtype=torch.float32)
