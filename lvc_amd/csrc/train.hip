@@ -1,0 +1,218 @@
+// train.hip -- training-time kernels of the fine-tune step (BASELINE config 3: only box_predictor trains).
+//   lvc_match_boxes        = pairwise_iou + Matcher.__call__ (+ set_low_quality_matches_)
+//       reference detectron2/structures/boxes.py:315-347, detectron2/modeling/matcher.py:61-126; used by
+//       RPN.label_and_sample_anchors (rpn.py:269-325, 268 569 anchors x G) and
+//       ROIHeads.label_and_sample_proposals (lvc/modeling/roi_heads/roi_heads.py:173-278)
+//   lvc_fast_rcnn_losses   = FastRCNNOutputs.losses (lvc/modeling/roi_heads/fast_rcnn.py:267-279 softmax CE "mean",
+//       :296-359 box_reg_loss smooth-L1 "sum" / #rows) forward AND the gradients w.r.t. logits / deltas
+//   lvc_rpn_losses         = RPN.losses (rpn.py:328-400): BCE-with-logits "sum" over valid anchors and smooth-L1 "sum"
+//       over positive anchors of get_deltas(anchor, gt), both / (batch_size_per_image * num_images); forward only
+//       (every shipped fine-tune config freezes the RPN).
+// Built with -ffp-contract=off like the other geometry files.
+#include "common.h"
+
+__device__ __forceinline__ float iou_ref(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2,
+                                         float by2) {
+  // boxes.py:315-347: wh = clamp(min(rb) - max(lt), 0); inter = w*h; iou = inter > 0 ? inter/(a1+a2-inter) : 0
+  const float a1 = (ax2 - ax1) * (ay2 - ay1), a2 = (bx2 - bx1) * (by2 - by1);
+  float w = fminf(ax2, bx2) - fmaxf(ax1, bx1);
+  float h = fminf(ay2, by2) - fmaxf(ay1, by1);
+  w = w < 0.f ? 0.f : w;
+  h = h < 0.f ? 0.f : h;
+  const float inter = w * h;
+  return inter > 0.f ? inter / (a1 + a2 - inter) : 0.f;
+}
+
+#define MAX_GT 512
+// pass 1: per box: max IoU over the G gt boxes + first arg-max; per gt: max IoU over boxes (atomicMax on the bits)
+__global__ __launch_bounds__(256) void match_pass1_kernel(const float* __restrict__ gt, int G,
+                                                          const float* __restrict__ boxes, int N,
+                                                          float* __restrict__ matched_vals,
+                                                          long long* __restrict__ matches,
+                                                          unsigned int* __restrict__ gt_best) {
+  __shared__ float sgt[MAX_GT * 4];
+  __shared__ unsigned int sbest[MAX_GT];
+  for (int i = threadIdx.x; i < G * 4; i += 256) sgt[i] = gt[i];
+  for (int i = threadIdx.x; i < G; i += 256) sbest[i] = 0u;
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) {
+    const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)n * 4);
+    float best = -1.f; int bi = 0;
+    for (int g = 0; g < G; ++g) {
+      const float v = iou_ref(sgt[g * 4], sgt[g * 4 + 1], sgt[g * 4 + 2], sgt[g * 4 + 3], b.x, b.y, b.z, b.w);
+      if (v > best) { best = v; bi = g; }
+      atomicMax(&sbest[g], __float_as_uint(v));  // v >= 0: bit pattern is monotone
+    }
+    matched_vals[n] = best;
+    matches[n] = bi;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < G; i += 256) atomicMax(&gt_best[i], sbest[i]);
+}
+
+// pass 2: labels from thresholds; low-quality matches: any gt whose best IoU equals this box's IoU with it -> 1
+__global__ __launch_bounds__(256) void match_pass2_kernel(const float* __restrict__ gt, int G,
+                                                          const float* __restrict__ boxes, int N,
+                                                          const float* __restrict__ matched_vals,
+                                                          const unsigned int* __restrict__ gt_best, float t0, float t1,
+                                                          int nthr, int l0, int l1, int l2, int allow_low_quality,
+                                                          signed char* __restrict__ labels) {
+  __shared__ float sgt[MAX_GT * 4];
+  __shared__ float sbest[MAX_GT];
+  for (int i = threadIdx.x; i < G * 4; i += 256) sgt[i] = gt[i];
+  for (int i = threadIdx.x; i < G; i += 256) sbest[i] = __uint_as_float(gt_best[i]);
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float v = matched_vals[n];
+  // thresholds = [-inf, t0, (t1,) +inf]; labels l0 below t0, l1 in [t0,t1), l2 above (nthr == 1: l0 / l1)
+  int lab;
+  if (nthr == 1) lab = v < t0 ? l0 : l1;
+  else lab = v < t0 ? l0 : (v < t1 ? l1 : l2);
+  if (allow_low_quality) {
+    const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)n * 4);
+    for (int g = 0; g < G; ++g) {
+      const float q = iou_ref(sgt[g * 4], sgt[g * 4 + 1], sgt[g * 4 + 2], sgt[g * 4 + 3], b.x, b.y, b.z, b.w);
+      if (q == sbest[g]) { lab = 1; break; }
+    }
+  }
+  labels[n] = (signed char)lab;
+}
+
+// gt [G,4], boxes [N,4] -> matches [N] int64 (arg-max gt, first on ties), labels [N] int8, matched_vals [N] fp32.
+// thresholds/labels as in Matcher(thresholds, labels): nthr in {1,2}.  d_gt_best: [G] uint32 scratch (zeroed here).
+extern "C" int lvc_match_boxes(const float* gt, int G, const float* boxes, int N, float t0, float t1, int nthr, int l0,
+                               int l1, int l2, int allow_low_quality, long long* matches, signed char* labels,
+                               float* matched_vals, unsigned int* d_gt_best, void* stream) {
+  LVC_CHECK_ARG(G > 0 && G <= MAX_GT, "1..512 ground-truth boxes (the G == 0 case is handled by the host)");
+  LVC_CHECK_ARG(N >= 0 && (nthr == 1 || nthr == 2), "bad arguments");
+  if (N == 0) return LVC_OK;
+  LVC_CHECK_ARG(gt && boxes && matches && labels && matched_vals && d_gt_best, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(d_gt_best, 0, sizeof(unsigned int) * G, st);
+  hipLaunchKernelGGL(match_pass1_kernel, dim3(lvc_cdiv(N, 256)), dim3(256), 0, st, gt, G, boxes, N, matched_vals,
+                     matches, d_gt_best);
+  LVC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(match_pass2_kernel, dim3(lvc_cdiv(N, 256)), dim3(256), 0, st, gt, G, boxes, N, matched_vals,
+                     d_gt_best, t0, t1, nthr, l0, l1, l2, allow_low_quality, labels);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+__device__ __forceinline__ void get_deltas(float sx1, float sy1, float sx2, float sy2, float tx1, float ty1, float tx2,
+                                           float ty2, float wx, float wy, float ww, float wh, float* d) {
+  // box_regression.py:40-71
+  const float sw = sx2 - sx1, sh = sy2 - sy1, scx = sx1 + 0.5f * sw, scy = sy1 + 0.5f * sh;
+  const float tw = tx2 - tx1, th = ty2 - ty1, tcx = tx1 + 0.5f * tw, tcy = ty1 + 0.5f * th;
+  d[0] = wx * (tcx - scx) / sw; d[1] = wy * (tcy - scy) / sh;
+  d[2] = ww * logf(tw / sw); d[3] = wh * logf(th / sh);
+}
+__device__ __forceinline__ float smooth_l1(float x, float t, float beta, float* grad) {
+  const float n = fabsf(x - t);
+  if (beta < 1e-5f) { *grad = x > t ? 1.f : (x < t ? -1.f : 0.f); return n; }
+  if (n < beta) { *grad = (x - t) / beta; return 0.5f * n * n / beta; }
+  *grad = x > t ? 1.f : -1.f;
+  return n - 0.5f * beta;
+}
+
+// one workgroup; R rows (<= a few thousand): loss_cls = mean CE, loss_box = sum smooth-L1 over fg rows / R
+__global__ __launch_bounds__(1024) void fast_rcnn_losses_kernel(
+    const float* __restrict__ logits, int ld_cls, const float* __restrict__ deltas, int ld_delta, int K,
+    int cls_agnostic, const float* __restrict__ proposals, const float* __restrict__ gt_boxes,
+    const long long* __restrict__ gt_classes, int R, float wx, float wy, float ww, float wh, float beta,
+    float* __restrict__ out_losses, float* __restrict__ dlogits, float* __restrict__ ddeltas) {
+  __shared__ double red[2][16];
+  double lc = 0.0, lb = 0.0;
+  for (int r = threadIdx.x; r < R; r += 1024) {
+    const float* lg = logits + (size_t)r * ld_cls;
+    const long long c = gt_classes[r];
+    float mx = -INFINITY;
+    for (int k = 0; k <= K; ++k) mx = fmaxf(mx, lg[k]);
+    float sum = 0.f;
+    for (int k = 0; k <= K; ++k) sum += expf(lg[k] - mx);
+    const float lse = mx + logf(sum);
+    lc += (double)(lse - lg[c]);
+    for (int k = 0; k <= K; ++k) dlogits[(size_t)r * (K + 1) + k] = (expf(lg[k] - lse) - (k == c ? 1.f : 0.f)) / (float)R;
+    const int nreg = cls_agnostic ? 4 : 4 * K;
+    for (int j = 0; j < nreg; ++j) ddeltas[(size_t)r * nreg + j] = 0.f;
+    if (c >= 0 && c < K) {
+      float t[4];
+      const float* p = proposals + (size_t)r * 4;
+      const float* g = gt_boxes + (size_t)r * 4;
+      get_deltas(p[0], p[1], p[2], p[3], g[0], g[1], g[2], g[3], wx, wy, ww, wh, t);
+      const int col = cls_agnostic ? 0 : 4 * (int)c;
+      for (int j = 0; j < 4; ++j) {
+        float gr;
+        lb += (double)smooth_l1(deltas[(size_t)r * ld_delta + col + j], t[j], beta, &gr);
+        ddeltas[(size_t)r * nreg + col + j] = gr / (float)R;
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { lc += __shfl_xor(lc, o); lb += __shfl_xor(lb, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lc; red[1][threadIdx.x >> 6] = lb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+    out_losses[0] = (float)(a / R);
+    out_losses[1] = (float)(b / R);
+  }
+}
+
+// logits [R, ld_cls] (K+1 used), deltas [R, ld_delta], proposals/gt_boxes [R,4], gt_classes [R] int64 (K = background)
+// out_losses [2] = (loss_cls, loss_box_reg) ; dlogits [R,K+1], ddeltas [R, 4K | 4] = d(loss)/d(input), dense.
+extern "C" int lvc_fast_rcnn_losses(const float* logits, int ld_cls, const float* deltas, int ld_delta, int K,
+                                    int cls_agnostic, const float* proposals, const float* gt_boxes,
+                                    const long long* gt_classes, int R, float wx, float wy, float ww, float wh,
+                                    float smooth_l1_beta, float* out_losses, float* dlogits, float* ddeltas,
+                                    void* stream) {
+  LVC_CHECK_ARG(R > 0 && K > 0, "empty batch");
+  LVC_CHECK_ARG(logits && deltas && proposals && gt_boxes && gt_classes && out_losses && dlogits && ddeltas, "null pointer");
+  hipLaunchKernelGGL(fast_rcnn_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld_cls, deltas,
+                     ld_delta, K, cls_agnostic, proposals, gt_boxes, gt_classes, R, wx, wy, ww, wh, smooth_l1_beta,
+                     out_losses, dlogits, ddeltas);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// RPN losses over S sampled anchors (labels in {0,1}); rows gathered by the host side index plumbing.
+__global__ __launch_bounds__(1024) void rpn_losses_kernel(const float* __restrict__ logits, const float* __restrict__ deltas,
+                                                          const float* __restrict__ anchors,
+                                                          const float* __restrict__ gt_boxes,
+                                                          const signed char* __restrict__ labels, int S, float beta,
+                                                          float normalizer, float* __restrict__ out) {
+  __shared__ double red[2][16];
+  double lc = 0.0, lb = 0.0;
+  for (int i = threadIdx.x; i < S; i += 1024) {
+    const float x = logits[i], y = (float)labels[i];
+    // F.binary_cross_entropy_with_logits: max(x,0) - x*y + log1p(exp(-|x|))
+    lc += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+    if (labels[i] == 1) {
+      float t[4], gr;
+      const float* a = anchors + (size_t)i * 4;
+      const float* g = gt_boxes + (size_t)i * 4;
+      get_deltas(a[0], a[1], a[2], a[3], g[0], g[1], g[2], g[3], 1.f, 1.f, 1.f, 1.f, t);
+      for (int j = 0; j < 4; ++j) lb += (double)smooth_l1(deltas[(size_t)i * 4 + j], t[j], beta, &gr);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { lc += __shfl_xor(lc, o); lb += __shfl_xor(lb, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lc; red[1][threadIdx.x >> 6] = lb; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0, b = 0;
+    for (int w = 0; w < 16; ++w) { a += red[0][w]; b += red[1][w]; }
+    out[0] = (float)(a / normalizer);
+    out[1] = (float)(b / normalizer);
+  }
+}
+
+extern "C" int lvc_rpn_losses(const float* logits, const float* deltas, const float* anchors, const float* gt_boxes,
+                              const signed char* labels, int S, float smooth_l1_beta, float normalizer, float* out_losses,
+                              void* stream) {
+  LVC_CHECK_ARG(S >= 0 && normalizer > 0.f && out_losses, "bad arguments");
+  hipLaunchKernelGGL(rpn_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, deltas, anchors, gt_boxes,
+                     labels, S, smooth_l1_beta, normalizer, out_losses);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

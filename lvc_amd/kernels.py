@@ -431,3 +431,61 @@ def knn_topk_vote(sims, num_shots, shot_classes, det_classes, k):
                                       ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(sims))
     check(rc, "lvc_knn_topk_vote")
     return top, keep
+
+
+# --------------------------------------------------------------------------- training-time kernels
+def match_boxes(gt_boxes, boxes, thresholds, labels, allow_low_quality_matches):
+    """pairwise_iou + Matcher on device.  gt_boxes [G,4] (G >= 1), boxes [N,4].
+    thresholds: 1 or 2 floats, labels: len(thresholds)+1 ints.  Returns (matches int64 [N], labels int8 [N], vals [N])."""
+    _req_cuda(gt_boxes, boxes)
+    G, N = gt_boxes.shape[0], boxes.shape[0]
+    gt_boxes = gt_boxes.contiguous().float()
+    boxes = boxes.contiguous().float()
+    dev = boxes.device
+    matches = torch.empty(N, dtype=torch.int64, device=dev)
+    mlabels = torch.empty(N, dtype=torch.int8, device=dev)
+    vals = torch.empty(N, dtype=torch.float32, device=dev)
+    scratch = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    nthr = len(thresholds)
+    assert nthr in (1, 2) and len(labels) == nthr + 1
+    t = list(thresholds) + [0.0]
+    lab = list(labels) + [0]
+    rc = _lib.lib().lvc_match_boxes(ptr(gt_boxes), c_int(G), ptr(boxes), c_int(N), c_float(t[0]), c_float(t[1]),
+                                    c_int(nthr), c_int(lab[0]), c_int(lab[1]), c_int(lab[2]),
+                                    c_int(1 if allow_low_quality_matches else 0), ptr(matches), ptr(mlabels), ptr(vals),
+                                    ptr(scratch), _stream(boxes))
+    check(rc, "lvc_match_boxes")
+    return matches, mlabels, vals
+
+
+def fast_rcnn_losses(logits, deltas, proposals, gt_boxes, gt_classes, num_classes, box_weights, smooth_l1_beta):
+    """Returns (losses [2] = (loss_cls, loss_box_reg), dlogits [R,K+1], ddeltas [R,4K|4])."""
+    _req_cuda(logits, deltas, proposals, gt_boxes, gt_classes)
+    R = logits.shape[0]
+    K = num_classes
+    nreg = deltas.shape[1] if deltas.shape[1] == 4 else 4 * K
+    dev = logits.device
+    out = torch.empty(2, device=dev, dtype=torch.float32)
+    dl = torch.empty(R, K + 1, device=dev, dtype=torch.float32)
+    dd = torch.empty(R, nreg, device=dev, dtype=torch.float32)
+    wx, wy, ww, wh = box_weights
+    assert logits.stride(1) == 1 and deltas.stride(1) == 1 and gt_classes.dtype == torch.int64
+    rc = _lib.lib().lvc_fast_rcnn_losses(ptr(logits), c_int(logits.stride(0)), ptr(deltas), c_int(deltas.stride(0)), c_int(K),
+                                         c_int(1 if nreg == 4 else 0), ptr(proposals.contiguous()), ptr(gt_boxes.contiguous()),
+                                         ptr(gt_classes.contiguous()), c_int(R), c_float(wx), c_float(wy), c_float(ww),
+                                         c_float(wh), c_float(smooth_l1_beta), ptr(out), ptr(dl), ptr(dd), _stream(logits))
+    check(rc, "lvc_fast_rcnn_losses")
+    return out, dl, dd
+
+
+def rpn_losses(logits, deltas, anchors, gt_boxes, labels, smooth_l1_beta, normalizer):
+    """Sampled-anchor RPN losses (forward only).  All inputs are rows gathered at the sampled anchors."""
+    _req_cuda(logits, deltas, anchors, gt_boxes, labels)
+    S = logits.shape[0]
+    out = torch.zeros(2, device=logits.device, dtype=torch.float32)
+    assert labels.dtype == torch.int8
+    rc = _lib.lib().lvc_rpn_losses(ptr(logits.contiguous()), ptr(deltas.contiguous()), ptr(anchors.contiguous()),
+                                   ptr(gt_boxes.contiguous()), ptr(labels.contiguous()), c_int(S), c_float(smooth_l1_beta),
+                                   c_float(normalizer), ptr(out), _stream(logits))
+    check(rc, "lvc_rpn_losses")
+    return out

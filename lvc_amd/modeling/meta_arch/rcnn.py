@@ -86,9 +86,30 @@ class GeneralizedRCNN(_RCNNBase):
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
-        raise NotImplementedError(
-            "GeneralizedRCNN training forward is not implemented in lvc_amd round 1 "
-            "(inference path first; see DESIGN.md 'what comes next')")
+        # training forward (reference rcnn.py:127-175): losses of the RPN (logged; frozen) and of the box predictor
+        images = self.preprocess_image(batched_inputs)
+        if "instances" in batched_inputs[0]:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        elif "targets" in batched_inputs[0]:
+            gt_instances = [x["targets"].to(self.device) for x in batched_inputs]
+        else:
+            gt_instances = None
+        with torch.no_grad():
+            if any(p.requires_grad for p in self.backbone.parameters()):
+                raise NotImplementedError(
+                    "backward through the trunk is not implemented; fine-tune configs freeze it (MODEL.BACKBONE.FREEZE)")
+            features = self.backbone(images.tensor)
+        if self.proposal_generator:
+            proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+        else:
+            assert "proposals" in batched_inputs[0]
+            proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+            proposal_losses = {}
+        _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
 
     # ------------------------------------------------------------------ device-side fast path
     def inference_batched(self, batched_inputs, do_postprocess=True):

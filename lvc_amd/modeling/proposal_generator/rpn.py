@@ -17,8 +17,11 @@ from ...layers.layout import require_device, to_nchw_view, to_nhwc
 from ...layers.wrappers import _PackedCache
 from ...structures import Boxes, Instances
 from ...utils.registry import Registry
+from ...utils.events import get_event_storage
 from ..anchor_generator import build_anchor_generator
 from ..box_regression import Box2BoxTransform
+from ..matcher import Matcher
+from ..sampling import subsample_labels
 from .build import PROPOSAL_GENERATOR_REGISTRY
 
 RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
@@ -94,6 +97,7 @@ class RPN(nn.Module):
                             "loss_rpn_loc": cfg.MODEL.RPN.BBOX_REG_LOSS_WEIGHT * cfg.MODEL.RPN.LOSS_WEIGHT}
         self.box_reg_loss_type = cfg.MODEL.RPN.BBOX_REG_LOSS_TYPE
         self.smooth_l1_beta = cfg.MODEL.RPN.SMOOTH_L1_BETA
+        self.anchor_matcher = Matcher(cfg.MODEL.RPN.IOU_THRESHOLDS, cfg.MODEL.RPN.IOU_LABELS, allow_low_quality_matches=True)
         assert tuple(self.box2box_transform.weights) == (1.0, 1.0, 1.0, 1.0), \
             "the fused RPN decode kernel assumes RPN.BBOX_REG_WEIGHTS == (1,1,1,1) (the default of every shipped config)"
 
@@ -108,13 +112,64 @@ class RPN(nn.Module):
                                list(self.anchor_generator.cell_anchors), self.anchor_generator.strides, image_sizes_dev,
                                self.pre_nms_topk[t], self.post_nms_topk[t], self.nms_thresh, self.min_box_size)
 
+    # ------------------------------------------------------------------ training (frozen RPN: losses are logged only)
+    @torch.no_grad()
+    def label_and_sample_anchors(self, anchors, gt_instances):
+        """reference rpn.py:269-325.  anchors: [R,4] tensor of all anchors; returns (labels [N,R] int8 in {-1,0,1},
+        matched gt boxes [N,R,4])."""
+        gt_labels, matched_gt_boxes = [], []
+        for inst in gt_instances:
+            gt = inst.gt_boxes.tensor
+            matched_idxs, labels = self.anchor_matcher.match(gt, anchors)
+            if self.anchor_boundary_thresh >= 0:
+                h, w = inst.image_size
+                t = self.anchor_boundary_thresh
+                inside = (anchors[:, 0] >= -t) & (anchors[:, 1] >= -t) & (anchors[:, 2] < w + t) & (anchors[:, 3] < h + t)
+                labels[~inside] = -1
+            pos_idx, neg_idx = subsample_labels(labels, self.batch_size_per_image, self.positive_fraction, 0)
+            labels.fill_(-1)
+            labels.scatter_(0, pos_idx, 1)
+            labels.scatter_(0, neg_idx, 0)
+            gt_labels.append(labels)
+            matched_gt_boxes.append(torch.zeros_like(anchors) if len(gt) == 0 else gt[matched_idxs])
+        return torch.stack(gt_labels), torch.stack(matched_gt_boxes)
+
+    @torch.no_grad()
+    def losses(self, anchors, flat_logits, gt_labels, flat_deltas, gt_boxes):
+        """reference rpn.py:328-400 (smooth_l1 branch).  flat_logits [N,R], flat_deltas [N,R,4]."""
+        if self.box_reg_loss_type != "smooth_l1":
+            raise NotImplementedError("RPN.BBOX_REG_LOSS_TYPE '{}'".format(self.box_reg_loss_type))
+        num_images = gt_labels.shape[0]
+        storage = get_event_storage()
+        storage.put_scalar("rpn/num_pos_anchors", float((gt_labels == 1).sum()) / num_images)
+        storage.put_scalar("rpn/num_neg_anchors", float((gt_labels == 0).sum()) / num_images)
+        img, idx = (gt_labels >= 0).nonzero(as_tuple=True)
+        out = K.rpn_losses(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gt_boxes[img, idx],
+                           gt_labels[img, idx], self.smooth_l1_beta, float(self.batch_size_per_image * num_images))
+        return {"loss_rpn_cls": out[0] * self.loss_weight.get("loss_rpn_cls", 1.0),
+                "loss_rpn_loc": out[1] * self.loss_weight.get("loss_rpn_loc", 1.0)}
+
     def forward(self, images, features, gt_instances=None):
         """Reference signature (rpn.py:402-451): -> (list[Instances], losses)."""
-        if self.training:
-            raise NotImplementedError("RPN losses are not implemented in lvc_amd round 1 (see DESIGN.md 'next')")
         feats = {f: to_nhwc(features[f]) for f in self.in_features}
         require_device(feats[self.in_features[0]], "RPN")
         sizes = torch.tensor([list(s) for s in images.image_sizes], dtype=torch.int32, device=images.tensor.device)
+        losses = {}
+        if self.training:
+            assert gt_instances is not None, "RPN requires gt_instances in training!"
+            if any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError(
+                    "training the RPN itself (backward through the RPN head) is not implemented; the shipped fine-tune "
+                    "configs freeze it (MODEL.PROPOSAL_GENERATOR.FREEZE)")
+            flist = [feats[f] for f in self.in_features]
+            fused = self.rpn_head.forward_nhwc(flist)
+            A = self.rpn_head.num_anchors
+            N = fused[0].shape[0]
+            flat_logits = torch.cat([f[..., :A].reshape(N, -1) for f in fused], 1)
+            flat_deltas = torch.cat([f[..., A:5 * A].reshape(N, -1, 4) for f in fused], 1)
+            anchors = torch.cat(self.anchor_generator._grid_anchors([f.shape[1:3] for f in flist]), 0)
+            gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)
+            losses = self.losses(anchors, flat_logits, gt_labels, flat_deltas, gt_boxes)
         boxes, logits, count = self.predict_proposals_batched(feats, sizes)
         counts = count.tolist()  # the one host sync of this entry point
         out = []
@@ -123,4 +178,4 @@ class RPN(nn.Module):
             inst.proposal_boxes = Boxes(boxes[i, : counts[i]])
             inst.objectness_logits = logits[i, : counts[i]]
             out.append(inst)
-        return out, {}
+        return out, losses

@@ -103,3 +103,54 @@ class CosineSimOutputLayers(_OutputLayersBase):
         scores = K.linear(xn, self._cos.get([w], build))
         deltas = self.bbox_pred(x)
         return scores, deltas
+
+
+class _PredictorLoss(torch.autograd.Function):
+    """FastRCNNOutputLayers forward + FastRCNNOutputs.losses (reference fast_rcnn.py:267-279, 296-359, 424-438) as one
+    differentiable op: forward = fused cls|bbox GEMM + lvc_fast_rcnn_losses (which also emits dlogits/ddeltas);
+    backward = dW = dY^T X on the same MFMA GEMM kernel, db = column sums.  Inputs `x` must not require grad (the
+    shipped fine-tune configs freeze everything below the predictor)."""
+
+    @staticmethod
+    def forward(ctx, x, wc, bc, wb, bb, proposals, gt_boxes, gt_classes, layer):
+        scores, deltas = layer(x)
+        out, dl, dd = K.fast_rcnn_losses(scores, deltas, proposals, gt_boxes, gt_classes, layer.num_classes,
+                                         layer.box2box_transform.weights, layer.smooth_l1_beta)
+        ctx.save_for_backward(x, dl, dd)
+        ctx.has_bias = (bc is not None, bb is not None)
+        pred = scores.argmax(dim=1)
+        ctx.mark_non_differentiable(pred)
+        return out[0], out[1], pred
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, _g_pred):
+        x, dl, dd = ctx.saved_tensors
+        R = x.shape[0]
+        pad = (-R) % 32  # the GEMM contracts over R: multiple of the 32-wide k chunk
+        xt = torch.zeros(x.shape[1], R + pad, device=x.device)
+        xt[:, :R] = x.t()
+        pc = K.pack_linear(xt)
+
+        def dweight(dy, g):
+            dyt = torch.zeros(dy.shape[1], R + pad, device=x.device)
+            dyt[:, :R] = (dy * g).t()
+            return K.linear(dyt, pc)  # [K_out, K_in]
+
+        dwc, dwb = dweight(dl, g_cls), dweight(dd, g_box)
+        dbc = (dl * g_cls).sum(0) if ctx.has_bias[0] else None
+        dbb = (dd * g_box).sum(0) if ctx.has_bias[1] else None
+        return None, dwc, dbc, dwb, dbb, None, None, None, None
+
+
+def fast_rcnn_losses(layer, x, proposals, gt_boxes, gt_classes):
+    """-> ({"loss_cls", "loss_box_reg"}, predicted classes) for a FastRCNNOutputLayers `layer`."""
+    if not isinstance(layer, FastRCNNOutputLayers):
+        raise NotImplementedError("training of {} is not implemented".format(type(layer).__name__))
+    if x.requires_grad:
+        raise NotImplementedError("backward below the box predictor is not implemented (set ROI_HEADS.FREEZE_FEAT)")
+    if layer.box_reg_loss_type != "smooth_l1":
+        raise NotImplementedError("ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE '{}'".format(layer.box_reg_loss_type))
+    lc, lb, pred = _PredictorLoss.apply(x, layer.cls_score.weight, layer.cls_score.bias, layer.bbox_pred.weight,
+                                         layer.bbox_pred.bias, proposals, gt_boxes, gt_classes, layer)
+    lw = layer.loss_weight
+    return {"loss_cls": lc * lw.get("loss_cls", 1.0), "loss_box_reg": lb * lw.get("loss_box_reg", 1.0)}, pred

@@ -12,8 +12,11 @@ from ... import kernels as K
 from ...layers import ShapeSpec
 from ...layers.layout import require_device, to_nhwc
 from ...structures import Boxes, Instances
+from ...utils.events import get_event_storage
 from ...utils.registry import Registry
 from ..box_regression import Box2BoxTransform
+from ..matcher import Matcher
+from ..sampling import subsample_labels
 from ..poolers import ROIPooler
 from .box_head import build_box_head
 from .fast_rcnn import ROI_HEADS_OUTPUT_REGISTRY
@@ -46,6 +49,61 @@ class ROIHeads(nn.Module):
         self.ignore_reg = RH.IGNORE_REG
         self.iou_thresholds, self.iou_labels = RH.IOU_THRESHOLDS, RH.IOU_LABELS
         self.box2box_transform = Box2BoxTransform(weights=BH.BBOX_REG_WEIGHTS)
+        self.proposal_matcher = Matcher(RH.IOU_THRESHOLDS, RH.IOU_LABELS, allow_low_quality_matches=False)
+
+    def _sample_proposals(self, matched_idxs, matched_labels, gt_classes, inference=False):
+        """reference lvc roi_heads.py:129-171."""
+        if gt_classes.numel() > 0:
+            gt_classes = gt_classes[matched_idxs]
+            gt_classes[matched_labels == 0] = self.num_classes
+            gt_classes[matched_labels == -1] = -1
+        else:
+            gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
+        fg, bg = subsample_labels(gt_classes, self.batch_size_per_image, self.positive_sample_fraction, self.num_classes,
+                                  inference)
+        sampled = torch.cat([fg, bg], dim=0)
+        return sampled, gt_classes[sampled]
+
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets, inference=False):
+        """reference lvc roi_heads.py:173-278: append GT, match (IoU kernel), gt_ignores toggle, subsample."""
+        out, num_fg, num_bg = [], [], []
+        for prop, tgt in zip(proposals, targets):
+            gt = tgt.gt_boxes.tensor
+            pboxes, plogits = prop.proposal_boxes.tensor, prop.objectness_logits
+            if self.proposal_append_gt:  # add_ground_truth_to_proposals: logit = log((1-1e-10)/(1-(1-1e-10)))
+                import math
+
+                gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+                pboxes = torch.cat([pboxes, gt], 0)
+                plogits = torch.cat([plogits, gt_logit * torch.ones(len(gt), device=gt.device)], 0)
+            matched_idxs, matched_labels = self.proposal_matcher.match(gt, pboxes)
+            if tgt.has("gt_ignores") and bool(tgt.gt_ignores.bool().sum()):
+                from ...structures import pairwise_iou
+
+                ig = tgt.gt_ignores.bool()
+                max_ig = pairwise_iou(Boxes(gt[ig]), Boxes(pboxes)).max(dim=0)[0]
+                matched_labels[max_ig > self.proposal_matcher.thresholds[1]] = -1
+            sampled, gt_classes = self._sample_proposals(matched_idxs, matched_labels, tgt.gt_classes, inference)
+            inst = Instances(prop.image_size)
+            inst.proposal_boxes = Boxes(pboxes[sampled])
+            inst.objectness_logits = plogits[sampled]
+            inst.gt_classes = gt_classes
+            if len(gt) > 0:
+                st = matched_idxs[sampled]
+                for name, val in tgt.get_fields().items():
+                    if name.startswith("gt_") and not inst.has(name):
+                        inst.set(name, val[st])
+            else:
+                inst.gt_boxes = Boxes(gt.new_zeros((len(sampled), 4)))
+            num_bg.append(int((gt_classes == self.num_classes).sum()))
+            num_fg.append(gt_classes.numel() - num_bg[-1])
+            out.append(inst)
+        if not inference:
+            storage = get_event_storage()
+            storage.put_scalar("roi_head/num_fg_samples", sum(num_fg) / max(1, len(num_fg)))
+            storage.put_scalar("roi_head/num_bg_samples", sum(num_bg) / max(1, len(num_bg)))
+        return out
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -86,8 +144,10 @@ class StandardROIHeads(ROIHeads):
 
     def forward(self, images, features, proposals, targets=None):
         """Reference signature (roi_heads.py:554-572): -> (list[Instances], losses)."""
-        if self.training or self.rbg:
-            raise NotImplementedError("ROI-head training / RBG evaluation is not implemented in lvc_amd round 1")
+        if self.rbg:
+            raise NotImplementedError("RBG (box-corrector) evaluation is not implemented in lvc_amd round 1")
+        if self.training:
+            return self._forward_train(features, proposals, targets)
         feats = {f: to_nhwc(features[f]) for f in self.in_features}
         dev = feats[self.in_features[0]].device
         require_device(feats[self.in_features[0]], "StandardROIHeads")
@@ -101,6 +161,43 @@ class StandardROIHeads(ROIHeads):
         ob, osc, ocl, orow, cnt = self.forward_batched(feats, boxes, torch.tensor(counts, dtype=torch.int32, device=dev),
                                                        sizes, status=status)
         return instances_from_batched(ob, osc, ocl, cnt, [p.image_size for p in proposals], status), {}
+
+
+def _forward_train(self, features, proposals, targets):
+    """StandardROIHeads training branch (reference roi_heads.py:554-629 + FastRCNNOutputs.losses)."""
+    from .fast_rcnn import fast_rcnn_losses
+
+    proposals = self.label_and_sample_proposals(proposals, targets)
+    feats = [to_nhwc(features[f]) for f in self.in_features]
+    dev = feats[0].device
+    counts = [len(p) for p in proposals]
+    B, R = len(proposals), max(max(counts), 1)
+    boxes = torch.zeros(B, R, 4, device=dev)
+    for i, p in enumerate(proposals):
+        boxes[i, : counts[i]] = p.proposal_boxes.tensor
+    with torch.no_grad():
+        pooled = self.box_pooler.pool_nhwc(feats, boxes)
+        if any(p.requires_grad for p in self.box_head.parameters()):
+            raise NotImplementedError("training the box head is not implemented (set MODEL.ROI_HEADS.FREEZE_FEAT)")
+        h = self.box_head.forward_nhwc(pooled)
+        keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
+        h = h[keep].contiguous()
+    pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+    gb = torch.cat([p.gt_boxes.tensor for p in proposals], 0)
+    gc = torch.cat([p.gt_classes for p in proposals], 0)
+    losses, pred = fast_rcnn_losses(self.box_predictor, h, pb, gb, gc)
+    # accuracy scalars (reference fast_rcnn.py _log_accuracy)
+    storage = get_event_storage()
+    fg = (gc >= 0) & (gc < self.num_classes)
+    nfg = int(fg.sum())
+    storage.put_scalar("fast_rcnn/cls_accuracy", float((pred == gc).sum()) / max(1, gc.numel()))
+    if nfg > 0:
+        storage.put_scalar("fast_rcnn/fg_cls_accuracy", float((pred[fg] == gc[fg]).sum()) / nfg)
+        storage.put_scalar("fast_rcnn/false_negative", float((pred[fg] == self.num_classes).sum()) / nfg)
+    return proposals, losses
+
+
+StandardROIHeads._forward_train = _forward_train
 
 
 def instances_from_batched(boxes, scores, classes, count, image_sizes, status=None):

@@ -280,10 +280,56 @@ def gen_knn():
          q_classes=torch.cat(dcls), **res)
 
 
+def gen_train():
+    """BASELINE config 3 (novel fine-tune): loss dict + the 4 trainable gradients for a fixed 2-image batch.
+    torch.randperm is patched to the identity permutation so that the sampled anchors / proposals are the FIRST
+    num_pos positives and num_neg negatives (the product test applies the same patch)."""
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/faster_rcnn_R_50_FPN_ft_novel_30shot.yaml")
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    g = torch.Generator().manual_seed(11)
+    batch = []
+    gts = {}
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        n = 5 + i
+        x1 = torch.rand(n, generator=g) * (w - 80)
+        y1 = torch.rand(n, generator=g) * (h - 80)
+        bw = 30 + torch.rand(n, generator=g) * 120
+        bh = 30 + torch.rand(n, generator=g) * 100
+        boxes = torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
+        classes = torch.randint(0, 20, (n,), generator=g)
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(boxes)
+        inst.gt_classes = classes
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "height": h, "width": w})
+        gts["gt_boxes%d" % i] = boxes
+        gts["gt_classes%d" % i] = classes
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    try:
+        with EventStorage(0) as storage:
+            losses = model(batch)
+            total = sum(losses.values())
+            total.backward()
+            scalars = {k: float(v[0]) if isinstance(v, tuple) else float(v) for k, v in storage.latest().items()}
+    finally:
+        torch.randperm = real
+    grads = {"grad." + n: p.grad for n, p in model.named_parameters() if p.requires_grad}
+    assert len(grads) == 4
+    print("  losses", {k: float(v) for k, v in losses.items()}, scalars)
+    save("train_novel_ft", **gts, **{"loss." + k: v.detach() for k, v in losses.items()}, **grads,
+         **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()
