@@ -144,6 +144,33 @@ int lvc_fast_rcnn_inference(const float* cls_logits, int ld_cls, const float* de
                             int* out_rows, int* d_out_count, int* d_status, void* workspace,
                             long long workspace_bytes, void* stream);
 
+/* One class-agnostic cascade stage of the box corrector: BoxOnlyLayersCascade.predict_boxes
+ * (lvc/modeling/roi_heads/roi_heads_cascade.py:197-211) + the clip of _create_proposals_from_boxes
+ * (cascade_rcnn.py:348-369).  deltas [M, ld] (4 used), boxes [M,4] = B images x R rows, d_image_sizes [B,2] or NULL. */
+int lvc_decode_boxes(const float* deltas, int ld, const float* boxes, int M, int R, const int* d_image_sizes,
+                     float wx, float wy, float ww, float wh, float scale_clamp, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Training-time kernels of the fine-tune step (BASELINE config 3; only the box predictor trains).
+ * lvc_match_boxes: pairwise_iou (detectron2/structures/boxes.py:315-347) + Matcher (modeling/matcher.py:61-126)
+ *   without materialising the G x N matrix.  gt [G,4] (1..512), boxes [N,4]; thresholds t0 (,t1), labels l0,l1(,l2);
+ *   outputs matches [N] int64 (first arg-max), labels [N] int8, matched_vals [N]; d_gt_best [G] uint32 scratch.
+ * lvc_fast_rcnn_losses: FastRCNNOutputs.losses (lvc/modeling/roi_heads/fast_rcnn.py:267-279, 296-359): mean softmax CE
+ *   and smooth-L1(sum)/R, plus d(loss)/d(logits) [R,K+1] and d(loss)/d(deltas) [R,4K|4].  gt_classes int64, K = bg.
+ * lvc_rpn_losses: RPN.losses (proposal_generator/rpn.py:328-400) over S sampled anchors, forward only:
+ *   out = (BCE-with-logits sum, smooth-L1 sum over positives) / normalizer.
+ */
+int lvc_match_boxes(const float* gt, int G, const float* boxes, int N, float t0, float t1, int nthr, int l0, int l1,
+                    int l2, int allow_low_quality, long long* matches, signed char* labels, float* matched_vals,
+                    unsigned int* d_gt_best, void* stream);
+int lvc_fast_rcnn_losses(const float* logits, int ld_cls, const float* deltas, int ld_delta, int K, int cls_agnostic,
+                         const float* proposals, const float* gt_boxes, const long long* gt_classes, int R, float wx,
+                         float wy, float ww, float wh, float smooth_l1_beta, float* out_losses, float* dlogits,
+                         float* ddeltas, void* stream);
+int lvc_rpn_losses(const float* logits, const float* deltas, const float* anchors, const float* gt_boxes,
+                   const signed char* labels, int S, float smooth_l1_beta, float normalizer, float* out_losses,
+                   void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Label-verification kNN (tools/run_nearest_neighbours.py:142-162, 214-227).
  * lvc_colmean: mu[d] = mean_m x[m,d].  lvc_knn_topk_vote: per query row, class ids of the 10 most similar

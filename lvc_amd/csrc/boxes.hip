@@ -546,3 +546,38 @@ extern "C" int lvc_fast_rcnn_inference(const float* cls_logits, int ld_cls, cons
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+// =====================================================================================
+// Class-agnostic decode + clip (one cascade stage of the box corrector):
+// BoxOnlyLayersCascade.predict_boxes (lvc/modeling/roi_heads/roi_heads_cascade.py:197-211) followed by the clip of
+// CascadeROIHeads._create_proposals_from_boxes (cascade_rcnn.py:348-369) / fast_rcnn_inference_single_image.
+// =====================================================================================
+__global__ void decode_boxes_kernel(const float* __restrict__ deltas, int ld, const float* __restrict__ boxes, int M,
+                                    int R, const int* __restrict__ image_sizes, float wx, float wy, float ww, float wh,
+                                    float scale_clamp, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float4 b = *reinterpret_cast<const float4*>(boxes + (size_t)i * 4);
+  const float* d = deltas + (size_t)i * ld;
+  float o[4];
+  apply_deltas(b.x, b.y, b.z, b.w, d[0], d[1], d[2], d[3], wx, wy, ww, wh, scale_clamp, o);
+  if (image_sizes) {
+    const int img = i / R;
+    const float h = (float)image_sizes[img * 2], w = (float)image_sizes[img * 2 + 1];
+    o[0] = clampf(o[0], 0.f, w); o[1] = clampf(o[1], 0.f, h); o[2] = clampf(o[2], 0.f, w); o[3] = clampf(o[3], 0.f, h);
+  }
+  float4 r = {o[0], o[1], o[2], o[3]};
+  *reinterpret_cast<float4*>(out + (size_t)i * 4) = r;
+}
+
+// deltas [M, ld] (first 4 columns used), boxes [M,4] = B images x R rows, d_image_sizes [B,2] (h,w) or NULL (no clip).
+extern "C" int lvc_decode_boxes(const float* deltas, int ld, const float* boxes, int M, int R, const int* d_image_sizes,
+                                float wx, float wy, float ww, float wh, float scale_clamp, float* out, void* stream) {
+  LVC_CHECK_ARG(M >= 0 && R > 0 && ld >= 4, "bad shape");
+  if (M == 0) return LVC_OK;
+  LVC_CHECK_ARG(deltas && boxes && out, "null pointer");
+  hipLaunchKernelGGL(decode_boxes_kernel, dim3(lvc_cdiv(M, 256)), dim3(256), 0, (hipStream_t)stream, deltas, ld, boxes, M, R,
+                     d_image_sizes, wx, wy, ww, wh, scale_clamp, out);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

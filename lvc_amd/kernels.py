@@ -489,3 +489,18 @@ def rpn_losses(logits, deltas, anchors, gt_boxes, labels, smooth_l1_beta, normal
                                    c_float(normalizer), ptr(out), _stream(logits))
     check(rc, "lvc_rpn_losses")
     return out
+
+
+def decode_boxes(deltas, boxes, weights, image_sizes=None):
+    """Class-agnostic apply_deltas (+ clip to the row's image): deltas [B*R, >=4], boxes [B,R,4] -> [B,R,4]."""
+    _req_cuda(deltas, boxes, image_sizes)
+    B, R, _ = boxes.shape
+    boxes = boxes.contiguous()
+    out = torch.empty_like(boxes)
+    assert deltas.stride(1) == 1 and deltas.shape[0] == B * R
+    wx, wy, ww, wh = weights
+    rc = _lib.lib().lvc_decode_boxes(ptr(deltas), c_int(deltas.stride(0)), ptr(boxes), c_int(B * R), c_int(R), ptr(image_sizes),
+                                     c_float(wx), c_float(wy), c_float(ww), c_float(wh), c_float(SCALE_CLAMP), ptr(out),
+                                     _stream(boxes))
+    check(rc, "lvc_decode_boxes")
+    return out

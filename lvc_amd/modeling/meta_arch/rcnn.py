@@ -188,3 +188,29 @@ class ProposalNetwork(_RCNNBase):
         for r, inp, size in zip(proposals, batched_inputs, images.image_sizes):
             processed.append({"proposals": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})
         return processed
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNNRegOnly(GeneralizedRCNN):
+    """Box-corrector inference over given (box, class) pseudo-labels (reference rcnn.py:336-410): every input dict
+    carries `instances` with `gt_boxes` / `gt_classes`; the output is the same dict with `pred_boxes` (corrected,
+    rescaled to height/width, empty boxes dropped) and `pred_classes` set on its instances, `image` removed."""
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        assert not self.training
+        if detected_instances is not None:
+            raise NotImplementedError("forward_with_given_boxes is not on the box-only path")
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        results, _ = self.roi_heads(images, features, None, gt_instances)
+        processed = []
+        for res, inp, size in zip(results, batched_inputs, images.image_sizes):
+            inst = inp["instances"].to(self.device)
+            inst.set("pred_boxes", res.pred_boxes)
+            inst.set("pred_classes", inst.gt_classes)
+            h, w = inp.get("height", size[0]), inp.get("width", size[1])
+            inp["instances"] = detector_postprocess(inst, h, w)
+            del inp["image"]
+            processed.append(inp)
+        return processed

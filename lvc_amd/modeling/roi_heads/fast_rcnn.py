@@ -105,6 +105,42 @@ class CosineSimOutputLayers(_OutputLayersBase):
         return scores, deltas
 
 
+class _BoxOnlyBase(nn.Module):
+    """Box-corrector output layer: one Linear(input, 4) (reference lvc/modeling/roi_heads/roi_heads_cascade.py:26-78
+    BoxOnlyLayers, :80-211 BoxOnlyLayersCascade).  forward -> (num_classes, deltas [M,4])."""
+
+    def __init__(self, cfg, input_shape, box2box_transform=None):
+        super().__init__()
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        self.bbox_pred = Linear(input_size, 4)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        nn.init.constant_(self.bbox_pred.bias, 0)
+        self.box2box_transform = box2box_transform or Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS)
+        self.lambda_ = cfg.MODEL.UBBR.LAMBDA
+        self.iterate = cfg.MODEL.ROI_HEADS.NAME != "CascadeROIHeads"
+
+    def forward(self, x):
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        return self.num_classes, self.bbox_pred(x.contiguous())
+
+    def losses(self, predictions, proposals):
+        raise NotImplementedError("box-corrector training (GIoU loss + backward through the trunk) is not implemented")
+
+
+@ROI_HEADS_OUTPUT_REGISTRY.register()
+class BoxOnlyLayers(_BoxOnlyBase):
+    pass
+
+
+@ROI_HEADS_OUTPUT_REGISTRY.register()
+class BoxOnlyLayersCascade(_BoxOnlyBase):
+    pass
+
+
 class _PredictorLoss(torch.autograd.Function):
     """FastRCNNOutputLayers forward + FastRCNNOutputs.losses (reference fast_rcnn.py:267-279, 296-359, 424-438) as one
     differentiable op: forward = fused cls|bbox GEMM + lvc_fast_rcnn_losses (which also emits dlogits/ddeltas);

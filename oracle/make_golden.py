@@ -326,10 +326,47 @@ def gen_train():
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
 
 
+def gen_box_corrector():
+    """Box-corrector inference over given pseudo-labels: GeneralizedRCNNRegOnly + CascadeROIHeads._forward_box_qe
+    (cascade_ubbr yaml with META_ARCHITECTURE switched, as tools/train_net_reg_qe.py does)."""
+    from detectron2.structures import Boxes, Instances
+
+    cfg, model = build_ref_model("COCO-detection/cascade_ubbr_R_50_FPN_base.yaml",
+                                 ["MODEL.META_ARCHITECTURE", "GeneralizedRCNNRegOnly"])
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
+    model.load_state_dict(sd, strict=True)
+    save("cascade_state_dict_keys", keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+    g = torch.Generator().manual_seed(21)
+    batch, d = [], {}
+    for i, (h, w, seed, oh, ow) in enumerate([(240, 320, 3, 480, 640), (200, 352, 4, 200, 352)]):
+        n = 12 + 3 * i
+        x1 = torch.rand(n, generator=g) * (w - 60)
+        y1 = torch.rand(n, generator=g) * (h - 60)
+        bw = 8 + torch.rand(n, generator=g).pow(2) * 250
+        bh = 8 + torch.rand(n, generator=g).pow(2) * 180
+        boxes = torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
+        classes = torch.randint(0, 60, (n,), generator=g)
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(boxes.clone())
+        inst.gt_classes = classes
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "height": oh, "width": ow})
+        d["in_boxes%d" % i] = boxes
+        d["in_classes%d" % i] = classes
+    with torch.no_grad():
+        out = model(batch)
+    for i, o in enumerate(out):
+        d["out_boxes%d" % i] = o["instances"].pred_boxes.tensor
+        d["out_classes%d" % i] = o["instances"].pred_classes
+        print("  image", i, "in", len(d["in_boxes%d" % i]), "out", len(d["out_boxes%d" % i]),
+              "mean |shift|", float((d["out_boxes%d" % i][: len(d["in_boxes%d" % i])] - 0).abs().mean()))
+    save("box_corrector", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()
