@@ -1,0 +1,415 @@
+// conv_bf16x3.hip -- fp32-accurate NHWC convolution / GEMM on the bf16 matrix cores (3-way operand split).
+//
+// Same contract, GEMM view, stream-K decomposition and epilogue as conv_igemm.hip (which stays the exact fp32 path
+// and serves the stem and the 64-channel layers).  The difference is the inner product: gfx950 has no TF32-like
+// mode, and fp32-input MFMA runs at 1/16 of the bf16 rate, so every fp32 operand is split exactly into three bf16
+// values
+//        a = a1 + a2 + a3,   a1 = bf16(a), a2 = bf16(a - a1), a3 = bf16(a - a1 - a2)      (8 + 8 + 8 mantissa bits)
+// and the product is assembled from the six bf16 MFMAs whose weight is >= 2^-16 of the leading term,
+//        a*b  ~=  a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1)                  (dropped: a2b3 + a3b2 + a3b3 <= 3 * 2^-24 |ab|),
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Each bf16 x bf16 product is exact in fp32, the accumulator rounds
+// once per 16-deep MFMA instead of once per product, so the result is as close to the exact dot product as the fp32
+// FMA chain of conv_igemm.hip (tests/test_gpu_kernels.py checks both against the same CPU oracle tolerance and
+// tests/test_gpu_e2e.py::test_trunk_error_vs_fp64 checks the whole trunk against an fp64 evaluation).
+// Cost: 6 bf16 MFMAs (6 x 32 cycles) per 32x32x16 block instead of 8 fp32 MFMAs (8 x 64 cycles): 2.67x fewer
+// matrix-pipe cycles; effective peak = 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent work.
+//
+// Weights are split once on the host into three bf16 planes [3][Kpad][Kg]; activations stay fp32 in HBM and are
+// split on the fly when a staged chunk is written to LDS (LDS holds bf16 planes, k-contiguous rows of 32 + 8 pad).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LROW 40          // bf16 elements per LDS row (32 + 8 pad = 80 B: conflict-free ds_read_b128)
+#define PLANE_A (BM * LROW)
+#define PLANE_B (BN * LROW)
+#define SPIN_LIMIT (1 << 24)
+
+struct ConvArgsB {
+  const float* x;
+  const unsigned short* w;   // [3][Kpad][Kg] bf16 planes
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  float* partials;
+  int* flags;
+  int N, H, W, C, K, R, S, stride, pad, Ho, Wo, M, Kg, relu, res_mode, ldy, ldr;
+  int tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
+  int x_bytes, w_plane_bytes;   // bytes of the input tensor / of ONE weight plane
+};
+
+__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)a;
+  const float r1 = a - (float)h;
+  m = (__bf16)r1;
+  const float r2 = r1 - (float)m;
+  l = (__bf16)r2;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
+  constexpr int STAGE_ELEMS = 3 * (PLANE_A + PLANE_B);                 // bf16 elements per buffer
+  constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;                      // double buffered
+  constexpr int CS_STRIDE = BN + 4;
+  constexpr int CS_BYTES = BM * CS_STRIDE * 4;
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  __bf16* stage = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;        // float4 slot of the A chunk row
+  const int row0 = tid >> 3;    // A rows row0 + 32*j
+
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 3 * p.w_plane_bytes, 0x00020000);
+
+  // fragment read offsets (bf16 elements) inside a plane: row (tile-local) * LROW + fh*8 (+ 16 per k16 step)
+  const int a_frag = (wm * 64 + fi) * LROW + fh * 8;
+  const int b_frag = (wn * 64 + fi) * LROW + fh * 8;
+  // B staging: 16-byte pieces; per plane 128 rows x 4 pieces = 512 -> 2 per thread
+  const int b_row[2] = {(tid) >> 2, (tid + 256) >> 2};
+  const int b_q4 = tid & 3;
+
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int kc0 = u - tile * p.nk;
+    const int kc1 = min(p.nk, kc0 + (u_end - u));
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    unsigned a_off[4], a_msk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + row0 + 32 * j;
+      const bool okm = m < p.M;
+      const int mm = okm ? m : 0;
+      const int n = mm / (p.Ho * p.Wo);
+      const int rem = mm - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      const int bh = ho * p.stride - p.pad, bw = wo * p.stride - p.pad;
+      a_off[j] = (unsigned)(((n * p.H + bh) * p.W + bw) * p.C + q * 4) * 4u;
+      unsigned msk = 0;
+      if (okm)
+        for (int r = 0; r < p.R; ++r)
+          for (int s2 = 0; s2 < p.S; ++s2)
+            if (bh + r >= 0 && bh + r < p.H && bw + s2 >= 0 && bw + s2 < p.W) msk |= 1u << (r * p.S + s2);
+      a_msk[j] = msk;
+    }
+    unsigned b_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b_off[j] = (unsigned)((n0 + b_row[j]) * p.Kg + b_q4 * 8) * 2u;
+
+    int ld_kc = kc0, ld_c, ld_r, ld_s;
+    {
+      const int RS = p.R * p.S;
+      ld_c = kc0 / RS;
+      const int rs0 = kc0 - ld_c * RS;
+      ld_r = rs0 / p.S;
+      ld_s = rs0 - ld_r * p.S;
+    }
+    f32x4 areg[4];
+    u32x4 breg[3][2];
+    auto load_next = [&]() {
+      const int rs = ld_r * p.S + ld_s;
+      const int coff = ((ld_r * p.W + ld_s) * p.C + ld_c * BK) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned vo = ((a_msk[j] >> rs) & 1u) ? a_off[j] + (unsigned)coff : 0x80000000u;
+        areg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vo, 0, 0));
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          breg[pl][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                      wres, b_off[j] + (unsigned)(pl * p.w_plane_bytes), ld_kc * (BK * 2), 0));
+      if (ld_kc + 1 < kc1) {
+        ++ld_kc;
+        if (++ld_s == p.S) { ld_s = 0; if (++ld_r == p.R) { ld_r = 0; ++ld_c; } }
+      }
+    };
+    auto store_chunk = [&](int buf) {
+      __bf16* sa = stage + buf * STAGE_ELEMS;
+      __bf16* sb = sa + 3 * PLANE_A;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x4 h, m, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          __bf16 hh, mm, ll;
+          split3(areg[j][e], hh, mm, ll);
+          h[e] = hh; m[e] = mm; l[e] = ll;
+        }
+        const int o = (row0 + 32 * j) * LROW + q * 4;
+        *reinterpret_cast<bf16x4*>(sa + o) = h;
+        *reinterpret_cast<bf16x4*>(sa + PLANE_A + o) = m;
+        *reinterpret_cast<bf16x4*>(sa + 2 * PLANE_A + o) = l;
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row[j] * LROW + b_q4 * 8) = breg[pl][j];
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    // One barrier per chunk, placed between the two k16 groups; everything else rides in the MFMA shadow:
+    //   group 0: 24 MFMA(s=0) | ds_read frags(s=1) | split + ds_write of chunk kc+1 into the idle buffer
+    //   barrier  (reads of this buffer issued+waited, writes of the other buffer visible)
+    //   group 1: 24 MFMA(s=1) | ds_read frags(s=0 of chunk kc+1, other buffer) | buffer_load of chunk kc+2
+    bf16x8 fa[2][2][3], fb[2][2][3];   // [frag buffer][mi|ni][plane]
+    auto read_frags = [&](int sel, const __bf16* sa, const __bf16* sb, int s2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fa[sel][mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * PLANE_A + a_frag + mi * 32 * LROW + s2 * 16);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fb[sel][ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + ni * 32 * LROW + s2 * 16);
+    };
+    auto mfma_group = [&](int sel) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          f32x16 c = acc[mi][ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][0], fb[sel][ni][2], c, 0, 0, 0);  // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][2], fb[sel][ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][1], fb[sel][ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][0], fb[sel][ni][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][1], fb[sel][ni][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][0], fb[sel][ni][0], c, 0, 0, 0);
+          acc[mi][ni] = c;
+        }
+    };
+
+    load_next();
+    store_chunk(0);
+    load_next();
+    __syncthreads();
+    int cur = 0;
+    read_frags(0, stage, stage + 3 * PLANE_A, 0);
+    for (int kc = kc0; kc < kc1; ++kc) {
+      const __bf16* sa = stage + cur * STAGE_ELEMS;
+      const __bf16* sb = sa + 3 * PLANE_A;
+      const __bf16* san = stage + (cur ^ 1) * STAGE_ELEMS;
+      const __bf16* sbn = san + 3 * PLANE_A;
+      // ---- group 0
+      read_frags(1, sa, sb, 1);
+      store_chunk(cur ^ 1);
+      mfma_group(0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);        // the 12 fragment reads first
+#pragma unroll
+      for (int i = 0; i < 18; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);       // ~6 VALU of the operand split
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // 1 DS write
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      // ---- group 1
+      read_frags(0, san, sbn, 0);
+      load_next();
+      mfma_group(1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 12, 1);
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);       // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);       // 1 VMEM read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      cur ^= 1;
+    }
+    __syncthreads();
+    u += kc1 - kc0;
+
+    // ---- split tiles (same protocol as conv_igemm.hip)
+    if (kc0 != 0) {
+      float* dst = p.partials + (size_t)lw * (256 * 64);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * 2 + ni) * 4 + e4) * 256 + tid) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (kc1 < p.nk) {
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int last_worker = last_unit / p.units_per_worker;
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (256 * 64);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * 2 + ni) * 4 + e4) * 256 + tid) * 4);
+              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
+              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
+            }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- epilogue through LDS (identical to conv_igemm.hip)
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int col = wn * 64 + ni * 32 + fi;
+          Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = 256 / C4;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    if (col < p.K) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+      for (int it = 0; it < BM / RPI; ++it) {
+        const int r = it * RPI + rsub;
+        const int row = m0 + r;
+        if (row < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+          v = v * sc + sh;
+          if (p.res_mode == 1) {
+            v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+          } else if (p.res_mode == 2) {
+            int n = row / (p.Ho * p.Wo);
+            int rem = row - n * (p.Ho * p.Wo);
+            int ho = rem / p.Wo;
+            int wo = rem - ho * p.Wo;
+            size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+          }
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+#define LVC_MAX_WORKERS 1024
+static int g_cus = 0;
+
+// Same argument meaning as lvc_conv2d_nhwc_f32 (mode 0 only) except `w_split`: three bf16 planes [3][Kpad][Kg]
+// (hi, mid, lo parts of the packed fp32 weights, k order (c/32, r, s, c%32)).  Requires K % 4 == 0, ldy % 4 == 0,
+// ldr % 4 == 0.  workspace: the lvc_conv_workspace_bytes() scratch shared with the fp32 kernel.
+extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_split, const float* scale,
+                                      const float* shift, const float* residual, float* y, int N, int H, int W, int C,
+                                      int K, int R, int S, int stride, int pad, int Kg, int relu, int res_mode, int ldy,
+                                      int ldr, void* workspace, void* stream) {
+  LVC_CHECK_ARG(x && w_split && y && workspace, "null pointer");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
+  LVC_CHECK_ARG(C % BK == 0 && Kg == R * S * C, "needs C % 32 == 0 and Kg == R*S*C");
+  LVC_CHECK_ARG(R * S <= 32, "at most 32 taps");
+  LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
+  int Ho = (H + 2 * pad - R) / stride + 1;
+  int Wo = (W + 2 * pad - S) / stride + 1;
+  LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
+  if (res_mode == 2) LVC_CHECK_ARG(Ho % 2 == 0 && Wo % 2 == 0, "upsample-add needs even output size");
+  ConvArgsB a;
+  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+  a.Ho = Ho; a.Wo = Wo;
+  long long Mll = (long long)N * Ho * Wo;
+  LVC_CHECK_ARG(Mll < (1ll << 31), "too many output pixels");
+  a.M = (int)Mll; a.Kg = Kg; a.relu = relu; a.res_mode = res_mode;
+  a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
+  LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
+  LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                    ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
+  a.tiles_n = lvc_cdiv(K, BN);
+  const int tiles_m = lvc_cdiv(a.M, BM);
+  a.nk = Kg / BK;
+  long long units = (long long)tiles_m * a.tiles_n * a.nk;
+  LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
+  a.total_units = (int)units;
+  const long long xb = (long long)N * H * W * C * 4, wb = (long long)(a.tiles_n * BN) * Kg * 2;
+  LVC_CHECK_ARG(xb < (1ll << 31) && 3 * wb < (1ll << 31), "input / weight tensor must be smaller than 2 GiB");
+  a.x_bytes = (int)xb; a.w_plane_bytes = (int)wb;
+  if (g_cus == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    g_cus = cus;
+  }
+  int cap = g_cus;  // one worker per CU: 120 KB of LDS per workgroup
+  if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
+  const int min_units = 4;
+  int workers = (int)((units + min_units - 1) / min_units);
+  if (workers > cap) workers = cap;
+  a.units_per_worker = (int)((units + workers - 1) / workers);
+  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker);
+  a.partials = (float*)workspace;
+  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
+  a.err_index = LVC_MAX_WORKERS;
+  hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(a.nworkers), dim3(256), 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

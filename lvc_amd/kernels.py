@@ -33,11 +33,22 @@ class PackedConv:
     scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
     """
 
-    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode")
+    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3")
 
     def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
         self.w, self.scale, self.shift = w, scale, shift
         self.K, self.C, self.R, self.S, self.stride, self.pad, self.Kg, self.mode = K, C, R, S, stride, pad, Kg, mode
+        self._w3 = None
+
+    def split3(self):
+        """[3, Kpad, Kg] bf16 planes (hi, mid, lo) of the packed weights: w == hi + mid + lo exactly."""
+        if self._w3 is None:
+            hi = self.w.to(torch.bfloat16)
+            r1 = self.w - hi.float()
+            mid = r1.to(torch.bfloat16)
+            lo = (r1 - mid.float()).to(torch.bfloat16)
+            self._w3 = torch.stack([hi, mid, lo]).contiguous()
+        return self._w3
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False):
@@ -124,6 +135,12 @@ class LaunchTimer:
 
 
 CONV_TIMER = None  # set to a LaunchTimer to instrument lvc_conv2d_nhwc_f32 launches
+# Inner-product engine of the conv/GEMM layers with >= 128 output channels:
+#   "bf16x3" = fp32-accurate 3-way bf16 operand split on the bf16 matrix cores (csrc/conv_bf16x3.hip)
+#   "f32"    = v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip); always used for the stem and the 64-channel layers
+import os as _os
+
+CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "f32")
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -146,13 +163,22 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    st = _lib.lib().lvc_conv2d_nhwc_f32(
-        ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
-        c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
-        c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
-        c_int(out.shape[-1]), c_int(residual.shape[-1] if residual is not None else 0),
-        c_int(pc.mode), ptr(conv_workspace(x.device)), _stream(x))
-    check(st, "lvc_conv2d_nhwc_f32")
+    ldr = residual.shape[-1] if residual is not None else 0
+    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K > 64 and pc.K % 4 == 0 and out.shape[-1] % 4 == 0
+            and ldr % 4 == 0):
+        st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
+            ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+            c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
+            c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
+            c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+        check(st, "lvc_conv2d_nhwc_bf16x3")
+    else:
+        st = _lib.lib().lvc_conv2d_nhwc_f32(
+            ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+            c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
+            c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
+            c_int(out.shape[-1]), c_int(ldr), c_int(pc.mode), ptr(conv_workspace(x.device)), _stream(x))
+        check(st, "lvc_conv2d_nhwc_f32")
     if timer is not None:
         e1.record()
         c_real = 3 if pc.mode == 1 else C
