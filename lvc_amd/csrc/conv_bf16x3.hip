@@ -55,7 +55,8 @@ __device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l)
   l = (__bf16)r2;
 }
 
-__global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
+#define NT 512   // 8 waves: two per SIMD, one workgroup (120 KB of LDS) per CU
+__global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(ConvArgsB p) {
   constexpr int STAGE_ELEMS = 3 * (PLANE_A + PLANE_B);                 // bf16 elements per buffer
   constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;                      // double buffered
   constexpr int CS_STRIDE = BN + 4;
@@ -67,10 +68,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: 64 (M) x 32 (N)
   const int fi = lane & 31, fh = lane >> 5;
   const int q = tid & 7;        // float4 slot of the A chunk row
-  const int row0 = tid >> 3;    // A rows row0 + 32*j
+  // staged row of this thread: consecutive 8-lane groups take rows r and r+4 (not r+1): with the 80-byte row pitch
+  // two rows 4 apart sit exactly half a bank cycle (64 B) apart, so the 16-lane ds_write_b64 / 8-lane ds_write_b128
+  // groups are conflict-free (rows r, r+1 overlap by 16 B -> every staging store took two LDS passes;
+  // SQ_LDS_BANK_CONFLICT 2.4e8 -> 0 on the p2 3x3)
+  const int arid = tid >> 3;
+  const int row0 = (arid & 1) * 4 + ((arid >> 1) & 3) + (arid >> 3) * 8;    // A rows row0 + 64*j, j = 0,1
 
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
   int u = lw * p.units_per_worker;
@@ -81,9 +87,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
 
   // fragment read offsets (bf16 elements) inside a plane: row (tile-local) * LROW + fh*8 (+ 16 per k16 step)
   const int a_frag = (wm * 64 + fi) * LROW + fh * 8;
-  const int b_frag = (wn * 64 + fi) * LROW + fh * 8;
-  // B staging: 16-byte pieces; per plane 128 rows x 4 pieces = 512 -> 2 per thread
-  const int b_row[2] = {(tid) >> 2, (tid + 256) >> 2};
+  const int b_frag = (wn * 32 + fi) * LROW + fh * 8;
+  // B staging: 16-byte pieces; per plane 128 rows x 4 pieces = 512 -> 1 per thread
+  const int brid = tid >> 2;
+  const int b_row = (brid & 1) * 4 + ((brid >> 1) & 3) + (brid >> 3) * 8;
   const int b_q4 = tid & 3;
 
   while (u < u_end) {
@@ -95,10 +102,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
-    unsigned a_off[4], a_msk[4];
+    unsigned a_off[2], a_msk[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + row0 + 32 * j;
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + row0 + 64 * j;
       const bool okm = m < p.M;
       const int mm = okm ? m : 0;
       const int n = mm / (p.Ho * p.Wo);
@@ -114,9 +121,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
             if (bh + r >= 0 && bh + r < p.H && bw + s2 >= 0 && bw + s2 < p.W) msk |= 1u << (r * p.S + s2);
       a_msk[j] = msk;
     }
-    unsigned b_off[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) b_off[j] = (unsigned)((n0 + b_row[j]) * p.Kg + b_q4 * 8) * 2u;
+    const unsigned b_off = (unsigned)((n0 + b_row) * p.Kg + b_q4 * 8) * 2u;
 
     int ld_kc = kc0, ld_c, ld_r, ld_s;
     {
@@ -126,22 +131,20 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
       ld_r = rs0 / p.S;
       ld_s = rs0 - ld_r * p.S;
     }
-    f32x4 areg[4];
-    u32x4 breg[3][2];
+    f32x4 areg[2];
+    u32x4 breg[3];
     auto load_next = [&]() {
       const int rs = ld_r * p.S + ld_s;
       const int coff = ((ld_r * p.W + ld_s) * p.C + ld_c * BK) * 4;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         const unsigned vo = ((a_msk[j] >> rs) & 1u) ? a_off[j] + (unsigned)coff : 0x80000000u;
         areg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, vo, 0, 0));
       }
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          breg[pl][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                      wres, b_off[j] + (unsigned)(pl * p.w_plane_bytes), ld_kc * (BK * 2), 0));
+        breg[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wres, b_off + (unsigned)(pl * p.w_plane_bytes), ld_kc * (BK * 2), 0));
       if (ld_kc + 1 < kc1) {
         ++ld_kc;
         if (++ld_s == p.S) { ld_s = 0; if (++ld_r == p.R) { ld_r = 0; ++ld_c; } }
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
       __bf16* sa = stage + buf * STAGE_ELEMS;
       __bf16* sb = sa + 3 * PLANE_A;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 2; ++j) {
         bf16x4 h, m, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -159,31 +162,27 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
           split3(areg[j][e], hh, mm, ll);
           h[e] = hh; m[e] = mm; l[e] = ll;
         }
-        const int o = (row0 + 32 * j) * LROW + q * 4;
+        const int o = (row0 + 64 * j) * LROW + q * 4;
         *reinterpret_cast<bf16x4*>(sa + o) = h;
         *reinterpret_cast<bf16x4*>(sa + PLANE_A + o) = m;
         *reinterpret_cast<bf16x4*>(sa + 2 * PLANE_A + o) = l;
       }
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row[j] * LROW + b_q4 * 8) = breg[pl][j];
+        *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row * LROW + b_q4 * 8) = breg[pl];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][1];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[a][0][e] = 0.f;
 
     // One barrier per chunk, placed between the two k16 groups; everything else rides in the MFMA shadow:
     //   group 0: 24 MFMA(s=0) | ds_read frags(s=1) | split + ds_write of chunk kc+1 into the idle buffer
     //   barrier  (reads of this buffer issued+waited, writes of the other buffer visible)
     //   group 1: 24 MFMA(s=1) | ds_read frags(s=0 of chunk kc+1, other buffer) | buffer_load of chunk kc+2
-    bf16x8 fa[2][2][3], fb[2][2][3];   // [frag buffer][mi|ni][plane]
+    bf16x8 fa[2][2][3], fb[2][1][3];   // [frag buffer][mi|ni][plane]
     auto read_frags = [&](int sel, const __bf16* sa, const __bf16* sb, int s2) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -191,16 +190,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
         for (int pl = 0; pl < 3; ++pl)
           fa[sel][mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * PLANE_A + a_frag + mi * 32 * LROW + s2 * 16);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          fb[sel][ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + ni * 32 * LROW + s2 * 16);
+      for (int pl = 0; pl < 3; ++pl)
+        fb[sel][0][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + s2 * 16);
     };
     auto mfma_group = [&](int sel) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < 1; ++ni) {
           f32x16 c = acc[mi][ni];
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][0], fb[sel][ni][2], c, 0, 0, 0);  // smallest terms first
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][2], fb[sel][ni][0], c, 0, 0, 0);
@@ -227,27 +224,27 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
       read_frags(1, sa, sb, 1);
       store_chunk(cur ^ 1);
       mfma_group(0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);        // the 12 fragment reads first
+      __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);         // the 9 fragment reads first
 #pragma unroll
-      for (int i = 0; i < 18; ++i) {
+      for (int i = 0; i < 9; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);       // ~6 VALU of the operand split
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // 1 DS write
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       // ---- group 1
       read_frags(0, san, sbn, 0);
       load_next();
       mfma_group(1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 9, 1);
 #pragma unroll
-      for (int i = 0; i < 10; ++i) {
+      for (int i = 0; i < 5; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);       // 2 MFMA
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);       // 1 VMEM read
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 1);
       __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
     }
@@ -256,16 +253,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
 
     // ---- split tiles (same protocol as conv_igemm.hip)
     if (kc0 != 0) {
-      float* dst = p.partials + (size_t)lw * (256 * 64);
+      float* dst = p.partials + (size_t)lw * (NT * 32);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) {
-            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
-            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * 2 + ni) * 4 + e4) * 256 + tid) * 4) = v;
-          }
+        for (int e4 = 0; e4 < 4; ++e4) {
+          f32x4 v = {acc[mi][0][e4 * 4 + 0], acc[mi][0][e4 * 4 + 1], acc[mi][0][e4 * 4 + 2], acc[mi][0][e4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(dst + ((size_t)(mi * 4 + e4) * NT + tid) * 4) = v;
+        }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
@@ -288,17 +283,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        const float* src = p.partials + (size_t)pw * (256 * 64);
+        const float* src = p.partials + (size_t)pw * (NT * 32);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * 2 + ni) * 4 + e4) * 256 + tid) * 4);
-              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
-              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
-            }
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(mi * 4 + e4) * NT + tid) * 4);
+            acc[mi][0][e4 * 4 + 0] += v[0]; acc[mi][0][e4 * 4 + 1] += v[1];
+            acc[mi][0][e4 * 4 + 2] += v[2]; acc[mi][0][e4 * 4 + 3] += v[3];
+          }
         __syncthreads();
         if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -309,16 +302,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3_kernel(ConvArgsB p) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const int col = wn * 64 + ni * 32 + fi;
-          Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
-        }
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int col = wn * 32 + fi;
+        Cs[row * CS_STRIDE + col] = acc[mi][0][e];
+      }
     __syncthreads();
     constexpr int C4 = BN / 4;
-    constexpr int RPI = 256 / C4;
+    constexpr int RPI = NT / C4;
     const int c4 = tid % C4, rsub = tid / C4;
     const int col = n0 + c4 * 4;
     if (col < p.K) {
@@ -409,7 +400,7 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(a.nworkers), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
