@@ -58,6 +58,15 @@ int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const float* scal
                         int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, int mode,
                         void* workspace, void* stream);
 
+/* Same layer contract on the bf16 matrix cores with fp32-level accuracy (csrc/conv_bf16x3.hip): every fp32 operand is
+ * split exactly into three bf16 values and the product assembled from six v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
+ * w_split: [3][Kpad][Kg] bf16 planes (hi, mid, lo) of the packed weights of lvc_conv2d_nhwc_f32 mode 0.
+ * Requires C % 32 == 0, K % 4 == 0, ldy % 4 == 0, ldr % 4 == 0.  Same workspace as lvc_conv2d_nhwc_f32. */
+int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                           const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
+                           int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
+                           void* stream);
+
 /* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
  * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero
  * outside h x w.  image: CHW, dtype 0 = fp32, 1 = uint8.  mean3/std3 are [host] arrays of 3 floats. */

@@ -125,13 +125,14 @@ class LaunchTimer:
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
     def __init__(self):
-        self.records = []  # (algorithmic flops, start event, end event)
+        self.records = []  # (algorithmic flops, start event, end event, engine)
 
-    def flops_and_ms(self):
+    def flops_and_ms(self, engine=None):
         torch.cuda.synchronize()
-        fl = sum(r[0] for r in self.records)
-        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return fl, ms, len(self.records)
+        recs = [r for r in self.records if engine is None or r[3] == engine]
+        fl = sum(r[0] for r in recs)
+        ms = sum(r[1].elapsed_time(r[2]) for r in recs)
+        return fl, ms, len(recs)
 
 
 CONV_TIMER = None  # set to a LaunchTimer to instrument lvc_conv2d_nhwc_f32 launches
@@ -140,7 +141,7 @@ CONV_TIMER = None  # set to a LaunchTimer to instrument lvc_conv2d_nhwc_f32 laun
 #   "f32"    = v_mfma_f32_32x32x2_f32 (csrc/conv_igemm.hip); always used for the stem and the 64-channel layers
 import os as _os
 
-CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "f32")
+CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "bf16x3")
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -164,8 +165,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     ldr = residual.shape[-1] if residual is not None else 0
+    engine = "f32"
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K > 64 and pc.K % 4 == 0 and out.shape[-1] % 4 == 0
             and ldr % 4 == 0):
+        engine = "bf16x3"
         st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
             ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
             c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
@@ -182,7 +185,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     if timer is not None:
         e1.record()
         c_real = 3 if pc.mode == 1 else C
-        timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1))
+        timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1, engine))
     return out
 
 
