@@ -20,7 +20,7 @@ shutil.copy(so, so + ".orig")
 try:
     for a in sys.argv[1:]:
         shutil.copy(os.path.join(ROOT, "build", "ablate", "lib_%s.so" % a), so)
-        for per in ("2", "1"):
+        for per in ("2",):
             print("ABLATE=%s workers/CU=%s" % (a, per), flush=True)
             subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LVC_CONV_WORKERS_PER_CU=per))
 finally:
