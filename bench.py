@@ -42,10 +42,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)  # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    assert world == args.gpus, "launch with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`"
 
     from lvc_amd import kernels as K
     from lvc_amd.config.presets import base_rcnn_fpn
@@ -65,7 +66,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -85,7 +86,7 @@ def main():
     n_det = out[3].tolist()
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_max = float(tmax.item())
     total_imgs = world * BATCH_PER_GPU * args.steps
@@ -158,7 +159,7 @@ def main():
                        "detections_per_image": n_det},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
