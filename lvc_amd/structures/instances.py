@@ -1,113 +1,108 @@
 """`Instances`: per-image field container returned by the detector (fields `pred_boxes`, `scores`,
 `pred_classes`) and by the RPN (`proposal_boxes`, `objectness_logits`).
 
-Contract restated from reference detectron2/structures/instances.py:7-185: attribute access is field
-access; `set()` asserts that every field has the same length; indexing applies to every field;
-`len()` of an empty Instances raises; `cat` concatenates tensors / lists / types with `.cat` and
-asserts equal image_size; `.to()` maps every field that has `.to`.
+Behavioural contract restated from reference detectron2/structures/instances.py:7-185:
+  * attribute access is field access (names not starting with "_"); unknown field -> AttributeError;
+  * every field must have the same `len` as the fields already present (AssertionError otherwise);
+  * indexing / masking applies to every field and returns a new Instances; an int index keeps length 1;
+  * `len()` of an Instances without fields raises NotImplementedError; iteration is refused;
+  * `Instances.cat` needs equal `image_size` and joins tensors (torch.cat), lists (+) and any type exposing a
+    `cat` classmethod (e.g. Boxes); `.to()` forwards to every field that has `.to`.
 """
-import itertools
-
 import torch
 
 
-class Instances:
-    def __init__(self, image_size, **kwargs):
-        self._image_size = image_size
-        self._fields = {}
-        for k, v in kwargs.items():
-            self.set(k, v)
+def _join(values):
+    head = values[0]
+    if torch.is_tensor(head):
+        return torch.cat(values, dim=0)
+    if isinstance(head, list):
+        merged = []
+        for v in values:
+            merged.extend(v)
+        return merged
+    joiner = getattr(type(head), "cat", None)
+    if joiner is None:
+        raise ValueError("Unsupported type {} for concatenation".format(type(head)))
+    return joiner(values)
 
+
+class Instances:
+    def __init__(self, image_size, **fields):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_fields", {})
+        for name, value in fields.items():
+            self.set(name, value)
+
+    # ---- field protocol -----------------------------------------------------------------------
     @property
     def image_size(self):
         return self._image_size
 
-    def __setattr__(self, name, val):
-        if name.startswith("_"):
-            super().__setattr__(name, val)
-        else:
-            self.set(name, val)
+    def __setattr__(self, name, value):
+        if name[:1] == "_":
+            object.__setattr__(self, name, value)
+            return
+        self.set(name, value)
 
     def __getattr__(self, name):
-        if name == "_fields" or name not in self._fields:
+        fields = self.__dict__.get("_fields")
+        if fields is None or name not in fields:
             raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
-        return self._fields[name]
+        return fields[name]
 
     def set(self, name, value):
-        data_len = len(value)
-        if len(self._fields):
-            assert len(self) == data_len, "Adding a field of length {} to a Instances of length {}".format(
-                data_len, len(self))
+        n = len(value)
+        if self._fields:
+            assert n == len(self), "Adding a field of length {} to a Instances of length {}".format(n, len(self))
         self._fields[name] = value
 
     def has(self, name):
         return name in self._fields
 
-    def remove(self, name):
-        del self._fields[name]
-
     def get(self, name):
         return self._fields[name]
+
+    def remove(self, name):
+        self._fields.pop(name)
 
     def get_fields(self):
         return self._fields
 
-    def to(self, *args, **kwargs):
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            if hasattr(v, "to"):
-                v = v.to(*args, **kwargs)
-            ret.set(k, v)
-        return ret
-
-    def __getitem__(self, item):
-        if type(item) == int:
-            if item >= len(self) or item < -len(self):
-                raise IndexError("Instances index out of range!")
-            item = slice(item, None, len(self))
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v[item])
-        return ret
-
+    # ---- container protocol -------------------------------------------------------------------
     def __len__(self):
-        for v in self._fields.values():
-            return len(v)
-        raise NotImplementedError("Empty Instances does not support __len__!")
+        if not self._fields:
+            raise NotImplementedError("Empty Instances does not support __len__!")
+        return len(next(iter(self._fields.values())))
 
     def __iter__(self):
         raise NotImplementedError("`Instances` object is not iterable!")
 
+    def __getitem__(self, item):
+        if type(item) is int:
+            n = len(self)
+            if not -n <= item < n:
+                raise IndexError("Instances index out of range!")
+            item = slice(item, None, n)  # keeps a leading dimension of 1
+        return Instances(self._image_size, **{k: v[item] for k, v in self._fields.items()})
+
+    def to(self, *args, **kwargs):
+        moved = {k: (v.to(*args, **kwargs) if hasattr(v, "to") else v) for k, v in self._fields.items()}
+        return Instances(self._image_size, **moved)
+
     @staticmethod
     def cat(instance_lists):
-        assert all(isinstance(i, Instances) for i in instance_lists)
-        assert len(instance_lists) > 0
+        assert len(instance_lists) > 0 and all(isinstance(i, Instances) for i in instance_lists)
+        first = instance_lists[0]
         if len(instance_lists) == 1:
-            return instance_lists[0]
-        image_size = instance_lists[0].image_size
-        for i in instance_lists[1:]:
-            assert i.image_size == image_size
-        ret = Instances(image_size)
-        for k in instance_lists[0]._fields.keys():
-            values = [i.get(k) for i in instance_lists]
-            v0 = values[0]
-            if isinstance(v0, torch.Tensor):
-                values = torch.cat(values, dim=0)
-            elif isinstance(v0, list):
-                values = list(itertools.chain(*values))
-            elif hasattr(type(v0), "cat"):
-                values = type(v0).cat(values)
-            else:
-                raise ValueError("Unsupported type {} for concatenation".format(type(v0)))
-            ret.set(k, values)
-        return ret
+            return first
+        assert all(i.image_size == first.image_size for i in instance_lists[1:])
+        return Instances(first.image_size,
+                         **{k: _join([i.get(k) for i in instance_lists]) for k in first.get_fields()})
 
-    def __str__(self):
-        s = self.__class__.__name__ + "("
-        s += "num_instances={}, ".format(len(self))
-        s += "image_height={}, ".format(self._image_size[0])
-        s += "image_width={}, ".format(self._image_size[1])
-        s += "fields=[{}])".format(", ".join("{}: {}".format(k, v) for k, v in self._fields.items()))
-        return s
+    def __repr__(self):
+        body = ", ".join("{}: {}".format(k, v) for k, v in self._fields.items())
+        return "Instances(num_instances={}, image_height={}, image_width={}, fields=[{}])".format(
+            len(self), self._image_size[0], self._image_size[1], body)
 
-    __repr__ = __str__
+    __str__ = __repr__
