@@ -136,3 +136,32 @@ def test_uint8_input_and_registry_surface():
         a = model([{"image": img.to(torch.uint8)}])[0]["instances"]
         b = model([{"image": img}])[0]["instances"]
     assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+
+
+def test_r101_trunk_matches_oracle():
+    """R101-FPN (BASELINE config 5 backbone): the trunk kernels are depth-agnostic; pin res4's 23 blocks against the
+    CPU oracle on a small image (uncalibrated FrozenBN -> large activations, so compare relative to the level's max)."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+
+    model = build_model(base_rcnn_fpn(depth=101)).eval()
+    cpu_sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sd = syn.conditioned_state_dict(cpu_sd, seed=3)
+    for k in sd:  # tame the residual growth without a calibration pass
+        if k.endswith("conv3.norm.weight"):
+            sd[k] = sd[k] * 0.3
+    model.load_state_dict(sd, strict=True)
+    assert sum(1 for k in sd if k.startswith("backbone.bottom_up.res4.") and k.endswith("conv1.weight")) == 23
+    inputs = [{"image": syn.synthetic_image(5, 128, 160)}]
+    spec = orc.RCNNSpec(depth=101)
+    with torch.no_grad():
+        imgs, _ = orc.preprocess([b["image"] for b in inputs], spec.pixel_mean, spec.pixel_std, 32)
+        ref = orc.fpn(sd, orc.resnet(sd, imgs, 101))
+        got = model.backbone(model.preprocess_image(inputs).tensor)
+    for k in ref:
+        s = float(ref[k].abs().max())
+        err = float((got[k].cpu() - ref[k]).abs().max()) / s
+        print(k, "relative error", err)
+        assert err <= 2e-4, k

@@ -210,3 +210,31 @@ def test_nms_empty():
     d = _dev()
     out = k.nms(torch.zeros(0, 4, device=d), torch.zeros(0, device=d), 0.5)
     assert out.numel() == 0 and out.dtype == torch.int64
+
+
+def test_c_abi_argument_errors_raise_runtime_error():
+    """Bad shapes come back as status 1 + message -> RuntimeError (reference: AT_ASSERTM -> RuntimeError)."""
+    from lvc_amd import kernels as k
+    from lvc_amd._lib import LvcNativeError
+
+    d = _dev()
+    w = torch.randn(64, 48, 1, 1, device=d)
+    with pytest.raises(AssertionError):
+        k.pack_conv(w)                       # in_channels % 32 != 0 is rejected while packing
+    pc = k.pack_conv(torch.randn(64, 64, 1, 1, device=d))
+    with pytest.raises(AssertionError):
+        k.conv2d_nhwc(torch.randn(1, 4, 4, 32, device=d), pc)   # channel mismatch
+    with pytest.raises(LvcNativeError, match="Nmax > 16384"):
+        k.batched_nms_batch(torch.zeros(1, 20000, 4, device=d), torch.zeros(1, 20000, device=d), None, None, 0.5)
+    assert issubclass(LvcNativeError, RuntimeError)
+
+
+def test_roi_align_negative_size_sets_status():
+    from lvc_amd import kernels as k
+    from lvc_amd.modeling.roi_heads.roi_heads import check_status
+
+    d = _dev()
+    st = k.new_status(d)
+    k.roi_align_forward(torch.zeros(1, 4, 8, 8, device=d), torch.tensor([[0, 5, 5, 2, 2.0]], device=d), 1.0, 7, 7, 0, True, status=st)
+    with pytest.raises(RuntimeError, match="non-negative size"):
+        check_status(int(st.item()))
