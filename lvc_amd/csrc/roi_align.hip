@@ -16,6 +16,7 @@
 // NCHW op signature through explicit strides (lane = channel is then strided; that entry point is a
 // drop-in convenience, the engine uses NHWC).
 #include "common.h"
+#include <stdlib.h>
 
 #define LVC_MAX_LEVELS 8
 
@@ -184,8 +185,115 @@ __global__ __launch_bounds__(64) void roi_align_fwd_nhwc4_kernel(RoiAlignArgs p)
   }
 }
 
+// NHWC LDS-staged path: one 512-thread workgroup per (RoI, output row ph), 256 channels (wave = bin, lane = 4 channels).  The feature window that
+// the 7 bins of that output row can touch -- rows [floor(y_first), floor(y_last)+1] x columns [floor(x_first),
+// floor(x_last)+1] -- is copied ONCE into LDS with fully coalesced 1-KiB pixel segments (64 lanes x dwordx4), then
+// every thread (bin pw = tid/64, 4 channels = tid%64) walks its bin's samples reading the four bilinear taps from
+// LDS (a wave reads one contiguous 1-KiB pixel: conflict-free ds_read_b128).  A small RoI touches each
+// feature pixel ~10 times (49 bins x g^2 samples x 4 taps over <= 9x9 pixels); after staging it is fetched from
+// L2/HBM once per output row (~3 rows each), which cuts the L2 read volume by ~3x.  Windows larger than
+// ROI_LDS_MAX_PIX pixels (very elongated boxes) take the direct-from-L2 loop: same arithmetic, same order.
+#define ROI_LDS_MAX_PIX 40
+__global__ __launch_bounds__(512) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArgs p) {
+  __shared__ __attribute__((aligned(16))) float win[ROI_LDS_MAX_PIX * 256];
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x / p.ph;
+  const int ph = blockIdx.x - k * p.ph;
+  const int cbase = blockIdx.y * 256;
+  const int cq = tid & 63, bin = tid >> 6;   // bin = pw (8 slots, p.pw <= 8 used)
+  const float* r = p.rois + (long long)k * 5;
+  const int lvl = p.levels ? p.levels[k] : 0;
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float spatial_scale = p.scale[lvl];
+  const int b = (int)r[0];
+  const float offset = p.aligned ? 0.5f : 0.0f;
+  const float roi_start_w = r[1] * spatial_scale - offset;
+  const float roi_start_h = r[2] * spatial_scale - offset;
+  const float roi_end_w = r[3] * spatial_scale - offset;
+  const float roi_end_h = r[4] * spatial_scale - offset;
+  float roi_width = roi_end_w - roi_start_w;
+  float roi_height = roi_end_h - roi_start_h;
+  if (p.aligned) {
+    if (!(roi_width >= 0 && roi_height >= 0)) {
+      if (p.status && tid == 0 && blockIdx.y == 0 && ph == 0) atomicOr(p.status, 1);
+    }
+  } else {
+    roi_width = roi_width > 1.f ? roi_width : 1.f;
+    roi_height = roi_height > 1.f ? roi_height : 1.f;
+  }
+  const float bin_h = roi_height / (float)p.ph;
+  const float bin_w = roi_width / (float)p.pw;
+  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_height / (float)p.ph);
+  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_width / (float)p.pw);
+  const int cnt = gh * gw > 1 ? gh * gw : 1;
+  const float count = (float)cnt;
+  const long long C = p.C;
+  const float* in = p.feat[lvl] + (long long)b * p.sb[lvl] + cbase + cq * 4;
+
+  // window of this output row (conservative: every tap of every in-range sample lies inside)
+  const float yf = roi_start_h + ph * bin_h, yl = roi_start_h + (ph + 1) * bin_h;
+  int y0 = (int)floorf(fmaxf(yf, 0.f)), y1 = (int)floorf(fmaxf(yl, 0.f)) + 1;
+  int x0 = (int)floorf(fmaxf(roi_start_w, 0.f)), x1 = (int)floorf(fmaxf(roi_start_w + roi_width, 0.f)) + 1;
+  y0 = min(y0, H - 1); y1 = min(y1, H - 1); x0 = min(x0, W - 1); x1 = min(x1, W - 1);
+  const int nrows = y1 - y0 + 1, ncols = x1 - x0 + 1;
+  const bool staged = (nrows > 0) && (ncols > 0) && (nrows * ncols <= ROI_LDS_MAX_PIX) && (cbase + 256 <= p.C);
+  if (staged) {
+    const int npix = nrows * ncols;
+    for (int px = bin; px < npix; px += 8) {   // 8 pixels per pass, one wave (64 lanes x 16 B) each
+      const int yy = px / ncols, xx = px - yy * ncols;
+      const float4 v = *reinterpret_cast<const float4*>(in + (long long)((y0 + yy) * W + x0 + xx) * C);
+      *reinterpret_cast<float4*>(win + px * 256 + cq * 4) = v;
+    }
+    __syncthreads();
+  }
+  if (bin >= p.pw || cbase + cq * 4 >= p.C) return;
+  const int pw = bin;
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int iy = 0; iy < gh; ++iy) {
+    const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+    for (int ix = 0; ix < gw; ++ix) {
+      const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+      float x = xx, y = yy;
+      if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+      if (y <= 0) y = 0;
+      if (x <= 0) x = 0;
+      int y_low = (int)y, x_low = (int)x, y_high, x_high;
+      if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+      if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+      const float ly = y - y_low, lx = x - x_low;
+      const float hy = 1.f - ly, hx = 1.f - lx;
+      const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+      float4 v1, v2, v3, v4;
+      if (staged) {
+        const float* wb = win + cq * 4;
+        v1 = *reinterpret_cast<const float4*>(wb + ((y_low - y0) * ncols + (x_low - x0)) * 256);
+        v2 = *reinterpret_cast<const float4*>(wb + ((y_low - y0) * ncols + (x_high - x0)) * 256);
+        v3 = *reinterpret_cast<const float4*>(wb + ((y_high - y0) * ncols + (x_low - x0)) * 256);
+        v4 = *reinterpret_cast<const float4*>(wb + ((y_high - y0) * ncols + (x_high - x0)) * 256);
+      } else {
+        v1 = *reinterpret_cast<const float4*>(in + (long long)(y_low * W + x_low) * C);
+        v2 = *reinterpret_cast<const float4*>(in + (long long)(y_low * W + x_high) * C);
+        v3 = *reinterpret_cast<const float4*>(in + (long long)(y_high * W + x_low) * C);
+        v4 = *reinterpret_cast<const float4*>(in + (long long)(y_high * W + x_high) * C);
+      }
+      acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+      acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+      acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+      acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+    }
+  }
+  float4 o = {acc.x / count, acc.y / count, acc.z / count, acc.w / count};
+  *reinterpret_cast<float4*>(p.out + (long long)k * p.so_k + ph * p.so_h + pw * p.so_w + cbase + cq * 4) = o;
+}
+
 static int launch(RoiAlignArgs& a, void* stream) {
   if (a.K == 0) return LVC_OK;
+  if (a.nhwc && (a.C & 255) == 0 && a.pw <= 8 && a.num_valid == nullptr && a.so_c == 1 && !getenv("LVC_ROI_DIRECT")) {
+    dim3 gridl(a.K * a.ph, a.C / 256), blockl(512);
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_lds_kernel, gridl, blockl, 0, (hipStream_t)stream, a);
+    LVC_CHECK_LAUNCH();
+    return LVC_OK;
+  }
   if (a.nhwc && (a.C & 3) == 0 && a.num_valid == nullptr && a.so_c == 1) {
     dim3 grid4(a.K * a.ph * a.pw, lvc_cdiv(a.C, 256)), block4(64);
     hipLaunchKernelGGL(roi_align_fwd_nhwc4_kernel, grid4, block4, 0, (hipStream_t)stream, a);
