@@ -29,6 +29,19 @@ def _freeze(module):
 
 
 class _RCNNBase(nn.Module):
+    def _dev_const(self, values, dtype):
+        """Small per-batch constants (image sizes, post-process scales) as cached device tensors: the same shapes
+        recur every batch, the H2D copy happens once, and the forward stays capturable in a hipGraph."""
+        cache = self.__dict__.setdefault("_const_cache", {})
+        key = (dtype, tuple(tuple(v) for v in values))
+        t = cache.get(key)
+        if t is None or t.device.type != torch.device(self.device).type:
+            if len(cache) > 256:
+                cache.clear()
+            t = torch.tensor([list(v) for v in values], dtype=dtype, device=self.device)
+            cache[key] = t
+        return t
+
     def _init_common(self, cfg):
         self.device = torch.device(cfg.MODEL.DEVICE)
         assert len(cfg.MODEL.PIXEL_MEAN) == len(cfg.MODEL.PIXEL_STD)
@@ -119,7 +132,7 @@ class GeneralizedRCNN(_RCNNBase):
         images = self.preprocess_image(batched_inputs)
         sizes = images.image_sizes
         dev = self.device
-        sizes_dev = torch.tensor([list(s) for s in sizes], dtype=torch.int32, device=dev)
+        sizes_dev = self._dev_const(sizes, torch.int32)
         N, _, Hp, Wp = images.tensor.shape
         x4 = images.tensor.as_strided((N, Hp, Wp, 4), (Hp * Wp * 4, Wp * 4, 4, 1), images.tensor.storage_offset())
         feats = self.backbone.forward_nhwc(x4)
@@ -130,7 +143,7 @@ class GeneralizedRCNN(_RCNNBase):
             for inp, (h, w) in zip(batched_inputs, sizes):
                 oh, ow = inp.get("height", h), inp.get("width", w)
                 rows.append([ow / w, oh / h, float(oh), float(ow)])
-            post = torch.tensor(rows, dtype=torch.float32, device=dev)
+            post = self._dev_const(rows, torch.float32)
         status = K.new_status(dev)
         ob, osc, ocl, _orow, cnt = self.roi_heads.forward_batched(feats, pboxes, pcount, sizes_dev, post=post, status=status)
         return ob, osc, ocl, cnt, status
