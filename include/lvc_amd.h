@@ -77,6 +77,12 @@ int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float
 int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
                        void* stream);
 
+/* Descriptor crops (lvc/data/utils.py:485-519 get_crops_qe): zero-pad the box window to a square and resize to
+ * out_size x out_size with F.interpolate(mode='nearest').  image [C,H,W]; d_windows [K,8] int32 =
+ * (x1,y1,x2,y2 inclusive, l_pad, t_pad, side_w, side_h) (integer bookkeeping done by the host); out [K,C,out,out]. */
+int lvc_crop_resize_nearest(const float* image_chw, int C, int H, int W, const int* d_windows, int K, int out_size,
+                            float* out, void* stream);
+
 /* Row-wise (x - mu) / den; den = |x-mu| + eps (mode 0, CosineSimOutputLayers fast_rcnn.py:822-833) or
  * max(|x-mu|, eps) (mode 1, F.cosine_similarity as used by tools/run_nearest_neighbours.py:150-153). */
 int lvc_rownorm(const float* x, const float* mu, float* y, int M, int D, int ldx, int ldy, float eps, int mode,

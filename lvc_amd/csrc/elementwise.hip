@@ -113,3 +113,44 @@ extern "C" int lvc_rownorm(const float* x, const float* mu, float* y, int M, int
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+// Context / pad crops for the label-verification descriptors: reference
+// lvc/data/utils.py:485-519 get_padding + get_crops_qe: the box window (already widened / clamped on the host, which
+// is integer bookkeeping) is zero-padded to a square and resized to out x out with F.interpolate(mode='nearest'),
+// i.e. src = min(floor(dst * in/out), in-1) with the scale held in fp32.
+// win[k] = (x1, y1, x2, y2, l_pad, t_pad, side_w, side_h) int32, inclusive window.
+__global__ void crop_resize_nearest_kernel(const float* __restrict__ img, int C, int H, int W, const int* __restrict__ win,
+                                           int K, int out, float* __restrict__ y) {
+  const long long total = (long long)K * C * out * out;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % out);
+    long long t = i / out;
+    const int oy = (int)(t % out); t /= out;
+    const int c = (int)(t % C);
+    const int k = (int)(t / C);
+    const int* w = win + k * 8;
+    const int side_w = w[6], side_h = w[7];
+    const float sx = (float)side_w / (float)out, sy = (float)side_h / (float)out;
+    int px = (int)floorf((float)ox * sx), py = (int)floorf((float)oy * sy);
+    px = px < side_w - 1 ? px : side_w - 1;
+    py = py < side_h - 1 ? py : side_h - 1;
+    const int xx = px - w[4] + w[0], yy = py - w[5] + w[1];
+    float v = 0.f;
+    if (xx >= w[0] && xx <= w[2] && yy >= w[1] && yy <= w[3]) v = img[((long long)c * H + yy) * W + xx];
+    y[i] = v;
+  }
+}
+
+extern "C" int lvc_crop_resize_nearest(const float* image_chw, int C, int H, int W, const int* d_windows, int K, int out_size,
+                                       float* out, void* stream) {
+  LVC_CHECK_ARG(K >= 0 && C > 0 && H > 0 && W > 0 && out_size > 0, "bad shape");
+  if (K == 0) return LVC_OK;
+  LVC_CHECK_ARG(image_chw && d_windows && out, "null pointer");
+  const long long total = (long long)K * C * out_size * out_size;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipLaunchKernelGGL(crop_resize_nearest_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, image_chw, C, H, W,
+                     d_windows, K, out_size, out);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

@@ -142,6 +142,7 @@ CONV_TIMER = None  # set to a LaunchTimer to instrument lvc_conv2d_nhwc_f32 laun
 import os as _os
 
 CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "bf16x3")
+_BF16X3_MIN_K = int(_os.environ.get("LVC_BF16X3_MIN_K", "128"))
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -166,7 +167,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         e0.record()
     ldr = residual.shape[-1] if residual is not None else 0
     engine = "f32"
-    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K > 64 and pc.K % 4 == 0 and out.shape[-1] % 4 == 0
+    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= _BF16X3_MIN_K and pc.K % 4 == 0 and out.shape[-1] % 4 == 0
             and ldr % 4 == 0):
         engine = "bf16x3"
         st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
@@ -532,4 +533,18 @@ def decode_boxes(deltas, boxes, weights, image_sizes=None):
                                      c_float(wx), c_float(wy), c_float(ww), c_float(wh), c_float(SCALE_CLAMP), ptr(out),
                                      _stream(boxes))
     check(rc, "lvc_decode_boxes")
+    return out
+
+
+def crop_resize_nearest(image, windows, out_size=224):
+    """image [C,H,W] fp32 device; windows [K,8] int32 device (x1,y1,x2,y2,l_pad,t_pad,side_w,side_h) -> [K,C,out,out]."""
+    _req_cuda(image, windows)
+    C, H, W = image.shape
+    Kn = windows.shape[0]
+    image = image.contiguous().float()
+    assert windows.dtype == torch.int32 and windows.is_contiguous()
+    out = torch.empty(Kn, C, out_size, out_size, device=image.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_crop_resize_nearest(ptr(image), c_int(C), c_int(H), c_int(W), ptr(windows), c_int(Kn), c_int(out_size),
+                                            ptr(out), _stream(image))
+    check(rc, "lvc_crop_resize_nearest")
     return out

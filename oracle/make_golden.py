@@ -363,10 +363,31 @@ def gen_box_corrector():
     save("box_corrector", **d)
 
 
+def gen_crops():
+    from detectron2.structures import Boxes, Instances
+    from lvc.data.utils import get_crops_qe
+
+    g = torch.Generator().manual_seed(31)
+    img = syn.synthetic_image(7, 300, 420)[None]
+    boxes = []
+    for _ in range(12):
+        x1 = int(torch.randint(0, 380, (1,), generator=g)); y1 = int(torch.randint(0, 260, (1,), generator=g))
+        w = int(torch.randint(3, 200, (1,), generator=g)); h = int(torch.randint(3, 150, (1,), generator=g))
+        boxes.append([x1, y1, min(x1 + w, 419), min(y1 + h, 299)])
+    boxes += [[0, 0, 419, 299], [5, 5, 5, 5], [400, 280, 419, 299]]
+    insts = [Instances((300, 420), gt_boxes=Boxes(torch.tensor([b], dtype=torch.float32))) for b in boxes]
+    d = {"boxes": torch.tensor(boxes)}
+    for op in ("pad", "context"):
+        crops = get_crops_qe(img, insts, op)
+        d["crops_" + op] = crops[:, :, ::7, ::7].contiguous()     # 32x32 sample of every crop
+        d["sum_" + op] = crops.double().sum(dim=(1, 2, 3))
+    save("crops", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "crops"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -320,3 +320,18 @@ def test_box_corrector_surface():
         model = build_model(cfg)
         g = gold("cascade_state_dict_keys")
         assert list(model.state_dict()) == g["keys"].tolist()
+
+
+def test_instances_to_coco_json_wire_format():
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.wire import crop_windows, get_padding, instances_to_coco_json
+
+    inst = Instances((100, 200), pred_boxes=Boxes(torch.tensor([[10.0, 20.0, 50.0, 80.0]])), scores=torch.tensor([0.75]),
+                     pred_classes=torch.tensor([3]))
+    rows = instances_to_coco_json(inst, 42)
+    assert rows == [{"image_id": 42, "category_id": 3, "bbox": [10.0, 20.0, 40.0, 60.0], "score": 0.75}]
+    assert inst.pred_boxes.tensor.tolist() == [[10.0, 20.0, 50.0, 80.0]]       # input not mutated
+    assert instances_to_coco_json(Instances((1, 1), pred_boxes=Boxes(torch.zeros(0, 4)), scores=torch.zeros(0),
+                                            pred_classes=torch.zeros(0, dtype=torch.int64)), 1) == []
+    assert get_padding(5, 10) == (0, 0, 3, 2) and get_padding(10, 10) == (0, 0, 0, 0)
+    assert crop_windows([[10, 10, 29, 19]], 100, 100, "pad") == [[10, 10, 29, 19, 0, 5, 20, 20]]
