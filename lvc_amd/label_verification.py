@@ -85,3 +85,20 @@ def get_nn_class_confirmatory(query_features, k):
             nn_class = torch.mode(votes[:, :k].cpu(), dim=1)[0]
             keep = (nn_class == inst.gt_classes.cpu()).to(torch.int64)
         inst.set("keep", keep)
+
+
+def knn_sweep_distributed(shot_classes, shot_descriptors, query_descriptors, detector_classes, k=10, cosine=True,
+                          sweep=None):
+    """Data-parallel form of the sweep (reference tools/run_nearest_neighbours.py:301-325): every rank contributes the
+    shots it extracted -> one all-gather of the fp32 rows (the reference pickles them through a gloo group), the shots
+    are re-sorted by class exactly as `assemble_tensors` does, each rank sweeps ITS queries, and the per-rank results
+    (top10 class ids, keep) are gathered to rank 0 in rank order.  Returns (top10, keep) on rank 0, (None, None)
+    elsewhere.  `sweep` defaults to `knn_sweep` (injectable so the collective plumbing can be tested on CPU/gloo)."""
+    from . import distributed as D
+
+    sweep = sweep or knn_sweep
+    all_desc = D.all_gather_rows(shot_descriptors.contiguous())
+    all_cls = D.all_gather_rows(shot_classes.contiguous())
+    order = all_cls.argsort(stable=True)
+    top, keep = sweep(all_cls[order], all_desc[order], query_descriptors, detector_classes, k, cosine)
+    return D.gather_rows(top), D.gather_rows(keep)

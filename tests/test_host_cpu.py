@@ -335,3 +335,49 @@ def test_instances_to_coco_json_wire_format():
                                             pred_classes=torch.zeros(0, dtype=torch.int64)), 1) == []
     assert get_padding(5, 10) == (0, 0, 3, 2) and get_padding(10, 10) == (0, 0, 0, 0)
     assert crop_windows([[10, 10, 29, 19]], 100, 100, "pad") == [[10, 10, 29, 19, 0, 5, 20, 20]]
+
+
+def _knn_dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from lvc_amd.label_verification import knn_sweep_distributed
+    from oracle import knn as oknn
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = gold("knn")
+        S = len(g["shot_classes"])
+        # each rank "extracted" an interleaved half of the shots and owns a contiguous shard of the queries
+        mine = torch.arange(rank, S, world)
+        from lvc_amd.distributed import shard_range
+
+        qr = shard_range(len(g["q_desc"]), rank, world)
+        qs = slice(qr.start, qr.stop)
+
+        def cpu_sweep(sc, sd, qd, dc, k, cosine):   # the CPU oracle stands in for the GPU sweep
+            top = oknn.dense(sc, sd, qd, cosine)
+            return top, oknn.get_nn_class_confirmatory(top, dc, k)
+
+        top, keep = knn_sweep_distributed(g["shot_classes"][mine], g["shots"][mine], g["q_desc"][qs], g["q_classes"][qs],
+                                          10, True, sweep=cpu_sweep)
+        q.put((rank, None if top is None else (torch.equal(top, g["top10_cos"]), torch.equal(keep, g["keep_cos"]))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_knn_sweep_distributed_world_size_2():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_knn_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == (True, True) and res[1] is None
