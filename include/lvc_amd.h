@@ -67,6 +67,15 @@ int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_split, const 
                            int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
                            void* stream);
 
+/* 3x3 / stride 1 / pad 1 specialisation of lvc_conv2d_nhwc_bf16x3 (csrc/conv3x3_halo.hip): identical arguments minus
+ * (R, S, stride, pad), identical packed weights, workspace and result contract -- the layers it serves are conv2 of
+ * every BottleneckBlock (detectron2/modeling/backbone/resnet.py:178-187 with STRIDE_IN_1X1), the FPN output convs
+ * (fpn.py:88-96) and the RPN head conv (rpn.py:83).  The output is tiled as 2-D pixel patches x 128 channels and the
+ * (PH+2) x (PW+2) activation window of a 32-channel chunk is staged once in LDS for all nine taps. */
+int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                            const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
+                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+
 /* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
  * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero
  * outside h x w.  image: CHW, dtype 0 = fp32, 1 = uint8.  mean3/std3 are [host] arrays of 3 floats. */

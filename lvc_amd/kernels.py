@@ -143,6 +143,8 @@ import os as _os
 
 CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "bf16x3")
 _BF16X3_MIN_K = int(_os.environ.get("LVC_BF16X3_MIN_K", "128"))
+# 3x3 / stride 1 / pad 1 layers of the bf16x3 engine go to the halo kernel (csrc/conv3x3_halo.hip)
+CONV_HALO = _os.environ.get("LVC_CONV_HALO", "1") != "0"
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -169,13 +171,21 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     engine = "f32"
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= _BF16X3_MIN_K and pc.K % 4 == 0 and out.shape[-1] % 4 == 0
             and ldr % 4 == 0):
-        engine = "bf16x3"
-        st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
-            ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
-            c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
-            c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
-            c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
-        check(st, "lvc_conv2d_nhwc_bf16x3")
+        if CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1:
+            engine = "bf16x3_halo"
+            st = _lib.lib().lvc_conv3x3_nhwc_bf16x3(
+                ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+                c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
+                c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv3x3_nhwc_bf16x3")
+        else:
+            engine = "bf16x3"
+            st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
+                ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+                c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
+                c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
+                c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv2d_nhwc_bf16x3")
     else:
         st = _lib.lib().lvc_conv2d_nhwc_f32(
             ptr(x), ptr(pc.w), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
