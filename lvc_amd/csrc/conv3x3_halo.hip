@@ -176,21 +176,24 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    bf16x8 fa[2][2][3], fb[2][2][3];   // [frag buffer][mi|ni][plane]
-    auto read_frags = [&](int sel, int tap_off, const __bf16* sb, int s2) {
+    // Fragments are single-buffered (48 VGPRs): with two waves per SIMD the sibling wave's MFMAs cover this wave's
+    // fragment reads, and 96 VGPRs of double-buffered fragments next to 64 accumulators + 36 prefetch registers
+    // spill (the first version of this kernel reloaded its LDS addresses from scratch every tap).
+    bf16x8 fa[2][3], fb[2][3];   // [mi|ni][plane]
+    auto read_frags = [&](int tap_off, const __bf16* sb, int s2) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          fa[sel][mi][pl] = *reinterpret_cast<const bf16x8*>(sA + pl * PLANE_A + a_frag[mi] + tap_off + s2 * 16);
+          fa[mi][pl] = *reinterpret_cast<const bf16x8*>(sA + pl * PLANE_A + a_frag[mi] + tap_off + s2 * 16);
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-          fb[sel][ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + ni * 32 * LROW + s2 * 16);
+          fb[ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + ni * 32 * LROW + s2 * 16);
     };
     // six split-precision terms, smallest first; the four accumulators are independent MFMA chains
-    auto mfma_group = [&](int sel) {
+    auto mfma_group = [&]() {
       constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
       constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
@@ -199,56 +202,24 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[sel][mi][TA[t]], fb[sel][ni][TB[t]], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][TA[t]], fb[ni][TB[t]], acc[mi][ni], 0, 0, 0);
     };
 
-    // Pipeline: per tap one barrier, placed between the two k16 groups (as conv_bf16x3.hip):
-    //   group 0: 24 MFMA(s=0) | ds_read frags(s=1) | ds_write weight planes of tap+1 into the idle buffer
-    //   barrier
-    //   group 1: 24 MFMA(s=1) | ds_read frags(s=0 of tap+1)          | buffer_load weight planes of tap+2
-    // The last halo read of a channel chunk (s=1 fragments of tap 8) is issued before tap 8's barrier, so the halo of
-    // the next chunk (loaded a whole chunk earlier) is split and written in the MFMA shadow of tap 8's group 1; the
-    // only exposed cost per chunk is one extra barrier before the first fragment read of the new halo.
+    // Per tap: two k16 groups out of the current weight buffer, the next tap's weight planes written to the idle
+    // buffer and the tap after that requested from L2, then ONE barrier (all reads of this buffer done, writes of the
+    // other visible).  Per 32-channel chunk one extra barrier pair around the halo refill (~1 % of the chunk).
     int cur = 0;
-    auto tap_step = [&](auto last_tag, int tap_off, int next_off, bool refill, int cc) {
-      constexpr bool LAST = decltype(last_tag)::value;
+    auto tap_step = [&](int tap_off) {
       const __bf16* sb = sB + cur * B_ELEMS;
-      const __bf16* sbn = sB + (cur ^ 1) * B_ELEMS;
-      // ---- group 0
-      read_frags(1, tap_off, sb, 1);
+      read_frags(tap_off, sb, 0);
       store_B(cur ^ 1);
-      mfma_group(0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);        // the 12 fragment reads first
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);       // 6 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);       // 1 DS write
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(tap_off, sb, 1);
+      load_B();
+      mfma_group();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
-      // ---- group 1
-      if constexpr (!LAST) {
-        read_frags(0, next_off, sbn, 0);
-        load_B();
-        mfma_group(1);
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 1);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 1);     // 1 VMEM read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 1);
-        __builtin_amdgcn_sched_barrier(0);
-      } else {
-        if (refill) {
-          store_A();
-          if (cc + 2 < cc1) load_A(cc + 2);
-        }
-        load_B();
-        mfma_group(1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
       cur ^= 1;
     };
 
@@ -259,20 +230,18 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
     load_B();
     if (cc0 + 1 < cc1) load_A(cc0 + 1);
     __syncthreads();
-    read_frags(0, 0, sB, 0);
     for (int cc = cc0; cc < cc1; ++cc) {
       int tap_off = 0;
       for (int r = 0; r < 3; ++r) {
-        const int o1 = tap_off + LROW, o2 = tap_off + 2 * LROW, o3 = tap_off + p.HW * LROW;
-        tap_step(std::false_type{}, tap_off, o1, false, cc);
-        tap_step(std::false_type{}, o1, o2, false, cc);
-        if (r < 2) tap_step(std::false_type{}, o2, o3, false, cc);
-        else tap_step(std::true_type{}, o2, 0, cc + 1 < cc1, cc);
-        tap_off = o3;
+        tap_step(tap_off);
+        tap_step(tap_off + LROW);
+        tap_step(tap_off + 2 * LROW);
+        tap_off += p.HW * LROW;
       }
       if (cc + 1 < cc1) {
-        __syncthreads();            // the refilled halo is visible
-        read_frags(0, 0, sB + cur * B_ELEMS, 0);
+        store_A();                  // every wave passed the last tap's barrier: nobody reads the old halo
+        if (cc + 2 < cc1) load_A(cc + 2);
+        __syncthreads();
       }
     }
     __syncthreads();
