@@ -94,9 +94,13 @@ def main():
 
     roofline = None
     if timer is not None:
-        # dominant kernel: conv_bf16x3_kernel (every conv/GEMM layer with >= 128 output channels); the exact-fp32 MFMA
-        # kernel (stem, 64-channel layers, 1024->16 RPN predictor) is reported beside it.
-        fl, ms, nlaunch = timer.flops_and_ms("bf16x3")
+        # dominant kernel = whichever split-precision kernel takes the most time per step: conv3x3_halo_kernel (3x3
+        # stride-1 layers) or conv_bf16x3_kernel (1x1 layers, FC, small maps); the other one and the exact-fp32 MFMA
+        # kernel (stem, 64-channel layers, RPN predictor) are reported beside it.
+        NAMES = {"bf16x3_halo": "conv3x3_halo_kernel", "bf16x3": "conv_bf16x3_kernel"}
+        per = {e: timer.flops_and_ms(e) for e in NAMES}
+        dom = max(per, key=lambda e: per[e][1])
+        fl, ms, nlaunch = per[dom]
         fl32, ms32, n32 = timer.flops_and_ms("f32")
         fl_all, ms_all, n_all = timer.flops_and_ms()
         traffic = None
@@ -106,13 +110,17 @@ def main():
         if nlaunch:
             achieved = fl / (ms * 1e-3) / 1e12
             roofline = {
-                "kernel": "conv_bf16x3_kernel (%d launches/step: fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16)" % (nlaunch // args.steps),
+                "kernel": "%s (%d launches/step: fp32-accurate 3-way bf16 split on v_mfma_f32_32x32x16_bf16)" % (NAMES[dom], nlaunch // args.steps),
                 "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16X3_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16X3_TFLOPS, 4),
                 "peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product; achieved counts algorithmic fp32 flops once",
                 "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "traffic_note": "fabric bytes of ONE p2 3x3 launch measured on the f32 kernel (same load pattern); see profiles/r01_conv_pmc.json",
+                "traffic": traffic, "traffic_note": "fabric bytes of ONE p2 3x3 launch measured on the f32 kernel; see profiles/r01_conv_pmc.json",
                 "kernel_ms_per_step": round(ms / args.steps, 3)}
+            for e in NAMES:
+                if e != dom and per[e][2]:
+                    roofline[NAMES[e]] = {"launches_per_step": per[e][2] // args.steps, "ms_per_step": round(per[e][1] / args.steps, 3),
+                                          "tflops": round(per[e][0] / (per[e][1] * 1e-3) / 1e12, 2), "peak": PEAK_BF16X3_TFLOPS}
         else:
             achieved = fl32 / (ms32 * 1e-3) / 1e12
             roofline = {"kernel": "conv_igemm_f32_kernel (all %d launches/step)" % (n32 // args.steps), "bound": "mfma",

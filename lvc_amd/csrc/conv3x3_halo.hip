@@ -348,6 +348,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #define LVC_MAX_WORKERS 1024
 static int g_cus_halo = 0;
 
+extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_split, const float* scale,
+                                      const float* shift, const float* residual, float* y, int N, int H, int W, int C,
+                                      int K, int R, int S, int stride, int pad, int Kg, int relu, int res_mode, int ldy,
+                                      int ldr, void* workspace, void* stream);
+
 // Patch shape for an H x W output: PH * PW <= 256 pixels, (PH + 2) * (PW + 2) <= HALO_MAX halo pixels, fewest patches
 // (every patch costs a full 256-row MFMA tile whatever its fill); ties go to the smaller halo.
 static void pick_patch(int H, int W, int* PH, int* PW) {
@@ -384,10 +389,19 @@ extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_s
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
   pick_patch(H, W, &a.PH, &a.PW);
+  if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
+    int ph = 0, pw = 0;
+    if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_MAX) { a.PH = ph; a.PW = pw; }
+  }
   a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
   a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
   a.tiles_n = lvc_cdiv(K, HN);
   a.nk = C / 32;
+  // small feature maps (p5 / p6 / a single image's res5): too few 256-pixel patches to fill 256 CUs before stream-K
+  // splits every tile eight ways -- the generic 128-row kernel measures faster there (scripts/probe_halo.py)
+  if ((long long)N * a.tiles_x * a.tiles_y * a.tiles_n < 128 && !getenv("LVC_HALO_FORCE"))
+    return lvc_conv2d_nhwc_bf16x3(x, w_split, scale, shift, residual, y, N, H, W, C, K, 3, 3, 1, 1, Kg, relu, res_mode,
+                                  ldy, ldr, workspace, stream);
   long long units = (long long)N * a.tiles_x * a.tiles_y * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
   a.total_units = (int)units;

@@ -73,6 +73,61 @@ def test_conv_residual_and_upsample_add():
     assert (y2.cpu().permute(0, 3, 1, 2) - (ref + up)).abs().max() < 1e-4
 
 
+@pytest.mark.parametrize(
+    "N,C,H,W,K,patch",
+    [
+        (1, 32, 7, 9, 128, None),        # one partial patch, one channel chunk
+        (2, 64, 13, 21, 132, None),      # K tail (132 = 128 + 4)
+        (1, 256, 50, 84, 256, None),     # p4-like: 9 x 2 patches of 6 x 42, stream-K splits tiles
+        (3, 96, 33, 47, 260, "16,16"),   # square patches, ragged right/bottom edge, 3 N tiles
+        (2, 128, 40, 60, 128, "3,70"),   # patch wider than the image
+        (1, 64, 64, 64, 128, "10,24"),   # fragment rows straddle patch rows
+    ],
+)
+def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
+    """csrc/conv3x3_halo.hip (forced even where the wrapper would pick the generic kernel) against F.conv2d on the
+    CPU, with bias, FrozenBN scale/shift, ReLU, residual add and FPN upsample-add epilogues."""
+    from lvc_amd import kernels as k
+
+    monkeypatch.setenv("LVC_HALO_FORCE", "1")
+    if patch:
+        monkeypatch.setenv("LVC_HALO_PATCH", patch)
+    monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
+    monkeypatch.setattr(k, "CONV_HALO", True)
+    g = torch.Generator().manual_seed(N * 1000 + C + K + H)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    bn = (torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.1,
+          torch.randn(K, generator=g) * 0.1, torch.rand(K, generator=g) + 0.5)
+    res = torch.randn(N, K, H, W, generator=g)
+    ref = F.conv2d(x, w, None, padding=1)
+    scale = bn[0] * (bn[3] + 1e-5).rsqrt()
+    ref_bn = F.relu(ref * scale[None, :, None, None] + (bn[1] - bn[2] * scale)[None, :, None, None] + res)
+    d = _dev()
+    xd = _nhwc(x).to(d)
+    timer = k.LaunchTimer()
+    monkeypatch.setattr(k, "CONV_TIMER", timer)
+    pc = k.pack_conv(w.to(d), bn=[t.to(d) for t in bn], stride=1, pad=1)
+    y = k.conv2d_nhwc(xd, pc, relu=True, residual=_nhwc(res).to(d), res_mode=1).cpu().permute(0, 3, 1, 2)
+    assert timer.records[-1][3] == "bf16x3_halo"
+    assert (y - ref_bn).abs().max() <= 2e-5 * float(ref_bn.abs().max())
+    pc2 = k.pack_conv(w.to(d), bias=b.to(d), stride=1, pad=1)
+    y2 = k.conv2d_nhwc(xd, pc2).cpu().permute(0, 3, 1, 2)
+    ref_bias = ref + b[None, :, None, None]
+    assert (y2 - ref_bias).abs().max() <= 2e-5 * float(ref_bias.abs().max())
+    # identical to the generic split-precision kernel up to the order in which stream-K partial tiles are added
+    monkeypatch.setattr(k, "CONV_HALO", False)
+    y3 = k.conv2d_nhwc(xd, pc2).cpu().permute(0, 3, 1, 2)
+    assert (y2 - y3).abs().max() <= 4e-6 * float(ref_bias.abs().max())
+    if H % 2 == 0 and W % 2 == 0:
+        monkeypatch.setattr(k, "CONV_HALO", True)
+        top = torch.randn(N, K, H // 2, W // 2, generator=g)
+        y4 = k.conv2d_nhwc(xd, pc2, residual=_nhwc(top).to(d), res_mode=2).cpu().permute(0, 3, 1, 2)
+        ref4 = ref_bias + F.interpolate(top, scale_factor=2, mode="nearest")
+        assert (y4 - ref4).abs().max() <= 2e-5 * float(ref4.abs().max())
+
+
 def test_conv_stem_7x7():
     from lvc_amd import kernels as k
 
