@@ -18,6 +18,7 @@
 // split on the fly when a staged chunk is written to LDS (LDS holds bf16 planes, k-contiguous rows of 32 + 8 pad).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -345,6 +346,327 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(ConvArgsB p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1) shape of the same kernel.  A 1x1 layer of the bottleneck trunk is an HBM stream with a short
+// reduction (2 - 16 chunks per tile); in the kernel above every tile then pays four serialized HBM round trips (first
+// chunk, second chunk, two batches of residual rows) and the layer sits at 2.3 TB/s where an elementwise add reaches
+// 5.8 (scripts/probe_hbm.py).  Here the activation loader runs three chunks ahead in three register sets and does not
+// stop at tile boundaries, the weight planes run one chunk ahead, and the residual rows of a tile are requested in one
+// batch before the LDS transpose.
+__global__ __launch_bounds__(NT, 2) void conv_pw_bf16x3_kernel(ConvArgsB p) {
+  constexpr int STAGE_ELEMS = 3 * (PLANE_A + PLANE_B);                 // bf16 elements per buffer
+  constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;                      // double buffered
+  constexpr int CS_STRIDE = BN + 4;
+  constexpr int CS_BYTES = BM * CS_STRIDE * 4;
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  __bf16* stage = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: 64 (M) x 32 (N)
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;        // float4 slot of the A chunk row
+  // staged row of this thread: consecutive 8-lane groups take rows r and r+4 (not r+1): with the 80-byte row pitch
+  // two rows 4 apart sit exactly half a bank cycle (64 B) apart, so the 16-lane ds_write_b64 / 8-lane ds_write_b128
+  // groups are conflict-free (rows r, r+1 overlap by 16 B -> every staging store took two LDS passes;
+  // SQ_LDS_BANK_CONFLICT 2.4e8 -> 0 on the p2 3x3)
+  const int arid = tid >> 3;
+  const int row0 = (arid & 1) * 4 + ((arid >> 1) & 3) + (arid >> 3) * 8;    // A rows row0 + 64*j, j = 0,1
+
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 3 * p.w_plane_bytes, 0x00020000);
+
+  // fragment read offsets (bf16 elements) inside a plane: row (tile-local) * LROW + fh*8 (+ 16 per k16 step)
+  const int a_frag = (wm * 64 + fi) * LROW + fh * 8;
+  const int b_frag = (wn * 32 + fi) * LROW + fh * 8;
+  // B staging: 16-byte pieces; per plane 128 rows x 4 pieces = 512 -> 1 per thread
+  const int brid = tid >> 2;
+  const int b_row = (brid & 1) * 4 + ((brid >> 1) & 3) + (brid >> 3) * 8;
+  const int b_q4 = tid & 3;
+
+  // ---- operand loader.  It runs LD chunks ahead of the MFMA loop and does NOT stop at tile boundaries: layers with
+  // short tiles (1x1 convolutions: 2 - 16 chunks) are HBM-bound streams, and with one chunk of run-ahead per CU the
+  // bytes in flight (16 KB x 256 CUs against ~2 us of HBM latency) capped them at ~2.4 TB/s; the first chunks of the
+  // next tile are now requested while this tile is still in its main loop / epilogue.
+  // Activations (HBM) run LD = 3 chunks ahead in three register sets; the weight planes (L2-resident) one chunk ahead
+  // in one set, as before.
+  constexpr int LD = 3;
+  f32x4 areg[LD][2];
+  u32x4 breg[3];
+  int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
+  unsigned l_aoff[2];
+  int lb = u, lb_kc = l_kc;
+  unsigned l_boff = (unsigned)(((l_tile % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+  // pointwise only: R = S = 1, pad = 0 -> one tap, always inside the image; a row is valid iff m < M
+  auto loader_enter = [&](int tile, int kc) {
+    l_tile = tile; l_kc = kc;
+    const int m0 = (tile / p.tiles_n) * BM;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + row0 + 64 * j;
+      const bool okm = m < p.M;
+      const int mm = okm ? m : 0;
+      const int n = mm / (p.Ho * p.Wo);
+      const int rem = mm - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      l_aoff[j] = okm ? (unsigned)(((n * p.H + ho * p.stride) * p.W + wo * p.stride) * p.C + q * 4) * 4u : 0x80000000u;
+    }
+  };
+  auto load_A = [&](auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    if (lu < u_end) {
+      if (l_kc == p.nk) loader_enter(l_tile + 1, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        areg[SL][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, l_aoff[j], l_kc * (BK * 4), 0));
+      ++l_kc;
+      ++lu;
+    }
+  };
+  auto load_B = [&]() {
+    if (lb < u_end) {
+      if (lb_kc == p.nk) {
+        lb_kc = 0;
+        l_boff = (unsigned)((((lb / p.nk) % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        breg[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wres, l_boff + (unsigned)(pl * p.w_plane_bytes), lb_kc * (BK * 2), 0));
+      ++lb_kc;
+      ++lb;
+    }
+  };
+  auto store_chunk = [&](auto slot_tag, int buf) {
+    constexpr int SL = decltype(slot_tag)::value;
+    __bf16* sa = stage + buf * STAGE_ELEMS;
+    __bf16* sb = sa + 3 * PLANE_A;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 hh, mm, ll;
+        split3(areg[SL][j][e], hh, mm, ll);
+        h[e] = hh; m[e] = mm; l[e] = ll;
+      }
+      const int o = (row0 + 64 * j) * LROW + q * 4;
+      *reinterpret_cast<bf16x4*>(sa + o) = h;
+      *reinterpret_cast<bf16x4*>(sa + PLANE_A + o) = m;
+      *reinterpret_cast<bf16x4*>(sa + 2 * PLANE_A + o) = l;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row * LROW + b_q4 * 8) = breg[pl];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  loader_enter(l_tile, l_kc);
+  load_A(S0{});
+  load_B();
+  load_A(S1{});
+  load_A(S2{});
+  int slot = 0;   // register set holding the next chunk to be staged
+
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int kc0 = u - tile * p.nk;
+    const int kc1 = min(p.nk, kc0 + (u_end - u));
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][0][e] = 0.f;
+
+    // Fragments are single-buffered here (36 VGPRs instead of 72, which is what lets three activation register sets
+    // and the residual prefetch live without spills -- a spill reload waits on the in-order vmcnt counter and would
+    // serialise the very loads that are supposed to stay in flight); the sibling wave of the SIMD covers the reads.
+    bf16x8 fa[2][3], fb[3];   // [mi][plane], [plane]
+    auto read_frags = [&](const __bf16* sa, const __bf16* sb, int s2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fa[mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * PLANE_A + a_frag + mi * 32 * LROW + s2 * 16);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        fb[pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + s2 * 16);
+    };
+    auto mfma_group = [&]() {
+      constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][TA[t]], fb[TB[t]], acc[mi][0], 0, 0, 0);
+    };
+    int cur = 0;
+    // chunk body for every chunk but the tile's last: stages chunk kc+1 out of register set SL and refills SL
+    auto body = [&](auto slot_tag) {
+      const __bf16* sa = stage + cur * STAGE_ELEMS;
+      const __bf16* sb = sa + 3 * PLANE_A;
+      read_frags(sa, sb, 0);
+      store_chunk(slot_tag, cur ^ 1);
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(sa, sb, 1);
+      load_A(slot_tag);
+      load_B();
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      cur ^= 1;
+    };
+
+    // tile prologue: the tile's first chunk has been in flight since the previous tile
+    switch (slot) {
+      case 0: store_chunk(S0{}, 0); load_A(S0{}); break;
+      case 1: store_chunk(S1{}, 0); load_A(S1{}); break;
+      default: store_chunk(S2{}, 0); load_A(S2{}); break;
+    }
+    load_B();
+    slot = slot == LD - 1 ? 0 : slot + 1;
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = NT / C4;
+    constexpr int NIT = BM / RPI;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    f32x4 rv[NIT];
+    // residual rows of this tile: requested now, consumed by the epilogue a whole main loop later
+    if (p.res_mode != 0 && col < p.K && kc0 == 0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = m0 + it * RPI + rsub;
+        rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < p.M) {
+          size_t ro = (size_t)row;
+          if (p.res_mode == 2) {
+            const int n = row / (p.Ho * p.Wo);
+            const int rem = row - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+          }
+          rv[it] = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        }
+      }
+    }
+    for (int kc = kc0; kc + 1 < kc1; ++kc) {
+      switch (slot) {
+        case 0: body(S0{}); break;
+        case 1: body(S1{}); break;
+        default: body(S2{}); break;
+      }
+      slot = slot == LD - 1 ? 0 : slot + 1;
+    }
+    {  // the tile's last chunk: nothing to stage (the next chunk belongs to the next tile and stays in its registers)
+      const __bf16* sa = stage + cur * STAGE_ELEMS;
+      const __bf16* sb = sa + 3 * PLANE_A;
+      read_frags(sa, sb, 0);
+      mfma_group();
+      read_frags(sa, sb, 1);
+      mfma_group();
+    }
+    __syncthreads();
+    u += kc1 - kc0;
+
+    // ---- split tiles (same protocol as conv_igemm.hip)
+    if (kc0 != 0) {
+      float* dst = p.partials + (size_t)lw * (NT * 32);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          f32x4 v = {acc[mi][0][e4 * 4 + 0], acc[mi][0][e4 * 4 + 1], acc[mi][0][e4 * 4 + 2], acc[mi][0][e4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(dst + ((size_t)(mi * 4 + e4) * NT + tid) * 4) = v;
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (kc1 < p.nk) {
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int last_worker = last_unit / p.units_per_worker;
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (NT * 32);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(mi * 4 + e4) * NT + tid) * 4);
+            acc[mi][0][e4 * 4 + 0] += v[0]; acc[mi][0][e4 * 4 + 1] += v[1];
+            acc[mi][0][e4 * 4 + 2] += v[2]; acc[mi][0][e4 * 4 + 3] += v[3];
+          }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- epilogue through LDS (the residual rows were requested at the start of the tile)
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int ccol = wn * 32 + fi;
+        Cs[row * CS_STRIDE + ccol] = acc[mi][0][e];
+      }
+    __syncthreads();
+    if (col < p.K) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + rsub;
+        const int row = m0 + r;
+        if (row < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+          v = v * sc + sh;
+          if (p.res_mode != 0) v += rv[it];
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
 #define LVC_MAX_WORKERS 1024
 static int g_cus = 0;
 
@@ -400,7 +722,12 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  static int pw_mode = -1;   // LVC_CONV_PW=0 disables the pointwise shape (experiments)
+  if (pw_mode < 0) { const char* e = getenv("LVC_CONV_PW"); pw_mode = e ? atoi(e) : 1; }
+  if (pw_mode && R == 1 && S == 1 && a.nk <= 16)
+    hipLaunchKernelGGL(conv_pw_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
