@@ -28,12 +28,10 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define HM 256           // output pixels per tile (patch area <= HM)
-#define HN 128           // output channels per tile
 #define LROW 40          // bf16 elements per LDS row (32 + 8 pad = 80 B: conflict-free ds_read_b128)
 #define HALO_MAX 384     // halo pixels per tile: 6 x 512 threads x one float4
 #define NJ 6
 #define PLANE_A (HALO_MAX * LROW)
-#define PLANE_B (HN * LROW)
 #define NT 512
 #define SPIN_LIMIT (1 << 24)
 
@@ -60,7 +58,12 @@ __device__ __forceinline__ void split3h(float a, __bf16& h, __bf16& m, __bf16& l
   l = (__bf16)r2;
 }
 
+// NI = 32-column MFMA blocks per wave: NI = 2 -> 128 output channels per tile (wave tile 64 x 64), NI = 1 -> 64 output
+// channels per tile (wave tile 64 x 32; the 64-channel res2 layers, which would waste half of a 128-wide tile).
+template <int NI>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
+  constexpr int HN = 64 * NI;
+  constexpr int PLANE_B = HN * LROW;
   constexpr int A_ELEMS = 3 * PLANE_A;
   constexpr int B_ELEMS = 3 * PLANE_B;
   constexpr int STAGE_BYTES = (A_ELEMS + 2 * B_ELEMS) * 2;   // 92,160 + 61,440
@@ -80,10 +83,13 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
   const int q = tid & 7;
   const int arid = tid >> 3;
   const int hrow = (arid & 1) * 4 + ((arid >> 1) & 3) + (arid >> 3) * 8;    // halo pixels hrow + 64*j
-  // weight staging: 16-byte pieces; per plane 128 rows x 4 pieces = 512 -> one per thread
-  const int brid = tid >> 2;
+  // weight staging: 16-byte pieces, HN rows x 4 pieces per plane.  NI = 2: 512 pieces per plane, thread t stages piece t
+  // of every plane.  NI = 1: 256 pieces per plane, thread t stages piece t % 256 of plane t / 256 and (t < 256) of plane 2.
+  const int brid = (NI == 2 ? tid : (tid & 255)) >> 2;
   const int b_row = (brid & 1) * 4 + ((brid >> 1) & 3) + (brid >> 3) * 8;
   const int b_q4 = tid & 3;
+  constexpr int NB = NI == 2 ? 3 : 2;                 // staged pieces per thread
+  const int b_pl0 = NI == 2 ? 0 : (tid >> 8);         // plane of piece i: b_pl0 + (NI == 2 ? i : 2 * i)
 
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
   int u = lw * p.units_per_worker;
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
     const int py = mm / p.PW, px = mm - py * p.PW;
     a_frag[mi] = (py * p.HW + px) * LROW + fh * 8;
   }
-  const int b_frag = (wn * 64 + fi) * LROW + fh * 8;
+  const int b_frag = (wn * 32 * NI + fi) * LROW + fh * 8;
 
   while (u < u_end) {
     const int tile = u / p.nk;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
     const unsigned b_off = (unsigned)((n0 + b_row) * (9 * p.C) + b_q4 * 8) * 2u;
 
     f32x4 areg[NJ];
-    u32x4 breg[3];
+    u32x4 breg[NB];
     auto load_A = [&](int cc) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
@@ -156,30 +162,35 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
     const int step_end = cc1 * 9;
     auto load_B = [&]() {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        breg[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 wres, b_off + (unsigned)(pl * p.w_plane_bytes), ld_step * 64, 0));
+      for (int i = 0; i < NB; ++i) {
+        const int pl = b_pl0 + (NI == 2 ? i : 2 * i);
+        if (pl < 3)
+          breg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  wres, b_off + (unsigned)(pl * p.w_plane_bytes), ld_step * 64, 0));
+      }
       if (ld_step + 1 < step_end) ++ld_step;
     };
     auto store_B = [&](int buf) {
       __bf16* sb = sB + buf * B_ELEMS;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row * LROW + b_q4 * 8) = breg[pl];
+      for (int i = 0; i < NB; ++i) {
+        const int pl = b_pl0 + (NI == 2 ? i : 2 * i);
+        if (pl < 3) *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row * LROW + b_q4 * 8) = breg[i];
+      }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NI; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     // Fragments are single-buffered (48 VGPRs): with two waves per SIMD the sibling wave's MFMAs cover this wave's
     // fragment reads, and 96 VGPRs of double-buffered fragments next to 64 accumulators + 36 prefetch registers
     // spill (the first version of this kernel reloaded its LDS addresses from scratch every tap).
-    bf16x8 fa[2][3], fb[2][3];   // [mi|ni][plane]
+    bf16x8 fa[2][3], fb[NI][3];   // [mi|ni][plane]
     auto read_frags = [&](int tap_off, const __bf16* sb, int s2) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
         for (int pl = 0; pl < 3; ++pl)
           fa[mi][pl] = *reinterpret_cast<const bf16x8*>(sA + pl * PLANE_A + a_frag[mi] + tap_off + s2 * 16);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           fb[ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * PLANE_B + b_frag + ni * 32 * LROW + s2 * 16);
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][TA[t]], fb[ni][TB[t]], acc[mi][ni], 0, 0, 0);
     };
 
@@ -249,15 +260,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
 
     // ---- split tiles: a worker that does not own the tile's first chunk hands its partial sums to the one that does
     if (cc0 != 0) {
-      float* dst = p.partials + (size_t)lw * (NT * 64);
+      float* dst = p.partials + (size_t)lw * (NT * 32 * NI);
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
-            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * 2 + ni) * 4 + e4) * NT + tid) * 4) = v;
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4) = v;
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -281,14 +292,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        const float* src = p.partials + (size_t)pw * (NT * 64);
+        const float* src = p.partials + (size_t)pw * (NT * 32 * NI);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * 2 + ni) * 4 + e4) * NT + tid) * 4);
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4);
               acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
               acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
             }
@@ -302,11 +313,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const int col = wn * 64 + ni * 32 + fi;
+          const int col = wn * 32 * NI + ni * 32 + fi;
           Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
         }
     __syncthreads();
@@ -395,6 +406,8 @@ extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_s
   }
   a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
   a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
+  const int ni = K <= 64 ? 1 : 2;   // 64-wide tiles for the 64-channel layers
+  const int HN = 64 * ni;
   a.tiles_n = lvc_cdiv(K, HN);
   a.nk = C / 32;
   // small feature maps (p5 / p6 / a single image's res5): too few 256-pixel patches to fill 256 CUs before stream-K
@@ -405,7 +418,7 @@ extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_s
   long long units = (long long)N * a.tiles_x * a.tiles_y * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
   a.total_units = (int)units;
-  const long long xb = (long long)N * H * W * C * 4, wb = (long long)(a.tiles_n * HN) * Kg * 2;
+  const long long xb = (long long)N * H * W * C * 4, wb = (long long)(lvc_cdiv(K, 128) * 128) * Kg * 2;   // planes are padded to 128 rows
   LVC_CHECK_ARG(xb < (1ll << 31) && 3 * wb < (1ll << 31), "input / weight tensor must be smaller than 2 GiB");
   a.x_bytes = (int)xb; a.w_plane_bytes = (int)wb;
   if (g_cus_halo == 0) {
@@ -422,7 +435,10 @@ extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_s
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  hipLaunchKernelGGL(conv3x3_halo_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  if (ni == 1)
+    hipLaunchKernelGGL(conv3x3_halo_kernel<1>, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv3x3_halo_kernel<2>, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

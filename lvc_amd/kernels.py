@@ -169,9 +169,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         e0.record()
     ldr = residual.shape[-1] if residual is not None else 0
     engine = "f32"
-    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= _BF16X3_MIN_K and pc.K % 4 == 0 and out.shape[-1] % 4 == 0
-            and ldr % 4 == 0):
-        if CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1:
+    halo = CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0
+    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else _BF16X3_MIN_K) and pc.K % 4 == 0
+            and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
+        if halo:
             engine = "bf16x3_halo"
             st = _lib.lib().lvc_conv3x3_nhwc_bf16x3(
                 ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),

@@ -82,6 +82,8 @@ def test_conv_residual_and_upsample_add():
         (3, 96, 33, 47, 260, "16,16"),   # square patches, ragged right/bottom edge, 3 N tiles
         (2, 128, 40, 60, 128, "3,70"),   # patch wider than the image
         (1, 64, 64, 64, 128, "10,24"),   # fragment rows straddle patch rows
+        (2, 64, 40, 56, 64, None),       # 64-wide N tile (res2 conv2)
+        (1, 32, 30, 30, 64, "8,32"),     # 64-wide N tile, one channel chunk
     ],
 )
 def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
