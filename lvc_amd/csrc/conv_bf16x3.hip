@@ -667,6 +667,303 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_bf16x3_kernel(ConvArgsB p) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Pointwise shape for LONG reductions (1x1 convolutions with >= 1024 input channels, the box-head FC layers): these are
+// matrix-pipe bound, and what the 128 x 128 kernels above lack there is MFMA work per barrier and per fragment read.
+// Tile 256 x 128, 8 waves as 4 x 2, wave tile 64 x 64: 48 MFMAs per barrier and 24 MFMAs per 12 fragment reads (the
+// numbers of conv3x3_halo.hip), weight traffic per flop halved.  Two 72 KB stages only fit the 160 KB of LDS without
+// row padding, so rows are 64 B and the 16-byte granule g of row r is stored at g ^ ((r >> 2) & 3): each 16-lane group of
+// a ds_read_b128 (MI355X_MICROARCH.md: rows {0-3,12-15,20-27}, {4-11,16-19,28-31} of a 32-row fragment) then covers
+// all 16 granule slots of the 64 banks exactly once.
+#define G_BM 256
+#define G_PA (G_BM * 32)        // bf16 elements of one A plane (256 rows x 32)
+#define G_PB (BN * 32)
+__global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
+  constexpr int STAGE_ELEMS = 3 * (G_PA + G_PB);                        // 36,864 elements = 73,728 B
+  constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;
+  constexpr int CS_STRIDE = BN + 4;
+  constexpr int CS_BYTES = G_BM * CS_STRIDE * 4;                        // 135,168
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  __bf16* stage = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;   // wave tile: 64 (M) x 64 (N)
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;                     // float4 slot of the 32-channel A row
+  const int rslot = tid >> 3;                // A rows rslot + 64*j, j = 0..3
+  const int b_q4 = tid & 3;
+  const int b_row = tid >> 2;                // one 16-byte piece of every weight plane
+  // swizzled store offsets (bf16 elements inside a row)
+  const int a_st = ((((q >> 1) ^ ((rslot >> 2) & 3)) * 8) + (q & 1) * 4);   // (rslot + 64j) >> 2 & 3 == rslot >> 2 & 3
+  const int b_st = ((b_q4 ^ ((b_row >> 2) & 3)) * 8);
+  // swizzled fragment offsets: row * 32 + ((fh + 2*s2) ^ x) * 8 with x = (row >> 2) & 3 = (fi >> 2) & 3
+  const int fx = (fi >> 2) & 3;
+  const int f_off0 = ((fh ^ fx) * 8), f_off1 = (((fh + 2) ^ fx) * 8);
+  const int a_frag = (wm * 64 + fi) * 32;
+  const int b_frag = (wn * 64 + fi) * 32;
+
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 3 * p.w_plane_bytes, 0x00020000);
+
+  // operand loader (as conv_pw_bf16x3_kernel, across tile boundaries), one register set: these layers are matrix-pipe
+  // bound and a second activation set (16 more VGPRs next to 64 accumulators + 48 fragment registers) spills
+  constexpr int LD = 1;
+  f32x4 areg[LD][4];
+  u32x4 breg[3];
+  int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
+  unsigned l_aoff[4];
+  int lb = u, lb_kc = l_kc;
+  unsigned l_boff = (unsigned)(((l_tile % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+  auto loader_enter = [&](int tile, int kc) {
+    l_tile = tile; l_kc = kc;
+    const int m0 = (tile / p.tiles_n) * G_BM;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + rslot + 64 * j;
+      const bool okm = m < p.M;
+      const int mm = okm ? m : 0;
+      const int n = mm / (p.Ho * p.Wo);
+      const int rem = mm - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      l_aoff[j] = okm ? (unsigned)(((n * p.H + ho * p.stride) * p.W + wo * p.stride) * p.C + q * 4) * 4u : 0x80000000u;
+    }
+  };
+  auto load_A = [&](auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    if (lu < u_end) {
+      if (l_kc == p.nk) loader_enter(l_tile + 1, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        areg[SL][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, l_aoff[j], l_kc * (BK * 4), 0));
+      ++l_kc;
+      ++lu;
+    }
+  };
+  auto load_B = [&]() {
+    if (lb < u_end) {
+      if (lb_kc == p.nk) {
+        lb_kc = 0;
+        l_boff = (unsigned)((((lb / p.nk) % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        breg[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wres, l_boff + (unsigned)(pl * p.w_plane_bytes), lb_kc * (BK * 2), 0));
+      ++lb_kc;
+      ++lb;
+    }
+  };
+  auto store_chunk = [&](auto slot_tag, int buf) {
+    constexpr int SL = decltype(slot_tag)::value;
+    __bf16* sa = stage + buf * STAGE_ELEMS;
+    __bf16* sb = sa + 3 * G_PA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 h, m, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        __bf16 hh, mm, ll;
+        split3(areg[SL][j][e], hh, mm, ll);
+        h[e] = hh; m[e] = mm; l[e] = ll;
+      }
+      const int o = (rslot + 64 * j) * 32 + a_st;
+      *reinterpret_cast<bf16x4*>(sa + o) = h;
+      *reinterpret_cast<bf16x4*>(sa + G_PA + o) = m;
+      *reinterpret_cast<bf16x4*>(sa + 2 * G_PA + o) = l;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      *reinterpret_cast<u32x4*>(sb + pl * G_PB + b_row * 32 + b_st) = breg[pl];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  loader_enter(l_tile, l_kc);
+  load_A(S0{});
+  load_B();
+
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int kc0 = u - tile * p.nk;
+    const int kc1 = min(p.nk, kc0 + (u_end - u));
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * G_BM;
+    const int n0 = tile_n * BN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    bf16x8 fa[2][3], fb[2][3];
+    auto read_frags = [&](const __bf16* sa, const __bf16* sb, int fo) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fa[mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * G_PA + a_frag + mi * 32 * 32 + fo);
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          fb[ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * G_PB + b_frag + ni * 32 * 32 + fo);
+    };
+    auto mfma_group = [&]() {
+      constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+      constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][TA[t]], fb[ni][TB[t]], acc[mi][ni], 0, 0, 0);
+    };
+    int cur = 0;
+    auto body = [&](auto slot_tag) {
+      const __bf16* sa = stage + cur * STAGE_ELEMS;
+      const __bf16* sb = sa + 3 * G_PA;
+      read_frags(sa, sb, f_off0);
+      store_chunk(slot_tag, cur ^ 1);
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(sa, sb, f_off1);
+      load_A(slot_tag);
+      load_B();
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      cur ^= 1;
+    };
+
+    store_chunk(S0{}, 0);
+    load_A(S0{});
+    load_B();
+    __syncthreads();
+    for (int kc = kc0; kc + 1 < kc1; ++kc) {
+      body(S0{});
+    }
+    {
+      const __bf16* sa = stage + cur * STAGE_ELEMS;
+      const __bf16* sb = sa + 3 * G_PA;
+      read_frags(sa, sb, f_off0);
+      mfma_group();
+      read_frags(sa, sb, f_off1);
+      mfma_group();
+    }
+    __syncthreads();
+    u += kc1 - kc0;
+
+    // ---- split tiles
+    if (kc0 != 0) {
+      float* dst = p.partials + (size_t)lw * (NT * 64);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * 2 + ni) * 4 + e4) * NT + tid) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (kc1 < p.nk) {
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int last_worker = last_unit / p.units_per_worker;
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (NT * 64);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * 2 + ni) * 4 + e4) * NT + tid) * 4);
+              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
+              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
+            }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- epilogue through LDS
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int ccol = wn * 64 + ni * 32 + fi;
+          Cs[row * CS_STRIDE + ccol] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = NT / C4;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    if (col < p.K) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+      for (int it = 0; it < G_BM / RPI; ++it) {
+        const int r = it * RPI + rsub;
+        const int row = m0 + r;
+        if (row < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+          v = v * sc + sh;
+          if (p.res_mode == 1) {
+            v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+          } else if (p.res_mode == 2) {
+            int n = row / (p.Ho * p.Wo);
+            int rem = row - n * (p.Ho * p.Wo);
+            int ho = rem / p.Wo;
+            int wo = rem - ho * p.Wo;
+            size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+          }
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 #define LVC_MAX_WORKERS 1024
 static int g_cus = 0;
 
@@ -697,9 +994,24 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
-  a.tiles_n = lvc_cdiv(K, BN);
-  const int tiles_m = lvc_cdiv(a.M, BM);
+  // kernel shape: 0 = general implicit GEMM (128 x 128 tiles), 1 = pointwise, short reduction (conv_pw_bf16x3_kernel),
+  // 2 = pointwise, long reduction (conv_pw256_bf16x3_kernel, 256 x 128 tiles).  LVC_CONV_PW: 0 disables both pointwise
+  // shapes, 1 only the 256-row one (experiments).
+  static int pw_mode = -1;
+  if (pw_mode < 0) { const char* e = getenv("LVC_CONV_PW"); pw_mode = e ? atoi(e) : 2; }
   a.nk = Kg / BK;
+  int shape = 0;
+  if (R == 1 && S == 1 && pad == 0) {
+    // measured on the R50-FPN layer set (scripts/probe_layers_list.py): the 256-row shape wins from 512 input channels
+    // up, and from 256 when there is no residual stream; below that the layer is an HBM stream and the deeper
+    // activation run-ahead of the 128-row pointwise shape wins
+    static int min_nk256 = -1;
+    if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 16; }
+    if (pw_mode >= 2 && a.M >= 2048 && (a.nk >= min_nk256 || (a.nk >= min_nk256 / 2 && res_mode == 0))) shape = 2;
+    else if (a.nk <= 16) shape = pw_mode >= 1 ? 1 : 0;
+  }
+  a.tiles_n = lvc_cdiv(K, BN);
+  const int tiles_m = lvc_cdiv(a.M, shape == 2 ? G_BM : BM);
   long long units = (long long)tiles_m * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
   a.total_units = (int)units;
@@ -722,9 +1034,9 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  static int pw_mode = -1;   // LVC_CONV_PW=0 disables the pointwise shape (experiments)
-  if (pw_mode < 0) { const char* e = getenv("LVC_CONV_PW"); pw_mode = e ? atoi(e) : 1; }
-  if (pw_mode && R == 1 && S == 1 && a.nk <= 16)
+  if (shape == 2)
+    hipLaunchKernelGGL(conv_pw256_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else if (shape == 1)
     hipLaunchKernelGGL(conv_pw_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(conv_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);

@@ -130,6 +130,45 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
         assert (y4 - ref4).abs().max() <= 2e-5 * float(ref4.abs().max())
 
 
+@pytest.mark.parametrize(
+    "N,C,H,W,K,stride,res_mode",
+    [
+        (2, 64, 40, 56, 256, 1, 1),      # short reduction (2 chunks), residual: conv_pw_bf16x3_kernel
+        (2, 128, 30, 44, 512, 1, 1),     # 4 chunks, M tail
+        (3, 256, 24, 36, 1024, 1, 1),    # 8 chunks with residual stays on the 128-row pointwise shape
+        (3, 256, 24, 36, 512, 2, 0),     # 8 chunks, no residual, stride 2: conv_pw256_bf16x3_kernel (M = 648 < 2048 -> 128-row)
+        (4, 256, 48, 64, 512, 2, 0),     # same with M = 3072: 256-row shape
+        (2, 512, 40, 52, 128, 1, 0),     # 16 chunks: 256-row shape, M tail (4160 = 16 * 256 + 64)
+        (2, 1024, 30, 36, 256, 1, 0),    # 32 chunks: stream-K splits tiles of the 256-row shape
+        (2, 512, 40, 52, 256, 1, 2),     # FPN lateral with top-down upsample-add
+    ],
+)
+def test_pointwise_shapes_match_cpu(N, C, H, W, K, stride, res_mode):
+    """1x1 layers through the pointwise shapes of the split-precision kernel (csrc/conv_bf16x3.hip) against F.conv2d."""
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(N * 100 + C + K + stride)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C, 1, 1, generator=g) * (2.0 / C) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    ref = F.conv2d(x, w, b, stride=stride)
+    Ho, Wo = ref.shape[2:]
+    d = _dev()
+    res = None
+    if res_mode == 1:
+        r = torch.randn(N, K, Ho, Wo, generator=g)
+        ref = ref + r
+        res = _nhwc(r).to(d)
+    elif res_mode == 2:
+        r = torch.randn(N, K, Ho // 2, Wo // 2, generator=g)
+        ref = ref + F.interpolate(r, scale_factor=2, mode="nearest")
+        res = _nhwc(r).to(d)
+    ref = F.relu(ref)
+    pc = k.pack_conv(w.to(d), bias=b.to(d), stride=stride, pad=0)
+    y = k.conv2d_nhwc(_nhwc(x).to(d), pc, relu=True, residual=res, res_mode=res_mode).cpu().permute(0, 3, 1, 2)
+    assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
+
+
 def test_conv_stem_7x7():
     from lvc_amd import kernels as k
 
