@@ -124,8 +124,9 @@ class LaunchTimer:
     """Optional per-launch HIP-event bracket for the conv/GEMM kernel (bench.py's roofline leg).
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []  # (algorithmic flops, start event, end event, engine)
+        self.only = only   # None = bracket every launch; else the set of engine tags to bracket
 
     def flops_and_ms(self, engine=None):
         torch.cuda.synchronize()
@@ -163,24 +164,26 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         assert residual.is_contiguous() and residual.dtype == torch.float32
         if res_mode == 0:
             res_mode = 1
-    timer = CONV_TIMER
-    if timer is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
     ldr = residual.shape[-1] if residual is not None else 0
     engine = "f32"
     halo = CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else _BF16X3_MIN_K) and pc.K % 4 == 0
             and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
+        engine = "bf16x3_halo" if halo else "bf16x3"
+    timer = CONV_TIMER
+    if timer is not None and timer.only is not None and engine not in timer.only:
+        timer = None
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if engine != "f32":
         if halo:
-            engine = "bf16x3_halo"
             st = _lib.lib().lvc_conv3x3_nhwc_bf16x3(
                 ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
         else:
-            engine = "bf16x3"
             st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
                 ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
