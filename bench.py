@@ -125,7 +125,7 @@ def main():
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate); achieved counts algorithmic fp32 flops once; the kernel runs at the 1.4 kW socket power cap (profiles/README.md)",
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_note": "fabric bytes of ONE p2 3x3 launch measured on the f32 kernel; see profiles/r01_conv_pmc.json",
+            "traffic": traffic, "traffic_note": "fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) of ONE p2 3x3 launch of this kernel vs 1.10 GB algorithmic; see profiles/r01_conv_pmc.json",
             "kernel_ms_per_step": round(ms / args.steps, 3), "launch_avg_ms": round(ms / nlaunch, 4)}
         other = {}
         for e in NAMES:
