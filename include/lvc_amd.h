@@ -114,6 +114,19 @@ int lvc_roi_align_fpn_nhwc(const float* const* feats, const int* Hs, const int* 
                            int pooled_h, int pooled_w, int sampling_ratio, int aligned, float* output,
                            int* d_status, void* stream);
 
+/* ROIAlign backward (csrc/vision.cpp:97 roi_align_backward; ROIAlign_cuda.cu:142-306 / ROIAlign_cpu.cpp:219-406):
+ *   grad [K,C,pooled_h,pooled_w] contiguous -> grad_input [B,C,H,W], zeroed by the call (the reference returns a
+ *   fresh at::zeros tensor).  Scatter by fp32 atomic adds like the reference CUDA kernel: equal to the reference CPU
+ *   kernel up to summation order.  The _fpn_ form is the gradient of lvc_roi_align_fpn_nhwc: grad
+ *   [K,pooled_h,pooled_w,C] -> grad_feats[l] [B,H_l,W_l,C] (grad_feats/Hs/Ws/scales are [host] arrays of L entries). */
+int lvc_roi_align_backward_nchw(const float* grad, const float* rois, float* grad_input, int B, int C, int H, int W,
+                                int K, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                                int aligned, int* d_status, void* stream);
+int lvc_roi_align_fpn_backward_nhwc(const float* grad, float* const* grad_feats, const int* Hs, const int* Ws,
+                                    const float* scales, int L, int B, int C, const float* rois, const int* levels,
+                                    const int* d_num_valid, int K, int pooled_h, int pooled_w, int sampling_ratio,
+                                    int aligned, int* d_status, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Batched NMS, B images per call.  Replaces torchvision.ops.boxes.batched_nms / nms as called from
  * detectron2/layers/nms.py:10-29 (consumers proposal_utils.py:104, lvc fast_rcnn.py:128).  Keep indices are

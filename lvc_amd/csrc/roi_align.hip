@@ -1,4 +1,4 @@
-// roi_align.hip -- ROIAlign forward for gfx950 (HBM/L2-bound gather; no matrix work).
+// roi_align.hip -- ROIAlign forward and backward for gfx950 (HBM/L2-bound gather; no matrix work).
 //
 // Replaces reference detectron2/layers/csrc/ROIAlign/ROIAlign_cuda.cu:65-139 (RoIAlignForward)
 // and its CPU twin ROIAlign_cpu.cpp:20-218, reached through detectron2/layers/roi_align.py:63-117
@@ -302,6 +302,142 @@ static int launch(RoiAlignArgs& a, void* stream) {
   }
   dim3 grid(a.K, lvc_cdiv(a.C, 256)), block(256);
   hipLaunchKernelGGL(roi_align_fwd_kernel, grid, block, 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ROIAlign backward.  Replaces ROIAlign_cuda.cu:142-306 (bilinear_interpolate_gradient + RoIAlignBackwardFeature) and
+// its CPU twin ROIAlign_cpu.cpp:219-406: every pooled element scatters grad * w / count into the four neighbours of
+// each of its gh x gw sampling points (same sample positions, clamps and weights as the forward).  Like the reference
+// CUDA kernel the scatter uses fp32 atomic adds, so the summation order -- and the last bits -- are not deterministic;
+// the reference CPU kernel (single thread, fixed order) is what oracle.c restates bit-exactly, and tests compare the
+// two within 1e-6 of the gradient scale.  Same mapping as the scalar forward: one workgroup per (RoI, 256-channel
+// slice), lane = channel (coalesced atomics for NHWC gradients; strided for the NCHW drop-in entry point).
+// RoiAlignArgs is reused with feat[] = grad_input (written) and out = grad_output (read).
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignArgs p) {
+  const int k = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (p.num_valid && k >= *p.num_valid) return;
+  const bool c_ok = c < p.C;
+  const float* gk = p.out + (long long)k * p.so_k + (long long)(c_ok ? c : 0) * p.so_c;
+  const float* r = p.rois + (long long)k * 5;
+  const int lvl = p.levels ? p.levels[k] : 0;
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float spatial_scale = p.scale[lvl];
+  const int b = (int)r[0];
+  const float offset = p.aligned ? 0.5f : 0.0f;
+  const float roi_start_w = r[1] * spatial_scale - offset;
+  const float roi_start_h = r[2] * spatial_scale - offset;
+  const float roi_end_w = r[3] * spatial_scale - offset;
+  const float roi_end_h = r[4] * spatial_scale - offset;
+  float roi_width = roi_end_w - roi_start_w;
+  float roi_height = roi_end_h - roi_start_h;
+  if (p.aligned) {
+    if (!(roi_width >= 0 && roi_height >= 0)) {
+      if (p.status && threadIdx.x == 0 && blockIdx.y == 0) atomicOr(p.status, 1);
+    }
+  } else {
+    roi_width = roi_width > 1.f ? roi_width : 1.f;
+    roi_height = roi_height > 1.f ? roi_height : 1.f;
+  }
+  const float bin_h = roi_height / (float)p.ph;
+  const float bin_w = roi_width / (float)p.pw;
+  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_height / (float)p.ph);
+  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_width / (float)p.pw);
+  const float count = (float)(gh * gw);
+
+  long long s_pix, s_c;
+  if (p.nhwc) { s_pix = p.C; s_c = 1; } else { s_pix = 1; s_c = (long long)H * W; }
+  float* gin = const_cast<float*>(p.feat[lvl]) + (long long)b * p.sb[lvl] + (long long)(c_ok ? c : 0) * s_c;
+
+  for (int ph = 0; ph < p.ph; ++ph) {
+    for (int pw = 0; pw < p.pw; ++pw) {
+      const float g = c_ok ? gk[ph * p.so_h + pw * p.so_w] : 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int y_low = (int)y, x_low = (int)x, y_high, x_high;
+          if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+          if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+          const float ly = y - y_low, lx = x - x_low;
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          if (c_ok) {
+            unsafeAtomicAdd(gin + (long long)(y_low * W + x_low) * s_pix, g * w1 / count);
+            unsafeAtomicAdd(gin + (long long)(y_low * W + x_high) * s_pix, g * w2 / count);
+            unsafeAtomicAdd(gin + (long long)(y_high * W + x_low) * s_pix, g * w3 / count);
+            unsafeAtomicAdd(gin + (long long)(y_high * W + x_high) * s_pix, g * w4 / count);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Reference-shaped op (csrc/vision.cpp:97, ROIAlign.h:88-128): grad [K,C,ph,pw] contiguous -> grad_input [B,C,H,W],
+// zeroed here (the reference returns a fresh at::zeros tensor, ROIAlign_cuda.cu:392).
+extern "C" int lvc_roi_align_backward_nchw(const float* grad, const float* rois, float* grad_input, int B, int C,
+                                           int H, int W, int K, int pooled_h, int pooled_w, float spatial_scale,
+                                           int sampling_ratio, int aligned, int* d_status, void* stream) {
+  LVC_CHECK_ARG(grad_input && (K == 0 || (grad && rois)), "null pointer");
+  LVC_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && K >= 0, "bad shape");
+  if (hipMemsetAsync(grad_input, 0, (size_t)B * C * H * W * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+    lvc_set_error("%s: hipMemsetAsync failed", __func__);
+    return LVC_ERR_HIP;
+  }
+  if (K == 0) return LVC_OK;
+  RoiAlignArgs a;
+  memset(&a, 0, sizeof a);
+  a.feat[0] = grad_input; a.H[0] = H; a.W[0] = W; a.scale[0] = spatial_scale;
+  a.sb[0] = (long long)C * H * W;
+  a.nhwc = 0; a.C = C; a.rois = rois; a.levels = nullptr; a.num_valid = nullptr;
+  a.K = K; a.ph = pooled_h; a.pw = pooled_w; a.sampling_ratio = sampling_ratio; a.aligned = aligned;
+  a.out = const_cast<float*>(grad);
+  a.so_k = (long long)C * pooled_h * pooled_w; a.so_c = (long long)pooled_h * pooled_w;
+  a.so_h = pooled_w; a.so_w = 1;
+  a.status = d_status;
+  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// Engine op: gradient of lvc_roi_align_fpn_nhwc.  grad [K, ph, pw, C] channels-last -> grad_feats[l] [B, Hl, Wl, C]
+// (zeroed here), one launch over all RoIs: the backward of the per-level gather/scatter loop of
+// detectron2/modeling/poolers.py:236-246.
+extern "C" int lvc_roi_align_fpn_backward_nhwc(const float* grad, float* const* grad_feats, const int* Hs,
+                                               const int* Ws, const float* scales, int L, int B, int C,
+                                               const float* rois, const int* levels, const int* d_num_valid, int K,
+                                               int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                                               int* d_status, void* stream) {
+  LVC_CHECK_ARG(L >= 1 && L <= LVC_MAX_LEVELS, "1..8 levels");
+  LVC_CHECK_ARG(grad_feats && Hs && Ws && scales && (K == 0 || (grad && rois)), "null pointer");
+  LVC_CHECK_ARG(B > 0 && C > 0 && pooled_h > 0 && pooled_w > 0 && K >= 0, "bad shape");
+  LVC_CHECK_ARG(L == 1 || levels, "levels required when L > 1");
+  RoiAlignArgs a;
+  memset(&a, 0, sizeof a);
+  for (int l = 0; l < L; ++l) {
+    LVC_CHECK_ARG(grad_feats[l] && Hs[l] > 0 && Ws[l] > 0, "bad level");
+    if (hipMemsetAsync(grad_feats[l], 0, (size_t)B * Hs[l] * Ws[l] * C * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      lvc_set_error("%s: hipMemsetAsync failed", __func__);
+      return LVC_ERR_HIP;
+    }
+    a.feat[l] = grad_feats[l]; a.H[l] = Hs[l]; a.W[l] = Ws[l]; a.scale[l] = scales[l];
+    a.sb[l] = (long long)C * Hs[l] * Ws[l];
+  }
+  if (K == 0) return LVC_OK;
+  a.nhwc = 1; a.C = C; a.rois = rois; a.levels = levels; a.num_valid = d_num_valid;
+  a.K = K; a.ph = pooled_h; a.pw = pooled_w; a.sampling_ratio = sampling_ratio; a.aligned = aligned;
+  a.out = const_cast<float*>(grad);
+  a.so_k = (long long)C * pooled_h * pooled_w; a.so_c = 1;
+  a.so_h = (long long)pooled_w * C; a.so_w = C;
+  a.status = d_status;
+  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -261,6 +261,48 @@ def roi_align_fpn_nhwc(feats, scales, rois, levels, pooled_h, pooled_w, sampling
     return out
 
 
+def roi_align_backward(grad, rois, spatial_scale, pooled_h, pooled_w, batch_size, channels, height, width,
+                       sampling_ratio, aligned, status=None):
+    """Reference-shaped op (csrc/vision.cpp:97): grad [K,C,ph,pw], rois [K,5] -> grad_input [B,C,H,W]."""
+    _req_cuda(grad, rois)
+    grad = grad.contiguous().float()
+    rois = rois.contiguous().float()
+    K = rois.shape[0]
+    assert grad.shape == (K, channels, pooled_h, pooled_w)
+    gin = torch.empty(batch_size, channels, height, width, device=grad.device, dtype=torch.float32)
+    st = _lib.lib().lvc_roi_align_backward_nchw(
+        ptr(grad), ptr(rois), ptr(gin), c_int(batch_size), c_int(channels), c_int(height), c_int(width), c_int(K),
+        c_int(pooled_h), c_int(pooled_w), c_float(spatial_scale), c_int(sampling_ratio),
+        c_int(1 if aligned else 0), ptr(status), _stream(grad))
+    check(st, "lvc_roi_align_backward_nchw")
+    return gin
+
+
+def roi_align_fpn_backward_nhwc(grad, shapes, scales, rois, levels, sampling_ratio, aligned, num_valid=None,
+                                status=None):
+    """Gradient of roi_align_fpn_nhwc.  grad [K,ph,pw,C]; shapes: list of (B,H_l,W_l,C).  Returns the list of
+    NHWC level gradients."""
+    _req_cuda(grad, rois)
+    grad = grad.contiguous().float()
+    rois = rois.contiguous().float()
+    K, ph, pw, C = grad.shape
+    L = len(shapes)
+    B = shapes[0][0]
+    outs = [torch.empty(*sh, device=grad.device, dtype=torch.float32) for sh in shapes]
+    FP = c_void_p * L
+    IP = c_int * L
+    FL = c_float * L
+    if levels is not None:
+        assert levels.dtype == torch.int32 and levels.is_contiguous()
+    st = _lib.lib().lvc_roi_align_fpn_backward_nhwc(
+        ptr(grad), FP(*[o.data_ptr() for o in outs]), IP(*[sh[1] for sh in shapes]), IP(*[sh[2] for sh in shapes]),
+        FL(*[float(s) for s in scales]), c_int(L), c_int(B), c_int(C), ptr(rois), ptr(levels), ptr(num_valid),
+        c_int(K), c_int(ph), c_int(pw), c_int(sampling_ratio), c_int(1 if aligned else 0), ptr(status),
+        _stream(grad))
+    check(st, "lvc_roi_align_fpn_backward_nhwc")
+    return outs
+
+
 # --------------------------------------------------------------------------- NMS
 def batched_nms_batch(boxes, scores, idxs, counts, iou_threshold, max_keep=0):
     """boxes [B,Nmax,4], scores [B,Nmax], idxs [B,Nmax] int32 or None, counts [B] int32 device or None.

@@ -66,7 +66,12 @@ def gen_roi_align():
             for sr in (0, 2):
                 key = "out_s%g_a%d_sr%d" % (scale, aligned, sr)
                 outs[key] = _C.roi_align_forward(feat, rois, scale, 7, 7, sr, aligned)
-    save("roi_align", feat=feat, rois=rois, **outs)
+    # backward (csrc/vision.cpp:97): one upstream gradient, the reference's own CPU kernel, three configurations
+    grad = torch.randn(rois.shape[0], 8, 7, 7, generator=g)
+    for scale, aligned, sr in ((0.25, True, 0), (0.0625, True, 2), (0.125, False, 0)):
+        outs["bwd_s%g_a%d_sr%d" % (scale, aligned, sr)] = _C.roi_align_backward(
+            grad, rois, scale, 7, 7, 2, 8, 50, 84, sr, aligned)
+    save("roi_align", feat=feat, rois=rois, grad=grad, **outs)
 
 
 def gen_nms():

@@ -19,6 +19,7 @@ def lib():
             subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
         L = ctypes.CDLL(so)
         L.orc_roi_align_forward.restype = ctypes.c_int
+        L.orc_roi_align_backward.restype = ctypes.c_int
         L.orc_nms.restype = ctypes.c_int64
         _LIB = L
     return _LIB
@@ -40,6 +41,21 @@ def roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_r
     if rc != 0:
         raise RuntimeError("ROIs in ROIAlign cannot have non-negative size!")
     return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_h, pooled_w, batch_size, channels, height, width,
+                       sampling_ratio, aligned):
+    """Same signature as the reference `_C.roi_align_backward` (csrc/vision.cpp:97, ROIAlign.h:88-128)."""
+    grad = grad.contiguous().float()
+    rois = rois.contiguous().float()
+    K = rois.shape[0]
+    gin = torch.zeros(batch_size, channels, height, width, dtype=torch.float32)
+    rc = lib().orc_roi_align_backward(_p(grad), _p(rois), _p(gin), K, batch_size, channels, height, width,
+                                      pooled_h, pooled_w, ctypes.c_float(spatial_scale), sampling_ratio,
+                                      int(bool(aligned)))
+    if rc != 0:
+        raise RuntimeError("ROIs in ROIAlign do not have non-negative size!")
+    return gin
 
 
 def nms(boxes, scores, iou_threshold):

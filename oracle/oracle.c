@@ -8,7 +8,8 @@
  * /root/reference).  Parity pins:
  *   - orc_roi_align_forward is checked against the reference's own
  *     ROIAlign_cpu.cpp compiled into oracle/_ref (tests/test_oracle_pins.py)
- *     and against golden vectors produced by it (tests/golden/roi_align_*.npz).
+ *     and against golden vectors produced by it (tests/golden/roi_align_*.npz);
+ *     orc_roi_align_backward likewise (golden roi_align.npz keys bwd_*).
  *   - orc_nms restates torchvision 0.8.2's nms_cpu_kernel, a third-party
  *     dependency that is NOT under /root/reference (README.md:65-67 pins
  *     torchvision 0.8.2; call sites detectron2/layers/nms.py:6-7,20,25).
@@ -105,6 +106,70 @@ int orc_roi_align_forward(const float* input, const float* rois, float* output, 
       }
     }
     free(taps);
+  }
+  return 0;
+}
+
+/* ---- ROIAlign backward --------------------------------------------------
+ * Restates ROIAlign_cpu.cpp:219-281 (bilinear_interpolate_gradient) and :288-406 (ROIAlignBackward), T=float:
+ * every pooled element (n, c, ph, pw), visited in that index order, scatters grad * w / count into the four
+ * neighbours of each of its gh x gw sampling points; samples outside [-1, H] x [-1, W] contribute nothing.
+ * grad_output [K,C,ph,pw] contiguous, grad_input [B,C,H,W] (zeroed here, like ROIAlign_backward_cpu's at::zeros).
+ * The single-threaded accumulation order of the reference is kept, so results are bit-identical to it.
+ */
+int orc_roi_align_backward(const float* grad_output, const float* rois, float* grad_input, int K, int B, int C,
+                           int H, int W, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
+                           int aligned) {
+  memset(grad_input, 0, (size_t)B * C * H * W * sizeof(float));
+  for (int n = 0; n < K; n++) {
+    const float* r = rois + (size_t)n * 5;
+    int b = (int)r[0];
+    float offset = aligned ? 0.5f : 0.0f;
+    float roi_start_w = r[1] * spatial_scale - offset;
+    float roi_start_h = r[2] * spatial_scale - offset;
+    float roi_end_w = r[3] * spatial_scale - offset;
+    float roi_end_h = r[4] * spatial_scale - offset;
+    float roi_width = roi_end_w - roi_start_w;
+    float roi_height = roi_end_h - roi_start_h;
+    if (aligned) {
+      if (!(roi_width >= 0 && roi_height >= 0)) return -1;
+    } else {
+      roi_width = roi_width > 1.f ? roi_width : 1.f;
+      roi_height = roi_height > 1.f ? roi_height : 1.f;
+    }
+    float bin_h = roi_height / (float)pooled_h;
+    float bin_w = roi_width / (float)pooled_w;
+    int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
+    int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
+    float count = (float)(gh * gw);
+    for (int c = 0; c < C; c++) {
+      float* gin = grad_input + ((size_t)b * C + c) * H * W;
+      const float* gout = grad_output + ((size_t)n * C + c) * pooled_h * pooled_w;
+      for (int ph = 0; ph < pooled_h; ph++)
+        for (int pw = 0; pw < pooled_w; pw++) {
+          float g = gout[ph * pooled_w + pw];
+          for (int iy = 0; iy < gh; iy++) {
+            float y0 = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+            for (int ix = 0; ix < gw; ix++) {
+              float x = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+              float y = y0;
+              if (y < -1.0 || y > H || x < -1.0 || x > W) continue;
+              if (y <= 0) y = 0;
+              if (x <= 0) x = 0;
+              int y_low = (int)y, x_low = (int)x, y_high, x_high;
+              if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+              if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+              float ly = y - y_low, lx = x - x_low;
+              float hy = (float)(1. - ly), hx = (float)(1. - lx);
+              float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+              gin[y_low * W + x_low] += g * w1 / count;
+              gin[y_low * W + x_high] += g * w2 / count;
+              gin[y_high * W + x_low] += g * w3 / count;
+              gin[y_high * W + x_high] += g * w4 / count;
+            }
+          }
+        }
+    }
   }
   return 0;
 }

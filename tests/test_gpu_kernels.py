@@ -251,6 +251,69 @@ def test_roi_align_fpn_nhwc_matches_oracle():
         assert (out[sel] - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("scale,aligned,sr", [(0.25, True, 0), (1 / 32, True, 0), (0.0625, False, 2)])
+def test_roi_align_backward_nchw_matches_oracle(scale, aligned, sr):
+    """lvc_roi_align_backward_nchw (atomic scatter, like ROIAlign_cuda.cu) vs the oracle's restatement of the
+    reference CPU kernel: equal up to fp32 summation order -> 1e-5 of the largest accumulated gradient."""
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(21)
+    B, C = 2, 40
+    H, W = int(800 * scale), int(1344 * scale)
+    rois = _rand_rois(g, 200, B, 1333, 800)
+    extra = torch.tensor([[0, 10, 10, 10, 10], [1, 0, 0, 1333, 800], [0, 1300, 780, 1333, 800],
+                          [1, 0, 0, 0.5, 0.5], [0, 5, 5, 5, 300]], dtype=torch.float32)
+    rois = torch.cat([rois, extra])
+    grad = torch.randn(rois.shape[0], C, 7, 7, generator=g)
+    ref = oops.roi_align_backward(grad, rois, scale, 7, 7, B, C, H, W, sr, aligned)
+    d = _dev()
+    out = k.roi_align_backward(grad.to(d), rois.to(d), scale, 7, 7, B, C, H, W, sr, aligned).cpu()
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_roi_align_backward_golden_and_autograd():
+    """The reference's own `_C.roi_align_backward` outputs (tests/golden/roi_align.npz, bwd_*) and the autograd
+    wiring of layers.ROIAlign (reference roi_align.py:22-57): d(sum(out * g))/d(input) == roi_align_backward(g)."""
+    from helpers import gold
+    from lvc_amd import kernels as k
+    from lvc_amd.layers import ROIAlign
+
+    gd = gold("roi_align")
+    d = _dev()
+    for key in [kk for kk in gd if kk.startswith("bwd_")]:
+        _, s, a, sr = key.split("_")
+        out = k.roi_align_backward(gd["grad"].to(d), gd["rois"].to(d), float(s[1:]), 7, 7, 2, 8, 50, 84,
+                                   int(sr[2:]), bool(int(a[1:]))).cpu()
+        assert (out - gd[key]).abs().max() <= 1e-5 * max(1.0, float(gd[key].abs().max())), key
+    feat = gd["feat"].to(d).requires_grad_(True)
+    y = ROIAlign((7, 7), 0.25, 0, True)(feat, gd["rois"].to(d))
+    (y * gd["grad"].to(d)).sum().backward()
+    assert (feat.grad.cpu() - gd["bwd_s0.25_a1_sr0"]).abs().max() <= 1e-5 * float(gd["bwd_s0.25_a1_sr0"].abs().max())
+
+
+def test_roi_align_fpn_backward_nhwc_matches_oracle():
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(22)
+    B, C = 2, 256
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    shapes = [(B, int(800 * s), int(1344 * s), C) for s in scales]
+    rois = _rand_rois(g, 300, B, 1333, 800)
+    levels = torch.randint(0, 4, (300,), generator=g).int()
+    grad = torch.randn(300, 7, 7, C, generator=g)
+    d = _dev()
+    outs = k.roi_align_fpn_backward_nhwc(grad.to(d), shapes, scales, rois.to(d), levels.to(d), 0, True)
+    for l in range(4):
+        sel = (levels == l).nonzero().view(-1)
+        ref = oops.roi_align_backward(grad[sel].permute(0, 3, 1, 2), rois[sel], scales[l], 7, 7, B, C,
+                                      shapes[l][1], shapes[l][2], 0, True)
+        got = outs[l].cpu().permute(0, 3, 1, 2)
+        assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
 def _nms_case(g, n, nidx, jitter):
     base = _rand_rois(g, max(4, n // 6), 1, 1333, 800, 8, 300)[:, 1:]
     pick = torch.randint(0, base.shape[0], (n,), generator=g)

@@ -18,6 +18,17 @@ def test_roi_align_matches_reference_kernel():
         assert torch.equal(out, g[key]), key  # same arithmetic, same order: bit-exact
 
 
+def test_roi_align_backward_matches_reference_kernel():
+    """orc_roi_align_backward against the reference's own `_C.roi_align_backward` (CPU, csrc/vision.cpp:97)."""
+    g = gold("roi_align")
+    keys = [k for k in g if k.startswith("bwd_")]
+    assert len(keys) == 3
+    for key in keys:
+        _, s, a, sr = key.split("_")
+        gin = oops.roi_align_backward(g["grad"], g["rois"], float(s[1:]), 7, 7, 2, 8, 50, 84, int(sr[2:]), bool(int(a[1:])))
+        assert torch.equal(gin, g[key]), key  # same single-threaded accumulation order: bit-exact
+
+
 def test_roi_align_negative_size_raises():
     feat = torch.zeros(1, 1, 8, 8)
     with pytest.raises(RuntimeError):
