@@ -208,6 +208,20 @@ int lvc_rpn_losses(const float* logits, const float* deltas, const float* anchor
                    const signed char* labels, int S, float smooth_l1_beta, float normalizer, float* out_losses,
                    void* stream);
 
+/* Box-corrector training (BASELINE config 5; the shipped fine-tune yaml freezes the backbone).
+ * lvc_giou_box_loss: BoxOnlyLayersCascade.box_reg_loss / BoxOnlyLayers.box_reg_loss
+ *   (lvc/modeling/roi_heads/roi_heads_cascade.py:165-195): apply_deltas (box_regression.py:73-110, weights wx..wh,
+ *   clamp) on the foreground rows (gt_classes in [0,K)) -> GIoU loss (fvcore.nn.giou_loss, eps 1e-7) -> mean; with
+ *   iterate != 0: mean(max(loss_after - lambda * loss_before, 0)).  out_loss [1] (NaN when no row is foreground, as the
+ *   reference's mean of an empty tensor), ddeltas [R,4] = d(loss)/d(deltas).
+ * lvc_relu_backward: out = y > 0 ? dy : 0 (backward of the fused Linear+ReLU of FastRCNNConvFCHead, box_head.py:82-91).
+ * lvc_colsum: out[n] = sum_m x[m*ldx + n], rows added in order (bias gradients). */
+int lvc_giou_box_loss(const float* deltas, int ld_delta, const float* proposals, const float* gt_boxes,
+                      const long long* gt_classes, int R, int K, float wx, float wy, float ww, float wh,
+                      float scale_clamp, int iterate, float lambda, float* out_loss, float* ddeltas, void* stream);
+int lvc_relu_backward(const float* dy, const float* y, long long n, float* out, void* stream);
+int lvc_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Label-verification kNN (tools/run_nearest_neighbours.py:142-162, 214-227).
  * lvc_colmean: mu[d] = mean_m x[m,d].  lvc_knn_topk_vote: per query row, class ids of the 10 most similar

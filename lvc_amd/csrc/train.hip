@@ -216,3 +216,148 @@ extern "C" int lvc_rpn_losses(const float* logits, const float* deltas, const fl
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+// =====================================================================================
+// Box-corrector regression loss: BoxOnlyLayersCascade.box_reg_loss / BoxOnlyLayers.box_reg_loss
+// (lvc/modeling/roi_heads/roi_heads_cascade.py:165-195) = Box2BoxTransform.apply_deltas (box_regression.py:73-110) on
+// the foreground rows -> fvcore.nn.giou_loss (third-party, eps = 1e-7; restated in oracle/refshim.py) -> mean, or with
+// `iterate` mean(max(loss_after - lambda * loss_before, 0)).  Emits d(loss)/d(deltas) [R,4] (zero on background rows)
+// so that the backward of the op is one multiply.  An empty foreground set gives NaN, as .mean() of an empty tensor does.
+// =====================================================================================
+__device__ __forceinline__ float giou_terms(float x1, float y1, float x2, float y2, float gx1, float gy1, float gx2,
+                                            float gy2, float* g /* dL/d(x1,y1,x2,y2) or nullptr */) {
+  const float eps = 1e-7f;
+  const float xk1 = fmaxf(x1, gx1), yk1 = fmaxf(y1, gy1), xk2 = fminf(x2, gx2), yk2 = fminf(y2, gy2);
+  const bool m = (yk2 > yk1) && (xk2 > xk1);
+  const float I = m ? (xk2 - xk1) * (yk2 - yk1) : 0.f;
+  const float A = (x2 - x1) * (y2 - y1);
+  const float U = A + (gx2 - gx1) * (gy2 - gy1) - I;
+  const float iou = I / (U + eps);
+  const float xc1 = fminf(x1, gx1), yc1 = fminf(y1, gy1), xc2 = fmaxf(x2, gx2), yc2 = fmaxf(y2, gy2);
+  const float C = (xc2 - xc1) * (yc2 - yc1);
+  const float L = 1.f - (iou - (C - U) / (C + eps));
+  if (g) {
+    // subgradient of max/min at ties = 1/2, as torch.max / torch.min (binary) backward
+    auto gt_ = [](float a, float b) { return a > b ? 1.f : (a == b ? 0.5f : 0.f); };
+    const float dI[4] = {m ? -gt_(x1, gx1) * (yk2 - yk1) : 0.f, m ? -gt_(y1, gy1) * (xk2 - xk1) : 0.f,
+                         m ? gt_(gx2, x2) * (yk2 - yk1) : 0.f, m ? gt_(gy2, y2) * (xk2 - xk1) : 0.f};
+    const float dA[4] = {-(y2 - y1), -(x2 - x1), (y2 - y1), (x2 - x1)};
+    const float dC[4] = {-gt_(gx1, x1) * (yc2 - yc1), -gt_(gy1, y1) * (xc2 - xc1), gt_(x2, gx2) * (yc2 - yc1),
+                         gt_(y2, gy2) * (xc2 - xc1)};
+    for (int j = 0; j < 4; ++j) {
+      const float dU = dA[j] - dI[j];
+      const float diou = (dI[j] * (U + eps) - I * dU) / ((U + eps) * (U + eps));
+      const float dterm = ((dC[j] - dU) * (C + eps) - (C - U) * dC[j]) / ((C + eps) * (C + eps));
+      g[j] = -(diou - dterm);
+    }
+  }
+  return L;
+}
+
+__global__ __launch_bounds__(1024) void giou_box_loss_kernel(const float* __restrict__ deltas, int ld_delta,
+                                                             const float* __restrict__ proposals,
+                                                             const float* __restrict__ gt_boxes,
+                                                             const long long* __restrict__ gt_classes, int R, int K,
+                                                             float wx, float wy, float ww, float wh, float scale_clamp,
+                                                             int iterate, float lambda, float* __restrict__ out_loss,
+                                                             float* __restrict__ ddeltas) {
+  __shared__ double red[16];
+  __shared__ int redn[16];
+  __shared__ int s_nfg;
+  double ls = 0.0;
+  int nfg = 0;
+  for (int r = threadIdx.x; r < R; r += 1024) {
+    float* dd = ddeltas + (size_t)r * 4;
+    dd[0] = dd[1] = dd[2] = dd[3] = 0.f;
+    const long long c = gt_classes[r];
+    if (!(c >= 0 && c < K)) continue;
+    ++nfg;
+    const float* p = proposals + (size_t)r * 4;
+    const float* g = gt_boxes + (size_t)r * 4;
+    const float* d = deltas + (size_t)r * ld_delta;
+    const float w = p[2] - p[0], h = p[3] - p[1];
+    const float cx = p[0] + 0.5f * w, cy = p[1] + 0.5f * h;
+    const float dx = d[0] / wx, dy = d[1] / wy;
+    const float dw0 = d[2] / ww, dh0 = d[3] / wh;
+    const float dw = fminf(dw0, scale_clamp), dh = fminf(dh0, scale_clamp);
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    const float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    float gl[4];
+    float La = giou_terms(x1, y1, x2, y2, g[0], g[1], g[2], g[3], gl);
+    float pass = 1.f;
+    if (iterate) {
+      const float Lb = giou_terms(p[0], p[1], p[2], p[3], g[0], g[1], g[2], g[3], nullptr);
+      const float diff = La - Lb * lambda;
+      pass = diff > 0.f ? 1.f : (diff == 0.f ? 0.5f : 0.f);
+      La = fmaxf(diff, 0.f);
+    }
+    ls += (double)La;
+    dd[0] = pass * (gl[0] + gl[2]) * (w / wx);
+    dd[1] = pass * (gl[1] + gl[3]) * (h / wy);
+    dd[2] = pass * (0.5f * (gl[2] - gl[0])) * (dw0 <= scale_clamp ? pw / ww : 0.f);
+    dd[3] = pass * (0.5f * (gl[3] - gl[1])) * (dh0 <= scale_clamp ? ph / wh : 0.f);
+  }
+  for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o); nfg += __shfl_xor(nfg, o); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = ls; redn[threadIdx.x >> 6] = nfg; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double a = 0;
+    int n = 0;
+    for (int w = 0; w < 16; ++w) { a += red[w]; n += redn[w]; }
+    s_nfg = n;
+    out_loss[0] = n > 0 ? (float)(a / n) : NAN;
+  }
+  __syncthreads();
+  const float inv = s_nfg > 0 ? 1.f / (float)s_nfg : 0.f;
+  for (int r = threadIdx.x; r < R; r += 1024)
+    for (int j = 0; j < 4; ++j) ddeltas[(size_t)r * 4 + j] *= inv;
+}
+
+// deltas [R, ld_delta] (first 4 columns: class-agnostic regression), proposals / gt_boxes [R,4], gt_classes [R] int64
+// (foreground = [0, K)); out_loss [1]; ddeltas [R,4] = d(loss)/d(deltas).
+extern "C" int lvc_giou_box_loss(const float* deltas, int ld_delta, const float* proposals, const float* gt_boxes,
+                                 const long long* gt_classes, int R, int K, float wx, float wy, float ww, float wh,
+                                 float scale_clamp, int iterate, float lambda, float* out_loss, float* ddeltas,
+                                 void* stream) {
+  LVC_CHECK_ARG(R > 0 && K > 0 && ld_delta >= 4, "empty batch");
+  LVC_CHECK_ARG(deltas && proposals && gt_boxes && gt_classes && out_loss && ddeltas, "null pointer");
+  hipLaunchKernelGGL(giou_box_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, deltas, ld_delta, proposals,
+                     gt_boxes, gt_classes, R, K, wx, wy, ww, wh, scale_clamp, iterate, lambda, out_loss, ddeltas);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// =====================================================================================
+// Backward helpers of the fused Linear(+bias)(+ReLU) layers of the box head (FastRCNNConvFCHead, box_head.py:82-91):
+// masked upstream gradient dz = dy * (y > 0) and the bias gradient = column sums of dz (fixed row order per column ->
+// deterministic).  dX and dW are GEMMs on the conv/GEMM kernel.
+// =====================================================================================
+__global__ void relu_backward_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n,
+                                     float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = y[i] > 0.f ? dy[i] : 0.f;
+}
+
+extern "C" int lvc_relu_backward(const float* dy, const float* y, long long n, float* out, void* stream) {
+  LVC_CHECK_ARG(n >= 0 && (n == 0 || (dy && y && out)), "bad arguments");
+  if (n == 0) return LVC_OK;
+  hipLaunchKernelGGL(relu_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dy, y, n, out);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+__global__ void colsum_kernel(const float* __restrict__ x, int M, int N, int ldx, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N) return;
+  float s = 0.f;
+  for (int r = 0; r < M; ++r) s += x[(size_t)r * ldx + c];
+  out[c] = s;
+}
+
+extern "C" int lvc_colsum(const float* x, int M, int N, int ldx, float* out, void* stream) {
+  LVC_CHECK_ARG(M >= 0 && N > 0 && ldx >= N && x && out, "bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3(lvc_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, x, M, N, ldx, out);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

@@ -564,6 +564,69 @@ def fast_rcnn_losses(logits, deltas, proposals, gt_boxes, gt_classes, num_classe
     return out, dl, dd
 
 
+def giou_box_loss(deltas, proposals, gt_boxes, gt_classes, num_classes, box_weights, scale_clamp, iterate=False,
+                  lambda_=0.0):
+    """Box-corrector regression loss.  Returns (loss [1], ddeltas [R,4])."""
+    _req_cuda(deltas, proposals, gt_boxes, gt_classes)
+    R = deltas.shape[0]
+    out = torch.empty(1, device=deltas.device, dtype=torch.float32)
+    dd = torch.empty(R, 4, device=deltas.device, dtype=torch.float32)
+    wx, wy, ww, wh = box_weights
+    assert deltas.stride(1) == 1 and gt_classes.dtype == torch.int64
+    rc = _lib.lib().lvc_giou_box_loss(ptr(deltas), c_int(deltas.stride(0)), ptr(proposals.contiguous()),
+                                      ptr(gt_boxes.contiguous()), ptr(gt_classes.contiguous()), c_int(R),
+                                      c_int(num_classes), c_float(wx), c_float(wy), c_float(ww), c_float(wh),
+                                      c_float(scale_clamp), c_int(1 if iterate else 0), c_float(lambda_), ptr(out),
+                                      ptr(dd), _stream(deltas))
+    check(rc, "lvc_giou_box_loss")
+    return out, dd
+
+
+def relu_backward(dy, y):
+    _req_cuda(dy, y)
+    dy, y = dy.contiguous(), y.contiguous()
+    out = torch.empty_like(dy)
+    check(_lib.lib().lvc_relu_backward(ptr(dy), ptr(y), c_longlong(dy.numel()), ptr(out), _stream(dy)), "lvc_relu_backward")
+    return out
+
+
+def colsum(x):
+    """x [M,N] row-major -> [N] column sums (rows added in order)."""
+    _req_cuda(x)
+    x = x.contiguous()
+    M, N = x.shape
+    out = torch.empty(N, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lvc_colsum(ptr(x), c_int(M), c_int(N), c_int(N), ptr(out), _stream(x)), "lvc_colsum")
+    return out
+
+
+def linear_backward(x, weight, dz, need_dx=True, need_dw=True):
+    """Gradients of y = x @ weight.T on the conv/GEMM kernel.  x [M,Kin], weight [Kout,Kin], dz [M,Kout] (already
+    masked by the activation).  Returns (dx [M,Kin] or None, dw [Kout,Kin] or None).  Both products contract over a
+    dimension that is zero-padded to the kernel's 32-wide k chunk (Kout for dx, M for dw)."""
+    M, Kin = x.shape
+    Kout = weight.shape[0]
+    dev = x.device
+    dx = dw = None
+    if need_dx:   # dx = dz @ W: contraction over Kout, "weights" = W^T [Kin rows, Kout]
+        pk = (-Kout) % 32
+        wt = torch.zeros(Kin, Kout + pk, device=dev)
+        wt[:, :Kout] = weight.detach().t()
+        dzp = dz
+        if pk:
+            dzp = torch.zeros(M, Kout + pk, device=dev)
+            dzp[:, :Kout] = dz
+        dx = linear(dzp.contiguous(), pack_linear(wt))
+    if need_dw:   # dw = dz^T @ x: contraction over M, "weights" = x^T [Kin rows, M]
+        pm = (-M) % 32
+        xt = torch.zeros(Kin, M + pm, device=dev)
+        xt[:, :M] = x.detach().t()
+        dzt = torch.zeros(Kout, M + pm, device=dev)
+        dzt[:, :M] = dz.t()
+        dw = linear(dzt, pack_linear(xt))
+    return dx, dw
+
+
 def rpn_losses(logits, deltas, anchors, gt_boxes, labels, smooth_l1_beta, normalizer):
     """Sampled-anchor RPN losses (forward only).  All inputs are rows gathered at the sampled anchors."""
     _req_cuda(logits, deltas, anchors, gt_boxes, labels)

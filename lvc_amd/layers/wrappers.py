@@ -88,6 +88,42 @@ class Conv2d(nn.Module):
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding)
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = act(x @ W^T + b) with the fused GEMM epilogue; backward = masked upstream gradient (lvc_relu_backward),
+    bias gradient (lvc_colsum) and the two GEMMs dX = dZ W, dW = dZ^T X on the same conv/GEMM kernel
+    (`kernels.linear_backward`).  `w_view` maps a gradient in the layout of the packed weight back to the layout of
+    the parameter (the box head packs fc1 in (h, w, c) column order for channels-last RoI features)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, relu, w_packed_layout, w_view):
+        y = K.linear(x.contiguous(), packed, relu=relu)
+        ctx.save_for_backward(x, y if relu else None)
+        ctx.relu = relu
+        ctx.weight = w_packed_layout() if w_packed_layout is not None else weight
+        ctx.w_view = w_view
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        dz = K.relu_backward(dy, y) if ctx.relu else dy.contiguous()
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        dx, dw = K.linear_backward(x, ctx.weight, dz, need_dx=need_dx, need_dw=need_dw)
+        if dw is not None and ctx.w_view is not None:
+            dw = ctx.w_view(dw)
+        db = K.colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db, None, None, None, None
+
+
+def linear_fn(x, weight, bias, packed, relu=False, w_packed_layout=None, w_view=None):
+    """Differentiable fused linear layer when anything requires grad, plain kernel call otherwise."""
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return _LinearFn.apply(x, weight, bias, packed, relu, w_packed_layout, w_view)
+    return K.linear(x.contiguous(), packed, relu=relu)
+
+
 class Linear(nn.Module):
     """nn.Linear-compatible parameters (`weight` [out,in], `bias`), forward on the MFMA GEMM kernel."""
 
@@ -104,7 +140,7 @@ class Linear(nn.Module):
 
     def forward(self, x, relu=False):
         require_device(x, "Linear")
-        return K.linear(x.contiguous(), self.packed(), relu=relu)
+        return linear_fn(x, self.weight, self.bias, self.packed(), relu=relu)
 
     def extra_repr(self):
         return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features, self.bias is not None)

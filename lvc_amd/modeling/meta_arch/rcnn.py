@@ -112,7 +112,13 @@ class GeneralizedRCNN(_RCNNBase):
                 raise NotImplementedError(
                     "backward through the trunk is not implemented; fine-tune configs freeze it (MODEL.BACKBONE.FREEZE)")
             features = self.backbone(images.tensor)
-        if self.proposal_generator:
+        from ..proposal_generator.rbg import RBG
+
+        if isinstance(self.proposal_generator, RBG):  # reference rcnn.py:150-155: loaded proposals -> jittered GT boxes
+            proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+            proposal_losses = {}
+            proposals, _ = self.proposal_generator(proposals, gt_instances)
+        elif self.proposal_generator:
             proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
         else:
             assert "proposals" in batched_inputs[0]

@@ -10,7 +10,7 @@ from torch import nn
 
 from ... import kernels as K
 from ...layers import Conv2d, Linear, ShapeSpec, get_norm
-from ...layers.wrappers import _PackedCache
+from ...layers.wrappers import _PackedCache, linear_fn
 from ...utils import weight_init
 from ...utils.registry import Registry
 
@@ -65,7 +65,12 @@ class FastRCNNConvFCHead(nn.Module):
             x = layer.forward_nhwc(x)
         if len(self.fcs):
             M = x.shape[0]
-            x = K.linear(x.reshape(M, -1), self._packed_fc1_hwc(), relu=True)
+            fc = self.fcs[0]
+            C, Hh, Ww = self._fc1_chw
+            x = linear_fn(
+                x.reshape(M, -1), fc.weight, fc.bias, self._packed_fc1_hwc(), relu=True,
+                w_packed_layout=lambda: fc.weight.detach().view(fc.out_features, C, Hh, Ww).permute(0, 2, 3, 1).reshape(fc.out_features, -1),
+                w_view=lambda dw: dw.view(fc.out_features, Hh, Ww, C).permute(0, 3, 1, 2).reshape(fc.out_features, -1))
             for fc in self.fcs[1:]:
                 x = fc(x, relu=True)
         return x

@@ -4,8 +4,11 @@ reference (`box_head.{k}.fc{1,2,3}`, `box_predictor.{k}.bbox_pred`).
 
 Implemented: the inference branch used by `GeneralizedRCNNRegOnly` (`_forward_box_qe`, :167-203: correct a given set
 of (box, class) pseudo-labels), batched on device: per stage one ROIAlign launch over all levels, three fused
-bias+ReLU GEMMs, one 1024->4 GEMM and one decode+clip kernel.  Training (GIoU losses, `_ScaleGradient`, backward
-into the trunk) and the RBG evaluation branch are not implemented.
+bias+ReLU GEMMs, one 1024->4 GEMM and one decode+clip kernel; and the TRAINING branch (`_forward_box` :205-238,
+`_match_and_label_boxes` :279-327, `_run_stage` :329-346, `_create_proposals_from_boxes` :348-369) with the GIoU
+loss kernel and GEMM backward through the three heads, for a frozen trunk (`MODEL.BACKBONE.FREEZE`, the shipped
+`cascade_ubbr_*_ft_*` yaml; backward into the trunk -- conv dgrad/wgrad -- is not implemented).  The RBG evaluation
+branch (which subsamples with `randperm` even in eval) is not implemented.
 """
 import torch
 from torch import nn
@@ -69,9 +72,11 @@ class CascadeROIHeads(ROIHeads):
         return cur
 
     def forward(self, images, features, proposals, targets=None):
-        """Reference signature (cascade_rcnn.py:143-165).  Only the GeneralizedRCNNRegOnly evaluation branch."""
+        """Reference signature (cascade_rcnn.py:143-165): training -> (proposals, losses); evaluation only through
+        GeneralizedRCNNRegOnly."""
         if self.training:
-            raise NotImplementedError("CascadeROIHeads training is not implemented in lvc_amd")
+            proposals = self.label_and_sample_proposals(proposals, targets, inference=False)
+            return proposals, self._forward_box_train(features, proposals, targets)
         if global_cfg.get("MODEL", {}).get("META_ARCHITECTURE", None) != "GeneralizedRCNNRegOnly":
             raise NotImplementedError("CascadeROIHeads evaluation with RBG proposals is not implemented; use "
                                       "META_ARCHITECTURE GeneralizedRCNNRegOnly (and call set_global_cfg(cfg))")
@@ -99,3 +104,80 @@ class CascadeROIHeads(ROIHeads):
             inst.pred_classes = t.gt_classes[keep]
             results.append(inst)
         return tuple(results), None
+
+    # ------------------------------------------------------------------ training (frozen trunk)
+    def _forward_box_train(self, features, proposals, targets):
+        """reference cascade_rcnn.py:205-238 (training half)."""
+        feats = [to_nhwc(features[f]) for f in self.box_in_features]
+        if any(f.requires_grad for f in feats):
+            raise NotImplementedError("backward into the trunk is not implemented (set MODEL.BACKBONE.FREEZE)")
+        image_sizes = [p.image_size for p in proposals]
+        head_outputs = []
+        prev = None
+        for k in range(self.num_cascade_stages):
+            if k > 0:
+                proposals = self._create_proposals_from_boxes(prev, image_sizes)
+                proposals = self._match_and_label_boxes(proposals, k, targets)
+            predictions = self._run_stage(feats, proposals, k)
+            prev = self.box_predictor[k].predict_boxes(predictions, proposals)
+            head_outputs.append((self.box_predictor[k], predictions, proposals))
+        losses = {}
+        for stage, (predictor, predictions, props) in enumerate(head_outputs):
+            for name, v in predictor.losses(predictions, props).items():
+                losses[name + "_stage{}".format(stage)] = v
+        return losses
+
+    def _run_stage(self, feats_nhwc, proposals, stage):
+        """reference :329-346.  `_ScaleGradient` (:22-30) scales the gradient flowing from the head back into the
+        pooled features by 1/num_stages; with a frozen trunk that gradient is never formed, so the pooled rows enter
+        the head as constants."""
+        counts = [len(p) for p in proposals]
+        B, R = len(proposals), max(max(counts), 1)
+        dev = feats_nhwc[0].device
+        boxes = torch.zeros(B, R, 4, device=dev)
+        for i, p in enumerate(proposals):
+            boxes[i, : counts[i]] = p.proposal_boxes.tensor
+        with torch.no_grad():
+            pooled = self.box_pooler.pool_nhwc(feats_nhwc, boxes)
+            keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
+            pooled = pooled[keep].contiguous()
+        h = self.box_head[stage].forward_nhwc(pooled)
+        return self.box_predictor[stage](h)
+
+    @torch.no_grad()
+    def _match_and_label_boxes(self, proposals, stage, targets):
+        """reference :279-327: label the stage's input boxes with this stage's IoU threshold (no subsampling)."""
+        from ...utils.events import get_event_storage
+
+        num_fg, num_bg = [], []
+        for prop, tgt in zip(proposals, targets):
+            gt = tgt.gt_boxes.tensor
+            matched_idxs, labels = self.proposal_matchers[stage].match(gt, prop.proposal_boxes.tensor)
+            if len(tgt) > 0:
+                gt_classes = tgt.gt_classes[matched_idxs]
+                gt_classes[labels == 0] = self.num_classes
+                gt_boxes = Boxes(gt[matched_idxs])
+            else:
+                gt_classes = torch.zeros_like(matched_idxs) + self.num_classes
+                gt_boxes = Boxes(gt.new_zeros((len(prop), 4)))
+            prop.gt_classes = gt_classes
+            prop.gt_boxes = gt_boxes
+            num_fg.append(int((labels == 1).sum()))
+            num_bg.append(labels.numel() - num_fg[-1])
+        storage = get_event_storage()
+        storage.put_scalar("stage{}/roi_head/num_fg_samples".format(stage), sum(num_fg) / len(num_fg))
+        storage.put_scalar("stage{}/roi_head/num_bg_samples".format(stage), sum(num_bg) / len(num_bg))
+        return proposals
+
+    def _create_proposals_from_boxes(self, boxes, image_sizes):
+        """reference :348-369: detach, clip, drop empty boxes (training only)."""
+        out = []
+        for b, size in zip(boxes, image_sizes):
+            bx = Boxes(b.detach().clone())
+            bx.clip(size)
+            if self.training:
+                bx = bx[bx.nonempty()]
+            prop = Instances(size)
+            prop.proposal_boxes = bx
+            out.append(prop)
+        return out

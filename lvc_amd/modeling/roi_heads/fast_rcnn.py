@@ -128,7 +128,22 @@ class _BoxOnlyBase(nn.Module):
         return self.num_classes, self.bbox_pred(x.contiguous())
 
     def losses(self, predictions, proposals):
-        raise NotImplementedError("box-corrector training (GIoU loss + backward through the trunk) is not implemented")
+        """reference roi_heads_cascade.py:141-163 (+ box_reg_loss :165-195) on lvc_giou_box_loss."""
+        _, deltas = predictions
+        gt_classes = torch.cat([p.gt_classes for p in proposals], 0)
+        pboxes = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+        assert not pboxes.requires_grad, "Proposals should not require gradients"
+        gboxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], 0)
+        return {"loss_box_reg": _GIoUBoxLoss.apply(deltas, pboxes, gboxes, gt_classes, self)}
+
+    def predict_boxes(self, predictions, proposals):
+        """reference roi_heads_cascade.py:197-211: decoded boxes per image (no clipping here)."""
+        _, deltas = predictions
+        n = [len(p) for p in proposals]
+        pboxes = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+        boxes = K.decode_boxes(deltas.detach().contiguous(), pboxes.view(1, -1, 4).contiguous(),
+                               self.box2box_transform.weights, None)
+        return boxes.view(-1, 4).split(n, dim=0)
 
 
 @ROI_HEADS_OUTPUT_REGISTRY.register()
@@ -139,6 +154,23 @@ class BoxOnlyLayers(_BoxOnlyBase):
 @ROI_HEADS_OUTPUT_REGISTRY.register()
 class BoxOnlyLayersCascade(_BoxOnlyBase):
     pass
+
+
+class _GIoUBoxLoss(torch.autograd.Function):
+    """deltas -> scalar loss; the kernel emits d(loss)/d(deltas) in the forward pass."""
+
+    @staticmethod
+    def forward(ctx, deltas, pboxes, gboxes, gt_classes, layer):
+        loss, dd = K.giou_box_loss(deltas, pboxes, gboxes, gt_classes, layer.num_classes,
+                                   layer.box2box_transform.weights, layer.box2box_transform.scale_clamp,
+                                   iterate=layer.iterate, lambda_=layer.lambda_)
+        ctx.save_for_backward(dd)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dd,) = ctx.saved_tensors
+        return dd * g, None, None, None, None
 
 
 class _PredictorLoss(torch.autograd.Function):

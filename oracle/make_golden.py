@@ -368,6 +368,82 @@ def gen_box_corrector():
     save("box_corrector", **d)
 
 
+def gen_box_corrector_train():
+    """BASELINE config 5, fine-tune flavour (cascade_ubbr_R_50_FPN_ft_all_30shot_aug_ftmore.yaml: BACKBONE.FREEZE):
+    one training step of GeneralizedRCNN + RBG + CascadeROIHeads/BoxOnlyLayersCascade on a fixed 2-image batch.
+    Stored: the proposals RBG produced (its jitter draws from torch's CPU generator, which a GPU run cannot
+    reproduce -- the product test feeds these boxes through a patched RBG), the three stage losses, and for every
+    trainable tensor its gradient's sum, L2 norm and a strided sample of <= 4096 entries (fc1 gradients are 51 MB).
+    torch.randperm is patched to the identity as in gen_train."""
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/cascade_ubbr_R_50_FPN_ft_all_30shot_aug_ftmore.yaml")
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    g = torch.Generator().manual_seed(31)
+    batch, d = [], {}
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        n = 4 + i
+        x1 = torch.rand(n, generator=g) * (w - 100)
+        y1 = torch.rand(n, generator=g) * (h - 100)
+        bw = 40 + torch.rand(n, generator=g) * 140
+        bh = 40 + torch.rand(n, generator=g) * 110
+        boxes = torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
+        classes = torch.randint(0, 80, (n,), generator=g)
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(boxes)
+        inst.gt_classes = classes
+        # loaded proposals: noisy copies of the GT (some pass RBG's IoU > t filter, some do not) + far-away boxes
+        noisy = boxes.repeat(3, 1) + torch.randn(3 * n, 4, generator=g) * 18
+        far = torch.stack([torch.rand(4, generator=g) * 40, torch.rand(4, generator=g) * 40,
+                           60 + torch.rand(4, generator=g) * 30, 60 + torch.rand(4, generator=g) * 30], 1)
+        pb = torch.cat([noisy, far])
+        pb[:, 2:] = torch.max(pb[:, 2:], pb[:, :2] + 4)
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(pb)
+        props.objectness_logits = torch.randn(len(pb), generator=g)
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+        d["gt_boxes%d" % i], d["gt_classes%d" % i] = boxes, classes
+        d["loaded_boxes%d" % i], d["loaded_logits%d" % i] = pb, props.objectness_logits
+    rbg_out = []
+    orig = model.proposal_generator.forward
+
+    def recording(proposals, targets):
+        out, extra = orig(proposals, targets)
+        rbg_out.extend(out)
+        return out, extra
+
+    model.proposal_generator.forward = recording
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    torch.manual_seed(5)
+    try:
+        with EventStorage(0) as storage:
+            losses = model(batch)
+            sum(losses.values()).backward()
+            scalars = {k: float(v[0]) if isinstance(v, tuple) else float(v) for k, v in storage.latest().items()}
+    finally:
+        torch.randperm = real
+    for i, p in enumerate(rbg_out):
+        d["rbg_boxes%d" % i] = p.proposal_boxes.tensor
+        d["rbg_logits%d" % i] = p.objectness_logits
+    ntrain = 0
+    for n_, p_ in model.named_parameters():
+        if p_.requires_grad:
+            ntrain += 1
+            gflat = p_.grad.flatten()
+            stride = max(1, gflat.numel() // 4096)
+            d["grad_sample." + n_] = gflat[::stride][:4096].clone()
+            d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
+    print("  losses", {k: float(v) for k, v in losses.items()}, "trainable tensors", ntrain,
+          "rbg proposals", [len(p) for p in rbg_out], scalars)
+    save("box_corrector_train", **d, **{"loss." + k: v.detach() for k, v in losses.items()},
+         **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
+
+
 def gen_crops():
     from detectron2.structures import Boxes, Instances
     from lvc.data.utils import get_crops_qe
@@ -392,7 +468,7 @@ def gen_crops():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "crops"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "box_corrector_train", "crops"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

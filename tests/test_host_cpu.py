@@ -381,3 +381,36 @@ def test_knn_sweep_distributed_world_size_2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == (True, True) and res[1] is None
+
+
+def test_rbg_reproduces_reference_jitter_on_cpu():
+    """RBG (reference lvc/modeling/proposal_generator/rbg.py:52-160) is RNG-driven: on CPU tensors, under the same
+    torch seed, the product's RBG must draw the same jitter in the same order and keep the same boxes as the
+    reference did when the box-corrector training golden was generated (tests/golden/box_corrector_train.npz)."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling.proposal_generator.rbg import RBG
+    from lvc_amd.structures import Boxes, Instances
+
+    g = gold("box_corrector_train")
+    cfg = base_rcnn_fpn(num_classes=80)
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 64
+    cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION = 1.0
+    rbg = RBG(cfg).train()
+    props, tgts = [], []
+    for i, (h, w) in enumerate([(240, 320), (200, 352)]):
+        t = Instances((h, w))
+        t.gt_boxes = Boxes(g["gt_boxes%d" % i])
+        t.gt_classes = g["gt_classes%d" % i]
+        p = Instances((h, w))
+        p.proposal_boxes = Boxes(g["loaded_boxes%d" % i])
+        p.objectness_logits = g["loaded_logits%d" % i]
+        props.append(p)
+        tgts.append(t)
+    torch.manual_seed(5)
+    out, losses = rbg(props, tgts)
+    assert losses == {}
+    for i, o in enumerate(out):
+        ref = g["rbg_boxes%d" % i]
+        assert o.proposal_boxes.tensor.shape == ref.shape
+        assert (o.proposal_boxes.tensor - ref).abs().max() <= 1e-4
+        assert torch.equal(o.objectness_logits, g["rbg_logits%d" % i])
