@@ -78,13 +78,18 @@ __global__ __launch_bounds__(1024) void nms_prep_kernel(const float* __restrict_
   __syncthreads();
   const float maxp1 = red[0] + 1.0f;
 
-  for (int i = tid; i < NPAD; i += 1024)
+  // sort only the power of two that covers this image's n (the detection stage allocates for 16 384 candidates
+  // per image and typically has a few thousand)
+  int npad = 1024;
+  while (npad < n) npad <<= 1;
+  if (npad > NPAD) npad = NPAD;
+  for (int i = tid; i < npad; i += 1024)
     keys[i] = i < n ? (((u64)ordered_desc_key(sc[i]) << 32) | (unsigned)i) : ~0ull;
   __syncthreads();
   // bitonic sort ascending on 64-bit keys
-  for (int k = 2; k <= NPAD; k <<= 1) {
+  for (int k = 2; k <= npad; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < NPAD / 2; t += 1024) {
+      for (int t = tid; t < npad / 2; t += 1024) {
         int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         int hi = lo | j;
         bool up = (lo & k) == 0;
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const u64* __restrict__ 
     }
     nk += __popcll(kept);
     // OR the rows of the kept boxes into the removed words of later chunks
-    for (int w0 = c + 1; w0 < nwords; w0 += 64) {
+    for (int w0 = c + 1; w0 < nchunks; w0 += 64) {   // words of chunks past n are never read
       const int w = w0 + lane;
       const int wc = w < nwords ? w : nwords - 1;  // clamped: out-of-range lanes load a valid word
       u64 acc = 0;
