@@ -116,51 +116,58 @@ __global__ __launch_bounds__(1024) void nms_prep_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------- 2. suppression mask via ballot
+#define NMS_MASK_STRIDE 96
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes,
                                                       const int* __restrict__ sidx,
                                                       const int* __restrict__ counts, int Nmax,
                                                       int nwords, double thr, u64* __restrict__ mask) {
-  const int wj = blockIdx.x, ci = blockIdx.y, img = blockIdx.z;
-  if (wj < ci) return;  // lower triangle never read
+  // grid (NMS_MASK_STRIDE, nwords, B): workgroup (x, ci) walks the column words wj = ci + x, ci + x + STRIDE, ... of its
+  // 64-row chunk (upper triangle only).  The grid is sized for Nmax, the loop for this image's n: the detection stage
+  // (Nmax = 16 384, a few thousand real candidates) no longer dispatches 256 x 256 mostly empty workgroups per image.
+  const int ci = blockIdx.y, img = blockIdx.z;
   int n = counts ? counts[img] : Nmax;
   if (n > Nmax) n = Nmax;
-  if (ci * 64 >= n || wj * 64 >= n) return;
+  if (ci * 64 >= n) return;
+  const int nchunks = (n + 63) >> 6;
   const int lane = threadIdx.x;
   const float* sb = sboxes + (size_t)img * Nmax * 4;
   const int* si = sidx + (size_t)img * Nmax;
-  const int i_me = ci * 64 + lane, j_me = wj * 64 + lane;
+  const int i_me = ci * 64 + lane;
   // row box held by lane i (broadcast later), column box held by lane j
   float ix1 = 0, iy1 = 0, ix2 = 0, iy2 = 0; int iid = -1;
   if (i_me < n) {
     const float4 b = *reinterpret_cast<const float4*>(sb + (size_t)i_me * 4);
     ix1 = b.x; iy1 = b.y; ix2 = b.z; iy2 = b.w; iid = si[i_me];
   }
-  float jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0; int jid = -2;
-  if (j_me < n) {
-    const float4 b = *reinterpret_cast<const float4*>(sb + (size_t)j_me * 4);
-    jx1 = b.x; jy1 = b.y; jx2 = b.z; jy2 = b.w; jid = si[j_me];
-  }
   const float iarea_me = (ix2 - ix1) * (iy2 - iy1);
-  const float jarea = (jx2 - jx1) * (jy2 - jy1);
-  u64 my_word = 0;
   const int rows = min(64, n - ci * 64);
-  for (int r = 0; r < rows; ++r) {
-    const float ax1 = __shfl(ix1, r), ay1 = __shfl(iy1, r), ax2 = __shfl(ix2, r), ay2 = __shfl(iy2, r);
-    const float aarea = __shfl(iarea_me, r);
-    const int aid = __shfl(iid, r);
-    const float xx1 = ax1 < jx1 ? jx1 : ax1;   // std::max(a, b)
-    const float yy1 = ay1 < jy1 ? jy1 : ay1;
-    const float xx2 = jx2 < ax2 ? jx2 : ax2;   // std::min(a, b)
-    const float yy2 = jy2 < ay2 ? jy2 : ay2;
-    float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
-    float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
-    const float inter = w * h;
-    const float ovr = inter / (aarea + jarea - inter);
-    const bool hit = (j_me < n) && (j_me > ci * 64 + r) && (aid == jid) && ((double)ovr > thr);
-    const u64 word = __ballot(hit);
-    if (lane == r) my_word = word;
+  for (int wj = ci + blockIdx.x; wj < nchunks; wj += gridDim.x) {
+    const int j_me = wj * 64 + lane;
+    float jx1 = 0, jy1 = 0, jx2 = 0, jy2 = 0; int jid = -2;
+    if (j_me < n) {
+      const float4 b = *reinterpret_cast<const float4*>(sb + (size_t)j_me * 4);
+      jx1 = b.x; jy1 = b.y; jx2 = b.z; jy2 = b.w; jid = si[j_me];
+    }
+    const float jarea = (jx2 - jx1) * (jy2 - jy1);
+    u64 my_word = 0;
+    for (int r = 0; r < rows; ++r) {
+      const float ax1 = __shfl(ix1, r), ay1 = __shfl(iy1, r), ax2 = __shfl(ix2, r), ay2 = __shfl(iy2, r);
+      const float aarea = __shfl(iarea_me, r);
+      const int aid = __shfl(iid, r);
+      const float xx1 = ax1 < jx1 ? jx1 : ax1;   // std::max(a, b)
+      const float yy1 = ay1 < jy1 ? jy1 : ay1;
+      const float xx2 = jx2 < ax2 ? jx2 : ax2;   // std::min(a, b)
+      const float yy2 = jy2 < ay2 ? jy2 : ay2;
+      float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
+      float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
+      const float inter = w * h;
+      const float ovr = inter / (aarea + jarea - inter);
+      const bool hit = (j_me < n) && (j_me > ci * 64 + r) && (aid == jid) && ((double)ovr > thr);
+      const u64 word = __ballot(hit);
+      if (lane == r) my_word = word;
+    }
+    if (i_me < n) mask[((size_t)img * Nmax + i_me) * nwords + wj] = my_word;
   }
-  if (i_me < n) mask[((size_t)img * Nmax + i_me) * nwords + wj] = my_word;
 }
 
 // ---------------------------------------------------------------- 3. ordered reduce
@@ -286,7 +293,7 @@ extern "C" int lvc_batched_nms(const float* boxes, const float* scores, const in
   }
 #undef LAUNCH_PREP
   LVC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords, nwords, B), dim3(64), 0, st, sboxes, sidx, d_counts,
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nwords < NMS_MASK_STRIDE ? nwords : NMS_MASK_STRIDE, nwords, B), dim3(64), 0, st, sboxes, sidx, d_counts,
                      Nmax, nwords, iou_threshold, mask);
   LVC_CHECK_LAUNCH();
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, st, mask, order, d_counts, Nmax, nwords,
