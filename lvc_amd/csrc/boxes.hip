@@ -15,6 +15,7 @@
 // (level-major candidate order, row-major (roi, class) order, score-sorted keep) are reproduced by
 // ORDERED compaction (block scan), never by atomics.
 #include "common.h"
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 
@@ -85,16 +86,41 @@ struct RpnLevels {
   int L, A;
 };
 
+// first 256 threads: digit d with  sum(h[0..d-1]) < krem <= sum(h[0..d]);  returns through sh[8] = d, sh[9] = sum(h[0..d-1])
+__device__ __forceinline__ void find_digit(const int* __restrict__ h, int krem, int* sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int x = 0, incl = 0;
+  if (tid < 256) {
+    x = h[tid];
+    incl = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) sh[wave] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += sh[w];
+    incl += off;
+    if (incl - x < krem && krem <= incl) { sh[8] = tid; sh[9] = incl - x; }
+  }
+  __syncthreads();
+}
+
 #define TOPK_PAD 2048
 __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnLevels lv, int topk, unsigned int* __restrict__ wkeys,
                                                         float* __restrict__ cand_score,
-                                                        int* __restrict__ cand_idx, int Ntot) {
+                                                        int* __restrict__ cand_idx, int Ntot, int small_only) {
   __shared__ u64 sortbuf[TOPK_PAD];
   __shared__ int hist[256];
   __shared__ int sh[20];
-  __shared__ int s_prefix_digit, s_krem, s_nlt;
+  __shared__ int s_nlt;
   const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int A = lv.A, HW = lv.H[l] * lv.W[l], n = HW * A;
+  if (n > small_only) return;   // handled by the multi-workgroup phases
   const int k = topk < n ? topk : n;
   const int ld = lv.ld_logit[l];
   const float* lg = lv.logits[l] + (size_t)b * HW * ld;
@@ -123,20 +149,10 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnLevels lv, int topk, 
       }
       __syncthreads();
     }
-    if (tid == 0) {
-      int cum = 0, d = 0;
-      for (; d < 256; ++d) {
-        int c = hist[d];
-        if (cum + c >= krem) break;
-        cum += c;
-      }
-      s_prefix_digit = d;
-      s_krem = krem - cum;
-    }
-    __syncthreads();
-    prefix |= (unsigned int)s_prefix_digit << shift;
+    find_digit(hist, krem, sh);   // parallel scan of the 256 bins (a serial scan by one thread cost ~12 us per pass)
+    prefix |= (unsigned int)sh[8] << shift;
     pmask |= 255u << shift;
-    krem = s_krem;
+    krem -= sh[9];
     __syncthreads();
   }
   // prefix = threshold key T; take every key < T, and the first `krem` (by index) with key == T
@@ -169,6 +185,160 @@ __global__ __launch_bounds__(1024) void rpn_topk_kernel(RpnLevels lv, int topk, 
     int p = i / A, a = i - p * A;
     cand_idx[(size_t)b * Ntot + lv.cand_off[l] + r] = i;
     cand_score[(size_t)b * Ntot + lv.cand_off[l] + r] = lg[(size_t)p * ld + a];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-workgroup form of the same selection for the large levels (p2 has 201 600 anchors per image: one workgroup per
+// (image, level) sweeping them six times was 0.43 ms per batch on 40 workgroups).  Same radix select, same tie rule,
+// same output; the sweeps are spread over slices of TK_SLICE anchors:
+//   phase 0..3  every slice adds its 256-bin digit histogram (of the keys matching the prefix found so far) to the
+//               level's global histogram; phase 0 also materialises the keys
+//   phase 4     threshold T known: keys < T are appended (atomic slot, order irrelevant: they are sorted afterwards),
+//               the indices of keys == T go to a tie list (first TOPK_PAD of them)
+//   final       one workgroup per (image, level): ties ordered by index (sorted tie list, or -- if there were more
+//               than TOPK_PAD -- the ordered scan of the single-workgroup kernel), bitonic sort, output
+// Integer atomics only: every count, and therefore the result, is deterministic.
+#define TK_SLICE 8192
+#define TK_HSTRIDE 1040          // ints per (image, level): 4 x 256 histogram bins, [1024] = #(key < T), [1025] = #(key == T)
+
+// prefix / remaining count after `npass` digit passes (uniform over the workgroup)
+__device__ __forceinline__ void topk_prefix(const int* __restrict__ H, int npass, int k, int* sh, unsigned int* prefix,
+                                            int* krem) {
+  unsigned int pf = 0;
+  int kr = k;
+  for (int ps = 0; ps < npass; ++ps) {
+    find_digit(H + ps * 256, kr, sh);
+    pf |= (unsigned int)sh[8] << (24 - 8 * ps);
+    kr -= sh[9];
+    __syncthreads();
+  }
+  *prefix = pf;
+  *krem = kr;
+}
+
+__global__ __launch_bounds__(1024) void rpn_topk_phase_kernel(RpnLevels lv, int topk, unsigned int* __restrict__ wkeys,
+                                                              int* __restrict__ hist_all, u64* __restrict__ ckeys,
+                                                              int* __restrict__ ties, int Ntot, int phase) {
+  __shared__ int hist[256];
+  __shared__ int sh[16];
+  const int slice = blockIdx.x, l = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+  const int A = lv.A, HW = lv.H[l] * lv.W[l], n = HW * A;
+  if (n <= TK_SLICE) return;                 // small levels: rpn_topk_kernel
+  const int i0 = slice * TK_SLICE;
+  if (i0 >= n) return;
+  const int i1 = min(n, i0 + TK_SLICE);
+  const int k = topk < n ? topk : n;
+  const int ld = lv.ld_logit[l];
+  const float* lg = lv.logits[l] + (size_t)b * HW * ld;
+  unsigned int* keys = wkeys + (size_t)b * lv.key_off[lv.L] + lv.key_off[l];
+  int* H = hist_all + ((size_t)b * lv.L + l) * TK_HSTRIDE;
+  unsigned int prefix;
+  int krem;
+  topk_prefix(H, phase < 4 ? phase : 4, k, sh, &prefix, &krem);
+  if (phase < 4) {
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned int pmask = phase ? 0xFFFFFFFFu << (32 - 8 * phase) : 0u;
+    const int shift = 24 - 8 * phase;
+    for (int ib = i0; ib < i1; ib += 1024) {
+      const int i = ib + tid;
+      unsigned int key = 0;
+      bool act = false;
+      if (i < i1) {
+        if (phase == 0) {
+          const int pp = i / A, a = i - pp * A;
+          key = desc_key(lg[(size_t)pp * ld + a]);
+          keys[i] = key;
+        } else {
+          key = keys[i];
+        }
+        act = (key & pmask) == prefix;
+      }
+      // wave-aggregated LDS histogram: objectness logits cluster in a few exponent bins, so a plain atomicAdd per
+      // lane would serialise most of the wave on one address
+      const unsigned int d = (key >> shift) & 255u;
+      u64 m = __ballot(act);
+      while (m) {
+        const int first = __ffsll((long long)m) - 1;
+        const unsigned int dd = (unsigned int)__shfl((int)d, first);
+        const u64 same = __ballot(act && d == dd);
+        if (lane == first) atomicAdd(&hist[dd], __popcll(same));
+        m &= ~same;
+      }
+    }
+    __syncthreads();
+    if (tid < 256 && hist[tid]) atomicAdd(&H[phase * 256 + tid], hist[tid]);
+  } else {
+    const unsigned int T = prefix;
+    u64* ck = ckeys + (size_t)b * Ntot + lv.cand_off[l];
+    int* tl = ties + ((size_t)b * lv.L + l) * TOPK_PAD;
+    for (int i = i0 + tid; i < i1; i += 1024) {
+      const unsigned int key = keys[i];
+      if (key < T) {
+        const int slot = atomicAdd(&H[1024], 1);
+        ck[slot] = ((u64)key << 32) | (unsigned)i;
+      } else if (key == T) {
+        const int slot = atomicAdd(&H[1025], 1);
+        if (slot < TOPK_PAD) tl[slot] = i;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void rpn_topk_final_kernel(RpnLevels lv, int topk, const unsigned int* __restrict__ wkeys,
+                                                              const int* __restrict__ hist_all,
+                                                              const u64* __restrict__ ckeys, const int* __restrict__ ties,
+                                                              float* __restrict__ cand_score, int* __restrict__ cand_idx,
+                                                              int Ntot) {
+  __shared__ u64 sortbuf[TOPK_PAD];
+  __shared__ unsigned int tiebuf[TOPK_PAD];
+  __shared__ int sh[20];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int A = lv.A, HW = lv.H[l] * lv.W[l], n = HW * A;
+  if (n <= TK_SLICE) return;
+  const int k = topk < n ? topk : n;
+  const int ld = lv.ld_logit[l];
+  const float* lg = lv.logits[l] + (size_t)b * HW * ld;
+  const unsigned int* keys = wkeys + (size_t)b * lv.key_off[lv.L] + lv.key_off[l];
+  const int* H = hist_all + ((size_t)b * lv.L + l) * TK_HSTRIDE;
+  unsigned int T;
+  int need_eq;
+  topk_prefix(H, 4, k, sh, &T, &need_eq);
+  const int n_lt = k - need_eq;
+  const int npad = k <= 1024 ? 1024 : TOPK_PAD;
+  const u64* ck = ckeys + (size_t)b * Ntot + lv.cand_off[l];
+  for (int i = tid; i < npad; i += 1024) sortbuf[i] = i < n_lt ? ck[i] : ~0ull;
+  const int tie_total = H[1025];
+  __syncthreads();
+  if (tie_total <= TOPK_PAD) {
+    // ties at the threshold: the `need_eq` lowest indices
+    const int* tl = ties + ((size_t)b * lv.L + l) * TOPK_PAD;
+    int tp = 64;
+    while (tp < tie_total) tp <<= 1;
+    for (int i = tid; i < tp; i += 1024) tiebuf[i] = i < tie_total ? (unsigned int)tl[i] : 0xFFFFFFFFu;
+    __syncthreads();
+    bitonic_sort_lds(tiebuf, tp);
+    for (int r = tid; r < need_eq; r += 1024) sortbuf[n_lt + r] = ((u64)T << 32) | tiebuf[r];
+  } else {
+    // more equal keys than the tie list holds (e.g. constant logits): ordered scan, stops once need_eq are found
+    int eq_base = 0;
+    for (int i0 = 0; i0 < n && eq_base < need_eq; i0 += 1024) {
+      const int i = i0 + tid;
+      const bool is_eq = i < n && keys[i] == T;
+      int tot;
+      const int rank = eq_base + block_excl_scan_1024(is_eq ? 1 : 0, sh, &tot);
+      if (is_eq && rank < need_eq) sortbuf[n_lt + rank] = ((u64)T << 32) | (unsigned)i;
+      eq_base += tot;
+    }
+  }
+  __syncthreads();
+  bitonic_sort_lds(sortbuf, npad);
+  for (int r = tid; r < k; r += 1024) {
+    const int i = (int)(sortbuf[r] & 0xFFFFFFFFu);
+    const int pp = i / A, a = i - pp * A;
+    cand_idx[(size_t)b * Ntot + lv.cand_off[l] + r] = i;
+    cand_score[(size_t)b * Ntot + lv.cand_off[l] + r] = lg[(size_t)pp * ld + a];
   }
 }
 
@@ -265,15 +435,17 @@ static long long align16(long long x) { return (x + 15) & ~15ll; }
 struct RpnPlan {
   int Ntot;
   long long nkeys;  // per image
-  long long off_keys, off_cscore, off_cidx, off_cboxes, off_cscores2, off_clevels, off_ccount, off_keep, off_nms, total;
+  long long off_keys, off_cscore, off_cidx, off_cboxes, off_cscores2, off_clevels, off_ccount, off_keep, off_hist, off_ckeys, off_ties, off_nms, total;
+  int max_slices;
 };
 static RpnPlan rpn_plan(int B, int L, int A, const int* Hs, const int* Ws, int pre_topk) {
   RpnPlan p;
-  p.Ntot = 0; p.nkeys = 0;
+  p.Ntot = 0; p.nkeys = 0; p.max_slices = 0;
   for (int l = 0; l < L; ++l) {
     long long n = (long long)Hs[l] * Ws[l] * A;
     p.nkeys += n;
     p.Ntot += (int)(n < pre_topk ? n : pre_topk);
+    if (n > TK_SLICE) { int sl = (int)((n + TK_SLICE - 1) / TK_SLICE); if (sl > p.max_slices) p.max_slices = sl; }
   }
   long long o = 0;
   p.off_keys = o; o = align16(o + (long long)B * p.nkeys * 4);
@@ -284,6 +456,9 @@ static RpnPlan rpn_plan(int B, int L, int A, const int* Hs, const int* Ws, int p
   p.off_clevels = o; o = align16(o + (long long)B * p.Ntot * 4);
   p.off_ccount = o; o = align16(o + (long long)B * 4);
   p.off_keep = o; o = align16(o + (long long)B * p.Ntot * 4);
+  p.off_hist = o; o = align16(o + (long long)B * L * TK_HSTRIDE * 4);
+  p.off_ckeys = o; o = align16(o + (long long)B * p.Ntot * 8);
+  p.off_ties = o; o = align16(o + (long long)B * L * TOPK_PAD * 4);
   p.off_nms = o; o = align16(o + lvc_batched_nms_workspace_bytes(B, p.Ntot));
   p.total = o;
   return p;
@@ -333,8 +508,25 @@ extern "C" int lvc_rpn_proposals(const float* const* logits, const int* ld_logit
   int* clevels = (int*)(ws + p.off_clevels);
   int* ccount = (int*)(ws + p.off_ccount);
   int* keep = (int*)(ws + p.off_keep);
+  static int topk_multi = -1;   // LVC_TOPK_MULTI=0: single-workgroup selection for every level (experiments)
+  if (topk_multi < 0) { const char* e = getenv("LVC_TOPK_MULTI"); topk_multi = e ? atoi(e) : 1; }
+  const bool multi = topk_multi && p.max_slices > 0;
+  if (multi) {
+    int* hist = (int*)(ws + p.off_hist);
+    u64* ckeys = (u64*)(ws + p.off_ckeys);
+    int* ties = (int*)(ws + p.off_ties);
+    if (hipMemsetAsync(hist, 0, (size_t)B * L * TK_HSTRIDE * 4, st) != hipSuccess) {
+      lvc_set_error("%s: hipMemsetAsync failed", __func__);
+      return LVC_ERR_HIP;
+    }
+    for (int phase = 0; phase <= 4; ++phase)
+      hipLaunchKernelGGL(rpn_topk_phase_kernel, dim3(p.max_slices, L, B), dim3(1024), 0, st, lv, pre_nms_topk, keys,
+                         hist, ckeys, ties, p.Ntot, phase);
+    hipLaunchKernelGGL(rpn_topk_final_kernel, dim3(L, B), dim3(1024), 0, st, lv, pre_nms_topk, keys, hist, ckeys, ties,
+                       cand_score, cand_idx, p.Ntot);
+  }
   hipLaunchKernelGGL(rpn_topk_kernel, dim3(L, B), dim3(1024), 0, st, lv, pre_nms_topk, keys, cand_score,
-                     cand_idx, p.Ntot);
+                     cand_idx, p.Ntot, multi ? TK_SLICE : 0x7FFFFFFF);
   LVC_CHECK_LAUNCH();
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
                      d_image_sizes, scale_clamp, min_box_size, cboxes, cscores, clevels, ccount);

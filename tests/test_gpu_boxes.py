@@ -65,6 +65,46 @@ def test_rpn_proposals_random_vs_oracle(seed, pre, post):
         assert float(boxes[n, len(rb):].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("tie_mode", ["few", "many", "constant"])
+def test_rpn_proposals_full_size_levels_vs_oracle(tie_mode):
+    """800x1344 pyramid (p2 = 201 600 anchors per image): the multi-workgroup radix select of the large levels must give
+    the oracle's candidates in the oracle's order, including ties at the selection threshold: a handful ("few": sorted
+    tie list), thousands ("many": every 7th logit equal -> the ordered-scan fallback) and a constant level."""
+    from lvc_amd import kernels as k
+    from oracle import rcnn as orc
+
+    g = torch.Generator().manual_seed(5)
+    shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    N = 2
+    logits = [torch.randn(N, h * w * 3, generator=g) * 2 for h, w in shapes]
+    if tie_mode == "few":
+        for lg in logits:
+            kk = min(1000, lg.shape[1])
+            v = lg.topk(kk, dim=1)[0][:, -1:]           # the k-th largest value ...
+            lg[:, 11:4000:97] = v                       # ... planted at a few dozen more positions
+    elif tie_mode == "many":
+        for lg in logits:
+            lg[:, ::7] = 1.25
+    else:
+        logits[0][:] = 0.5
+        logits[1][1] = -0.0
+    deltas = [torch.randn(N, h * w * 3, 4, generator=g) * 0.5 for h, w in shapes]
+    sizes = [(800, 1333), (750, 1344)]
+    cell = [orc.generate_cell_anchors((s,), (0.5, 1.0, 2.0)) for s in (32, 64, 128, 256, 512)]
+    anchors = orc.grid_anchors(cell, shapes, [4, 8, 16, 32, 64])
+    ref = orc.find_top_rpn_proposals(anchors, logits, deltas, sizes, 0.7, 1000, 1000)
+    fused = [t.to(D) for t in _nhwc_rpn(logits, deltas, shapes)]
+    boxes, olog, count = k.rpn_proposals([f[..., :3] for f in fused], [f[..., 3:] for f in fused],
+                                         [c.to(D) for c in cell], [4, 8, 16, 32, 64],
+                                         torch.tensor(sizes, dtype=torch.int32, device=D), 1000, 1000, 0.7)
+    for n in range(N):
+        rb, rl = ref[n]
+        assert int(count[n]) == len(rb)
+        assert torch.equal(olog[n, : len(rl)].cpu(), rl)
+        # one fp32 ulp at x ~ 1055 px is 1.2e-4: expf differs by <= 1 ulp between libm and ocml
+        assert (boxes[n, : len(rb)].cpu() - rb).abs().max() <= 2.5e-4
+
+
 def test_assign_levels_golden():
     from lvc_amd import kernels as k
 
