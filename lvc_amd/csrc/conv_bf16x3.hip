@@ -914,7 +914,32 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
       }
     }
 
-    // ---- epilogue through LDS
+    // ---- epilogue through LDS; the residual rows are requested before the transpose (their latency then overlaps
+    // the LDS round trip; at this point the fragment and operand registers are dead, so 16 float4 fit)
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = NT / C4;
+    constexpr int NIT = G_BM / RPI;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    f32x4 rv[NIT];
+    if (p.res_mode != 0 && col < p.K) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = m0 + it * RPI + rsub;
+        rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < p.M) {
+          size_t ro = (size_t)row;
+          if (p.res_mode == 2) {
+            const int n = row / (p.Ho * p.Wo);
+            const int rem = row - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+          }
+          rv[it] = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        }
+      }
+    }
     float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -927,31 +952,18 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
           Cs[row * CS_STRIDE + ccol] = acc[mi][ni][e];
         }
     __syncthreads();
-    constexpr int C4 = BN / 4;
-    constexpr int RPI = NT / C4;
-    const int c4 = tid % C4, rsub = tid / C4;
-    const int col = n0 + c4 * 4;
     if (col < p.K) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-#pragma unroll 4
-      for (int it = 0; it < G_BM / RPI; ++it) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
         const int r = it * RPI + rsub;
         const int row = m0 + r;
         if (row < p.M) {
           f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
           v = v * sc + sh;
-          if (p.res_mode == 1) {
-            v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-          } else if (p.res_mode == 2) {
-            int n = row / (p.Ho * p.Wo);
-            int rem = row - n * (p.Ho * p.Wo);
-            int ho = rem / p.Wo;
-            int wo = rem - ho * p.Wo;
-            size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
-            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
-          }
+          if (p.res_mode != 0) v += rv[it];
           if (p.relu) {
             v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
             v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
@@ -1002,12 +1014,12 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   a.nk = Kg / BK;
   int shape = 0;
   if (R == 1 && S == 1 && pad == 0) {
-    // measured on the R50-FPN layer set (scripts/probe_layers_list.py): the 256-row shape wins from 512 input channels
-    // up, and from 256 when there is no residual stream; below that the layer is an HBM stream and the deeper
-    // activation run-ahead of the 128-row pointwise shape wins
+    // measured on the R50-FPN layer set (scripts/probe_layers_list.py): with its residual rows requested before the
+    // LDS transpose the 256-row shape wins from 128 input channels up; the 64-channel layers (2 chunks per tile) are
+    // pure HBM streams and keep the 128-row shape with its deeper activation run-ahead
     static int min_nk256 = -1;
-    if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 16; }
-    if (pw_mode >= 2 && a.M >= 2048 && (a.nk >= min_nk256 || (a.nk >= min_nk256 / 2 && res_mode == 0))) shape = 2;
+    if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 4; }
+    if (pw_mode >= 2 && a.M >= 2048 && (K > 64 || a.nk > 16) && a.nk >= min_nk256) shape = 2;
     else if (a.nk <= 16) shape = pw_mode >= 1 ? 1 : 0;
   }
   a.tiles_n = lvc_cdiv(K, BN);
