@@ -76,6 +76,14 @@ int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_split, const
                             const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                             int res_mode, int ldy, int ldr, void* workspace, void* stream);
 
+/* BasicStem in one launch (detectron2/modeling/backbone/resnet.py:588-592): conv 7x7 s2 p3 (3 -> 64) -> FrozenBN fold
+ * (scale/shift, NULL = identity) -> ReLU -> max_pool2d 3x3 s2 p1, on the split-precision bf16 MFMA path
+ * (csrc/stem_pool.hip).  x [N,H,W,4] NHWC4 (the layout lvc_preprocess_nhwc4 writes), w_split = the three bf16 planes
+ * [3][Kpad][224] of the mode-1 packed stem weights of lvc_conv2d_nhwc_f32 (k = r*32 + s*4 + c), Kpad >= 64 rows per
+ * plane; y [N,Hp,Wp,64] with Ho = (H-1)/2+1, Hp = (Ho-1)/2+1 (same for W). */
+int lvc_stem_conv_pool_nhwc4(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                             float* y, int N, int H, int W, int Kpad, int relu, void* stream);
+
 /* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
  * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero
  * outside h x w.  image: CHW, dtype 0 = fp32, 1 = uint8.  mean3/std3 are [host] arrays of 3 floats. */

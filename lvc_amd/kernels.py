@@ -146,6 +146,8 @@ CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "bf16x3")
 _BF16X3_MIN_K = int(_os.environ.get("LVC_BF16X3_MIN_K", "128"))
 # 3x3 / stride 1 / pad 1 layers of the bf16x3 engine go to the halo kernel (csrc/conv3x3_halo.hip)
 CONV_HALO = _os.environ.get("LVC_CONV_HALO", "1") != "0"
+# BasicStem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2) as one fused split-precision kernel (csrc/stem_pool.hip)
+STEM_FUSED = _os.environ.get("LVC_STEM_FUSED", "1") != "0"
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -201,6 +203,23 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         e1.record()
         c_real = 3 if pc.mode == 1 else C
         timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1, engine))
+    return out
+
+
+def stem_conv_pool(x4, pc, relu=True):
+    """x4 [N,H,W,4] NHWC4, pc = pack_conv(stem weight 64x3x7x7, bn=..., stride=2, pad=3, stem=True) ->
+    [N,Hp,Wp,64]: conv 7x7/2 + affine + ReLU + max-pool 3x3/2 in one launch."""
+    _req_cuda(x4)
+    assert x4.dim() == 4 and x4.shape[3] == 4 and x4.is_contiguous() and x4.dtype == torch.float32
+    assert pc.mode == 1 and pc.K == 64 and pc.R == 7 and pc.stride == 2 and pc.pad == 3
+    N, H, W, _ = x4.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    out = torch.empty(N, Hp, Wp, 64, device=x4.device, dtype=torch.float32)
+    st = _lib.lib().lvc_stem_conv_pool_nhwc4(ptr(x4), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(out),
+                                             c_int(N), c_int(H), c_int(W), c_int(pc.w.shape[0]), c_int(1 if relu else 0),
+                                             _stream(x4))
+    check(st, "lvc_stem_conv_pool_nhwc4")
     return out
 
 

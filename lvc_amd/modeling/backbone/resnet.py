@@ -73,6 +73,8 @@ class BasicStem(CNNBlockBase):
 
     def forward_nhwc(self, x4):
         """x4: [N,H,W,4] (RGB + zero slot)."""
+        if K.CONV_ENGINE == "bf16x3" and K.STEM_FUSED and self.conv1.out_channels == 64 and self.conv1.norm is not None:
+            return K.stem_conv_pool(x4, self.conv1.packed(), relu=True)   # conv + FrozenBN + ReLU + max-pool, one launch
         y = self.conv1.forward_nhwc(x4)
         return K.maxpool2d_nhwc(y, 3, 2, 1)
 

@@ -184,6 +184,30 @@ def test_conv_stem_7x7():
     assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("N,H,W", [(1, 64, 96), (2, 70, 134), (1, 37, 41), (1, 800, 1344)])
+def test_stem_conv_pool_fused_matches_cpu(N, H, W):
+    """csrc/stem_pool.hip: conv 7x7/2 + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch vs the same chain on the
+    CPU (reference BasicStem.forward, resnet.py:588-592), including odd sizes whose patches straddle the borders."""
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(N, 3, H, W, generator=g) * 50
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    bn = (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.5,
+          torch.randn(64, generator=g) * 0.5, torch.rand(64, generator=g) + 0.5)
+    scale = bn[0] * (bn[3] + 1e-5).rsqrt()
+    ref = F.conv2d(x, w, stride=2, padding=3)
+    ref = F.relu(ref * scale[None, :, None, None] + (bn[1] - bn[2] * scale)[None, :, None, None])
+    ref = F.max_pool2d(ref, kernel_size=3, stride=2, padding=1)
+    d = _dev()
+    x4 = torch.zeros(N, H, W, 4)
+    x4[..., :3] = x.permute(0, 2, 3, 1)
+    pc = k.pack_conv(w.to(d), bn=[t.to(d) for t in bn], stride=2, pad=3, stem=True)
+    y = k.stem_conv_pool(x4.to(d), pc).cpu().permute(0, 3, 1, 2)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
+
+
 def test_linear_matches_cpu():
     from lvc_amd import kernels as k
 
