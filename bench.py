@@ -164,7 +164,7 @@ def main():
             "metric": "img/s COCO 800x1333 R50-FPN inference (GeneralizedRCNN forward, 1000 proposals, 100 detections)",
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (conv/GEMM inner products: exact 3-way bf16 operand split on bf16 MFMA, fp32 accumulate; fp32 MFMA for stem/64-ch layers)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (conv/GEMM inner products: exact 3-way bf16 operand split on bf16 MFMA, fp32 accumulate; fp32 MFMA for the 256->64 1x1 layers and the RPN predictors)", "data": "synthetic",
             "config": {"workload": "COCO-detection R50-FPN inference, bs=8 synthetic 3x800x1333 per GPU, 1000 pre/post-NMS "
                                    "proposals per level/image, 80 classes, conditioned random-init weights",
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,
