@@ -677,11 +677,21 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_bf16x3_kernel(ConvArgsB p) {
 // all 16 granule slots of the 64 banks exactly once.
 #define G_BM 256
 #define G_PA (G_BM * 32)        // bf16 elements of one A plane (256 rows x 32)
-#define G_PB (BN * 32)
+// WN x NI = 32-column blocks of the tile: <2,2> = 128 output channels (wave grid 4 x 2, wave tile 64 x 64); <1,2> = 64
+// and <1,1> = 32 output channels (wave grid 8 x 1, wave tile 32 x 64 / 32 x 32) for the narrow layers (256 -> 64
+// reductions, the 15-channel RPN predictors): with a 128-wide tile those spend 2 - 8x their MFMA time on zero weight
+// rows, and since a 128 x 32 activation chunk costs the matrix pipe as long as HBM needs to deliver it, that waste --
+// not the memory system -- held them at 2.5 - 3 TB/s (scripts/micro/stream_patterns.hip: the same 128-byte-per-row
+// access pattern alone streams at 5.8 TB/s).
+template <int WN, int NI>
 __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
-  constexpr int STAGE_ELEMS = 3 * (G_PA + G_PB);                        // 36,864 elements = 73,728 B
+  constexpr int GBN = 32 * WN * NI;                 // output channels per tile
+  constexpr int WM = 8 / WN;                        // waves along M
+  constexpr int MI = G_BM / (32 * WM);              // 32-row blocks per wave
+  constexpr int G_PB = GBN * 32;
+  constexpr int STAGE_ELEMS = 3 * (G_PA + G_PB);                        // <2,2>: 36,864 elements = 73,728 B
   constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;
-  constexpr int CS_STRIDE = BN + 4;
+  constexpr int CS_STRIDE = GBN + 4;
   constexpr int CS_BYTES = G_BM * CS_STRIDE * 4;                        // 135,168
   constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
@@ -690,20 +700,29 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;   // wave tile: 64 (M) x 64 (N)
+  const int wm = wave / WN, wn = wave % WN;
   const int fi = lane & 31, fh = lane >> 5;
   const int q = tid & 7;                     // float4 slot of the 32-channel A row
   const int rslot = tid >> 3;                // A rows rslot + 64*j, j = 0..3
+  // weight staging: GBN * 4 pieces of 16 B per plane; piece (tid + 512 i) -> (plane, row, quarter)
+  constexpr int B_PPP = GBN * 4;
+  constexpr int NB = (3 * B_PPP + NT - 1) / NT;
   const int b_q4 = tid & 3;
-  const int b_row = tid >> 2;                // one 16-byte piece of every weight plane
+  int b_pl[NB], b_row[NB], b_st[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int pc = tid + NT * i;
+    b_pl[i] = pc / B_PPP;
+    b_row[i] = (pc % B_PPP) >> 2;
+    b_st[i] = ((b_q4 ^ ((b_row[i] >> 2) & 3)) * 8);
+  }
   // swizzled store offsets (bf16 elements inside a row)
   const int a_st = ((((q >> 1) ^ ((rslot >> 2) & 3)) * 8) + (q & 1) * 4);   // (rslot + 64j) >> 2 & 3 == rslot >> 2 & 3
-  const int b_st = ((b_q4 ^ ((b_row >> 2) & 3)) * 8);
   // swizzled fragment offsets: row * 32 + ((fh + 2*s2) ^ x) * 8 with x = (row >> 2) & 3 = (fi >> 2) & 3
   const int fx = (fi >> 2) & 3;
   const int f_off0 = ((fh ^ fx) * 8), f_off1 = (((fh + 2) ^ fx) * 8);
-  const int a_frag = (wm * 64 + fi) * 32;
-  const int b_frag = (wn * 64 + fi) * 32;
+  const int a_frag = (wm * MI * 32 + fi) * 32;
+  const int b_frag = (wn * NI * 32 + fi) * 32;
 
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
   int u = lw * p.units_per_worker;
@@ -716,11 +735,11 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
   // bound and a second activation set (16 more VGPRs next to 64 accumulators + 48 fragment registers) spills
   constexpr int LD = 1;
   f32x4 areg[LD][4];
-  u32x4 breg[3];
+  u32x4 breg[NB];
   int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
   unsigned l_aoff[4];
   int lb = u, lb_kc = l_kc;
-  unsigned l_boff = (unsigned)(((l_tile % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+  unsigned l_bbase = (unsigned)((l_tile % p.tiles_n) * GBN);   // first weight row of the loader's tile
   auto loader_enter = [&](int tile, int kc) {
     l_tile = tile; l_kc = kc;
     const int m0 = (tile / p.tiles_n) * G_BM;
@@ -751,12 +770,14 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
     if (lb < u_end) {
       if (lb_kc == p.nk) {
         lb_kc = 0;
-        l_boff = (unsigned)((((lb / p.nk) % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+        l_bbase = (unsigned)(((lb / p.nk) % p.tiles_n) * GBN);
       }
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl)
-        breg[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                 wres, l_boff + (unsigned)(pl * p.w_plane_bytes), lb_kc * (BK * 2), 0));
+      for (int i = 0; i < NB; ++i)
+        if (b_pl[i] < 3)
+          breg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  wres, ((l_bbase + b_row[i]) * p.Kg + b_q4 * 8) * 2u + (unsigned)(b_pl[i] * p.w_plane_bytes),
+                                                  lb_kc * (BK * 2), 0));
       ++lb_kc;
       ++lb;
     }
@@ -780,8 +801,8 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
       *reinterpret_cast<bf16x4*>(sa + 2 * G_PA + o) = l;
     }
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      *reinterpret_cast<u32x4*>(sb + pl * G_PB + b_row * 32 + b_st) = breg[pl];
+    for (int i = 0; i < NB; ++i)
+      if (b_pl[i] < 3) *reinterpret_cast<u32x4*>(sb + b_pl[i] * G_PB + b_row[i] * 32 + b_st[i]) = breg[i];
   };
   using S0 = std::integral_constant<int, 0>;
   loader_enter(l_tile, l_kc);
@@ -795,25 +816,25 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
     const int tile_n = tile % p.tiles_n;
     const int tile_m = tile / p.tiles_n;
     const int m0 = tile_m * G_BM;
-    const int n0 = tile_n * BN;
+    const int n0 = tile_n * GBN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < NI; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    bf16x8 fa[2][3], fb[2][3];
+    bf16x8 fa[MI][3], fb[NI][3];
     auto read_frags = [&](const __bf16* sa, const __bf16* sb, int fo) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           fa[mi][pl] = *reinterpret_cast<const bf16x8*>(sa + pl * G_PA + a_frag + mi * 32 * 32 + fo);
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
           fb[ni][pl] = *reinterpret_cast<const bf16x8*>(sb + pl * G_PB + b_frag + ni * 32 * 32 + fo);
@@ -824,9 +845,9 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
 #pragma unroll
       for (int t = 0; t < 6; ++t)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi][TA[t]], fb[ni][TB[t]], acc[mi][ni], 0, 0, 0);
     };
     int cur = 0;
@@ -866,15 +887,15 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
 
     // ---- split tiles
     if (kc0 != 0) {
-      float* dst = p.partials + (size_t)lw * (NT * 64);
+      float* dst = p.partials + (size_t)lw * (NT * 16 * MI * NI);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
-            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * 2 + ni) * 4 + e4) * NT + tid) * 4) = v;
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4) = v;
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -898,14 +919,14 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        const float* src = p.partials + (size_t)pw * (NT * 64);
+        const float* src = p.partials + (size_t)pw * (NT * 16 * MI * NI);
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
+          for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * 2 + ni) * 4 + e4) * NT + tid) * 4);
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4);
               acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
               acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
             }
@@ -916,7 +937,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
 
     // ---- epilogue through LDS; the residual rows are requested before the transpose (their latency then overlaps
     // the LDS round trip; at this point the fragment and operand registers are dead, so 16 float4 fit)
-    constexpr int C4 = BN / 4;
+    constexpr int C4 = GBN / 4;
     constexpr int RPI = NT / C4;
     constexpr int NIT = G_BM / RPI;
     const int c4 = tid % C4, rsub = tid / C4;
@@ -942,13 +963,13 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
     }
     float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
+      for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const int ccol = wn * 64 + ni * 32 + fi;
+          const int row = wm * MI * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int ccol = wn * NI * 32 + ni * 32 + fi;
           Cs[row * CS_STRIDE + ccol] = acc[mi][ni][e];
         }
     __syncthreads();
@@ -1019,15 +1040,17 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
     // pure HBM streams and keep the 128-row shape with its deeper activation run-ahead
     static int min_nk256 = -1;
     if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 4; }
-    if (pw_mode >= 2 && a.M >= 2048 && (K > 64 || a.nk > 16) && a.nk >= min_nk256) shape = 2;
+    if (pw_mode >= 2 && a.M >= 2048 && a.nk >= min_nk256) shape = 2;
     else if (a.nk <= 16) shape = pw_mode >= 1 ? 1 : 0;
   }
-  a.tiles_n = lvc_cdiv(K, BN);
+  // the 256-row pointwise shape has 128-, 64- and 32-channel tiles
+  const int gbn = shape == 2 ? (K <= 32 ? 32 : K <= 64 ? 64 : 128) : BN;
+  a.tiles_n = lvc_cdiv(K, gbn);
   const int tiles_m = lvc_cdiv(a.M, shape == 2 ? G_BM : BM);
   long long units = (long long)tiles_m * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
   a.total_units = (int)units;
-  const long long xb = (long long)N * H * W * C * 4, wb = (long long)(a.tiles_n * BN) * Kg * 2;
+  const long long xb = (long long)N * H * W * C * 4, wb = (long long)(lvc_cdiv(K, BN) * BN) * Kg * 2;   // planes are padded to 128 rows
   LVC_CHECK_ARG(xb < (1ll << 31) && 3 * wb < (1ll << 31), "input / weight tensor must be smaller than 2 GiB");
   a.x_bytes = (int)xb; a.w_plane_bytes = (int)wb;
   if (g_cus == 0) {
@@ -1046,8 +1069,12 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  if (shape == 2)
-    hipLaunchKernelGGL(conv_pw256_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  if (shape == 2 && gbn == 32)
+    hipLaunchKernelGGL((conv_pw256_bf16x3_kernel<1, 1>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else if (shape == 2 && gbn == 64)
+    hipLaunchKernelGGL((conv_pw256_bf16x3_kernel<1, 2>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else if (shape == 2)
+    hipLaunchKernelGGL((conv_pw256_bf16x3_kernel<2, 2>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   else if (shape == 1)
     hipLaunchKernelGGL(conv_pw_bf16x3_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   else

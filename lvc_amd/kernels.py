@@ -148,6 +148,7 @@ _BF16X3_MIN_K = int(_os.environ.get("LVC_BF16X3_MIN_K", "128"))
 CONV_HALO = _os.environ.get("LVC_CONV_HALO", "1") != "0"
 # BasicStem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2) as one fused split-precision kernel (csrc/stem_pool.hip)
 STEM_FUSED = _os.environ.get("LVC_STEM_FUSED", "1") != "0"
+_PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -169,8 +170,11 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     ldr = residual.shape[-1] if residual is not None else 0
     engine = "f32"
     halo = CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0
-    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else _BF16X3_MIN_K) and pc.K % 4 == 0
-            and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
+    # narrow 1x1 layers (256 -> 64 reductions, the 15-channel RPN predictors) go to the 64- / 32-channel tiles of the
+    # 256-row pointwise shape
+    pw_narrow = _PW_NARROW and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128 and pc.C % 32 == 0 and N * Ho * Wo >= 2048
+    if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else 4 if pw_narrow else _BF16X3_MIN_K)
+            and pc.K % 4 == 0 and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
         engine = "bf16x3_halo" if halo else "bf16x3"
     timer = CONV_TIMER
     if timer is not None and timer.only is not None and engine not in timer.only:
