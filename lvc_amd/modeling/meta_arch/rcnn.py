@@ -159,6 +159,8 @@ class GeneralizedRCNN(_RCNNBase):
         assert not self.training
         if detected_instances is not None:
             raise NotImplementedError("forward_with_given_boxes (mask/keypoint heads) is not on the box-only path")
+        if getattr(self, "output_layer", None) == "BoxOnlyLayersCascade":
+            return self._inference_box_corrector(batched_inputs)
         if not (isinstance(self.proposal_generator, RPN) and isinstance(self.roi_heads, StandardROIHeads)):
             return self._inference_modular(batched_inputs, do_postprocess)
         ob, osc, ocl, cnt, status = self.inference_batched(batched_inputs, do_postprocess)
@@ -168,6 +170,26 @@ class GeneralizedRCNN(_RCNNBase):
             out_sizes.append((inp.get("height", h), inp.get("width", w)) if do_postprocess else (h, w))
         insts = instances_from_batched(ob, osc, ocl, cnt, out_sizes, status)
         return [{"instances": r} for r in insts] if do_postprocess else insts
+
+    def _inference_box_corrector(self, batched_inputs):
+        """reference rcnn.py:201-230: evaluation of the box corrector = IoU with the matched GT before and after the
+        cascade, for the (sub)sampled foreground proposals.  Not a hot path: the IoUs come from the match kernel's
+        pairwise form on the host side of the tensors."""
+        from ...structures import pairwise_iou
+
+        images = self.preprocess_image(batched_inputs)
+        with torch.no_grad():
+            features = self.backbone(images.tensor)
+        gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+        out_results, in_proposals = self.roi_heads(images, features, proposals, gt_instances)
+        input_ious, output_ious, gt_classes = [], [], []
+        for out, inp in zip(out_results, in_proposals):
+            gt = inp.gt_boxes
+            input_ious.append(torch.diag(pairwise_iou(inp.proposal_boxes, gt)))
+            output_ious.append(torch.diag(pairwise_iou(out.pred_boxes, gt)))
+            gt_classes.append(inp.gt_classes)
+        return {"input_ious": torch.cat(input_ious), "output_ious": torch.cat(output_ious), "gt_classes": torch.cat(gt_classes)}
 
     def _inference_modular(self, batched_inputs, do_postprocess):
         images = self.preprocess_image(batched_inputs)

@@ -7,8 +7,9 @@ of (box, class) pseudo-labels), batched on device: per stage one ROIAlign launch
 bias+ReLU GEMMs, one 1024->4 GEMM and one decode+clip kernel; and the TRAINING branch (`_forward_box` :205-238,
 `_match_and_label_boxes` :279-327, `_run_stage` :329-346, `_create_proposals_from_boxes` :348-369) with the GIoU
 loss kernel and GEMM backward through the three heads, for a frozen trunk (`MODEL.BACKBONE.FREEZE`, the shipped
-`cascade_ubbr_*_ft_*` yaml; backward into the trunk -- conv dgrad/wgrad -- is not implemented).  The RBG evaluation
-branch (which subsamples with `randperm` even in eval) is not implemented.
+`cascade_ubbr_*_ft_*` yaml; backward into the trunk -- conv dgrad/wgrad -- is not implemented).  The evaluation branch of
+the box-corrector training configs (`_forward_box` eval half with `reg_only`: subsamples with `randperm` even in eval,
+SURVEY row 20) returns the corrected foreground boxes and the proposals they came from.
 """
 import torch
 from torch import nn
@@ -77,10 +78,39 @@ class CascadeROIHeads(ROIHeads):
         if self.training:
             proposals = self.label_and_sample_proposals(proposals, targets, inference=False)
             return proposals, self._forward_box_train(features, proposals, targets)
-        if global_cfg.get("MODEL", {}).get("META_ARCHITECTURE", None) != "GeneralizedRCNNRegOnly":
-            raise NotImplementedError("CascadeROIHeads evaluation with RBG proposals is not implemented; use "
-                                      "META_ARCHITECTURE GeneralizedRCNNRegOnly (and call set_global_cfg(cfg))")
-        return self._forward_box_qe(features, None, targets)
+        if global_cfg.get("MODEL", {}).get("META_ARCHITECTURE", None) == "GeneralizedRCNNRegOnly":
+            return self._forward_box_qe(features, None, targets)
+        if not self.reg_only:
+            raise NotImplementedError("CascadeROIHeads evaluation is implemented for BoxOnlyLayersCascade only")
+        # reference :147-149, :160-162: detectron2's label_and_sample_proposals (still `randperm`-subsamples in eval,
+        # only the logging is skipped), then the reg_only branch of _forward_box
+        proposals = self.label_and_sample_proposals(proposals, targets, inference=False, log=False)
+        return self._forward_box_eval(features, proposals)
+
+    def _forward_box_eval(self, features, proposals):
+        """reference cascade_rcnn.py:205-227 + :248-266 (reg_only evaluation): run the cascade on the sampled
+        proposals; the result per image holds the last stage's boxes (clipped) of the FOREGROUND rows, in row order, with
+        score 1 and the matched class -- what fast_rcnn_inference(one-hot scores, thresh 0.1, nms 1.0, topk 1e10)
+        followed by the argsort of the kept row indices produces.  Returns (results, filtered stage-0 proposals)."""
+        feats = {f: to_nhwc(features[f]) for f in self.box_in_features}
+        dev = feats[self.box_in_features[0]].device
+        counts = [len(p) for p in proposals]
+        B, R = len(proposals), max(max(counts), 1)
+        boxes = torch.zeros(B, R, 4, device=dev)
+        for i, p in enumerate(proposals):
+            boxes[i, : counts[i]] = p.proposal_boxes.tensor
+        sizes = torch.tensor([list(p.image_size) for p in proposals], dtype=torch.int32, device=dev)
+        out = self.refine_boxes_batched(feats, boxes, sizes)
+        results, kept = [], []
+        for i, p in enumerate(proposals):
+            fg = p.gt_classes < self.num_classes
+            inst = Instances(p.image_size)
+            inst.pred_boxes = Boxes(out[i, : counts[i]][fg])
+            inst.scores = torch.ones(int(fg.sum()), device=dev)
+            inst.pred_classes = p.gt_classes[fg]
+            results.append(inst)
+            kept.append(p[fg])
+        return tuple(results), kept
 
     def _forward_box_qe(self, features, proposals, targets):
         """reference cascade_rcnn.py:167-203: proposals = the targets' gt_boxes; output = corrected boxes of every

@@ -65,8 +65,10 @@ class ROIHeads(nn.Module):
         return sampled, gt_classes[sampled]
 
     @torch.no_grad()
-    def label_and_sample_proposals(self, proposals, targets, inference=False):
-        """reference lvc roi_heads.py:173-278: append GT, match (IoU kernel), gt_ignores toggle, subsample."""
+    def label_and_sample_proposals(self, proposals, targets, inference=False, log=None):
+        """reference lvc roi_heads.py:173-278: append GT, match (IoU kernel), gt_ignores toggle, subsample.
+        `log` (default: not inference) controls only the EventStorage scalars: CascadeROIHeads inherits detectron2's
+        label_and_sample_proposals, whose evaluation call still subsamples and merely skips the logging."""
         out, num_fg, num_bg = [], [], []
         for prop, tgt in zip(proposals, targets):
             gt = tgt.gt_boxes.tensor
@@ -99,7 +101,7 @@ class ROIHeads(nn.Module):
             num_bg.append(int((gt_classes == self.num_classes).sum()))
             num_fg.append(gt_classes.numel() - num_bg[-1])
             out.append(inst)
-        if not inference:
+        if (not inference) if log is None else log:
             storage = get_event_storage()
             storage.put_scalar("roi_head/num_fg_samples", sum(num_fg) / max(1, len(num_fg)))
             storage.put_scalar("roi_head/num_bg_samples", sum(num_bg) / max(1, len(num_bg)))

@@ -444,6 +444,38 @@ def gen_box_corrector_train():
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
 
 
+def gen_box_corrector_eval():
+    """Evaluation of the same box-corrector config (GeneralizedRCNN.inference, rcnn.py:201-230): IoU with the matched GT
+    before / after the cascade for the subsampled foreground proposals.  Same batch as gen_box_corrector_train (GT and
+    loaded proposals are read back from its fixture), randperm = identity."""
+    from detectron2.structures import Boxes, Instances
+
+    cfg, model = build_ref_model("COCO-detection/cascade_ubbr_R_50_FPN_ft_all_30shot_aug_ftmore.yaml")
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "box_corrector_train.npz")).items()}
+    batch = []
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
+        inst.gt_classes = t["gt_classes%d" % i]
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(t["loaded_boxes%d" % i])
+        props.objectness_logits = t["loaded_logits%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    try:
+        with torch.no_grad():
+            out = model(batch)
+    finally:
+        torch.randperm = real
+    print("  rows", len(out["gt_classes"]), "mean IoU in %.4f out %.4f" % (float(out["input_ious"].mean()), float(out["output_ious"].mean())))
+    save("box_corrector_eval", **{k: v for k, v in out.items()})
+
+
 def gen_crops():
     from detectron2.structures import Boxes, Instances
     from lvc.data.utils import get_crops_qe
@@ -468,7 +500,7 @@ def gen_crops():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "box_corrector_train", "crops"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "box_corrector_train", "box_corrector_eval", "crops"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

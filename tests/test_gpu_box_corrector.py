@@ -270,3 +270,34 @@ def test_giou_box_loss_kernel_matches_torch_autograd():
         out, dd = k.giou_box_loss(d.to(dev), p.to(dev), gt.to(dev), cls.to(dev), K, w, clamp, iterate=iterate, lambda_=lam)
         assert abs(float(out[0]) - float(L)) <= 1e-5 * max(1.0, abs(float(L)))
         assert (dd.cpu() - dl.grad).abs().max() <= 1e-5 * float(dl.grad.abs().max())
+
+
+def test_box_corrector_evaluation_matches_reference(monkeypatch):
+    """GeneralizedRCNN.inference with BoxOnlyLayersCascade (reference rcnn.py:201-230 -> CascadeROIHeads._forward_box
+    reg_only evaluation): IoU with the matched GT before and after the three cascade stages, for the foreground
+    proposals that detectron2's label_and_sample_proposals keeps (it subsamples with randperm even in eval: identity
+    on both sides).  Same rows, same classes; IoUs within 1e-3 (three decode stages on the fp32 trunk)."""
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.utils import synthetic as syn
+
+    g = gold("box_corrector_eval")
+    t = gold("box_corrector_train")
+    model = _train_model().eval()
+    batch = []
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
+        inst.gt_classes = t["gt_classes%d" % i]
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(t["loaded_boxes%d" % i])
+        props.objectness_logits = t["loaded_logits%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with torch.no_grad():
+        out = model(batch)
+    assert set(out) == {"input_ious", "output_ious", "gt_classes"}
+    assert out["gt_classes"].cpu().tolist() == g["gt_classes"].tolist()
+    assert (out["input_ious"].cpu() - g["input_ious"]).abs().max() <= 1e-5
+    err = float((out["output_ious"].cpu() - g["output_ious"]).abs().max())
+    print("max |IoU_out - ref|", err)
+    assert err <= 1e-3
