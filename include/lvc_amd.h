@@ -76,6 +76,16 @@ int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_split, const
                             const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                             int res_mode, int ldy, int ldr, void* workspace, void* stream);
 
+/* Two-way fp16 operand split (Ootomo & Yokota 2022) form of lvc_conv3x3_nhwc_bf16x3 (csrc/conv3x3_halo_h2.hip):
+ * a = a1 + 2^-11 a2 with a1 = fp16(a), a2 = fp16((a - a1) * 2048); products a1 b1 (main accumulator) and a1 b2 + a2 b1
+ * (cross accumulator, folded in as cross / 2048): three fp16 MFMAs per block instead of six bf16 ones, two operand planes
+ * instead of three, fp32-level accuracy.  w_split: [2][Kpad][Kg] fp16 planes (w1, (w - w1) * 2048), same k order and
+ * padding as the bf16 planes.  Operands beyond fp16's range (|a| > 65504, NaN) set bit 1 of the workspace error word
+ * (the word after the LVC worker flags; lvc_amd.kernels.conv_error_word reads it).  No small-map fallback. */
+int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                           const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
+                           int res_mode, int ldy, int ldr, void* workspace, void* stream);
+
 /* BasicStem in one launch (detectron2/modeling/backbone/resnet.py:588-592): conv 7x7 s2 p3 (3 -> 64) -> FrozenBN fold
  * (scale/shift, NULL = identity) -> ReLU -> max_pool2d 3x3 s2 p1, on the split-precision bf16 MFMA path
  * (csrc/stem_pool.hip).  x [N,H,W,4] NHWC4 (the layout lvc_preprocess_nhwc4 writes), w_split = the three bf16 planes

@@ -33,12 +33,13 @@ class PackedConv:
     scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
     """
 
-    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3")
+    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h")
 
     def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
         self.w, self.scale, self.shift = w, scale, shift
         self.K, self.C, self.R, self.S, self.stride, self.pad, self.Kg, self.mode = K, C, R, S, stride, pad, Kg, mode
         self._w3 = None
+        self._w2h = None
 
     def split3(self):
         """[3, Kpad, Kg] bf16 planes (hi, mid, lo) of the packed weights: w == hi + mid + lo exactly."""
@@ -49,6 +50,16 @@ class PackedConv:
             lo = (r1 - mid.float()).to(torch.bfloat16)
             self._w3 = torch.stack([hi, mid, lo]).contiguous()
         return self._w3
+
+    def split2h(self):
+        """[2, Kpad, Kg] fp16 planes of the packed weights for the two-way fp16 split (csrc/conv3x3_halo_h2.hip):
+        w1 = fp16(w), w2 = fp16((w - w1) * 2048)  ->  w ~= w1 + w2 / 2048 to 2^-23 relative (|w| >= 2.4e-4)."""
+        if self._w2h is None:
+            assert float(self.w.abs().max()) <= 65504.0, "weights beyond the fp16 range: use LVC_CONV_SPLIT=bf16x3"
+            w1 = self.w.to(torch.float16)
+            w2 = ((self.w - w1.float()) * 2048.0).to(torch.float16)
+            self._w2h = torch.stack([w1, w2]).contiguous()
+        return self._w2h
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False):
@@ -149,6 +160,9 @@ CONV_HALO = _os.environ.get("LVC_CONV_HALO", "1") != "0"
 # BasicStem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2) as one fused split-precision kernel (csrc/stem_pool.hip)
 STEM_FUSED = _os.environ.get("LVC_STEM_FUSED", "1") != "0"
 _PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
+# operand split of the split-precision kernels that have both forms: "f16x2" = two fp16 planes, 3 MFMAs per block
+# (Ootomo & Yokota; csrc/conv3x3_halo_h2.hip), "bf16x3" = three bf16 planes, 6 MFMAs per block (no range limit)
+CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -183,7 +197,13 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if halo:
+        if halo and CONV_SPLIT == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= 128:
+            st = _lib.lib().lvc_conv3x3_nhwc_f16x2(
+                ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+                c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
+                c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv3x3_nhwc_f16x2")
+        elif halo:
             st = _lib.lib().lvc_conv3x3_nhwc_bf16x3(
                 ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),

@@ -20,8 +20,9 @@ for (N, C, H, W, K) in shapes:
     res = torch.randn(N, H, W, K, device=d)
     pc = k.pack_conv(w, bias=b, stride=1, pad=1)
     out = {}
-    for halo in (False, True):
-        k.CONV_HALO = halo
+    for halo in (False, True, "f16x2"):
+        k.CONV_HALO = bool(halo)
+        k.CONV_SPLIT = "f16x2" if halo == "f16x2" else "bf16x3"
         y = k.conv2d_nhwc(x, pc, relu=True, residual=res, res_mode=1)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,12 +33,13 @@ for (N, C, H, W, K) in shapes:
         e1.record(); torch.cuda.synchronize()
         out[halo] = (y.clone(), e0.elapsed_time(e1) / reps)
     fl = 2.0 * N * H * W * K * C * 9
-    line = "N%d C%d %dx%d K%d: generic %.3f ms %.1f TF | halo %.3f ms %.1f TF | max|halo-generic| %.3g" % (
+    line = "N%d C%d %dx%d K%d: generic %.3f ms %.1f TF | halo %.3f ms %.1f TF | halo f16x2 %.3f ms %.1f TF | max|halo-generic| %.3g" % (
         N, C, H, W, K, out[False][1], fl / out[False][1] / 1e9, out[True][1], fl / out[True][1] / 1e9,
-        (out[True][0] - out[False][0]).abs().max().item())
+        out["f16x2"][1], fl / out["f16x2"][1] / 1e9, (out[True][0] - out[False][0]).abs().max().item())
     if N * H * W * K * C < 3e9:
         ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1) + res.double()
         ref = ref.clamp_min(0)
-        line += " | vs fp64: halo %.3g generic %.3g" % ((out[True][0].double() - ref).abs().max().item(),
+        line += " | vs fp64: halo %.3g f16x2 %.3g generic %.3g" % ((out[True][0].double() - ref).abs().max().item(),
+                                                        (out["f16x2"][0].double() - ref).abs().max().item(),
                                                         (out[False][0].double() - ref).abs().max().item())
     print(line, flush=True)
