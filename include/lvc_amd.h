@@ -86,6 +86,13 @@ int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_split, const 
                            const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
 
+/* Two-way fp16 split form of the POINTWISE shapes of lvc_conv2d_nhwc_bf16x3 (csrc/conv_f16x2.hip): R = S = 1, pad 0
+ * and (C <= 512 or N*Ho*Wo >= 2048); anything else returns LVC_ERR_INVALID.  w_split as lvc_conv3x3_nhwc_f16x2. */
+int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                          const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
+                          void* stream);
+
 /* BasicStem in one launch (detectron2/modeling/backbone/resnet.py:588-592): conv 7x7 s2 p3 (3 -> 64) -> FrozenBN fold
  * (scale/shift, NULL = identity) -> ReLU -> max_pool2d 3x3 s2 p1, on the split-precision bf16 MFMA path
  * (csrc/stem_pool.hip).  x [N,H,W,4] NHWC4 (the layout lvc_preprocess_nhwc4 writes), w_split = the three bf16 planes

@@ -1,0 +1,804 @@
+// conv_f16x2.hip -- the pointwise (1x1 / FC) shapes of conv_bf16x3.hip with the two-way fp16 operand split of
+// conv3x3_halo_h2.hip (a = a1 + 2^-11 a2, three fp16 MFMAs per block into a main and a cross accumulator, fp32-level
+// accuracy, half the matrix-pipe work and two thirds of the operand bytes of the six-term bf16 split; operands beyond
+// fp16's range raise bit 1 of the workspace error word).  Kernel structure, tiling, loaders, stream-K protocol and
+// epilogues are those of conv_bf16x3.hip's conv_pw_f16x2_kernel / conv_pw256_f16x2_kernel; weights are the two fp16
+// planes [2][Kpad][Kg] of PackedConv.split2h().  Layers that are not pointwise stay on the bf16 kernels.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LROW 40          // bf16 elements per LDS row (32 + 8 pad = 80 B: conflict-free ds_read_b128)
+#define PLANE_A (BM * LROW)
+#define PLANE_B (BN * LROW)
+#define SPIN_LIMIT (1 << 24)
+
+struct ConvArgsH {
+  const float* x;
+  const unsigned short* w;   // [2][Kpad][Kg] fp16 planes
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  float* partials;
+  int* flags;
+  int N, H, W, C, K, R, S, stride, pad, Ho, Wo, M, Kg, relu, res_mode, ldy, ldr;
+  int tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
+  int x_bytes, w_plane_bytes;   // bytes of the input tensor / of ONE weight plane
+};
+
+__device__ __forceinline__ void split2h(float a, f16& h, f16& m) {
+  h = (f16)a;
+  m = (f16)((a - (float)h) * 2048.f);
+}
+
+#define NT 512   // 8 waves: two per SIMD, one workgroup per CU
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1) shape of the same kernel.  A 1x1 layer of the bottleneck trunk is an HBM stream with a short
+// reduction (2 - 16 chunks per tile); in the kernel above every tile then pays four serialized HBM round trips (first
+// chunk, second chunk, two batches of residual rows) and the layer sits at 2.3 TB/s where an elementwise add reaches
+// 5.8 (scripts/probe_hbm.py).  Here the activation loader runs three chunks ahead in three register sets and does not
+// stop at tile boundaries, the weight planes run one chunk ahead, and the residual rows of a tile are requested in one
+// batch before the LDS transpose.
+__global__ __launch_bounds__(NT, 2) void conv_pw_f16x2_kernel(ConvArgsH p) {
+  constexpr int STAGE_ELEMS = 2 * (PLANE_A + PLANE_B);                 // bf16 elements per buffer
+  constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;                      // double buffered
+  constexpr int CS_STRIDE = BN + 4;
+  constexpr int CS_BYTES = BM * CS_STRIDE * 4;
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  f16* stage = reinterpret_cast<f16*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  int range_err = 0;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;   // wave tile: 64 (M) x 32 (N)
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;        // float4 slot of the A chunk row
+  // staged row of this thread: consecutive 8-lane groups take rows r and r+4 (not r+1): with the 80-byte row pitch
+  // two rows 4 apart sit exactly half a bank cycle (64 B) apart, so the 16-lane ds_write_b64 / 8-lane ds_write_b128
+  // groups are conflict-free (rows r, r+1 overlap by 16 B -> every staging store took two LDS passes;
+  // SQ_LDS_BANK_CONFLICT 2.4e8 -> 0 on the p2 3x3)
+  const int arid = tid >> 3;
+  const int row0 = (arid & 1) * 4 + ((arid >> 1) & 3) + (arid >> 3) * 8;    // A rows row0 + 64*j, j = 0,1
+
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 2 * p.w_plane_bytes, 0x00020000);
+
+  // fragment read offsets (bf16 elements) inside a plane: row (tile-local) * LROW + fh*8 (+ 16 per k16 step)
+  const int a_frag = (wm * 64 + fi) * LROW + fh * 8;
+  const int b_frag = (wn * 32 + fi) * LROW + fh * 8;
+  // B staging: 16-byte pieces; per plane 128 rows x 4 pieces = 512 -> 1 per thread
+  const int brid = tid >> 2;
+  const int b_row = (brid & 1) * 4 + ((brid >> 1) & 3) + (brid >> 3) * 8;
+  const int b_q4 = tid & 3;
+
+  // ---- operand loader.  It runs LD chunks ahead of the MFMA loop and does NOT stop at tile boundaries: layers with
+  // short tiles (1x1 convolutions: 2 - 16 chunks) are HBM-bound streams, and with one chunk of run-ahead per CU the
+  // bytes in flight (16 KB x 256 CUs against ~2 us of HBM latency) capped them at ~2.4 TB/s; the first chunks of the
+  // next tile are now requested while this tile is still in its main loop / epilogue.
+  // Activations (HBM) run LD = 3 chunks ahead in three register sets; the weight planes (L2-resident) one chunk ahead
+  // in one set, as before.
+  constexpr int LD = 3;
+  f32x4 areg[LD][2];
+  u32x4 breg[2];
+  int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
+  unsigned l_aoff[2];
+  int lb = u, lb_kc = l_kc;
+  unsigned l_boff = (unsigned)(((l_tile % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+  // pointwise only: R = S = 1, pad = 0 -> one tap, always inside the image; a row is valid iff m < M
+  auto loader_enter = [&](int tile, int kc) {
+    l_tile = tile; l_kc = kc;
+    const int m0 = (tile / p.tiles_n) * BM;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + row0 + 64 * j;
+      const bool okm = m < p.M;
+      const int mm = okm ? m : 0;
+      const int n = mm / (p.Ho * p.Wo);
+      const int rem = mm - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      l_aoff[j] = okm ? (unsigned)(((n * p.H + ho * p.stride) * p.W + wo * p.stride) * p.C + q * 4) * 4u : 0x80000000u;
+    }
+  };
+  auto load_A = [&](auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    if (lu < u_end) {
+      if (l_kc == p.nk) loader_enter(l_tile + 1, 0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        areg[SL][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, l_aoff[j], l_kc * (BK * 4), 0));
+      ++l_kc;
+      ++lu;
+    }
+  };
+  auto load_B = [&]() {
+    if (lb < u_end) {
+      if (lb_kc == p.nk) {
+        lb_kc = 0;
+        l_boff = (unsigned)((((lb / p.nk) % p.tiles_n) * BN + b_row) * p.Kg + b_q4 * 8) * 2u;
+      }
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        breg[pl] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 wres, l_boff + (unsigned)(pl * p.w_plane_bytes), lb_kc * (BK * 2), 0));
+      ++lb_kc;
+      ++lb;
+    }
+  };
+  auto store_chunk = [&](auto slot_tag, int buf) {
+    constexpr int SL = decltype(slot_tag)::value;
+    f16* sa = stage + buf * STAGE_ELEMS;
+    f16* sb = sa + 2 * PLANE_A;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f16x4 h, m;
+      float big = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16 hh, mm;
+        split2h(areg[SL][j][e], hh, mm);
+        h[e] = hh; m[e] = mm;
+        big = fmaxf(big, fabsf(areg[SL][j][e]));
+      }
+      if (!(big <= 65504.f)) range_err = 1;   // beyond fp16 (or NaN): reported through the workspace error word
+      const int o = (row0 + 64 * j) * LROW + q * 4;
+      *reinterpret_cast<f16x4*>(sa + o) = h;
+      *reinterpret_cast<f16x4*>(sa + PLANE_A + o) = m;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+      *reinterpret_cast<u32x4*>(sb + pl * PLANE_B + b_row * LROW + b_q4 * 8) = breg[pl];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  loader_enter(l_tile, l_kc);
+  load_A(S0{});
+  load_B();
+  load_A(S1{});
+  load_A(S2{});
+  int slot = 0;   // register set holding the next chunk to be staged
+
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int kc0 = u - tile * p.nk;
+    const int kc1 = min(p.nk, kc0 + (u_end - u));
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    f32x16 acc[2][1], accx[2][1];   // main (a1 b1) and cross (a1 b2 + a2 b1, weight 2^-11) accumulators
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { acc[a][0][e] = 0.f; accx[a][0][e] = 0.f; }
+
+    // Fragments are single-buffered here (36 VGPRs instead of 72, which is what lets three activation register sets
+    // and the residual prefetch live without spills -- a spill reload waits on the in-order vmcnt counter and would
+    // serialise the very loads that are supposed to stay in flight); the sibling wave of the SIMD covers the reads.
+    f16x8 fa[2][2], fb[2];   // [mi][plane], [plane]
+    auto read_frags = [&](const f16* sa, const f16* sb, int s2) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          fa[mi][pl] = *reinterpret_cast<const f16x8*>(sa + pl * PLANE_A + a_frag + mi * 32 * LROW + s2 * 16);
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        fb[pl] = *reinterpret_cast<const f16x8*>(sb + pl * PLANE_B + b_frag + s2 * 16);
+    };
+    auto mfma_group = [&]() {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) accx[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[1], accx[mi][0], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[0], acc[mi][0], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) accx[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[0], accx[mi][0], 0, 0, 0);
+    };
+    int cur = 0;
+    // chunk body for every chunk but the tile's last: stages chunk kc+1 out of register set SL and refills SL
+    auto body = [&](auto slot_tag) {
+      const f16* sa = stage + cur * STAGE_ELEMS;
+      const f16* sb = sa + 2 * PLANE_A;
+      read_frags(sa, sb, 0);
+      store_chunk(slot_tag, cur ^ 1);
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(sa, sb, 1);
+      load_A(slot_tag);
+      load_B();
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      cur ^= 1;
+    };
+
+    // tile prologue: the tile's first chunk has been in flight since the previous tile
+    switch (slot) {
+      case 0: store_chunk(S0{}, 0); load_A(S0{}); break;
+      case 1: store_chunk(S1{}, 0); load_A(S1{}); break;
+      default: store_chunk(S2{}, 0); load_A(S2{}); break;
+    }
+    load_B();
+    slot = slot == LD - 1 ? 0 : slot + 1;
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    constexpr int RPI = NT / C4;
+    constexpr int NIT = BM / RPI;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    f32x4 rv[NIT];
+    // residual rows of this tile: requested now, consumed by the epilogue a whole main loop later
+    if (p.res_mode != 0 && col < p.K && kc0 == 0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = m0 + it * RPI + rsub;
+        rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < p.M) {
+          size_t ro = (size_t)row;
+          if (p.res_mode == 2) {
+            const int n = row / (p.Ho * p.Wo);
+            const int rem = row - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+          }
+          rv[it] = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        }
+      }
+    }
+    for (int kc = kc0; kc + 1 < kc1; ++kc) {
+      switch (slot) {
+        case 0: body(S0{}); break;
+        case 1: body(S1{}); break;
+        default: body(S2{}); break;
+      }
+      slot = slot == LD - 1 ? 0 : slot + 1;
+    }
+    {  // the tile's last chunk: nothing to stage (the next chunk belongs to the next tile and stays in its registers)
+      const f16* sa = stage + cur * STAGE_ELEMS;
+      const f16* sb = sa + 2 * PLANE_A;
+      read_frags(sa, sb, 0);
+      mfma_group();
+      read_frags(sa, sb, 1);
+      mfma_group();
+    }
+    __syncthreads();
+    u += kc1 - kc0;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mi][0][e] += accx[mi][0][e] * (1.f / 2048.f);
+
+    // ---- split tiles (same protocol as conv_igemm.hip)
+    if (kc0 != 0) {
+      float* dst = p.partials + (size_t)lw * (NT * 32);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+          f32x4 v = {acc[mi][0][e4 * 4 + 0], acc[mi][0][e4 * 4 + 1], acc[mi][0][e4 * 4 + 2], acc[mi][0][e4 * 4 + 3]};
+          *reinterpret_cast<f32x4*>(dst + ((size_t)(mi * 4 + e4) * NT + tid) * 4) = v;
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (kc1 < p.nk) {
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int last_worker = last_unit / p.units_per_worker;
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (NT * 32);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(mi * 4 + e4) * NT + tid) * 4);
+            acc[mi][0][e4 * 4 + 0] += v[0]; acc[mi][0][e4 * 4 + 1] += v[1];
+            acc[mi][0][e4 * 4 + 2] += v[2]; acc[mi][0][e4 * 4 + 3] += v[3];
+          }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- epilogue through LDS (the residual rows were requested at the start of the tile)
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int ccol = wn * 32 + fi;
+        Cs[row * CS_STRIDE + ccol] = acc[mi][0][e];
+      }
+    __syncthreads();
+    if (col < p.K) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + rsub;
+        const int row = m0 + r;
+        if (row < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+          v = v * sc + sh;
+          if (p.res_mode != 0) v += rv[it];
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (range_err) atomicOr(p.flags + p.err_index, 2);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pointwise shape for LONG reductions (1x1 convolutions with >= 1024 input channels, the box-head FC layers): these are
+// matrix-pipe bound, and what the 128 x 128 kernels above lack there is MFMA work per barrier and per fragment read.
+// Tile 256 x 128, 8 waves as 4 x 2, wave tile 64 x 64: 48 MFMAs per barrier and 24 MFMAs per 12 fragment reads (the
+// numbers of conv3x3_halo.hip), weight traffic per flop halved.  Two 72 KB stages only fit the 160 KB of LDS without
+// row padding, so rows are 64 B and the 16-byte granule g of row r is stored at g ^ ((r >> 2) & 3): each 16-lane group of
+// a ds_read_b128 (MI355X_MICROARCH.md: rows {0-3,12-15,20-27}, {4-11,16-19,28-31} of a 32-row fragment) then covers
+// all 16 granule slots of the 64 banks exactly once.
+#define G_BM 256
+#define G_PA (G_BM * 32)        // bf16 elements of one A plane (256 rows x 32)
+// WN x NI = 32-column blocks of the tile: <2,2> = 128 output channels (wave grid 4 x 2, wave tile 64 x 64); <1,2> = 64
+// and <1,1> = 32 output channels (wave grid 8 x 1, wave tile 32 x 64 / 32 x 32) for the narrow layers (256 -> 64
+// reductions, the 15-channel RPN predictors): with a 128-wide tile those spend 2 - 8x their MFMA time on zero weight
+// rows, and since a 128 x 32 activation chunk costs the matrix pipe as long as HBM needs to deliver it, that waste --
+// not the memory system -- held them at 2.5 - 3 TB/s (scripts/micro/stream_patterns.hip: the same 128-byte-per-row
+// access pattern alone streams at 5.8 TB/s).
+template <int WN, int NI>
+__global__ __launch_bounds__(NT, 2) void conv_pw256_f16x2_kernel(ConvArgsH p) {
+  constexpr int GBN = 32 * WN * NI;                 // output channels per tile
+  constexpr int WM = 8 / WN;                        // waves along M
+  constexpr int MI = G_BM / (32 * WM);              // 32-row blocks per wave
+  constexpr int G_PB = GBN * 32;
+  constexpr int STAGE_ELEMS = 2 * (G_PA + G_PB);                        // <2,2>: 36,864 elements = 73,728 B
+  constexpr int STAGE_BYTES = 2 * STAGE_ELEMS * 2;
+  constexpr int CS_STRIDE = GBN + 4;
+  constexpr int CS_BYTES = G_BM * CS_STRIDE * 4;                        // 135,168
+  constexpr int SMEM_BYTES = STAGE_BYTES > CS_BYTES ? STAGE_BYTES : CS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
+  f16* stage = reinterpret_cast<f16*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  int range_err = 0;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;                     // float4 slot of the 32-channel A row
+  const int rslot = tid >> 3;                // A rows rslot + 64*j, j = 0..3
+  // weight staging: GBN * 4 pieces of 16 B per plane; piece (tid + 512 i) -> (plane, row, quarter)
+  constexpr int B_PPP = GBN * 4;
+  constexpr int NB = (2 * B_PPP + NT - 1) / NT;
+  const int b_q4 = tid & 3;
+  int b_pl[NB], b_row[NB], b_st[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int pc = tid + NT * i;
+    b_pl[i] = pc / B_PPP;
+    b_row[i] = (pc % B_PPP) >> 2;
+    b_st[i] = ((b_q4 ^ ((b_row[i] >> 2) & 3)) * 8);
+  }
+  // swizzled store offsets (bf16 elements inside a row)
+  const int a_st = ((((q >> 1) ^ ((rslot >> 2) & 3)) * 8) + (q & 1) * 4);   // (rslot + 64j) >> 2 & 3 == rslot >> 2 & 3
+  // swizzled fragment offsets: row * 32 + ((fh + 2*s2) ^ x) * 8 with x = (row >> 2) & 3 = (fi >> 2) & 3
+  const int fx = (fi >> 2) & 3;
+  const int f_off0 = ((fh ^ fx) * 8), f_off1 = (((fh + 2) ^ fx) * 8);
+  const int a_frag = (wm * MI * 32 + fi) * 32;
+  const int b_frag = (wn * NI * 32 + fi) * 32;
+
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 2 * p.w_plane_bytes, 0x00020000);
+
+  // operand loader (as conv_pw_f16x2_kernel, across tile boundaries), one register set: these layers are matrix-pipe
+  // bound and a second activation set (16 more VGPRs next to 64 accumulators + 48 fragment registers) spills
+  constexpr int LD = 1;
+  f32x4 areg[LD][4];
+  u32x4 breg[NB];
+  int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
+  unsigned l_aoff[4];
+  int lb = u, lb_kc = l_kc;
+  unsigned l_bbase = (unsigned)((l_tile % p.tiles_n) * GBN);   // first weight row of the loader's tile
+  auto loader_enter = [&](int tile, int kc) {
+    l_tile = tile; l_kc = kc;
+    const int m0 = (tile / p.tiles_n) * G_BM;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + rslot + 64 * j;
+      const bool okm = m < p.M;
+      const int mm = okm ? m : 0;
+      const int n = mm / (p.Ho * p.Wo);
+      const int rem = mm - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      l_aoff[j] = okm ? (unsigned)(((n * p.H + ho * p.stride) * p.W + wo * p.stride) * p.C + q * 4) * 4u : 0x80000000u;
+    }
+  };
+  auto load_A = [&](auto slot_tag) {
+    constexpr int SL = decltype(slot_tag)::value;
+    if (lu < u_end) {
+      if (l_kc == p.nk) loader_enter(l_tile + 1, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        areg[SL][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, l_aoff[j], l_kc * (BK * 4), 0));
+      ++l_kc;
+      ++lu;
+    }
+  };
+  auto load_B = [&]() {
+    if (lb < u_end) {
+      if (lb_kc == p.nk) {
+        lb_kc = 0;
+        l_bbase = (unsigned)(((lb / p.nk) % p.tiles_n) * GBN);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (b_pl[i] < 2)
+          breg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                  wres, ((l_bbase + b_row[i]) * p.Kg + b_q4 * 8) * 2u + (unsigned)(b_pl[i] * p.w_plane_bytes),
+                                                  lb_kc * (BK * 2), 0));
+      ++lb_kc;
+      ++lb;
+    }
+  };
+  auto store_chunk = [&](auto slot_tag, int buf) {
+    constexpr int SL = decltype(slot_tag)::value;
+    f16* sa = stage + buf * STAGE_ELEMS;
+    f16* sb = sa + 2 * G_PA;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f16x4 h, m;
+      float big = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f16 hh, mm;
+        split2h(areg[SL][j][e], hh, mm);
+        h[e] = hh; m[e] = mm;
+        big = fmaxf(big, fabsf(areg[SL][j][e]));
+      }
+      if (!(big <= 65504.f)) range_err = 1;   // beyond fp16 (or NaN): reported through the workspace error word
+      const int o = (rslot + 64 * j) * 32 + a_st;
+      *reinterpret_cast<f16x4*>(sa + o) = h;
+      *reinterpret_cast<f16x4*>(sa + G_PA + o) = m;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (b_pl[i] < 2) *reinterpret_cast<u32x4*>(sb + b_pl[i] * G_PB + b_row[i] * 32 + b_st[i]) = breg[i];
+  };
+  using S0 = std::integral_constant<int, 0>;
+  loader_enter(l_tile, l_kc);
+  load_A(S0{});
+  load_B();
+
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int kc0 = u - tile * p.nk;
+    const int kc1 = min(p.nk, kc0 + (u_end - u));
+    const int tile_n = tile % p.tiles_n;
+    const int tile_m = tile / p.tiles_n;
+    const int m0 = tile_m * G_BM;
+    const int n0 = tile_n * GBN;
+
+    f32x16 acc[MI][NI], accx[MI][NI];   // main and cross accumulators
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc[a][b][e] = 0.f; accx[a][b][e] = 0.f; }
+
+    f16x8 fa[MI][2], fb[NI][2];
+    auto read_frags = [&](const f16* sa, const f16* sb, int fo) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          fa[mi][pl] = *reinterpret_cast<const f16x8*>(sa + pl * G_PA + a_frag + mi * 32 * 32 + fo);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          fb[ni][pl] = *reinterpret_cast<const f16x8*>(sb + pl * G_PB + b_frag + ni * 32 * 32 + fo);
+    };
+    auto mfma_group = [&]() {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], accx[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], accx[mi][ni], 0, 0, 0);
+    };
+    int cur = 0;
+    auto body = [&](auto slot_tag) {
+      const f16* sa = stage + cur * STAGE_ELEMS;
+      const f16* sb = sa + 2 * G_PA;
+      read_frags(sa, sb, f_off0);
+      store_chunk(slot_tag, cur ^ 1);
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(sa, sb, f_off1);
+      load_A(slot_tag);
+      load_B();
+      mfma_group();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      cur ^= 1;
+    };
+
+    store_chunk(S0{}, 0);
+    load_A(S0{});
+    load_B();
+    __syncthreads();
+    for (int kc = kc0; kc + 1 < kc1; ++kc) {
+      body(S0{});
+    }
+    {
+      const f16* sa = stage + cur * STAGE_ELEMS;
+      const f16* sb = sa + 2 * G_PA;
+      read_frags(sa, sb, f_off0);
+      mfma_group();
+      read_frags(sa, sb, f_off1);
+      mfma_group();
+    }
+    __syncthreads();
+    u += kc1 - kc0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] += accx[mi][ni][e] * (1.f / 2048.f);
+
+    // ---- split tiles
+    if (kc0 != 0) {
+      float* dst = p.partials + (size_t)lw * (NT * 16 * MI * NI);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (kc1 < p.nk) {
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int last_worker = last_unit / p.units_per_worker;
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (NT * 16 * MI * NI);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4);
+              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
+              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
+            }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- epilogue through LDS; the residual rows are requested before the transpose (their latency then overlaps
+    // the LDS round trip; at this point the fragment and operand registers are dead, so 16 float4 fit)
+    constexpr int C4 = GBN / 4;
+    constexpr int RPI = NT / C4;
+    constexpr int NIT = G_BM / RPI;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    f32x4 rv[NIT];
+    if (p.res_mode != 0 && col < p.K) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int row = m0 + it * RPI + rsub;
+        rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < p.M) {
+          size_t ro = (size_t)row;
+          if (p.res_mode == 2) {
+            const int n = row / (p.Ho * p.Wo);
+            const int rem = row - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+          }
+          rv[it] = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        }
+      }
+    }
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * MI * 32 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int ccol = wn * NI * 32 + ni * 32 + fi;
+          Cs[row * CS_STRIDE + ccol] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    if (col < p.K) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int r = it * RPI + rsub;
+        const int row = m0 + r;
+        if (row < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+          v = v * sc + sh;
+          if (p.res_mode != 0) v += rv[it];
+          if (p.relu) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (range_err) atomicOr(p.flags + p.err_index, 2);
+}
+
+#define LVC_MAX_WORKERS 1024
+static int g_cus_h = 0;
+
+// Pointwise layers (R = S = 1, pad 0) only; same arguments as lvc_conv2d_nhwc_bf16x3 except `w_split`: two fp16 planes
+// [2][Kpad][Kg] (w1 = fp16(w), w2 = fp16((w - w1) * 2048)).  Returns LVC_ERR_INVALID for anything the pointwise shapes do
+// not cover (the caller keeps those on the bf16 kernels).
+extern "C" int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale,
+                                      const float* shift, const float* residual, float* y, int N, int H, int W, int C,
+                                      int K, int R, int S, int stride, int pad, int Kg, int relu, int res_mode, int ldy,
+                                      int ldr, void* workspace, void* stream) {
+  LVC_CHECK_ARG(x && w_split && y && workspace, "null pointer");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
+  LVC_CHECK_ARG(C % BK == 0 && Kg == R * S * C, "needs C % 32 == 0 and Kg == R*S*C");
+  LVC_CHECK_ARG(R * S <= 32, "at most 32 taps");
+  LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
+  int Ho = (H + 2 * pad - R) / stride + 1;
+  int Wo = (W + 2 * pad - S) / stride + 1;
+  LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output");
+  if (res_mode == 2) LVC_CHECK_ARG(Ho % 2 == 0 && Wo % 2 == 0, "upsample-add needs even output size");
+  ConvArgsH a;
+  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+  a.Ho = Ho; a.Wo = Wo;
+  long long Mll = (long long)N * Ho * Wo;
+  LVC_CHECK_ARG(Mll < (1ll << 31), "too many output pixels");
+  a.M = (int)Mll; a.Kg = Kg; a.relu = relu; a.res_mode = res_mode;
+  a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
+  LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
+  LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                    ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
+  // kernel shape: 0 = general implicit GEMM (128 x 128 tiles), 1 = pointwise, short reduction (conv_pw_f16x2_kernel),
+  // 2 = pointwise, long reduction (conv_pw256_f16x2_kernel, 256 x 128 tiles).  LVC_CONV_PW: 0 disables both pointwise
+  // shapes, 1 only the 256-row one (experiments).
+  static int pw_mode = -1;
+  if (pw_mode < 0) { const char* e = getenv("LVC_CONV_PW"); pw_mode = e ? atoi(e) : 2; }
+  a.nk = Kg / BK;
+  int shape = 0;
+  if (R == 1 && S == 1 && pad == 0) {
+    // measured on the R50-FPN layer set (scripts/probe_layers_list.py): with its residual rows requested before the
+    // LDS transpose the 256-row shape wins from 128 input channels up; the 64-channel layers (2 chunks per tile) are
+    // pure HBM streams and keep the 128-row shape with its deeper activation run-ahead
+    static int min_nk256 = -1;
+    if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 4; }
+    if (pw_mode >= 2 && a.M >= 2048 && a.nk >= min_nk256) shape = 2;
+    else if (a.nk <= 16) shape = pw_mode >= 1 ? 1 : 0;
+  }
+  LVC_CHECK_ARG(shape != 0, "only pointwise layers (1x1, pad 0, <= 512 input channels or >= 2048 rows) have an fp16x2 form");
+  // the 256-row pointwise shape has 128-, 64- and 32-channel tiles
+  const int gbn = shape == 2 ? (K <= 32 ? 32 : K <= 64 ? 64 : 128) : BN;
+  a.tiles_n = lvc_cdiv(K, gbn);
+  const int tiles_m = lvc_cdiv(a.M, shape == 2 ? G_BM : BM);
+  long long units = (long long)tiles_m * a.tiles_n * a.nk;
+  LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
+  a.total_units = (int)units;
+  const long long xb = (long long)N * H * W * C * 4, wb = (long long)(lvc_cdiv(K, BN) * BN) * Kg * 2;   // planes are padded to 128 rows
+  LVC_CHECK_ARG(xb < (1ll << 31) && 2 * wb < (1ll << 31), "input / weight tensor must be smaller than 2 GiB");
+  a.x_bytes = (int)xb; a.w_plane_bytes = (int)wb;
+  if (g_cus_h == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    g_cus_h = cus;
+  }
+  int cap = g_cus_h;  // one worker per CU
+  if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
+  const int min_units = 4;
+  int workers = (int)((units + min_units - 1) / min_units);
+  if (workers > cap) workers = cap;
+  a.units_per_worker = (int)((units + workers - 1) / workers);
+  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker);
+  a.partials = (float*)workspace;
+  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
+  a.err_index = LVC_MAX_WORKERS;
+  if (shape == 2 && gbn == 32)
+    hipLaunchKernelGGL((conv_pw256_f16x2_kernel<1, 1>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else if (shape == 2 && gbn == 64)
+    hipLaunchKernelGGL((conv_pw256_f16x2_kernel<1, 2>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else if (shape == 2)
+    hipLaunchKernelGGL((conv_pw256_f16x2_kernel<2, 2>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  else if (shape == 1)
+    hipLaunchKernelGGL(conv_pw_f16x2_kernel, dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

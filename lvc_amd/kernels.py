@@ -209,6 +209,14 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
+        elif (CONV_SPLIT == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0
+              and pc.C >= 128 and N * Ho * Wo >= 2048):   # the 256-row pointwise shape; 64-channel streams stay bf16x3
+            st = _lib.lib().lvc_conv2d_nhwc_f16x2(
+                ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+                c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
+                c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
+                c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv2d_nhwc_f16x2")
         else:
             st = _lib.lib().lvc_conv2d_nhwc_bf16x3(
                 ptr(x), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
