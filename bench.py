@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16X3_TFLOPS = 2500.0 / 6  # dense bf16 MFMA peak / 6 bf16 MFMAs per fp32-accurate product
+PEAK_F16X2_TFLOPS = 2500.0 / 3   # dense fp16 MFMA peak / 3 fp16 MFMAs per fp32-accurate product (two-way fp16 split)
 BATCH_PER_GPU = 8
 
 
@@ -77,7 +78,8 @@ def main():
     # one fully bracketed untimed step; ~150 event records per step cost ~0.7 ms of host time inside the timed region),
     # the per-kernel breakdown of every conv/GEMM launch comes from two more untimed steps after it.
     timer = full = None
-    NAMES = {"bf16x3_halo": "conv3x3_halo_kernel", "bf16x3": "conv_bf16x3_kernel (+ pointwise shapes)", "f32": "conv_igemm_f32_kernel"}
+    NAMES = {"f16x2_halo": "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw256_f16x2_kernel", "bf16x3_halo": "conv3x3_halo_kernel",
+             "bf16x3": "conv_bf16x3_kernel (+ bf16 pointwise shapes)", "f32": "conv_igemm_f32_kernel"}
     if not args.no_launch_timer:
         probe = K.LaunchTimer()
         K.CONV_TIMER = probe
@@ -102,6 +104,7 @@ def main():
         K.CONV_TIMER = None
     from lvc_amd.modeling.roi_heads.roi_heads import check_status
     check_status(int(out[4].item()))
+    K.check_conv_error_word(dev)   # stream-K timeout / fp16x2 operand-range word of the conv kernels
     n_det = out[3].tolist()
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -119,11 +122,11 @@ def main():
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         achieved = fl / (ms * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_BF16X3_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_F16X2_TFLOPS if dom.startswith("f16x2") else PEAK_BF16X3_TFLOPS
         roofline = {
             "kernel": "%s (%d launches/step)" % (NAMES[dom], nlaunch // args.steps),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate); achieved counts algorithmic fp32 flops once; the kernel runs at the 1.4 kW socket power cap (profiles/README.md)",
+            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split a = a1 + 2^-11 a2, main + cross fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once; the kernel runs at the 1.4 kW socket power cap (profiles/README.md)",
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "traffic_note": "fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) of ONE p2 3x3 launch of this kernel vs 1.10 GB algorithmic; see profiles/r01_conv_pmc.json",
             "kernel_ms_per_step": round(ms / args.steps, 3), "launch_avg_ms": round(ms / nlaunch, 4)}
@@ -164,7 +167,7 @@ def main():
             "metric": "img/s COCO 800x1333 R50-FPN inference (GeneralizedRCNN forward, 1000 proposals, 100 detections)",
             "value": round(value, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 (conv/GEMM inner products: exact 3-way bf16 operand split on bf16 MFMA, fp32 accumulate; fp32 MFMA for the 256->64 1x1 layers and the RPN predictors)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32 (conv/GEMM inner products on the fp16 / bf16 matrix cores through fp32-accurate operand splits: two-way fp16 with main + cross fp32 accumulators for the 3x3 and wide 1x1 / FC layers, three-way bf16 for the rest; error vs fp64 below the CPU fp32 reference, tests/test_gpu_e2e.py)", "data": "synthetic",
             "config": {"workload": "COCO-detection R50-FPN inference, bs=8 synthetic 3x800x1333 per GPU, 1000 pre/post-NMS "
                                    "proposals per level/image, 80 classes, conditioned random-init weights",
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world,

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import c_double, c_float, c_int, c_longlong, c_void_p, check, ptr
+from ._lib import LvcNativeError, c_double, c_float, c_int, c_longlong, c_void_p, check, ptr
 
 BK = 32  # gemm-K chunk of the implicit-GEMM kernel
 BN = 128
@@ -131,6 +131,24 @@ def conv_error_word(device):
     return int(ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4].view(torch.int32).item())
 
 
+def clear_conv_error_word(device):
+    ws = conv_workspace(device)
+    ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4].zero_()
+
+
+def check_conv_error_word(device):
+    """Raise for a set bit of the conv workspace error word (bit 0: a stream-K worker timed out waiting for a partial
+    tile; bit 1: an operand beyond fp16's range reached a two-way fp16 split kernel).  Synchronises: call it where the
+    results are read anyway."""
+    e = conv_error_word(device)
+    if e & 1:
+        raise LvcNativeError("conv/GEMM kernel: a stream-K worker timed out waiting for a partial tile")
+    if e & 2:
+        clear_conv_error_word(device)
+        raise LvcNativeError("conv/GEMM kernel: an operand with |a| > 65504 (or NaN) reached the fp16x2 split; "
+                             "set LVC_CONV_SPLIT=bf16x3 for range-free kernels")
+
+
 class LaunchTimer:
     """Optional per-launch HIP-event bracket for the conv/GEMM kernel (bench.py's roofline leg).
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
@@ -163,6 +181,7 @@ _PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
 # operand split of the split-precision kernels that have both forms: "f16x2" = two fp16 planes, 3 MFMAs per block
 # (Ootomo & Yokota; csrc/conv3x3_halo_h2.hip), "bf16x3" = three bf16 planes, 6 MFMAs per block (no range limit)
 CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
+_HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
@@ -189,7 +208,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     pw_narrow = _PW_NARROW and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128 and pc.C % 32 == 0 and N * Ho * Wo >= 2048
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else 4 if pw_narrow else _BF16X3_MIN_K)
             and pc.K % 4 == 0 and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
-        engine = "bf16x3_halo" if halo else "bf16x3"
+        h2_halo = halo and CONV_SPLIT == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES
+        h2_pw = (not halo and CONV_SPLIT == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128
+                 and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3
+        engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
     timer = CONV_TIMER
     if timer is not None and timer.only is not None and engine not in timer.only:
         timer = None
@@ -197,7 +219,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if halo and CONV_SPLIT == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= 128:
+        if engine == "f16x2_halo":
             st = _lib.lib().lvc_conv3x3_nhwc_f16x2(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
@@ -209,8 +231,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
-        elif (CONV_SPLIT == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0
-              and pc.C >= 128 and N * Ho * Wo >= 2048):   # the 256-row pointwise shape; 64-channel streams stay bf16x3
+        elif engine == "f16x2_pw":
             st = _lib.lib().lvc_conv2d_nhwc_f16x2(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),

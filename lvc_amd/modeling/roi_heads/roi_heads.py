@@ -208,6 +208,7 @@ def instances_from_batched(boxes, scores, classes, count, image_sizes, status=No
         meta = torch.cat([count, status]).tolist()
         counts, st = meta[:-1], meta[-1]
         check_status(st)
+        K.check_conv_error_word(count.device)   # spin timeout / fp16x2 range word of the conv kernels (already synced)
     else:
         counts = count.tolist()
     out = []

@@ -86,7 +86,8 @@ def test_conv_residual_and_upsample_add():
         (1, 32, 30, 30, 64, "8,32"),     # 64-wide N tile, one channel chunk
     ],
 )
-def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
+@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, split, monkeypatch):
     """csrc/conv3x3_halo.hip (forced even where the wrapper would pick the generic kernel) against F.conv2d on the
     CPU, with bias, FrozenBN scale/shift, ReLU, residual add and FPN upsample-add epilogues."""
     from lvc_amd import kernels as k
@@ -96,6 +97,8 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
         monkeypatch.setenv("LVC_HALO_PATCH", patch)
     monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
     monkeypatch.setattr(k, "CONV_HALO", True)
+    monkeypatch.setattr(k, "CONV_SPLIT", split)
+    monkeypatch.setattr(k, "_HALO_H2_MIN_TILES", 0)
     g = torch.Generator().manual_seed(N * 1000 + C + K + H)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
@@ -112,7 +115,7 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
     monkeypatch.setattr(k, "CONV_TIMER", timer)
     pc = k.pack_conv(w.to(d), bn=[t.to(d) for t in bn], stride=1, pad=1)
     y = k.conv2d_nhwc(xd, pc, relu=True, residual=_nhwc(res).to(d), res_mode=1).cpu().permute(0, 3, 1, 2)
-    assert timer.records[-1][3] == "bf16x3_halo"
+    assert timer.records[-1][3] == split + "_halo"
     assert (y - ref_bn).abs().max() <= 2e-5 * float(ref_bn.abs().max())
     pc2 = k.pack_conv(w.to(d), bias=b.to(d), stride=1, pad=1)
     y2 = k.conv2d_nhwc(xd, pc2).cpu().permute(0, 3, 1, 2)
@@ -121,7 +124,7 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
     # identical to the generic split-precision kernel up to the order in which stream-K partial tiles are added
     monkeypatch.setattr(k, "CONV_HALO", False)
     y3 = k.conv2d_nhwc(xd, pc2).cpu().permute(0, 3, 1, 2)
-    assert (y2 - y3).abs().max() <= 4e-6 * float(ref_bias.abs().max())
+    assert (y2 - y3).abs().max() <= (4e-6 if split == "bf16x3" else 2e-5) * float(ref_bias.abs().max())
     if H % 2 == 0 and W % 2 == 0:
         monkeypatch.setattr(k, "CONV_HALO", True)
         top = torch.randn(N, K, H // 2, W // 2, generator=g)
@@ -141,12 +144,16 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, monkeypatch):
         (2, 512, 40, 52, 128, 1, 0),     # 16 chunks: 256-row shape, M tail (4160 = 16 * 256 + 64)
         (2, 1024, 30, 36, 256, 1, 0),    # 32 chunks: stream-K splits tiles of the 256-row shape
         (2, 512, 40, 52, 256, 1, 2),     # FPN lateral with top-down upsample-add
+        (2, 256, 40, 52, 64, 1, 0),      # narrow output: 64-channel tile of the 256-row shape
+        (2, 256, 40, 52, 16, 1, 0),      # RPN-predictor width: 32-channel tile
     ],
 )
-def test_pointwise_shapes_match_cpu(N, C, H, W, K, stride, res_mode):
+@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+def test_pointwise_shapes_match_cpu(N, C, H, W, K, stride, res_mode, split, monkeypatch):
     """1x1 layers through the pointwise shapes of the split-precision kernel (csrc/conv_bf16x3.hip) against F.conv2d."""
     from lvc_amd import kernels as k
 
+    monkeypatch.setattr(k, "CONV_SPLIT", split)
     g = torch.Generator().manual_seed(N * 100 + C + K + stride)
     x = torch.randn(N, C, H, W, generator=g)
     w = torch.randn(K, C, 1, 1, generator=g) * (2.0 / C) ** 0.5
@@ -167,6 +174,35 @@ def test_pointwise_shapes_match_cpu(N, C, H, W, K, stride, res_mode):
     pc = k.pack_conv(w.to(d), bias=b.to(d), stride=stride, pad=0)
     y = k.conv2d_nhwc(_nhwc(x).to(d), pc, relu=True, residual=res, res_mode=res_mode).cpu().permute(0, 3, 1, 2)
     assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
+
+
+def test_f16x2_range_overflow_is_reported():
+    """The two-way fp16 split cannot represent |a| > 65504: the staging code must raise bit 1 of the workspace error
+    word (and only then), for the 3x3 halo kernel and for the pointwise kernel."""
+    from lvc_amd import kernels as k
+
+    d = _dev()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 40, 52, 256, generator=g).to(d)
+    w3 = (torch.randn(128, 256, 3, 3, generator=g) * 0.02).to(d)
+    w1 = (torch.randn(128, 256, 1, 1, generator=g) * 0.05).to(d)
+    pc3, pc1 = k.pack_conv(w3, stride=1, pad=1), k.pack_conv(w1)
+    old_min = k._HALO_H2_MIN_TILES
+    k._HALO_H2_MIN_TILES = 0
+    try:
+        assert k.CONV_SPLIT == "f16x2"
+        k.conv2d_nhwc(x, pc3); k.conv2d_nhwc(x, pc1)
+        assert k.conv_error_word(x.device) & 2 == 0
+        xb = x.clone(); xb[1, 7, 9, 33] = 7.0e4
+        k.conv2d_nhwc(xb, pc1)
+        assert k.conv_error_word(x.device) & 2 == 2
+        k.clear_conv_error_word(x.device)
+        assert k.conv_error_word(x.device) == 0
+        k.conv2d_nhwc(xb, pc3)
+        assert k.conv_error_word(x.device) & 2 == 2
+        k.clear_conv_error_word(x.device)
+    finally:
+        k._HALO_H2_MIN_TILES = old_min
 
 
 def test_conv_stem_7x7():
