@@ -100,6 +100,10 @@ int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_split, const f
  * plane; y [N,Hp,Wp,64] with Ho = (H-1)/2+1, Hp = (Ho-1)/2+1 (same for W). */
 int lvc_stem_conv_pool_nhwc4(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                              float* y, int N, int H, int W, int Kpad, int relu, void* stream);
+/* The same with the two-way fp16 operand split (csrc/stem_pool_h2.hip): w_split = [2][Kpad][224] fp16 planes;
+ * d_error_word: device int whose bit 1 is set when an input beyond fp16's range is met (may be NULL). */
+int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                   float* y, int N, int H, int W, int Kpad, int relu, int* d_error_word, void* stream);
 
 /* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
  * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero

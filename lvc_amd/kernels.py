@@ -269,6 +269,14 @@ def stem_conv_pool(x4, pc, relu=True):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
     out = torch.empty(N, Hp, Wp, 64, device=x4.device, dtype=torch.float32)
+    if CONV_SPLIT == "f16x2":
+        ws = conv_workspace(x4.device)
+        err = ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4]   # the conv error word
+        st = _lib.lib().lvc_stem_conv_pool_nhwc4_f16x2(ptr(x4), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(out),
+                                                       c_int(N), c_int(H), c_int(W), c_int(pc.w.shape[0]),
+                                                       c_int(1 if relu else 0), ptr(err), _stream(x4))
+        check(st, "lvc_stem_conv_pool_nhwc4_f16x2")
+        return out
     st = _lib.lib().lvc_stem_conv_pool_nhwc4(ptr(x4), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(out),
                                              c_int(N), c_int(H), c_int(W), c_int(pc.w.shape[0]), c_int(1 if relu else 0),
                                              _stream(x4))

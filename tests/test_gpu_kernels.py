@@ -220,12 +220,14 @@ def test_conv_stem_7x7():
     assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("N,H,W", [(1, 64, 96), (2, 70, 134), (1, 37, 41), (1, 800, 1344)])
-def test_stem_conv_pool_fused_matches_cpu(N, H, W):
+def test_stem_conv_pool_fused_matches_cpu(N, H, W, split, monkeypatch):
     """csrc/stem_pool.hip: conv 7x7/2 + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch vs the same chain on the
     CPU (reference BasicStem.forward, resnet.py:588-592), including odd sizes whose patches straddle the borders."""
     from lvc_amd import kernels as k
 
+    monkeypatch.setattr(k, "CONV_SPLIT", split)
     g = torch.Generator().manual_seed(H * 7 + W)
     x = torch.randn(N, 3, H, W, generator=g) * 50
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
