@@ -935,32 +935,12 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
       }
     }
 
-    // ---- epilogue through LDS; the residual rows are requested before the transpose (their latency then overlaps
-    // the LDS round trip; at this point the fragment and operand registers are dead, so 16 float4 fit)
+    // ---- epilogue through LDS
     constexpr int C4 = GBN / 4;
     constexpr int RPI = NT / C4;
     constexpr int NIT = G_BM / RPI;
     const int c4 = tid % C4, rsub = tid / C4;
     const int col = n0 + c4 * 4;
-    f32x4 rv[NIT];
-    if (p.res_mode != 0 && col < p.K) {
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int row = m0 + it * RPI + rsub;
-        rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (row < p.M) {
-          size_t ro = (size_t)row;
-          if (p.res_mode == 2) {
-            const int n = row / (p.Ho * p.Wo);
-            const int rem = row - n * (p.Ho * p.Wo);
-            const int ho = rem / p.Wo;
-            const int wo = rem - ho * p.Wo;
-            ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
-          }
-          rv[it] = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
-        }
-      }
-    }
     float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
@@ -973,23 +953,49 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_bf16x3_kernel(ConvArgsB p) {
           Cs[row * CS_STRIDE + ccol] = acc[mi][ni][e];
         }
     __syncthreads();
-    if (col < p.K) {
+    // Residual rows are read in groups of eight, all eight requests of a group issued (branch-free: rows / columns past the
+    // edge read a clamped, unused address) before the group's LDS rows are consumed.  Requesting all sixteen ahead of the
+    // transpose made the register allocator spill them one by one behind a vmcnt(0) each (16 serialized round trips per
+    // tile and ~200 MB of scratch traffic per launch on the short-tile layers, scripts/probe_pw_traffic.sh).
+    if (col < p.K || p.res_mode != 0) {
+      const bool wr = col < p.K;
+      const int colc = wr ? col : p.K - 4;
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + colc);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + colc);
+      constexpr int RG = NIT < 8 ? NIT : 8;   // rows per group (NIT = 4 / 8 / 16 for 32- / 64- / 128-channel tiles)
+      for (int g8 = 0; g8 < NIT; g8 += RG) {
+        f32x4 rv[RG];
+        if (p.res_mode != 0) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int r = it * RPI + rsub;
-        const int row = m0 + r;
-        if (row < p.M) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
-          v = v * sc + sh;
-          if (p.res_mode != 0) v += rv[it];
-          if (p.relu) {
-            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          for (int i = 0; i < RG; ++i) {
+            int row = m0 + (g8 + i) * RPI + rsub;
+            row = row < p.M ? row : p.M - 1;
+            size_t ro = (size_t)row;
+            if (p.res_mode == 2) {
+              const int n = row / (p.Ho * p.Wo);
+              const int rem = row - n * (p.Ho * p.Wo);
+              const int ho = rem / p.Wo;
+              const int wo = rem - ho * p.Wo;
+              ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+            }
+            rv[i] = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + colc);
           }
-          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RG; ++i) {
+          const int r = (g8 + i) * RPI + rsub;
+          const int row = m0 + r;
+          if (wr && row < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+            v = v * sc + sh;
+            if (p.res_mode != 0) v += rv[i];
+            if (p.relu) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
+          }
         }
       }
     }
