@@ -251,6 +251,27 @@ int lvc_giou_box_loss(const float* deltas, int ld_delta, const float* proposals,
 int lvc_relu_backward(const float* dy, const float* y, long long n, float* out, void* stream);
 int lvc_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
 
+/* Backward into the trunk (BASELINE config 5 with `cascade_ubbr_R_50_FPN_base.yaml`: `BACKBONE.FREEZE_AT 2`, and the
+ * base / ft_all detector yamls): the reference trains through ATen's conv2d backward for BottleneckBlock
+ * (detectron2/modeling/backbone/resnet.py:195-211), FPN (backbone/fpn.py:109-144) and StandardRPNHead
+ * (proposal_generator/rpn.py:120-139).
+ * lvc_conv_wgrad_nhwc: dw[k][r][s][c] = scale[k] * sum_{n,oy,ox} dy[n,oy,ox,k] * x[n, oy*stride+r-pad, ox*stride+s-pad, c]
+ *   (x zero outside the map).  x [N,H,W,C], dy [N,Ho,Wo,*] with row pitch lddy floats, scale [K] or NULL (the
+ *   FrozenBatchNorm2d scale that follows the conv, batch_norm.py:45-65), dw [K,R,S,C] zeroed by the call.  Exact fp32
+ *   MFMA; partial sums over pixel ranges are combined with fp32 atomics (not run-to-run deterministic).
+ *   The data gradient needs no entry point of its own: it is lvc_conv2d_nhwc_* / lvc_conv3x3_nhwc_bf16x3 on dy with the
+ *   weights flipped and transposed (host: kernels.pack_conv_dgrad), followed for a stride-2 1x1 by lvc_scatter_stride2_nhwc.
+ * lvc_scatter_stride2_nhwc: y[n,2i,2j,:] = x[n,i,j,:], 0 elsewhere; x [N,(H-1)/2+1,(W-1)/2+1,C] -> y [N,H,W,C]
+ *   (input gradient of a stride-2 1x1 conv and of LastLevelMaxPool, fpn.py:165-177).
+ * lvc_downsum2x2_nhwc: y[n,i,j,:] = sum of x[n,2i..2i+1,2j..2j+1,:]; x [N,2Hs,2Ws,C] (backward of the nearest x2
+ *   upsample of the FPN top-down path, fpn.py:131-133).
+ * lvc_colsum_atomic: lvc_colsum for 10^5-row operands (conv bias gradients): row slabs combined with fp32 atomics. */
+int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
+                        int K, int R, int S, int stride, int pad, int lddy, void* stream);
+int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int lvc_downsum2x2_nhwc(const float* x, float* y, int N, int Hs, int Ws, int C, void* stream);
+int lvc_colsum_atomic(const float* x, int M, int N, int ldx, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Label-verification kNN (tools/run_nearest_neighbours.py:142-162, 214-227).
  * lvc_colmean: mu[d] = mean_m x[m,d].  lvc_knn_topk_vote: per query row, class ids of the 10 most similar

@@ -1,0 +1,254 @@
+// conv_wgrad.hip -- backward of the NHWC convolution w.r.t. its weights, plus the small data-movement kernels the
+// backward of the trunk needs (stride-2 scatter, 2x2 down-sum, column sums).
+//
+// Reference: the reference trains through ATen's conv2d backward (cudnn / mkldnn wgrad): BottleneckBlock
+// (detectron2/modeling/backbone/resnet.py:195-211), FPN (backbone/fpn.py:109-144), StandardRPNHead
+// (proposal_generator/rpn.py:120-139) when their parameters require grad -- `cascade_ubbr_R_50_FPN_base.yaml`
+// (`FREEZE_AT 2`), `faster_rcnn_R_50_FPN_base.yaml`, and the RPN / box head of the `ft_all` fine-tune yaml.
+//
+// GEMM view:   dW[k][tap][c] = scale[k] * sum_m dY[m][k] * X[pix(m, tap)][c]
+//   m   = output pixel (n, oy, ox): the CONTRACTION runs over pixels, so both operands are read exactly as they lie
+//         in HBM (a pixel's channels are contiguous in NHWC) and arrive in LDS already "k-major" for the MFMA:
+//         v_mfma_f32_32x32x2_f32 takes A[i][kk] / B[kk][j] with kk = lane/32, i.e. lanes 0-31 read 32 consecutive
+//         channels of pixel 2*ks, lanes 32-63 of pixel 2*ks+1 -- no transpose anywhere.
+//   tap = (r, s); X's pixel for tap is (oy*stride + r - pad, ox*stride + s - pad), zero outside the map.
+//   scale[k] = the FrozenBatchNorm2d affine scale that follows the conv (batch_norm.py:45-65): y = conv(x)*scale+shift,
+//         so dL/dW = scale[k] * (dL/dy (*) x).  NULL = 1.
+// Arithmetic: exact fp32 FMA chain (157 TF chip peak); gradients span too many binades for the fp16 split used by
+// the forward kernels.
+//
+// Work decomposition: one 256-thread workgroup = one 128(k) x 128(c) tile of one tap over a contiguous range of
+// 32-pixel chunks; grid.y splits the pixel range so that the launch has >= ~4 workgroups per CU whatever the
+// layer's tile count is (a 1x1 128->512 layer has 4 tiles and 33 600 pixels).  Partial sums are combined with fp32
+// atomic adds into the zero-initialised gradient (order not deterministic, as in the reference's GPU path).
+// 4 waves as 2x2, wave tile 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  LDS rows are 128 floats with the two
+// 32-float halves of every 64 swapped on odd rows, so lanes 32-63 (odd pixel) hit the other 32 banks.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradParams {
+  const float* x;
+  const float* dy;
+  const float* scale;
+  float* dw;
+  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, lddy;
+  int M;                 // N*Ho*Wo
+  int chunks_per_split;  // 32-pixel chunks per grid.y slice
+  int k_tiles, c_tiles;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+  __shared__ float sA[2][32][128];  // dY [pixel][k]
+  __shared__ float sB[2][32][128];  // X  [pixel][c]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int t = blockIdx.x;
+  const int ct = t % p.c_tiles; t /= p.c_tiles;
+  const int kt = t % p.k_tiles; t /= p.k_tiles;
+  const int tap = t, r = tap / p.S, s = tap % p.S;
+  const int k0 = kt * 128, c0 = ct * 128;
+  const int nchunks = (p.M + 31) >> 5;
+  const int chunk0 = blockIdx.y * p.chunks_per_split;
+  int chunk1 = chunk0 + p.chunks_per_split;
+  if (chunk1 > nchunks) chunk1 = nchunks;
+  if (chunk0 >= chunk1) return;
+
+  const int lrow = tid >> 5;        // rows lrow + 8*i
+  const int lcol = (tid & 31) * 4;  // first of 4 consecutive channels
+  const bool k_ok = k0 + lcol < p.K, c_ok = c0 + lcol < p.C;
+  f32x4 ra[4], rb[4];
+  auto load = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = chunk * 32 + lrow + 8 * i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (m < p.M) {
+        if (k_ok) a = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + k0 + lcol);
+        const int ox = m % p.Wo, q = m / p.Wo, oy = q % p.Ho, n = q / p.Ho;
+        const int iy = oy * p.stride + r - p.pad, ix = ox * p.stride + s - p.pad;
+        if (c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          b = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H + iy) * p.W + ix) * p.C + c0 + lcol);
+      }
+      ra[i] = a;
+      rb[i] = b;
+    }
+  };
+  auto store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = lrow + 8 * i;
+      const int col = lcol ^ ((row & 1) << 5);
+      *reinterpret_cast<f32x4*>(&sA[buf][row][col]) = ra[i];
+      *reinterpret_cast<f32x4*>(&sB[buf][row][col]) = rb[i];
+    }
+  };
+
+  const int wk = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int half = lane >> 5, l31 = lane & 31, sw = half << 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[mi][ni][j] = 0.f;
+
+  load(chunk0);
+  store(0);
+  __syncthreads();
+  int cur = 0;
+  for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+    const bool more = chunk + 1 < chunk1;
+    if (more) load(chunk + 1);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int row = 2 * ks + half;
+      const float a0 = sA[cur][row][(wk + l31) ^ sw], a1 = sA[cur][row][(wk + 32 + l31) ^ sw];
+      const float b0 = sB[cur][row][(wc + l31) ^ sw], b1 = sB[cur][row][(wc + 32 + l31) ^ sw];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // D[i][j]: j = lane & 31, i = 8*(e/4) + 4*(lane/32) + e%4
+  const int RS = p.R * p.S;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = k0 + wk + mi * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+      if (k >= p.K) continue;
+      const float sc = p.scale ? p.scale[k] : 1.f;
+      float* row = p.dw + ((size_t)k * RS + tap) * p.C;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int c = c0 + wc + ni * 32 + l31;
+        if (c < p.C) unsafeAtomicAdd(row + c, acc[mi][ni][e] * sc);
+      }
+    }
+}
+
+// dw [K][R][S][C] (the packed "KRSC" order of the forward kernels' weights); zeroed here.
+// x [N,H,W,C], dy [N,Ho,Wo,K] with row pitch lddy >= K floats.  K, C, lddy multiples of 4.
+extern "C" int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W,
+                                   int C, int K, int R, int S, int stride, int pad, int lddy, void* stream) {
+  LVC_CHECK_ARG(x && dy && dw, "null pointer");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "bad shape");
+  LVC_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && lddy >= K, "C, K and lddy must be multiples of 4");
+  LVC_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) == 0, "pointers must be 16-byte aligned");
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output map");
+  const long long M64 = (long long)N * Ho * Wo;
+  LVC_CHECK_ARG(M64 < (1ll << 31) - 64, "too many output pixels");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dw, 0, (size_t)K * R * S * C * sizeof(float), st) != hipSuccess) {
+    lvc_set_error("%s: hipMemsetAsync failed", __func__);
+    return LVC_ERR_HIP;
+  }
+  WgradParams p;
+  p.x = x; p.dy = dy; p.scale = scale; p.dw = dw;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.K = K; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.lddy = lddy; p.M = (int)M64;
+  p.k_tiles = lvc_cdiv(K, 128); p.c_tiles = lvc_cdiv(C, 128);
+  const int tiles = p.k_tiles * p.c_tiles * R * S;
+  const int nchunks = lvc_cdiv(p.M, 32);
+  int splits = lvc_cdiv(1024, tiles);                 // ~4 workgroups per CU
+  const int max_splits = lvc_cdiv(nchunks, 4);        // at least 128 pixels per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.chunks_per_split = lvc_cdiv(nchunks, splits);
+  splits = lvc_cdiv(nchunks, p.chunks_per_split);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// y[n, 2i, 2j, :] = x[n, i, j, :], every other pixel of y = 0.  Backward of a stride-2 1x1 convolution's input
+// sampling (conv1 / shortcut of the first block of res3..res5, resnet.py:117-160 with STRIDE_IN_1X1) and of
+// LastLevelMaxPool (fpn.py:165-177: max_pool2d(k=1, s=2)).  x [N,Hs,Ws,C] -> y [N,H,W,C], Hs = (H-1)/2+1.
+__global__ __launch_bounds__(256) void scatter_stride2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int H,
+                                                              int W, int Hs, int Ws, int C4, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  long long q = i / C4;
+  const int ix = (int)(q % W); q /= W;
+  const int iy = (int)(q % H);
+  const int n = (int)(q / H);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!((iy | ix) & 1)) v = x[(((long long)n * Hs + (iy >> 1)) * Ws + (ix >> 1)) * C4 + c];
+  y[i] = v;
+}
+
+extern "C" int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  LVC_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad arguments");
+  const int Hs = (H - 1) / 2 + 1, Ws = (W - 1) / 2 + 1;
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(scatter_stride2_kernel, dim3((unsigned)lvc_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), H, W, Hs, Ws, C / 4, total);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// y[n, i, j, :] = sum of the 2x2 block x[n, 2i..2i+1, 2j..2j+1, :].  Backward of the nearest x2 upsample of the FPN
+// top-down path (fpn.py:131-133).  x [N,2Hs,2Ws,C] -> y [N,Hs,Ws,C].
+__global__ __launch_bounds__(256) void downsum2x2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int Hs, int Ws,
+                                                         int C4, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  long long q = i / C4;
+  const int jx = (int)(q % Ws); q /= Ws;
+  const int jy = (int)(q % Hs);
+  const int n = (int)(q / Hs);
+  const long long W = 2ll * Ws;
+  const f32x4* r0 = x + (((long long)n * 2 * Hs + 2 * jy) * W + 2 * jx) * C4 + c;
+  const f32x4* r1 = r0 + W * C4;
+  y[i] = (r0[0] + r0[C4]) + (r1[0] + r1[C4]);
+}
+
+extern "C" int lvc_downsum2x2_nhwc(const float* x, float* y, int N, int Hs, int Ws, int C, void* stream) {
+  LVC_CHECK_ARG(x && y && N > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 4 == 0, "bad arguments");
+  const long long total = (long long)N * Hs * Ws * (C / 4);
+  hipLaunchKernelGGL(downsum2x2_kernel, dim3((unsigned)lvc_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(x), reinterpret_cast<f32x4*>(y), Hs, Ws, C / 4, total);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// out[c] = sum over rows of x[r][c] (bias gradients of the FPN / RPN convolutions: 10^5 rows x 256 columns).
+// One workgroup sums a 256-row slab for 64 columns (4 row phases x 64 lanes), then one atomic per column.
+__global__ __launch_bounds__(256) void colsum_slab_kernel(const float* __restrict__ x, int M, int Ncol, int ldx,
+                                                          float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * 256;
+  int r1 = r0 + 256;
+  if (r1 > M) r1 = M;
+  float sacc = 0.f;
+  if (c < Ncol)
+    for (int r = r0 + ph; r < r1; r += 4) sacc += x[(size_t)r * ldx + c];
+  part[ph][threadIdx.x & 63] = sacc;
+  __syncthreads();
+  if (ph == 0 && c < Ncol) unsafeAtomicAdd(out + c, (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+extern "C" int lvc_colsum_atomic(const float* x, int M, int Ncol, int ldx, float* out, void* stream) {
+  LVC_CHECK_ARG(M >= 0 && Ncol > 0 && ldx >= Ncol && x && out, "bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)Ncol * sizeof(float), st) != hipSuccess) {
+    lvc_set_error("%s: hipMemsetAsync failed", __func__);
+    return LVC_ERR_HIP;
+  }
+  if (M == 0) return LVC_OK;
+  hipLaunchKernelGGL(colsum_slab_kernel, dim3(lvc_cdiv(Ncol, 64), lvc_cdiv(M, 256)), dim3(256), 0, st, x, M, Ncol, ldx, out);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

@@ -184,8 +184,9 @@ CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
-def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
+def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None):
     """x: [N,H,W,C] fp32 contiguous (NHWC).  Returns [N,Ho,Wo,K].
+    split: None = the configured split (LVC_CONV_SPLIT); "bf16x3" keeps the fp32 exponent range (gradients).
     res_mode 1: residual has the output's shape; 2: residual is [N,Ho/2,Wo/2,K] and is
     nearest-x2-upsampled on the fly (FPN top-down path, reference fpn.py:131-133)."""
     _req_cuda(x, residual)
@@ -208,8 +209,8 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None):
     pw_narrow = _PW_NARROW and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128 and pc.C % 32 == 0 and N * Ho * Wo >= 2048
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else 4 if pw_narrow else _BF16X3_MIN_K)
             and pc.K % 4 == 0 and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
-        h2_halo = halo and CONV_SPLIT == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES
-        h2_pw = (not halo and CONV_SPLIT == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128
+        h2_halo = halo and (split or CONV_SPLIT) == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES
+        h2_pw = (not halo and (split or CONV_SPLIT) == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128
                  and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
     timer = CONV_TIMER
@@ -678,6 +679,84 @@ def colsum(x):
     out = torch.empty(N, device=x.device, dtype=torch.float32)
     check(_lib.lib().lvc_colsum(ptr(x), c_int(M), c_int(N), c_int(N), ptr(out), _stream(x)), "lvc_colsum")
     return out
+
+
+def colsum_rows(x2d):
+    """x2d [M,N] row-major with M up to 10^5-10^6 (conv bias gradients): slab sums + fp32 atomics."""
+    _req_cuda(x2d)
+    x2d = x2d.contiguous()
+    M, N = x2d.shape
+    out = torch.empty(N, device=x2d.device, dtype=torch.float32)
+    check(_lib.lib().lvc_colsum_atomic(ptr(x2d), c_int(M), c_int(N), c_int(N), ptr(out), _stream(x2d)), "lvc_colsum_atomic")
+    return out
+
+
+def conv_wgrad(x, dy, scale, R, S, stride, pad):
+    """dW of y = conv(x, W) (* scale per output channel): x [N,H,W,C], dy [N,Ho,Wo,K] -> [K,R,S,C] fp32."""
+    _req_cuda(x, dy, scale)
+    assert x.dim() == 4 and dy.dim() == 4 and x.is_contiguous() and dy.is_contiguous()
+    assert x.dtype == torch.float32 and dy.dtype == torch.float32
+    N, H, W, C = x.shape
+    K = dy.shape[3]
+    assert dy.shape[0] == N and dy.shape[1] == (H + 2 * pad - R) // stride + 1 and dy.shape[2] == (W + 2 * pad - S) // stride + 1
+    dw = torch.empty(K, R, S, C, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lvc_conv_wgrad_nhwc(ptr(x), ptr(dy), ptr(scale), ptr(dw), c_int(N), c_int(H), c_int(W), c_int(C),
+                                         c_int(K), c_int(R), c_int(S), c_int(stride), c_int(pad), c_int(K), _stream(x)),
+          "lvc_conv_wgrad_nhwc")
+    return dw
+
+
+def scatter_stride2(x, H, W):
+    """x [N,(H-1)//2+1,(W-1)//2+1,C] -> [N,H,W,C] with x at the even pixels and zeros elsewhere."""
+    _req_cuda(x)
+    x = x.contiguous()
+    N, Hs, Ws, C = x.shape
+    assert Hs == (H - 1) // 2 + 1 and Ws == (W - 1) // 2 + 1
+    y = torch.empty(N, H, W, C, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lvc_scatter_stride2_nhwc(ptr(x), ptr(y), c_int(N), c_int(H), c_int(W), c_int(C), _stream(x)),
+          "lvc_scatter_stride2_nhwc")
+    return y
+
+
+def downsum2x2(x):
+    """x [N,2Hs,2Ws,C] -> [N,Hs,Ws,C] sums of the 2x2 blocks."""
+    _req_cuda(x)
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    y = torch.empty(N, H // 2, W // 2, C, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lvc_downsum2x2_nhwc(ptr(x), ptr(y), c_int(N), c_int(H // 2), c_int(W // 2), c_int(C), _stream(x)),
+          "lvc_downsum2x2_nhwc")
+    return y
+
+
+def pack_conv_dgrad(weight, scale, pad):
+    """Packed weights of the DATA gradient of y = conv(x, weight, stride 1 after sub-sampling, pad) * scale:
+    dx = conv(dy, Wt, pad = R-1-pad) with Wt[c][k][r][s] = scale[k] * weight[k][c][R-1-r][S-1-s].  A strided 1x1 is
+    the same product on the sub-sampled grid followed by `scatter_stride2`.  Output channels of the forward conv
+    (the contraction here) are zero-padded to the kernels' 32-channel chunk."""
+    Kout, C, R, S = weight.shape
+    w = weight.detach().float()
+    if scale is not None:
+        w = w * scale.view(-1, 1, 1, 1)
+    wt = w.permute(1, 0, 2, 3).flip(2, 3)
+    pk = (-Kout) % 32
+    if pk:
+        wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, pk))
+    return pack_conv(wt.contiguous(), stride=1, pad=R - 1 - pad)
+
+
+def conv_dgrad(dy, pcd, x_shape, stride):
+    """dx [x_shape] of a conv whose `pack_conv_dgrad` is pcd.  dy [N,Ho,Wo,K] contiguous."""
+    N, H, W, C = x_shape
+    if dy.shape[3] != pcd.C:   # contraction padded to 32 channels
+        dy = torch.nn.functional.pad(dy, (0, pcd.C - dy.shape[3]))
+    dxs = conv2d_nhwc(dy.contiguous(), pcd, split="bf16x3")
+    if stride == 1:
+        assert tuple(dxs.shape) == (N, H, W, C), (dxs.shape, x_shape)
+        return dxs
+    assert stride == 2 and pcd.R == 1, "strided 3x3 convolutions are not on the path (STRIDE_IN_1X1)"
+    return scatter_stride2(dxs, H, W)
 
 
 def linear_backward(x, weight, dz, need_dx=True, need_dw=True):

@@ -58,6 +58,7 @@ class Conv2d(nn.Module):
         if activation is not None and activation not in (F.relu, F.relu_):
             raise NotImplementedError("only ReLU is fused (the only activation on the path)")
         self._cache = _PackedCache()
+        self._cache_dgrad = _PackedCache()
 
     def packed(self):
         bn = None
@@ -70,10 +71,21 @@ class Conv2d(nn.Module):
         return self._cache.get(srcs, lambda: K.pack_conv(self.weight, bias=self.bias, bn=bn, stride=self.stride,
                                                          pad=self.padding, eps=self.norm.eps if bn else 1e-5, stem=stem))
 
+    def packed_dgrad(self):
+        """Packed weights of the data gradient (flipped, transposed, times the FrozenBN scale)."""
+        srcs = [self.weight]
+        if self.norm is not None:
+            srcs += [self.norm.weight, self.norm.running_var]
+        return self._cache_dgrad.get(srcs, lambda: K.pack_conv_dgrad(self.weight, self.packed().scale, self.padding))
+
     def forward_nhwc(self, x, residual=None, res_mode=0, relu=None):
         """x: [N,H,W,C] contiguous.  relu=None -> this layer's own activation."""
         if relu is None:
             relu = self.activation is not None
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad
+                                        or (self.bias is not None and self.bias.requires_grad)
+                                        or (residual is not None and residual.requires_grad)):
+            return _ConvFn.apply(x, self.weight, self.bias, residual, self, res_mode if residual is not None else 0, relu)
         return K.conv2d_nhwc(x, self.packed(), relu=relu, residual=residual, res_mode=res_mode)
 
     def forward(self, x):
@@ -86,6 +98,44 @@ class Conv2d(nn.Module):
     def extra_repr(self):
         return "{}, {}, kernel_size={}, stride={}, padding={}".format(
             self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding)
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv(x, W) * bn_scale + shift (+ residual | + up2(residual))) as the ONE fused forward launch; backward:
+    ReLU mask (lvc_relu_backward), residual gradient (identity, or the 2x2 down-sum of the FPN top-down add), weight
+    gradient (lvc_conv_wgrad_nhwc, FrozenBN scale folded in), bias gradient (lvc_colsum_atomic) and data gradient (the
+    forward kernels on the flipped / transposed weights, `Conv2d.packed_dgrad`).  What ATen's conv2d / relu / add /
+    interpolate backward do for BottleneckBlock (reference detectron2/modeling/backbone/resnet.py:195-211), FPN
+    (fpn.py:109-144) and StandardRPNHead (rpn.py:120-139) when their parameters train."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, conv, res_mode, relu):
+        if conv.in_channels == 3:
+            raise NotImplementedError("training the 7x7 stem is not implemented (every shipped config has FREEZE_AT >= 1)")
+        y = K.conv2d_nhwc(x, conv.packed(), relu=relu, residual=residual, res_mode=res_mode)
+        ctx.save_for_backward(x, y if relu else None)
+        ctx.conv, ctx.res_mode, ctx.relu = conv, res_mode, relu
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        conv = ctx.conv
+        g = K.relu_backward(dy, y) if ctx.relu else dy.contiguous()
+        need_x, need_w, need_b, need_r = ctx.needs_input_grad[:4]
+        dx = dw = db = dres = None
+        if need_r:
+            dres = g if ctx.res_mode == 1 else K.downsum2x2(g)
+        if need_w:
+            R = conv.kernel_size[0]
+            dw = K.conv_wgrad(x, g, conv.packed().scale if conv.norm is not None else None, R, R, conv.stride, conv.padding)
+            dw = dw.permute(0, 3, 1, 2).contiguous()   # [K,R,S,C] -> the parameter's OIHW
+        if need_b:
+            db = K.colsum_rows(g.view(-1, g.shape[-1]))
+        if need_x:
+            dx = K.conv_dgrad(g, conv.packed_dgrad(), x.shape, conv.stride)
+        return dx, dw, db, dres, None, None, None
 
 
 class _LinearFn(torch.autograd.Function):

@@ -1,0 +1,129 @@
+"""Backward into the trunk (SURVEY row 20 / BASELINE config 5 with `cascade_ubbr_R_50_FPN_base.yaml`, FREEZE_AT 2): the
+weight-gradient kernel, the data gradient on the forward kernels, and the fused Conv2d / BottleneckBlock / FPN autograd
+against torch's own conv2d backward in fp64 on the CPU (what the reference trains through).  Floating point: the
+gradients must agree to 2e-5 of the tensor's norm (fp32 accumulation over up to 10^5 pixels; atomics reorder sums)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad,scaled", [
+    (2, 25, 42, 64, 64, 3, 1, 1, True),
+    (2, 51, 35, 256, 128, 1, 2, 0, True),
+    (1, 50, 84, 256, 16, 1, 1, 0, False),     # the padded 15-channel RPN predictor
+    (1, 13, 21, 256, 256, 3, 1, 1, False),
+    (300, 1, 1, 1024, 1024, 1, 1, 0, False),  # Linear as the 1x1 case
+    (2, 100, 168, 128, 512, 1, 1, 0, True),   # 4 tiles, 33 600 pixels: split over the pixel range
+])
+def test_conv_wgrad_matches_torch(N, H, W, C, K, R, stride, pad, scaled):
+    from lvc_amd import kernels as Kn
+    g = torch.Generator().manual_seed(H * 131 + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = torch.randn(N, K, Ho, Wo, generator=g) * 1e-4     # gradient-sized values
+    scale = torch.rand(K, generator=g) + 0.5 if scaled else None
+    w = torch.zeros(K, C, R, R, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, stride=stride, padding=pad)
+    if scaled:
+        y = y * scale.double().view(1, -1, 1, 1)
+    (y * dy.double()).sum().backward()
+    dev = torch.device("cuda:0")
+    dw = Kn.conv_wgrad(x.permute(0, 2, 3, 1).contiguous().to(dev), dy.permute(0, 2, 3, 1).contiguous().to(dev),
+                       scale.to(dev) if scaled else None, R, R, stride, pad)
+    assert _rel(dw.permute(0, 3, 1, 2), w.grad) < TOL
+
+
+def test_scatter_downsum_colsum():
+    from lvc_amd import kernels as Kn
+    dev = torch.device("cuda:0")
+    x = torch.randn(2, 13, 21, 64, device=dev)
+    y = Kn.scatter_stride2(x, 25, 42)
+    ref = torch.zeros(2, 25, 42, 64, device=dev)
+    ref[:, ::2, ::2] = x
+    assert torch.equal(y, ref)
+    y = Kn.scatter_stride2(x, 26, 41)
+    ref = torch.zeros(2, 26, 41, 64, device=dev)
+    ref[:, ::2, ::2] = x
+    assert torch.equal(y, ref)
+    z = torch.randn(2, 26, 42, 32, device=dev)
+    d = Kn.downsum2x2(z)
+    r = (z[:, ::2, ::2] + z[:, ::2, 1::2]) + (z[:, 1::2, ::2] + z[:, 1::2, 1::2])
+    assert torch.equal(d, r)
+    m = torch.randn(70001, 100, device=dev)
+    assert _rel(Kn.colsum_rows(m), m.double().sum(0)) < 1e-6
+
+
+def _ref_conv(x, w, b, bn, stride, pad, relu, residual, res_mode):
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if bn is not None:
+        bw, bb, rm, rv = [t.double() for t in bn]
+        sc = bw * (rv + 1e-5).rsqrt()
+        y = y * sc.view(1, -1, 1, 1) + (bb - rm * sc).view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + (residual if res_mode == 1 else F.interpolate(residual, scale_factor=2, mode="nearest"))
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("C,K,R,stride,pad,bn,bias,relu,res_mode,H,W", [
+    (256, 64, 1, 1, 0, True, False, True, 0, 50, 84),     # conv1
+    (64, 64, 3, 1, 1, True, False, True, 0, 50, 84),      # conv2
+    (64, 256, 1, 1, 0, True, False, True, 1, 50, 84),     # conv3 + shortcut + ReLU
+    (256, 128, 1, 2, 0, True, False, True, 0, 51, 85),    # strided conv1 (odd map)
+    (512, 256, 1, 1, 0, False, True, False, 2, 50, 84),   # FPN lateral + up2(top)
+    (256, 256, 3, 1, 1, False, True, False, 0, 26, 42),   # FPN output
+    (256, 256, 3, 1, 1, False, True, True, 0, 13, 21),    # RPN conv
+])
+def test_conv2d_module_backward(C, K, R, stride, pad, bn, bias, relu, res_mode, H, W):
+    from lvc_amd.layers import Conv2d, FrozenBatchNorm2d
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + K + R)
+    norm = FrozenBatchNorm2d(K) if bn else None
+    conv = Conv2d(C, K, kernel_size=R, stride=stride, padding=pad, bias=bias, norm=norm, activation=F.relu_ if relu else None)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(K, C, R, R, generator=g) * (2.0 / (C * R * R)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(K, generator=g) * 0.1)
+        if bn:
+            norm.weight.copy_(torch.rand(K, generator=g) + 0.5)
+            norm.bias.copy_(torch.randn(K, generator=g) * 0.1)
+            norm.running_mean.copy_(torch.randn(K, generator=g) * 0.1)
+            norm.running_var.copy_(torch.rand(K, generator=g) + 0.5)
+    conv = conv.to(dev)
+    N = 2
+    x = torch.randn(N, C, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    res = None
+    if res_mode == 1:
+        res = torch.randn(N, K, Ho, Wo, generator=g)
+    elif res_mode == 2:
+        res = torch.randn(N, K, Ho // 2, Wo // 2, generator=g)
+    dy = torch.randn(N, K, Ho, Wo, generator=g) * 1e-3
+    # fp64 reference
+    xr = x.double().requires_grad_(True)
+    wr = conv.weight.detach().cpu().double().requires_grad_(True)
+    br = conv.bias.detach().cpu().double().requires_grad_(True) if bias else None
+    rr = res.double().requires_grad_(True) if res is not None else None
+    bnr = [t.detach().cpu() for t in (norm.weight, norm.bias, norm.running_mean, norm.running_var)] if bn else None
+    yr = _ref_conv(xr, wr, br, bnr, stride, pad, relu, rr, res_mode)
+    (yr * dy.double()).sum().backward()
+    # device
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev).requires_grad_(True) if res is not None else None
+    yd = conv.forward_nhwc(xd, residual=rd, res_mode=res_mode)
+    assert _rel(yd.permute(0, 3, 1, 2), yr) < 1e-5
+    yd.backward(dy.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert _rel(xd.grad.permute(0, 3, 1, 2), xr.grad) < TOL
+    assert _rel(conv.weight.grad, wr.grad) < TOL
+    if bias:
+        assert _rel(conv.bias.grad, br.grad) < TOL
+    if res is not None:
+        assert _rel(rd.grad.permute(0, 3, 1, 2), rr.grad) < TOL
