@@ -776,7 +776,10 @@ def linear_backward(x, weight, dz, need_dx=True, need_dw=True):
             dzp = torch.zeros(M, Kout + pk, device=dev)
             dzp[:, :Kout] = dz
         dx = linear(dzp.contiguous(), pack_linear(wt))
-    if need_dw:   # dw = dz^T @ x: contraction over M, "weights" = x^T [Kin rows, M]
+    if need_dw and Kout % 4 == 0 and Kin % 4 == 0:   # dw = dz^T @ x on the pixel-contraction kernel (no transposes)
+        dw = conv_wgrad(x.detach().contiguous().view(M, 1, 1, Kin), dz.contiguous().view(M, 1, 1, Kout), None, 1, 1, 1, 0)
+        dw = dw.view(Kout, Kin)
+    elif need_dw:   # dw = dz^T @ x: contraction over M, "weights" = x^T [Kin rows, M]
         pm = (-M) % 32
         xt = torch.zeros(Kin, M + pm, device=dev)
         xt[:, :M] = x.detach().t()

@@ -7,6 +7,7 @@ coarser map (reference fpn.py:131-133 does interpolate + add as two extra passes
 """
 import math
 
+import torch
 from torch import nn
 
 from ... import kernels as K
@@ -15,6 +16,20 @@ from ...layers.layout import require_device, to_nchw_view
 from ...utils import weight_init
 from .backbone import BACKBONE_REGISTRY, Backbone
 from .resnet import _as_nhwc4, build_resnet_backbone
+
+
+class _Subsample2(torch.autograd.Function):
+    """max_pool2d(kernel 1, stride 2) = every other pixel; backward scatters the gradient back to those pixels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = (x.shape[1], x.shape[2])
+        return K.maxpool2d_nhwc(x, 1, 2, 0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return K.scatter_stride2(g, ctx.hw[0], ctx.hw[1])
 
 
 class LastLevelMaxPool(nn.Module):
@@ -26,6 +41,8 @@ class LastLevelMaxPool(nn.Module):
         self.in_feature = "p5"
 
     def forward_nhwc(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:
+            return [_Subsample2.apply(x)]
         return [K.maxpool2d_nhwc(x, 1, 2, 0)]
 
     def forward(self, x):

@@ -107,10 +107,8 @@ class GeneralizedRCNN(_RCNNBase):
             gt_instances = [x["targets"].to(self.device) for x in batched_inputs]
         else:
             gt_instances = None
-        with torch.no_grad():
-            if any(p.requires_grad for p in self.backbone.parameters()):
-                raise NotImplementedError(
-                    "backward through the trunk is not implemented; fine-tune configs freeze it (MODEL.BACKBONE.FREEZE)")
+        # frozen trunk (the fine-tune yamls): no graph; otherwise the fused Conv2d autograd records res3.. / FPN
+        with torch.set_grad_enabled(any(p.requires_grad for p in self.backbone.parameters())):
             features = self.backbone(images.tensor)
         from ..proposal_generator.rbg import RBG
 

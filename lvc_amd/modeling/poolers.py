@@ -14,6 +14,29 @@ from .. import kernels as K
 from ..layers.layout import to_nchw_view, to_nhwc
 
 
+class _PoolAllLevels(torch.autograd.Function):
+    """ROIAlign over all pyramid levels in one launch, differentiable w.r.t. the level maps (the scatter of
+    `lvc_roi_align_fpn_backward_nhwc`); boxes get no gradient, as in the reference's `_ROIAlign` (roi_align.py:22-57)."""
+
+    @staticmethod
+    def forward(ctx, pooler, boxes, status, *feats):
+        levels, rois = K.assign_levels_rois(boxes, pooler.min_level, pooler.max_level, pooler.canonical_box_size,
+                                            pooler.canonical_level)
+        if len(feats) == 1:
+            levels = None
+        ctx.pooler, ctx.rois, ctx.levels = pooler, rois, levels
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        return K.roi_align_fpn_nhwc(list(feats), pooler.scales, rois, levels, pooler.output_size[0], pooler.output_size[1],
+                                    pooler.sampling_ratio, pooler.aligned, status=status)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        pl = ctx.pooler
+        grads = K.roi_align_fpn_backward_nhwc(grad, ctx.shapes, pl.scales, ctx.rois, ctx.levels, pl.sampling_ratio, pl.aligned)
+        return (None, None, None) + tuple(grads)
+
+
 class ROIPooler(nn.Module):
     def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224, canonical_level=4):
         super().__init__()
@@ -43,6 +66,8 @@ class ROIPooler(nn.Module):
     def pool_nhwc(self, feats_nhwc, boxes, status=None):
         """feats_nhwc: list of [B,H,W,C]; boxes: [B,R,4] device tensor (zero rows = padding).
         Returns [B*R, ph, pw, C] (channels-last rows, the layout the box-head GEMM consumes)."""
+        if torch.is_grad_enabled() and any(f.requires_grad for f in feats_nhwc):
+            return _PoolAllLevels.apply(self, boxes.detach(), status, *feats_nhwc)
         levels, rois = K.assign_levels_rois(boxes, self.min_level, self.max_level, self.canonical_box_size,
                                             self.canonical_level)
         if len(feats_nhwc) == 1:

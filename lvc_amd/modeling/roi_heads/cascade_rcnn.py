@@ -7,7 +7,8 @@ of (box, class) pseudo-labels), batched on device: per stage one ROIAlign launch
 bias+ReLU GEMMs, one 1024->4 GEMM and one decode+clip kernel; and the TRAINING branch (`_forward_box` :205-238,
 `_match_and_label_boxes` :279-327, `_run_stage` :329-346, `_create_proposals_from_boxes` :348-369) with the GIoU
 loss kernel and GEMM backward through the three heads, for a frozen trunk (`MODEL.BACKBONE.FREEZE`, the shipped
-`cascade_ubbr_*_ft_*` yaml; backward into the trunk -- conv dgrad/wgrad -- is not implemented).  The evaluation branch of
+`cascade_ubbr_*_ft_*` yaml) or a training one (`cascade_ubbr_R_50_FPN_base.yaml`, FREEZE_AT 2: ROIAlign backward
+into p2..p5, then the fused Conv2d autograd of layers/wrappers.py through FPN and res5..res3).  The evaluation branch of
 the box-corrector training configs (`_forward_box` eval half with `reg_only`: subsamples with `randperm` even in eval,
 SURVEY row 20) returns the corrected foreground boxes and the proposals they came from.
 """
@@ -25,6 +26,19 @@ from ..poolers import ROIPooler
 from .box_head import build_box_head
 from .fast_rcnn import ROI_HEADS_OUTPUT_REGISTRY
 from .roi_heads import ROI_HEADS_REGISTRY, ROIHeads
+
+
+class _ScaleGradient(torch.autograd.Function):
+    """reference cascade_rcnn.py:22-30: identity forward, gradient times `scale` backward."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = scale
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -139,8 +153,6 @@ class CascadeROIHeads(ROIHeads):
     def _forward_box_train(self, features, proposals, targets):
         """reference cascade_rcnn.py:205-238 (training half)."""
         feats = [to_nhwc(features[f]) for f in self.box_in_features]
-        if any(f.requires_grad for f in feats):
-            raise NotImplementedError("backward into the trunk is not implemented (set MODEL.BACKBONE.FREEZE)")
         image_sizes = [p.image_size for p in proposals]
         head_outputs = []
         prev = None
@@ -159,7 +171,7 @@ class CascadeROIHeads(ROIHeads):
 
     def _run_stage(self, feats_nhwc, proposals, stage):
         """reference :329-346.  `_ScaleGradient` (:22-30) scales the gradient flowing from the head back into the
-        pooled features by 1/num_stages; with a frozen trunk that gradient is never formed, so the pooled rows enter
+        pooled features by 1/num_stages; with a frozen trunk that gradient is never formed and the pooled rows enter
         the head as constants."""
         counts = [len(p) for p in proposals]
         B, R = len(proposals), max(max(counts), 1)
@@ -167,10 +179,11 @@ class CascadeROIHeads(ROIHeads):
         boxes = torch.zeros(B, R, 4, device=dev)
         for i, p in enumerate(proposals):
             boxes[i, : counts[i]] = p.proposal_boxes.tensor
-        with torch.no_grad():
-            pooled = self.box_pooler.pool_nhwc(feats_nhwc, boxes)
-            keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
-            pooled = pooled[keep].contiguous()
+        pooled = self.box_pooler.pool_nhwc(feats_nhwc, boxes)
+        keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
+        pooled = pooled[keep].contiguous()
+        if pooled.requires_grad:   # reference :338: gradients of the stage are averaged into the trunk
+            pooled = _ScaleGradient.apply(pooled, 1.0 / self.num_cascade_stages)
         h = self.box_head[stage].forward_nhwc(pooled)
         return self.box_predictor[stage](h)
 

@@ -497,10 +497,74 @@ def gen_crops():
     save("crops", **d)
 
 
+def gen_box_corrector_train_base():
+    """BASELINE config 5 proper (cascade_ubbr_R_50_FPN_base.yaml: BACKBONE.FREEZE_AT 2, 60 classes): one training step
+    with the trunk TRAINING from res3 up -- ROIAlign backward into p2..p5, FPN, res5..res3.  Same 2-image batch as
+    gen_box_corrector_train (read back from its fixture, classes folded into the 60 base classes).  Stored: RBG's
+    proposals, the three stage losses, and per trainable tensor the gradient's sum, L2 norm and a strided sample."""
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/cascade_ubbr_R_50_FPN_base.yaml")
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "box_corrector_train.npz")).items()}
+    batch, d = [], {}
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
+        inst.gt_classes = t["gt_classes%d" % i] % 60
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(t["loaded_boxes%d" % i])
+        props.objectness_logits = t["loaded_logits%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+        d["gt_boxes%d" % i], d["gt_classes%d" % i] = inst.gt_boxes.tensor, inst.gt_classes
+        d["loaded_boxes%d" % i], d["loaded_logits%d" % i] = props.proposal_boxes.tensor, props.objectness_logits
+    rbg_out = []
+    orig = model.proposal_generator.forward
+
+    def recording(proposals, targets):
+        out, extra = orig(proposals, targets)
+        rbg_out.extend(out)
+        return out, extra
+
+    model.proposal_generator.forward = recording
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    torch.manual_seed(5)
+    try:
+        with EventStorage(0) as storage:
+            losses = model(batch)
+            sum(losses.values()).backward()
+            scalars = {k: float(v[0]) if isinstance(v, tuple) else float(v) for k, v in storage.latest().items()}
+    finally:
+        torch.randperm = real
+    for i, p in enumerate(rbg_out):
+        d["rbg_boxes%d" % i] = p.proposal_boxes.tensor
+        d["rbg_logits%d" % i] = p.objectness_logits
+    ntrain, frozen = 0, []
+    for n_, p_ in model.named_parameters():
+        if p_.requires_grad:
+            ntrain += 1
+            gflat = p_.grad.flatten()
+            stride = max(1, gflat.numel() // 2048)
+            d["grad_sample." + n_] = gflat[::stride][:2048].clone()
+            d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
+        else:
+            frozen.append(n_)
+    print("  losses", {k: float(v) for k, v in losses.items()}, "trainable tensors", ntrain, "frozen", len(frozen),
+          "rbg proposals", [len(p) for p in rbg_out], scalars)
+    d["frozen_names"] = np.array(frozen)
+    save("box_corrector_train_base", **d, **{"loss." + k: v.detach() for k, v in losses.items()},
+         **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "box_corrector_train", "box_corrector_eval", "crops"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -61,14 +61,15 @@ def test_box_corrector_matches_reference():
         assert err <= 0.1
 
 
-def _train_model():
-    """cascade_ubbr_R_50_FPN_ft_all_30shot_aug_ftmore.yaml: 80 classes, frozen backbone, RBG + CascadeROIHeads."""
+def _train_model(num_classes=80, freeze_backbone=True):
+    """cascade_ubbr_R_50_FPN_ft_all_30shot_aug_ftmore.yaml: 80 classes, frozen backbone, RBG + CascadeROIHeads
+    (num_classes=60, freeze_backbone=False: cascade_ubbr_R_50_FPN_base.yaml, FREEZE_AT 2)."""
     from lvc_amd.config import set_global_cfg
     from lvc_amd.config.presets import base_rcnn_fpn
     from lvc_amd.modeling import build_model
     from lvc_amd.utils import synthetic as syn
 
-    cfg = base_rcnn_fpn(num_classes=80)
+    cfg = base_rcnn_fpn(num_classes=num_classes)
     M = cfg.MODEL
     M.ROI_HEADS.NAME = "CascadeROIHeads"
     M.ROI_HEADS.OUTPUT_LAYER = "BoxOnlyLayersCascade"
@@ -80,7 +81,8 @@ def _train_model():
     M.ROI_BOX_HEAD.DROPOUT = 0.0
     M.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
     M.ROI_BOX_CASCADE_HEAD.IOUS = (0.3, 0.5, 0.7)
-    M.BACKBONE.FREEZE = True
+    M.BACKBONE.FREEZE = freeze_backbone
+    M.BACKBONE.FREEZE_AT = 2
     M.PROPOSAL_GENERATOR.NAME = "RBG"
     M.LOAD_PROPOSALS = True
     set_global_cfg(cfg)
@@ -171,6 +173,71 @@ def test_box_corrector_training_step_matches_reference(monkeypatch):
             assert cos >= 0.999 and nerr <= 3e-3, (name, ok, cos, nerr)
             if ".box_head.0." in name:
                 assert ok >= 0.85, (name, ok)
+
+
+def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch):
+    """BASELINE config 5 proper (cascade_ubbr_R_50_FPN_base.yaml, FREEZE_AT 2): the same step with the trunk training
+    from res3 up -- ROIAlign backward into p2..p5 (x 1/3, `_ScaleGradient`), FPN (3x3 output convs, laterals with the
+    fused nearest-x2 add -> 2x2 down-sum), res5..res3 (wgrad kernel, dgrad on the forward kernels, stride-2 scatter,
+    ReLU masks, FrozenBN scales) -- against the reference's CPU step (tests/golden/box_corrector_train_base.npz):
+    82 trainable tensors, the 11 of stem + res2 frozen.  Robust metrics as above (ReLU units within the trunk's noise
+    floor of zero flip); entrywise agreement is demanded where no such unit sits between loss and tensor."""
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("box_corrector_train_base")
+    model = _train_model(num_classes=60, freeze_backbone=False)
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert frozen == g["frozen_names"].tolist()
+    dev = torch.device("cuda:0")
+    batch = []
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(g["gt_boxes%d" % i])
+        inst.gt_classes = g["gt_classes%d" % i]
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(g["loaded_boxes%d" % i])
+        props.objectness_logits = g["loaded_logits%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+
+    def recorded_rbg(proposals, targets):
+        out = []
+        for i, t in enumerate(targets):
+            p = Instances(t.image_size)
+            p.proposal_boxes = Boxes(g["rbg_boxes%d" % i].to(dev))
+            p.objectness_logits = g["rbg_logits%d" % i].to(dev)
+            out.append(p)
+        return out, {}
+
+    monkeypatch.setattr(model.proposal_generator, "forward", recorded_rbg)
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with EventStorage(0):
+        losses = model(batch)
+        sum(losses.values()).backward()
+    for k in ("loss_box_reg_stage0", "loss_box_reg_stage1", "loss_box_reg_stage2"):
+        ref, got = float(g["loss." + k]), float(losses[k].detach())
+        print(k, got, ref)
+        assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    worst = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        gflat = p.grad.flatten().cpu()
+        s, nrm, stride = [float(v) for v in g["grad_stats." + name]]
+        sample = gflat[:: int(stride)][:2048].double()
+        ref = g["grad_sample." + name].double()
+        if nrm == 0.0:   # no RoI of this batch is pooled from p4 / p5: their output convs get exactly zero
+            assert float(gflat.abs().max()) == 0.0, name
+            continue
+        cos = float((sample * ref).sum() / (sample.norm() * ref.norm()).clamp_min(1e-30))
+        nerr = abs(float(gflat.double().norm()) - nrm) / max(nrm, 1e-12)
+        print("%-52s cos %.6f  norm err %.2e" % (name, cos, nerr))
+        worst[name] = (cos, nerr)
+    bad = {n: v for n, v in worst.items() if not (v[0] >= 0.998 and v[1] <= 1e-2)}
+    assert not bad, bad
 
 
 def test_box_head_backward_matches_torch_autograd():
