@@ -236,6 +236,11 @@ int lvc_fast_rcnn_losses(const float* logits, int ld_cls, const float* deltas, i
 int lvc_rpn_losses(const float* logits, const float* deltas, const float* anchors, const float* gt_boxes,
                    const signed char* labels, int S, float smooth_l1_beta, float normalizer, float* out_losses,
                    void* stream);
+/* lvc_rpn_losses plus the gradients the RPN head trains on (faster_rcnn_R_50_FPN_base.yaml, ft_all yaml):
+ * dlogits [S] = (sigmoid(x) - label) / normalizer, ddeltas [S,4] = smooth-L1' / normalizer on positive rows, else 0. */
+int lvc_rpn_losses_grad(const float* logits, const float* deltas, const float* anchors, const float* gt_boxes,
+                        const signed char* labels, int S, float smooth_l1_beta, float normalizer, float* out_losses,
+                        float* dlogits, float* ddeltas, void* stream);
 
 /* Box-corrector training (BASELINE config 5; the shipped fine-tune yaml freezes the backbone).
  * lvc_giou_box_loss: BoxOnlyLayersCascade.box_reg_loss / BoxOnlyLayers.box_reg_loss

@@ -6,8 +6,8 @@
 //   lvc_fast_rcnn_losses   = FastRCNNOutputs.losses (lvc/modeling/roi_heads/fast_rcnn.py:267-279 softmax CE "mean",
 //       :296-359 box_reg_loss smooth-L1 "sum" / #rows) forward AND the gradients w.r.t. logits / deltas
 //   lvc_rpn_losses         = RPN.losses (rpn.py:328-400): BCE-with-logits "sum" over valid anchors and smooth-L1 "sum"
-//       over positive anchors of get_deltas(anchor, gt), both / (batch_size_per_image * num_images); forward only
-//       (every shipped fine-tune config freezes the RPN).
+//       over positive anchors of get_deltas(anchor, gt), both / (batch_size_per_image * num_images);
+//       lvc_rpn_losses_grad also emits d/dlogits, d/ddeltas (the base / ft_all yamls train the RPN).
 // Built with -ffp-contract=off like the other geometry files.
 #include "common.h"
 
@@ -181,20 +181,28 @@ __global__ __launch_bounds__(1024) void rpn_losses_kernel(const float* __restric
                                                           const float* __restrict__ anchors,
                                                           const float* __restrict__ gt_boxes,
                                                           const signed char* __restrict__ labels, int S, float beta,
-                                                          float normalizer, float* __restrict__ out) {
+                                                          float normalizer, float* __restrict__ out,
+                                                          float* __restrict__ dlogits, float* __restrict__ ddeltas) {
   __shared__ double red[2][16];
   double lc = 0.0, lb = 0.0;
   for (int i = threadIdx.x; i < S; i += 1024) {
     const float x = logits[i], y = (float)labels[i];
-    // F.binary_cross_entropy_with_logits: max(x,0) - x*y + log1p(exp(-|x|))
+    // F.binary_cross_entropy_with_logits: max(x,0) - x*y + log1p(exp(-|x|));  d/dx = sigmoid(x) - y
     lc += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+    if (dlogits) dlogits[i] = (1.f / (1.f + expf(-x)) - y) / normalizer;
+    float gd[4] = {0.f, 0.f, 0.f, 0.f};
     if (labels[i] == 1) {
       float t[4], gr;
       const float* a = anchors + (size_t)i * 4;
       const float* g = gt_boxes + (size_t)i * 4;
       get_deltas(a[0], a[1], a[2], a[3], g[0], g[1], g[2], g[3], 1.f, 1.f, 1.f, 1.f, t);
-      for (int j = 0; j < 4; ++j) lb += (double)smooth_l1(deltas[(size_t)i * 4 + j], t[j], beta, &gr);
+      for (int j = 0; j < 4; ++j) {
+        lb += (double)smooth_l1(deltas[(size_t)i * 4 + j], t[j], beta, &gr);
+        gd[j] = gr / normalizer;
+      }
     }
+    if (ddeltas)
+      for (int j = 0; j < 4; ++j) ddeltas[(size_t)i * 4 + j] = gd[j];
   }
   for (int o = 32; o > 0; o >>= 1) { lc += __shfl_xor(lc, o); lb += __shfl_xor(lb, o); }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lc; red[1][threadIdx.x >> 6] = lb; }
@@ -212,7 +220,18 @@ extern "C" int lvc_rpn_losses(const float* logits, const float* deltas, const fl
                               void* stream) {
   LVC_CHECK_ARG(S >= 0 && normalizer > 0.f && out_losses, "bad arguments");
   hipLaunchKernelGGL(rpn_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, deltas, anchors, gt_boxes,
-                     labels, S, smooth_l1_beta, normalizer, out_losses);
+                     labels, S, smooth_l1_beta, normalizer, out_losses, (float*)nullptr, (float*)nullptr);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// same losses plus d(loss_cls)/d(logits) [S] and d(loss_loc)/d(deltas) [S,4] (zero rows for non-positive anchors)
+extern "C" int lvc_rpn_losses_grad(const float* logits, const float* deltas, const float* anchors, const float* gt_boxes,
+                                   const signed char* labels, int S, float smooth_l1_beta, float normalizer,
+                                   float* out_losses, float* dlogits, float* ddeltas, void* stream) {
+  LVC_CHECK_ARG(S >= 0 && normalizer > 0.f && out_losses && dlogits && ddeltas, "bad arguments");
+  hipLaunchKernelGGL(rpn_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, deltas, anchors, gt_boxes,
+                     labels, S, smooth_l1_beta, normalizer, out_losses, dlogits, ddeltas);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

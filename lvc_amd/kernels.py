@@ -789,12 +789,22 @@ def linear_backward(x, weight, dz, need_dx=True, need_dw=True):
     return dx, dw
 
 
-def rpn_losses(logits, deltas, anchors, gt_boxes, labels, smooth_l1_beta, normalizer):
-    """Sampled-anchor RPN losses (forward only).  All inputs are rows gathered at the sampled anchors."""
+def rpn_losses(logits, deltas, anchors, gt_boxes, labels, smooth_l1_beta, normalizer, with_grad=False):
+    """Sampled-anchor RPN losses.  All inputs are rows gathered at the sampled anchors.  with_grad: also returns
+    d(loss_cls)/d(logits) [S] and d(loss_loc)/d(deltas) [S,4]."""
     _req_cuda(logits, deltas, anchors, gt_boxes, labels)
     S = logits.shape[0]
     out = torch.zeros(2, device=logits.device, dtype=torch.float32)
     assert labels.dtype == torch.int8
+    if with_grad:
+        dl = torch.empty(S, device=logits.device, dtype=torch.float32)
+        dd = torch.empty(S, 4, device=logits.device, dtype=torch.float32)
+        rc = _lib.lib().lvc_rpn_losses_grad(ptr(logits.contiguous()), ptr(deltas.contiguous()), ptr(anchors.contiguous()),
+                                            ptr(gt_boxes.contiguous()), ptr(labels.contiguous()), c_int(S),
+                                            c_float(smooth_l1_beta), c_float(normalizer), ptr(out), ptr(dl), ptr(dd),
+                                            _stream(logits))
+        check(rc, "lvc_rpn_losses_grad")
+        return out, dl, dd
     rc = _lib.lib().lvc_rpn_losses(ptr(logits.contiguous()), ptr(deltas.contiguous()), ptr(anchors.contiguous()),
                                    ptr(gt_boxes.contiguous()), ptr(labels.contiguous()), c_int(S), c_float(smooth_l1_beta),
                                    c_float(normalizer), ptr(out), _stream(logits))

@@ -51,6 +51,7 @@ class StandardRPNHead(nn.Module):
             nn.init.normal_(l.weight, std=0.01)
             nn.init.constant_(l.bias, 0)
         self._fused = _PackedCache()
+        self._fused_dgrad = _PackedCache()
 
     def fused_predictor(self):
         o, d = self.objectness_logits, self.anchor_deltas
@@ -68,13 +69,68 @@ class StandardRPNHead(nn.Module):
     def forward_nhwc(self, feats):
         """feats: list of [B,H,W,C] -> list of fused [B,H,W,A+A*box_dim] tensors."""
         pc = self.fused_predictor()
-        return [K.conv2d_nhwc(self.conv.forward_nhwc(x), pc) for x in feats]
+        o, d = self.objectness_logits, self.anchor_deltas
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in (o.weight, o.bias, d.weight, d.bias))
+        out = []
+        for x in feats:
+            h = self.conv.forward_nhwc(x)
+            if train or (torch.is_grad_enabled() and h.requires_grad):
+                out.append(_FusedPredictorFn.apply(h, o.weight, o.bias, d.weight, d.bias, self))
+            else:
+                out.append(K.conv2d_nhwc(h, pc))
+        return out
+
+    def fused_predictor_dgrad(self):
+        o, d = self.objectness_logits, self.anchor_deltas
+        return self._fused_dgrad.get([o.weight, d.weight],
+                                     lambda: K.pack_conv_dgrad(torch.cat([o.weight, d.weight], 0), None, 0))
 
     def forward(self, features):
         """Reference signature: list of NCHW maps -> (list of [N,A,H,W], list of [N,A*box_dim,H,W])."""
         fused = self.forward_nhwc([to_nhwc(f) for f in features])
         A, Bd = self.num_anchors, self.box_dim
         return [to_nchw_view(t[..., :A]) for t in fused], [to_nchw_view(t[..., A:A + A * Bd]) for t in fused]
+
+
+class _FusedPredictorFn(torch.autograd.Function):
+    """objectness_logits | anchor_deltas as ONE 1x1 conv over the hidden map (forward: `fused_predictor`); backward
+    splits the fused weight / bias gradient back onto the two reference parameters (rpn.py:92-106)."""
+
+    @staticmethod
+    def forward(ctx, h, wo, bo, wd, bd, head):
+        ctx.save_for_backward(h)
+        ctx.head = head
+        return K.conv2d_nhwc(h, head.fused_predictor())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        head = ctx.head
+        A, Bd = head.num_anchors, head.box_dim
+        g = g.contiguous()
+        dw = K.conv_wgrad(h, g, None, 1, 1, 1, 0)            # [A+A*Bd (+pad), 1, 1, C]
+        dw = dw.permute(0, 3, 1, 2)
+        db = K.colsum_rows(g.view(-1, g.shape[-1]))
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = K.conv_dgrad(g[..., : A + A * Bd].contiguous(), head.fused_predictor_dgrad(), h.shape, 1)
+        return dh, dw[:A].contiguous(), db[:A].contiguous(), dw[A:A + A * Bd].contiguous(), db[A:A + A * Bd].contiguous(), None
+
+
+class _RpnLossFn(torch.autograd.Function):
+    """RPN.losses (reference rpn.py:328-400) on the sampled anchors; the kernel emits both gradients in the forward."""
+
+    @staticmethod
+    def forward(ctx, logits, deltas, anchors, gt_boxes, labels, beta, normalizer):
+        out, dl, dd = K.rpn_losses(logits, deltas, anchors, gt_boxes, labels, beta, normalizer, with_grad=True)
+        ctx.save_for_backward(dl, dd)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_loc):
+        dl, dd = ctx.saved_tensors
+        return dl * g_cls, dd * g_loc, None, None, None, None, None
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
@@ -101,18 +157,20 @@ class RPN(nn.Module):
         assert tuple(self.box2box_transform.weights) == (1.0, 1.0, 1.0, 1.0), \
             "the fused RPN decode kernel assumes RPN.BBOX_REG_WEIGHTS == (1,1,1,1) (the default of every shipped config)"
 
-    def predict_proposals_batched(self, feats_nhwc, image_sizes_dev):
-        """feats_nhwc: dict name -> [B,H,W,C]; image_sizes_dev: [B,2] int32 device (h,w).
-        Returns (boxes [B,post,4], objectness_logits [B,post], count [B] int32) on device."""
-        feats = [feats_nhwc[f] for f in self.in_features]
-        fused = self.rpn_head.forward_nhwc(feats)
+    def predict_proposals_batched(self, feats_nhwc, image_sizes_dev, fused=None):
+        """feats_nhwc: dict name -> [B,H,W,C]; image_sizes_dev: [B,2] int32 device (h,w); fused: the head's outputs
+        when the caller already has them (training).  Returns (boxes [B,post,4], objectness_logits [B,post],
+        count [B] int32) on device."""
+        if fused is None:
+            fused = self.rpn_head.forward_nhwc([feats_nhwc[f] for f in self.in_features])
+        fused = [f.detach() for f in fused]
         A = self.rpn_head.num_anchors
         t = int(self.training)
         return K.rpn_proposals([f[..., :A] for f in fused], [f[..., A:5 * A] for f in fused],
                                list(self.anchor_generator.cell_anchors), self.anchor_generator.strides, image_sizes_dev,
                                self.pre_nms_topk[t], self.post_nms_topk[t], self.nms_thresh, self.min_box_size)
 
-    # ------------------------------------------------------------------ training (frozen RPN: losses are logged only)
+    # ------------------------------------------------------------------ training
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors, gt_instances):
         """reference rpn.py:269-325.  anchors: [R,4] tensor of all anchors; returns (labels [N,R] int8 in {-1,0,1},
@@ -134,7 +192,6 @@ class RPN(nn.Module):
             matched_gt_boxes.append(torch.zeros_like(anchors) if len(gt) == 0 else gt[matched_idxs])
         return torch.stack(gt_labels), torch.stack(matched_gt_boxes)
 
-    @torch.no_grad()
     def losses(self, anchors, flat_logits, gt_labels, flat_deltas, gt_boxes):
         """reference rpn.py:328-400 (smooth_l1 branch).  flat_logits [N,R], flat_deltas [N,R,4]."""
         if self.box_reg_loss_type != "smooth_l1":
@@ -144,8 +201,13 @@ class RPN(nn.Module):
         storage.put_scalar("rpn/num_pos_anchors", float((gt_labels == 1).sum()) / num_images)
         storage.put_scalar("rpn/num_neg_anchors", float((gt_labels == 0).sum()) / num_images)
         img, idx = (gt_labels >= 0).nonzero(as_tuple=True)
-        out = K.rpn_losses(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gt_boxes[img, idx],
-                           gt_labels[img, idx], self.smooth_l1_beta, float(self.batch_size_per_image * num_images))
+        norm = float(self.batch_size_per_image * num_images)
+        if torch.is_grad_enabled() and flat_logits.requires_grad:
+            out = _RpnLossFn.apply(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gt_boxes[img, idx],
+                                   gt_labels[img, idx], self.smooth_l1_beta, norm)
+        else:
+            out = K.rpn_losses(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gt_boxes[img, idx],
+                               gt_labels[img, idx], self.smooth_l1_beta, norm)
         return {"loss_rpn_cls": out[0] * self.loss_weight.get("loss_rpn_cls", 1.0),
                 "loss_rpn_loc": out[1] * self.loss_weight.get("loss_rpn_loc", 1.0)}
 
@@ -157,12 +219,10 @@ class RPN(nn.Module):
         losses = {}
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"
-            if any(p.requires_grad for p in self.parameters()):
-                raise NotImplementedError(
-                    "training the RPN itself (backward through the RPN head) is not implemented; the shipped fine-tune "
-                    "configs freeze it (MODEL.PROPOSAL_GENERATOR.FREEZE)")
             flist = [feats[f] for f in self.in_features]
-            fused = self.rpn_head.forward_nhwc(flist)
+            trains = any(p.requires_grad for p in self.parameters()) or any(f.requires_grad for f in flist)
+            with torch.set_grad_enabled(trains and torch.is_grad_enabled()):
+                fused = self.rpn_head.forward_nhwc(flist)
             A = self.rpn_head.num_anchors
             N = fused[0].shape[0]
             flat_logits = torch.cat([f[..., :A].reshape(N, -1) for f in fused], 1)
@@ -170,7 +230,10 @@ class RPN(nn.Module):
             anchors = torch.cat(self.anchor_generator._grid_anchors([f.shape[1:3] for f in flist]), 0)
             gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)
             losses = self.losses(anchors, flat_logits, gt_labels, flat_deltas, gt_boxes)
-        boxes, logits, count = self.predict_proposals_batched(feats, sizes)
+            with torch.no_grad():
+                boxes, logits, count = self.predict_proposals_batched(feats, sizes, fused=fused)
+        else:
+            boxes, logits, count = self.predict_proposals_batched(feats, sizes)
         counts = count.tolist()  # the one host sync of this entry point
         out = []
         for i, size in enumerate(images.image_sizes):

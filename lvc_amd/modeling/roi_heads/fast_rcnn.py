@@ -176,15 +176,15 @@ class _GIoUBoxLoss(torch.autograd.Function):
 class _PredictorLoss(torch.autograd.Function):
     """FastRCNNOutputLayers forward + FastRCNNOutputs.losses (reference fast_rcnn.py:267-279, 296-359, 424-438) as one
     differentiable op: forward = fused cls|bbox GEMM + lvc_fast_rcnn_losses (which also emits dlogits/ddeltas);
-    backward = dW = dY^T X on the same MFMA GEMM kernel, db = column sums.  Inputs `x` must not require grad (the
-    shipped fine-tune configs freeze everything below the predictor)."""
+    backward = dW = dY^T X on the same MFMA GEMM kernel, db = column sums, and -- when the box head trains --
+    dX = [dlogits | ddeltas] [Wc ; Wb]."""
 
     @staticmethod
     def forward(ctx, x, wc, bc, wb, bb, proposals, gt_boxes, gt_classes, layer):
         scores, deltas = layer(x)
         out, dl, dd = K.fast_rcnn_losses(scores, deltas, proposals, gt_boxes, gt_classes, layer.num_classes,
                                          layer.box2box_transform.weights, layer.smooth_l1_beta)
-        ctx.save_for_backward(x, dl, dd)
+        ctx.save_for_backward(x, dl, dd, wc, wb)
         ctx.has_bias = (bc is not None, bb is not None)
         pred = scores.argmax(dim=1)
         ctx.mark_non_differentiable(pred)
@@ -192,7 +192,7 @@ class _PredictorLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_cls, g_box, _g_pred):
-        x, dl, dd = ctx.saved_tensors
+        x, dl, dd, wc, wb = ctx.saved_tensors
         R = x.shape[0]
         pad = (-R) % 32  # the GEMM contracts over R: multiple of the 32-wide k chunk
         xt = torch.zeros(x.shape[1], R + pad, device=x.device)
@@ -207,15 +207,17 @@ class _PredictorLoss(torch.autograd.Function):
         dwc, dwb = dweight(dl, g_cls), dweight(dd, g_box)
         dbc = (dl * g_cls).sum(0) if ctx.has_bias[0] else None
         dbb = (dd * g_box).sum(0) if ctx.has_bias[1] else None
-        return None, dwc, dbc, dwb, dbb, None, None, None, None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = K.linear_backward(x, torch.cat([wc, wb], 0), torch.cat([dl * g_cls, dd * g_box], 1).contiguous(),
+                                      need_dx=True, need_dw=False)
+        return dx, dwc, dbc, dwb, dbb, None, None, None, None
 
 
 def fast_rcnn_losses(layer, x, proposals, gt_boxes, gt_classes):
     """-> ({"loss_cls", "loss_box_reg"}, predicted classes) for a FastRCNNOutputLayers `layer`."""
     if not isinstance(layer, FastRCNNOutputLayers):
         raise NotImplementedError("training of {} is not implemented".format(type(layer).__name__))
-    if x.requires_grad:
-        raise NotImplementedError("backward below the box predictor is not implemented (set ROI_HEADS.FREEZE_FEAT)")
     if layer.box_reg_loss_type != "smooth_l1":
         raise NotImplementedError("ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE '{}'".format(layer.box_reg_loss_type))
     lc, lb, pred = _PredictorLoss.apply(x, layer.cls_score.weight, layer.cls_score.bias, layer.bbox_pred.weight,

@@ -177,13 +177,13 @@ def _forward_train(self, features, proposals, targets):
     boxes = torch.zeros(B, R, 4, device=dev)
     for i, p in enumerate(proposals):
         boxes[i, : counts[i]] = p.proposal_boxes.tensor
-    with torch.no_grad():
+    # no graph when everything below the predictor is frozen (ft_novel yaml); otherwise ROIAlign backward into the
+    # pyramid and the fused Linear autograd of the box head (base / ft_all yamls)
+    below = any(f.requires_grad for f in feats) or any(p.requires_grad for p in self.box_head.parameters())
+    with torch.set_grad_enabled(below and torch.is_grad_enabled()):
         pooled = self.box_pooler.pool_nhwc(feats, boxes)
-        if any(p.requires_grad for p in self.box_head.parameters()):
-            raise NotImplementedError("training the box head is not implemented (set MODEL.ROI_HEADS.FREEZE_FEAT)")
-        h = self.box_head.forward_nhwc(pooled)
         keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
-        h = h[keep].contiguous()
+        h = self.box_head.forward_nhwc(pooled[keep].contiguous())
     pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
     gb = torch.cat([p.gt_boxes.tensor for p in proposals], 0)
     gc = torch.cat([p.gt_classes for p in proposals], 0)

@@ -85,3 +85,59 @@ def test_sgd_step_and_ddp_bucket_single_process():
         model.eval()
         out = model([{"image": _batch(g)[0]["image"]}])
     assert "instances" in out[0]
+
+
+def _base_model():
+    """faster_rcnn_R_50_FPN_base.yaml: 60 classes, FREEZE_AT 2, everything above res2 trains."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+
+    cfg = base_rcnn_fpn(num_classes=60)
+    model = build_model(cfg)
+    syn.conditioned_r50_fpn_(model)
+    return model.train()
+
+
+def test_base_detector_training_step_matches_reference(monkeypatch):
+    """The whole detector training (faster_rcnn_R_50_FPN_base.yaml): RPN losses -> fused predictor / 3x3 conv of the
+    RPN head -> p2..p6 (p6 through LastLevelMaxPool's scatter); CE + smooth-L1 -> predictor -> 2-FC box head ->
+    ROIAlign backward -> p2..p5; FPN; res5..res3.  72 trainable tensors against the reference's CPU step
+    (tests/golden/train_base.npz).  Losses to 1e-4; gradients through robust metrics (direction and size): the same
+    ReLU-flip noise as in test_gpu_box_corrector.py, plus proposals that the RPN's own fp32 noise reorders."""
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_base")
+    model = _base_model()
+    frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
+    assert frozen == g["frozen_names"].tolist()
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with EventStorage(0) as storage:
+        losses = model(_batch(g))
+        sum(losses.values()).backward()
+    for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
+        ref, got = float(g["loss." + k]), float(losses[k].detach())
+        print(k, got, ref)
+        assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    lat = storage.latest()
+    assert lat["rpn/num_pos_anchors"] == float(g["scalar.rpn.num_pos_anchors"])
+    assert lat["roi_head/num_fg_samples"] == float(g["scalar.roi_head.num_fg_samples"])
+    bad = {}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        gflat = p.grad.flatten().cpu()
+        s, nrm, stride = [float(v) for v in g["grad_stats." + name]]
+        sample = gflat[:: int(stride)][:2048].double()
+        ref = g["grad_sample." + name].double()
+        if nrm == 0.0:   # identity randperm samples the first anchors (all on p2) and no RoI is pooled from p5
+            assert float(gflat.abs().max()) == 0.0, name
+            continue
+        cos = float((sample * ref).sum() / (sample.norm() * ref.norm()).clamp_min(1e-30))
+        nerr = abs(float(gflat.double().norm()) - nrm) / max(nrm, 1e-12)
+        print("%-52s cos %.6f  norm err %.2e" % (name, cos, nerr))
+        if not (cos >= 0.998 and nerr <= 1e-2):
+            bad[name] = (cos, nerr)
+    assert not bad, bad
