@@ -271,6 +271,15 @@ int lvc_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
  * lvc_downsum2x2_nhwc: y[n,i,j,:] = sum of x[n,2i..2i+1,2j..2j+1,:]; x [N,2Hs,2Ws,C] (backward of the nearest x2
  *   upsample of the FPN top-down path, fpn.py:131-133).
  * lvc_colsum_atomic: lvc_colsum for 10^5-row operands (conv bias gradients): row slabs combined with fp32 atomics. */
+/* Device-side packing of the reference's OIHW parameters (detectron2/layers/wrappers.py:41-99 keeps `weight` as
+ * [K,C,R,S]) into the conv kernels' operand: wp [rows_pad][R*S*cin_pad] fp32, k = (c/32, r, s, c%32).
+ *   mode 0 (forward): rows = K output channels, cin = C.   mode 1 (data gradient): rows = C, contraction over the K
+ *   output channels, taps flipped, times scale[k] (FrozenBatchNorm2d scale or NULL).  Padding rows/channels are zero.
+ * lvc_split_weights: planes == 3 -> out = 3 x n bf16 (hi, mid, lo), planes == 2 -> 2 x n fp16 (w1, (w - w1) * 2048);
+ *   |w| > 65504 in the fp16 split raises bit 1 of *err_word (the conv error word of lvc_conv_workspace). */
+int lvc_pack_conv_weights(const float* w, const float* scale, float* wp, int K, int C, int R, int S, int rows_pad,
+                          int cin_pad, int mode, void* stream);
+int lvc_split_weights(const float* wp, long long n, int planes, void* out, int* err_word, void* stream);
 int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                         int K, int R, int S, int stride, int pad, int lddy, void* stream);
 int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);

@@ -36,20 +36,24 @@ struct WgradParams {
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, lddy;
   int M;                 // N*Ho*Wo
   int chunks_per_split;  // 32-pixel chunks per grid.y slice
-  int k_tiles, c_tiles;
+  int k_tiles, c_tiles, tiles;
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   __shared__ float sA[2][32][128];  // dY [pixel][k]
   __shared__ float sB[2][32][128];  // X  [pixel][c]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int t = blockIdx.x;
+  // workgroups of one pixel range (all tiles, all taps) are consecutive logical ids -> same XCD, same L2: they walk
+  // the same dY / X rows at the same pace, so the slab is fetched from HBM about once per XCD
+  const int lid = lvc_xcd_remap(blockIdx.x, gridDim.x);
+  int t = lid % p.tiles;
+  const int split = lid / p.tiles;
   const int ct = t % p.c_tiles; t /= p.c_tiles;
   const int kt = t % p.k_tiles; t /= p.k_tiles;
   const int tap = t, r = tap / p.S, s = tap % p.S;
   const int k0 = kt * 128, c0 = ct * 128;
   const int nchunks = (p.M + 31) >> 5;
-  const int chunk0 = blockIdx.y * p.chunks_per_split;
+  const int chunk0 = split * p.chunks_per_split;
   int chunk1 = chunk0 + p.chunks_per_split;
   if (chunk1 > nchunks) chunk1 = nchunks;
   if (chunk0 >= chunk1) return;
@@ -157,6 +161,7 @@ extern "C" int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float*
   p.lddy = lddy; p.M = (int)M64;
   p.k_tiles = lvc_cdiv(K, 128); p.c_tiles = lvc_cdiv(C, 128);
   const int tiles = p.k_tiles * p.c_tiles * R * S;
+  p.tiles = tiles;
   const int nchunks = lvc_cdiv(p.M, 32);
   int splits = lvc_cdiv(1024, tiles);                 // ~4 workgroups per CU
   const int max_splits = lvc_cdiv(nchunks, 4);        // at least 128 pixels per workgroup
@@ -164,7 +169,7 @@ extern "C" int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float*
   if (splits < 1) splits = 1;
   p.chunks_per_split = lvc_cdiv(nchunks, splits);
   splits = lvc_cdiv(nchunks, p.chunks_per_split);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, splits), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * splits), dim3(256), 0, st, p);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -41,54 +41,33 @@ class PackedConv:
         self._w3 = None
         self._w2h = None
 
+    def _split(self, planes):
+        n = self.w.numel()
+        dt = torch.bfloat16 if planes == 3 else torch.float16
+        out = torch.empty((planes,) + tuple(self.w.shape), device=self.w.device, dtype=dt)
+        err = _conv_error_view(self.w.device) if planes == 2 else None
+        check(_lib.lib().lvc_split_weights(ptr(self.w), c_longlong(n), c_int(planes), ptr(out), ptr(err), _stream(self.w)),
+              "lvc_split_weights")
+        return out
+
     def split3(self):
         """[3, Kpad, Kg] bf16 planes (hi, mid, lo) of the packed weights: w == hi + mid + lo exactly."""
         if self._w3 is None:
-            hi = self.w.to(torch.bfloat16)
-            r1 = self.w - hi.float()
-            mid = r1.to(torch.bfloat16)
-            lo = (r1 - mid.float()).to(torch.bfloat16)
-            self._w3 = torch.stack([hi, mid, lo]).contiguous()
+            self._w3 = self._split(3)
         return self._w3
 
     def split2h(self):
         """[2, Kpad, Kg] fp16 planes of the packed weights for the two-way fp16 split (csrc/conv3x3_halo_h2.hip):
-        w1 = fp16(w), w2 = fp16((w - w1) * 2048)  ->  w ~= w1 + w2 / 2048 to 2^-23 relative (|w| >= 2.4e-4)."""
+        w1 = fp16(w), w2 = fp16((w - w1) * 2048)  ->  w ~= w1 + w2 / 2048 to 2^-23 relative (|w| >= 2.4e-4).  A weight
+        beyond the fp16 range raises bit 1 of the conv error word (`check_conv_error_word`: use LVC_CONV_SPLIT=bf16x3)."""
         if self._w2h is None:
-            assert float(self.w.abs().max()) <= 65504.0, "weights beyond the fp16 range: use LVC_CONV_SPLIT=bf16x3"
-            w1 = self.w.to(torch.float16)
-            w2 = ((self.w - w1.float()) * 2048.0).to(torch.float16)
-            self._w2h = torch.stack([w1, w2]).contiguous()
+            self._w2h = self._split(2)
         return self._w2h
 
 
-def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False):
-    """weight: [K, C, R, S] (OIHW, the reference's state_dict layout) on the target device.
-    bn: None or (weight, bias, running_mean, running_var) of a FrozenBatchNorm2d
-        (reference detectron2/layers/batch_norm.py:45-65: scale = w * rsqrt(var + eps),
-         shift = b - mean * scale).
-    stem=True packs the 3-channel 7x7 stem for the NHWC4 "row mode" of the kernel.
-    """
-    _req_cuda(weight)
-    K, C, R, S = weight.shape
-    dev = weight.device
-    w = weight.detach().float()
-    if stem:
-        assert C <= 4 and S <= 8
-        wk = torch.zeros(K, R, 8, 4, device=dev, dtype=torch.float32)
-        wk[:, :, :S, :C] = w.permute(0, 2, 3, 1)
-        Kg = R * BK
-        wk = wk.reshape(K, Kg)
-        Cphys, mode = 4, 1
-    else:
-        assert C % BK == 0, "implicit-GEMM kernel needs in_channels % 32 == 0 (got {})".format(C)
-        Kg = R * S * C
-        # k = (c // 32, r, s, c % 32): the taps of one 32-channel chunk are consecutive gemm-k chunks
-        wk = w.view(K, C // BK, BK, R, S).permute(0, 1, 3, 4, 2).reshape(K, Kg)
-        Cphys, mode = C, 0
-    Kpad = (K + BN - 1) // BN * BN
-    wp = torch.zeros(Kpad, Kg, device=dev, dtype=torch.float32)
-    wp[:K] = wk
+def conv_affine(bias=None, bn=None, eps=1e-5):
+    """(scale, shift) of y = conv * scale + shift: FrozenBatchNorm2d fold (reference detectron2/layers/batch_norm.py:
+    45-65: scale = w * rsqrt(var + eps), shift = b - mean * scale) and/or the conv bias; None where absent."""
     scale = shift = None
     if bn is not None:
         bw, bb, rm, rv = [t.detach().float() for t in bn]
@@ -102,7 +81,48 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False)
         scale = scale.contiguous()
     if shift is not None:
         shift = shift.contiguous()
-    return PackedConv(wp.contiguous(), scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
+    return scale, shift
+
+
+def _pack_weights(weight, scale, rows_pad, cin_pad, mode):
+    K, C, R, S = weight.shape
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    wp = torch.empty(rows_pad, R * S * cin_pad, device=w.device, dtype=torch.float32)
+    check(_lib.lib().lvc_pack_conv_weights(ptr(w), ptr(scale), ptr(wp), c_int(K), c_int(C), c_int(R), c_int(S),
+                                           c_int(rows_pad), c_int(cin_pad), c_int(mode), _stream(w)),
+          "lvc_pack_conv_weights")
+    return wp
+
+
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False, affine=None):
+    """weight: [K, C, R, S] (OIHW, the reference's state_dict layout) on the target device.
+    bn: None or (weight, bias, running_mean, running_var) of a FrozenBatchNorm2d; affine: a precomputed
+    `conv_affine(bias, bn, eps)` (the fold only changes when those tensors do, the weights change every step).
+    stem=True packs the 3-channel 7x7 stem for the NHWC4 "row mode" of the kernel.
+    """
+    _req_cuda(weight)
+    K, C, R, S = weight.shape
+    dev = weight.device
+    Kpad = (K + BN - 1) // BN * BN
+    if stem:
+        assert C <= 4 and S <= 8
+        w = weight.detach().float()
+        wk = torch.zeros(K, R, 8, 4, device=dev, dtype=torch.float32)
+        wk[:, :, :S, :C] = w.permute(0, 2, 3, 1)
+        Kg = R * BK
+        wp = torch.zeros(Kpad, Kg, device=dev, dtype=torch.float32)
+        wp[:K] = wk.reshape(K, Kg)
+        Cphys, mode = 4, 1
+    else:
+        assert C % BK == 0, "implicit-GEMM kernel needs in_channels % 32 == 0 (got {})".format(C)
+        Kg = R * S * C
+        # k = (c // 32, r, s, c % 32): the taps of one 32-channel chunk are consecutive gemm-k chunks
+        wp = _pack_weights(weight, None, Kpad, C, 0)
+        Cphys, mode = C, 0
+    scale, shift = affine if affine is not None else conv_affine(bias, bn, eps)
+    return PackedConv(wp, scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
 
 
 def pack_linear(weight, bias=None):
@@ -123,6 +143,11 @@ def conv_workspace(device):
         ws = torch.zeros(lib.lvc_conv_workspace_bytes(), dtype=torch.uint8, device=device)
         _CONV_WS[key] = ws
     return ws
+
+
+def _conv_error_view(device):
+    ws = conv_workspace(device)
+    return ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4]
 
 
 def conv_error_word(device):
@@ -736,14 +761,10 @@ def pack_conv_dgrad(weight, scale, pad):
     the same product on the sub-sampled grid followed by `scatter_stride2`.  Output channels of the forward conv
     (the contraction here) are zero-padded to the kernels' 32-channel chunk."""
     Kout, C, R, S = weight.shape
-    w = weight.detach().float()
-    if scale is not None:
-        w = w * scale.view(-1, 1, 1, 1)
-    wt = w.permute(1, 0, 2, 3).flip(2, 3)
-    pk = (-Kout) % 32
-    if pk:
-        wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, pk))
-    return pack_conv(wt.contiguous(), stride=1, pad=R - 1 - pad)
+    kin_pad = (Kout + 31) // 32 * 32
+    rows_pad = (C + BN - 1) // BN * BN
+    wp = _pack_weights(weight, scale, rows_pad, kin_pad, 1)
+    return PackedConv(wp, None, None, C, kin_pad, R, S, 1, R - 1 - pad, R * S * kin_pad, 0)
 
 
 def conv_dgrad(dy, pcd, x_shape, stride):

@@ -59,24 +59,30 @@ class Conv2d(nn.Module):
             raise NotImplementedError("only ReLU is fused (the only activation on the path)")
         self._cache = _PackedCache()
         self._cache_dgrad = _PackedCache()
+        self._cache_affine = _PackedCache()
 
-    def packed(self):
+    def _affine(self):
+        """FrozenBN fold / bias of the epilogue; rebuilt only when one of ITS tensors changes (not on every
+        optimizer step of the weights)."""
         bn = None
-        srcs = [self.weight, self.bias]
+        srcs = [self.bias]
         if self.norm is not None:
             assert isinstance(self.norm, FrozenBatchNorm2d)
             bn = (self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var)
             srcs += list(bn)
+        return self._cache_affine.get(srcs, lambda: K.conv_affine(self.bias, bn, self.norm.eps if bn else 1e-5))
+
+    def packed(self):
+        aff = self._affine()
+        srcs = [self.weight, aff[0], aff[1]]
         stem = self.in_channels == 3
-        return self._cache.get(srcs, lambda: K.pack_conv(self.weight, bias=self.bias, bn=bn, stride=self.stride,
-                                                         pad=self.padding, eps=self.norm.eps if bn else 1e-5, stem=stem))
+        return self._cache.get(srcs, lambda: K.pack_conv(self.weight, stride=self.stride, pad=self.padding, stem=stem,
+                                                         affine=aff))
 
     def packed_dgrad(self):
         """Packed weights of the data gradient (flipped, transposed, times the FrozenBN scale)."""
-        srcs = [self.weight]
-        if self.norm is not None:
-            srcs += [self.norm.weight, self.norm.running_var]
-        return self._cache_dgrad.get(srcs, lambda: K.pack_conv_dgrad(self.weight, self.packed().scale, self.padding))
+        scale = self._affine()[0] if self.norm is not None else None
+        return self._cache_dgrad.get([self.weight, scale], lambda: K.pack_conv_dgrad(self.weight, scale, self.padding))
 
     def forward_nhwc(self, x, residual=None, res_mode=0, relu=None):
         """x: [N,H,W,C] contiguous.  relu=None -> this layer's own activation."""
@@ -163,7 +169,7 @@ class _LinearFn(torch.autograd.Function):
         dx, dw = K.linear_backward(x, ctx.weight, dz, need_dx=need_dx, need_dw=need_dw)
         if dw is not None and ctx.w_view is not None:
             dw = ctx.w_view(dw)
-        db = K.colsum(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        db = K.colsum_rows(dz) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db, None, None, None, None
 
 
