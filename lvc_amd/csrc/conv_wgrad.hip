@@ -24,6 +24,7 @@
 // 4 waves as 2x2, wave tile 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).  LDS rows are 128 floats with the two
 // 32-float halves of every 64 swapped on odd rows, so lanes 32-63 (odd pixel) hit the other 32 banks.
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -163,8 +164,11 @@ extern "C" int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float*
   const int tiles = p.k_tiles * p.c_tiles * R * S;
   p.tiles = tiles;
   const int nchunks = lvc_cdiv(p.M, 32);
+  // every workgroup ends with 128x128 atomic adds (64 KB), the traffic of two 32-pixel chunks: a pixel range must be
+  // long enough to amortise it, even if that leaves fewer workgroups than the chip has slots
+  static const int min_chunks = getenv("LVC_WGRAD_MIN_CHUNKS") ? atoi(getenv("LVC_WGRAD_MIN_CHUNKS")) : 16;
   int splits = lvc_cdiv(1024, tiles);                 // ~4 workgroups per CU
-  const int max_splits = lvc_cdiv(nchunks, 4);        // at least 128 pixels per workgroup
+  const int max_splits = lvc_cdiv(nchunks, min_chunks);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   p.chunks_per_split = lvc_cdiv(nchunks, splits);
