@@ -125,6 +125,9 @@ int lvc_crop_resize_nearest(const float* image_chw, int C, int H, int W, const i
  * max(|x-mu|, eps) (mode 1, F.cosine_similarity as used by tools/run_nearest_neighbours.py:150-153). */
 int lvc_rownorm(const float* x, const float* mu, float* y, int M, int D, int ldx, int ldy, float eps, int mode,
                 void* stream);
+/* Backward of lvc_rownorm mode 0 without mu (CosineSimOutputLayers training, lvc/modeling/roi_heads/fast_rcnn.py:
+ * 823-825): dx = dy/(n+eps) - x (dy.x)/((n+eps)^2 n), n = |x| per row; accumulate != 0 adds to dx. */
+int lvc_rownorm_backward(const float* x, const float* dy, float* dx, int M, int D, float eps, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * ROIAlign forward.  Same arithmetic and operation order as ROIAlign_cpu.cpp:20-218 / ROIAlign_cuda.cu:65-139.

@@ -114,6 +114,42 @@ extern "C" int lvc_rownorm(const float* x, const float* mu, float* y, int M, int
   return LVC_OK;
 }
 
+// Backward of y = x / (|x| + eps) row-wise (mode 0 of lvc_rownorm without mu; CosineSimOutputLayers' input
+// normalisation, lvc/modeling/roi_heads/fast_rcnn.py:823-825: torch.norm's backward is x/|x|):
+//   dx = dy / (n + eps) - x * (dy . x) / ((n + eps)^2 * n),  n = |x|;  rows with n == 0 get dy / eps.
+// dx_accum != 0: added to what dx already holds (the bbox_pred branch's gradient of the same x).
+__global__ __launch_bounds__(256) void rownorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int M, int D, float eps, int accum) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  const float* gr = dy + (size_t)row * D;
+  float ss = 0.f, dot = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    ss += xr[d] * xr[d];
+    dot += gr[d] * xr[d];
+  }
+  for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o); dot += __shfl_xor(dot, o); }
+  const float n = sqrtf(ss), den = n + eps;
+  const float a = 1.f / den, b = n > 0.f ? dot / (den * den * n) : 0.f;
+  float* o_ = dx + (size_t)row * D;
+  for (int d = lane; d < D; d += 64) {
+    const float v = gr[d] * a - xr[d] * b;
+    o_[d] = accum ? o_[d] + v : v;
+  }
+}
+
+extern "C" int lvc_rownorm_backward(const float* x, const float* dy, float* dx, int M, int D, float eps, int accumulate,
+                                    void* stream) {
+  LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
+  if (M == 0) return LVC_OK;
+  LVC_CHECK_ARG(x && dy && dx, "null pointer");
+  hipLaunchKernelGGL(rownorm_backward_kernel, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, M, D, eps,
+                     accumulate);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
 // Context / pad crops for the label-verification descriptors: reference
 // lvc/data/utils.py:485-519 get_padding + get_crops_qe: the box window (already widened / clamped on the host, which
 // is integer bookkeeping) is zero-padded to a square and resized to out x out with F.interpolate(mode='nearest'),

@@ -598,6 +598,18 @@ def rownorm(x, mu=None, eps=1e-5, mode=0, out=None):
     return out
 
 
+def rownorm_backward(x, dy, eps=1e-5, accumulate_into=None):
+    """Gradient of `rownorm(x, eps=eps, mode=0)` w.r.t. x; accumulate_into: a [M,D] tensor the result is added to."""
+    _req_cuda(x, dy)
+    x, dy = x.contiguous(), dy.contiguous()
+    M, D = x.shape
+    dx = accumulate_into if accumulate_into is not None else torch.empty_like(x)
+    assert dx.is_contiguous() and dx.shape == x.shape
+    check(_lib.lib().lvc_rownorm_backward(ptr(x), ptr(dy), ptr(dx), c_int(M), c_int(D), c_float(eps),
+                                          c_int(1 if accumulate_into is not None else 0), _stream(x)), "lvc_rownorm_backward")
+    return dx
+
+
 # --------------------------------------------------------------------------- label-verification kNN
 def colmean(x):
     _req_cuda(x)

@@ -59,8 +59,8 @@ class FastRCNNConvFCHead(nn.Module):
 
     def forward_nhwc(self, x):
         """x: [M, h, w, C] channels-last pooled features."""
-        if self.training and not isinstance(self.dropout, nn.Identity):
-            raise NotImplementedError("dropout in the box head is a training-time op (not implemented)")
+        # dropout (reference box_head.py:88-89, after every FC's ReLU; identity in eval): torch's own nn.Dropout on the
+        # device tensor -- its mask comes from torch's generator exactly as the reference's does
         for layer in self.conv_norm_relus:
             x = layer.forward_nhwc(x)
         if len(self.fcs):
@@ -71,8 +71,9 @@ class FastRCNNConvFCHead(nn.Module):
                 x.reshape(M, -1), fc.weight, fc.bias, self._packed_fc1_hwc(), relu=True,
                 w_packed_layout=lambda: fc.weight.detach().view(fc.out_features, C, Hh, Ww).permute(0, 2, 3, 1).reshape(fc.out_features, -1),
                 w_view=lambda dw: dw.view(fc.out_features, Hh, Ww, C).permute(0, 3, 1, 2).reshape(fc.out_features, -1))
+            x = self.dropout(x)
             for fc in self.fcs[1:]:
-                x = fc(x, relu=True)
+                x = self.dropout(fc(x, relu=True))
         return x
 
     def forward(self, x):
@@ -82,7 +83,7 @@ class FastRCNNConvFCHead(nn.Module):
 
             return self.forward_nhwc(to_nhwc(x))
         for fc in self.fcs:
-            x = fc(x, relu=True)
+            x = self.dropout(fc(x, relu=True))
         return x
 
     @property

@@ -214,13 +214,53 @@ class _PredictorLoss(torch.autograd.Function):
         return dx, dwc, dbc, dwb, dbb, None, None, None, None
 
 
+class _CosinePredictorLoss(torch.autograd.Function):
+    """CosineSimOutputLayers forward (reference fast_rcnn.py:811-841) + FastRCNNOutputs.losses as one differentiable op.
+    The reference renormalises `cls_score.weight.data` in place before the product, so the classification weight's
+    gradient is that of the plain product scale * xn W^T (no gradient through the weight normalisation); the input
+    normalisation x / (|x| + 1e-5) is differentiated (`lvc_rownorm_backward`) when the box head trains."""
+
+    @staticmethod
+    def forward(ctx, x, wc, wb, bb, proposals, gt_boxes, gt_classes, layer):
+        scores, deltas = layer(x)      # renormalises wc.data in place, as every reference forward does
+        out, dl, dd = K.fast_rcnn_losses(scores, deltas, proposals, gt_boxes, gt_classes, layer.num_classes,
+                                         layer.box2box_transform.weights, layer.smooth_l1_beta)
+        ctx.save_for_backward(x, dl, dd, wc.detach().clone(), wb)
+        ctx.scale = float(layer.scale)
+        ctx.has_bias = bb is not None
+        pred = scores.argmax(dim=1)
+        ctx.mark_non_differentiable(pred)
+        return out[0], out[1], pred
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box, _g_pred):
+        x, dl, dd, wc, wb = ctx.saved_tensors
+        x = x.contiguous()
+        xn = K.rownorm(x, eps=1e-5, mode=0)
+        dls = (dl * (g_cls * ctx.scale)).contiguous()
+        ddg = (dd * g_box).contiguous()
+        need_x = ctx.needs_input_grad[0]
+        dxn, dwc = K.linear_backward(xn, wc, dls, need_dx=need_x, need_dw=True)
+        dx, dwb = K.linear_backward(x, wb, ddg, need_dx=need_x, need_dw=True)
+        if need_x:
+            dx = K.rownorm_backward(x, dxn, eps=1e-5, accumulate_into=dx.contiguous())
+        dbb = K.colsum_rows(ddg) if ctx.has_bias else None
+        return dx, dwc, dwb, dbb, None, None, None, None
+
+
 def fast_rcnn_losses(layer, x, proposals, gt_boxes, gt_classes):
     """-> ({"loss_cls", "loss_box_reg"}, predicted classes) for a FastRCNNOutputLayers `layer`."""
-    if not isinstance(layer, FastRCNNOutputLayers):
-        raise NotImplementedError("training of {} is not implemented".format(type(layer).__name__))
     if layer.box_reg_loss_type != "smooth_l1":
         raise NotImplementedError("ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE '{}'".format(layer.box_reg_loss_type))
+    lw = layer.loss_weight
+    if isinstance(layer, CosineSimOutputLayers):
+        if isinstance(layer.scale, nn.Parameter):
+            raise NotImplementedError("training with a learnable COSINE_SCALE (-1) is not used by the shipped configs")
+        lc, lb, pred = _CosinePredictorLoss.apply(x, layer.cls_score.weight, layer.bbox_pred.weight, layer.bbox_pred.bias,
+                                                  proposals, gt_boxes, gt_classes, layer)
+        return {"loss_cls": lc * lw.get("loss_cls", 1.0), "loss_box_reg": lb * lw.get("loss_box_reg", 1.0)}, pred
+    if not isinstance(layer, FastRCNNOutputLayers):
+        raise NotImplementedError("training of {} is not implemented".format(type(layer).__name__))
     lc, lb, pred = _PredictorLoss.apply(x, layer.cls_score.weight, layer.cls_score.bias, layer.bbox_pred.weight,
                                          layer.bbox_pred.bias, proposals, gt_boxes, gt_classes, layer)
-    lw = layer.loss_weight
     return {"loss_cls": lc * lw.get("loss_cls", 1.0), "loss_box_reg": lb * lw.get("loss_box_reg", 1.0)}, pred

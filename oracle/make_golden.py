@@ -377,6 +377,55 @@ def gen_train_base():
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
 
 
+def gen_train_ft_all():
+    """faster_rcnn_R_50_FPN_ft_all_30shot_aug_ftmore_dropout.yaml (the second fine-tune of BASELINE config 3: 80
+    classes, BACKBONE.FREEZE only -- RPN head, 2-FC box head and the CosineSimOutputLayers predictor train), with
+    ROI_BOX_HEAD.DROPOUT overridden to 0 (the yaml's 0.5 draws a mask from torch's generator, which a GPU run cannot
+    reproduce).  One step on the gen_train batch; randperm = identity."""
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/faster_rcnn_R_50_FPN_ft_all_30shot_aug_ftmore_dropout.yaml",
+                                 ["MODEL.ROI_BOX_HEAD.DROPOUT", 0.0])
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "train_novel_ft.npz")).items()}
+    batch, d = [], {}
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
+        inst.gt_classes = t["gt_classes%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "height": h, "width": w})
+        d["gt_boxes%d" % i], d["gt_classes%d" % i] = inst.gt_boxes.tensor, inst.gt_classes
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    try:
+        with EventStorage(0) as storage:
+            losses = model(batch)
+            sum(losses.values()).backward()
+            scalars = {k: float(v[0]) if isinstance(v, tuple) else float(v) for k, v in storage.latest().items()}
+    finally:
+        torch.randperm = real
+    ntrain, frozen = 0, []
+    for n_, p_ in model.named_parameters():
+        if p_.requires_grad:
+            ntrain += 1
+            gflat = p_.grad.flatten()
+            stride = max(1, gflat.numel() // 2048)
+            d["grad_sample." + n_] = gflat[::stride][:2048].clone()
+            d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
+        else:
+            frozen.append(n_)
+    print("  losses", {k: float(v.detach()) for k, v in losses.items()}, "trainable", ntrain, "frozen", len(frozen), scalars)
+    d["trainable_names"] = np.array([n_ for n_, p_ in model.named_parameters() if p_.requires_grad])
+    # the in-place renormalised classification weight after the forward (fast_rcnn.py:830-837)
+    d["cls_weight_after"] = model.roi_heads.box_predictor.cls_score.weight.detach()
+    save("train_ft_all", **d, **{"loss." + k: v.detach() for k, v in losses.items()},
+         **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
+
+
 def gen_box_corrector():
     """Box-corrector inference over given pseudo-labels: GeneralizedRCNNRegOnly + CascadeROIHeads._forward_box_qe
     (cascade_ubbr yaml with META_ARCHITECTURE switched, as tools/train_net_reg_qe.py does)."""
@@ -610,7 +659,7 @@ def gen_box_corrector_train_base():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -141,3 +141,70 @@ def test_base_detector_training_step_matches_reference(monkeypatch):
         if not (cos >= 0.998 and nerr <= 1e-2):
             bad[name] = (cos, nerr)
     assert not bad, bad
+
+
+def test_ft_all_cosine_training_step_matches_reference(monkeypatch):
+    """faster_rcnn_R_50_FPN_ft_all_30shot_aug_ftmore_dropout.yaml (frozen backbone; RPN head, box head and the
+    CosineSimOutputLayers predictor train; DROPOUT 0 on both sides): 13 trainable tensors vs the reference's CPU step
+    (tests/golden/train_ft_all.npz), incl. the in-place renormalised classification weight the forward leaves behind
+    and the gradient through the input normalisation (lvc_rownorm_backward)."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_ft_all")
+    cfg = base_rcnn_fpn(num_classes=80)
+    cfg.MODEL.ROI_HEADS.OUTPUT_LAYER = "CosineSimOutputLayers"
+    cfg.MODEL.BACKBONE.FREEZE = True
+    cfg.MODEL.ROI_BOX_HEAD.DROPOUT = 0.0
+    model = build_model(cfg)
+    syn.conditioned_r50_fpn_(model)
+    model.train()
+    assert [n for n, p in model.named_parameters() if p.requires_grad] == g["trainable_names"].tolist()
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with EventStorage(0):
+        losses = model(_batch(g))
+        sum(losses.values()).backward()
+    for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
+        ref, got = float(g["loss." + k]), float(losses[k].detach())
+        print(k, got, ref)
+        assert abs(got - ref) <= 2e-4 * max(1.0, abs(ref)), k
+    w = model.roi_heads.box_predictor.cls_score.weight.detach().cpu()
+    assert float((w - g["cls_weight_after"]).abs().max()) <= 1e-6
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        gflat = p.grad.flatten().cpu()
+        s, nrm, stride = [float(v) for v in g["grad_stats." + name]]
+        sample = gflat[:: int(stride)][:2048].double()
+        ref = g["grad_sample." + name].double()
+        cos = float((sample * ref).sum() / (sample.norm() * ref.norm()).clamp_min(1e-30))
+        nerr = abs(float(gflat.double().norm()) - nrm) / max(nrm, 1e-12)
+        print("%-52s cos %.6f  norm err %.2e" % (name, cos, nerr))
+        assert cos >= 0.999 and nerr <= 3e-3, (name, cos, nerr)
+
+
+def test_box_head_dropout_is_applied_in_training_only():
+    """ROI_BOX_HEAD.DROPOUT (the ft_all yaml's 0.5): after every FC's ReLU in training (reference box_head.py:82-91),
+    identity in eval; the surviving units are scaled by 1/(1-p)."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.layers import ShapeSpec
+    from lvc_amd.modeling.roi_heads.box_head import build_box_head
+
+    cfg = base_rcnn_fpn(num_classes=80)
+    cfg.MODEL.ROI_BOX_HEAD.DROPOUT = 0.5
+    dev = torch.device("cuda:0")
+    head = build_box_head(cfg, ShapeSpec(channels=256, height=7, width=7)).to(dev)
+    x = torch.randn(64, 7, 7, 256, device=dev)
+    head.eval()
+    with torch.no_grad():
+        e1, e2 = head.forward_nhwc(x), head.forward_nhwc(x)
+    assert torch.equal(e1, e2)
+    head.train()
+    torch.manual_seed(3)
+    t = head.forward_nhwc(x)
+    zeros = float((t == 0).float().mean())
+    assert zeros > 0.5 + 0.1     # ReLU zeros plus the dropped half of the rest
+    t.sum().backward()
+    assert head.fc1.weight.grad is not None and float(head.fc1.weight.grad.abs().sum()) > 0
