@@ -279,6 +279,61 @@ def test_data_parallel_helpers_world_size_2():
     assert g0 == [0.0, 1.0, 1.0] and g1 is None
 
 
+def _bucket_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from lvc_amd import distributed as D
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                  torch.nn.Linear(16, 3))
+        unused = torch.nn.Parameter(torch.ones(7))                     # never reaches the loss
+        params = list(net.parameters()) + [unused]
+        x, y = torch.randn(8, 6), torch.randn(8, 3)
+        full = [p.detach().clone().requires_grad_(True) for p in net.parameters()]
+        h = torch.relu(torch.nn.functional.linear(x, full[0], full[1]))
+        h = torch.relu(torch.nn.functional.linear(h, full[2], full[3]))
+        ((torch.nn.functional.linear(h, full[4], full[5]) - y) ** 2).mean().backward()
+        buckets = D.GradientBuckets(params, bucket_bytes=600)          # 3 buckets: forces the in-order launch logic
+        nb = len(buckets.buckets)
+        oks = []
+        for step in range(2):                                          # second step: gradients already live in the buckets
+            for p in params:
+                p.grad = None if step == 0 else (p.grad.zero_() if p.grad is not None else None)
+            xs, ys = x[rank * 4:(rank + 1) * 4], y[rank * 4:(rank + 1) * 4]
+            ((net(xs) - ys) ** 2).mean().backward()
+            nbytes = buckets.finish()
+            oks.append(all(torch.allclose(p.grad, f.grad, atol=1e-6) for p, f in zip(net.parameters(), full)))
+            oks.append(unused.grad is not None and float(unused.grad.abs().sum()) == 0.0)
+        q.put((rank, nb, oks, nbytes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_world_size_2():
+    """Bucketed, backward-overlapped all-reduce: averaged bucket gradients == gradient of the concatenated batch;
+    unused parameters contribute zeros; a second step reuses the bucket-resident gradients."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nb, oks, nbytes in res:
+        assert nb >= 3 and all(oks), (rank, nb, oks)
+        assert nbytes == (6 * 16 + 16 + 16 * 16 + 16 + 16 * 3 + 3 + 7) * 4
+
+
 def test_shard_range_single_process():
     from lvc_amd.distributed import shard_range
 
