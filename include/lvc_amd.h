@@ -112,6 +112,17 @@ int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float
                          float* out, int Hp, int Wp, void* stream);
 
 /* F.max_pool2d on NHWC (BasicStem resnet.py:591: k3 s2 p1; LastLevelMaxPool fpn.py:176: k1 s2 p0). */
+/* Test-time input pipeline: ResizeShortestEdge's Pillow bilinear resize of a uint8 HWC image
+ * (detectron2/data/transforms/transform.py:101-109), bit-exact with Pillow's ImagingResample (22-bit fixed point,
+ * horizontal then vertical pass, uint8 intermediate), optionally fused with preprocess_image's normalise + zero-pad
+ * (lvc/modeling/meta_arch/rcnn.py:324-333) into the batch's NHWC4 slot.
+ *   image [H,W,3] u8; xb [new_w,2] / xk [new_w,kxs] int32 = (first source column, count) and coefficients of each
+ *   output column (NULL when new_w == W; host: lvc_amd/data/transforms.py resample_coeffs = Pillow's
+ *   precompute_coeffs + normalize_coeffs_8bpc); yb / yk / kys likewise for rows; tmp: H*new_w*3 bytes of scratch;
+ *   out_u8 [new_h,new_w,3] and out_nhwc4 [Hp,Wp,4] fp32 are each optional; mean3 / std3: host float[3]. */
+int lvc_resize_bilinear_u8(const unsigned char* image, int H, int W, int new_h, int new_w, const int* xb, const int* xk,
+                           int kxs, const int* yb, const int* yk, int kys, unsigned char* tmp, unsigned char* out_u8,
+                           float* out_nhwc4, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
 int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
                        void* stream);
 

@@ -572,6 +572,37 @@ def preprocess_into(image, out_slot, mean, std):
     check(rc, "lvc_preprocess_nhwc4")
 
 
+def resize_bilinear_u8(img, new_h, new_w, coeffs_fn, out_slot=None, mean=None, std=None):
+    """Pillow-exact bilinear resize of a uint8 [H,W,3] image on the device (csrc/resize.hip).  coeffs_fn(in, out,
+    device) -> (bounds, coefficients, ksize) (lvc_amd.data.transforms.resample_coeffs).  Returns the uint8
+    [new_h,new_w,3] result; with out_slot [Hp,Wp,4] fp32 also writes the normalised, zero-padded NHWC4 pixels."""
+    if not img.is_cuda:
+        raise RuntimeError("resize_bilinear_u8 needs a device tensor (move the uint8 image first: 1 byte per sample)")
+    img = img.contiguous()
+    H, W, _ = img.shape
+    dev = img.device
+    xb = xk = yb = yk = tmp = None
+    kxs = kys = 0
+    if new_w != W:
+        xb, xk, kxs = coeffs_fn(W, new_w, dev)
+        tmp = torch.empty(H * new_w * 3, dtype=torch.uint8, device=dev)
+    if new_h != H:
+        yb, yk, kys = coeffs_fn(H, new_h, dev)
+    out = torch.empty(new_h, new_w, 3, dtype=torch.uint8, device=dev)
+    Hp = Wp = 0
+    m = s = None
+    if out_slot is not None:
+        Hp, Wp, four = out_slot.shape
+        assert four == 4 and out_slot.is_contiguous() and out_slot.dtype == torch.float32
+        m = (c_float * 3)(*[float(v) for v in mean])
+        s = (c_float * 3)(*[float(v) for v in std])
+    rc = _lib.lib().lvc_resize_bilinear_u8(ptr(img), c_int(H), c_int(W), c_int(new_h), c_int(new_w), ptr(xb), ptr(xk),
+                                           c_int(kxs), ptr(yb), ptr(yk), c_int(kys), ptr(tmp), ptr(out), ptr(out_slot),
+                                           c_int(Hp), c_int(Wp), m, s, _stream(img))
+    check(rc, "lvc_resize_bilinear_u8")
+    return out
+
+
 def maxpool2d_nhwc(x, k, stride, pad):
     _req_cuda(x)
     assert x.is_contiguous() and x.dtype == torch.float32

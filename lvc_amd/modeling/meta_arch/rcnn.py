@@ -48,16 +48,41 @@ class _RCNNBase(nn.Module):
         self.pixel_mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
         self.pixel_std = [float(v) for v in cfg.MODEL.PIXEL_STD]
         assert len(self.pixel_mean) == 3, "the stem kernel is built for 3-channel images"
+        self._input_cfg = cfg
 
     def preprocess_image(self, batched_inputs):
         """Normalize, pad and batch (reference rcnn.py:324-333).  Storage is NHWC with 4 channel slots;
         `.tensor` is the NCHW-shaped [N,3,Hp,Wp] view of it."""
+        if "image" not in batched_inputs[0] and "raw" in batched_inputs[0]:
+            return self._preprocess_raw(batched_inputs)
         images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
         sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
         buf = torch.empty(len(images), Hp, Wp, 4, device=self.device, dtype=torch.float32)
         for i, im in enumerate(images):
             K.preprocess_into(im, buf[i], self.pixel_mean, self.pixel_std)
+        return ImageList(buf.permute(0, 3, 1, 2)[:, :3], sizes)
+
+    def _preprocess_raw(self, batched_inputs):
+        """Inputs that still carry the decoded file: {"raw": uint8 [H,W,3] in INPUT.FORMAT channel order, ...}.  The
+        test-time ResizeShortestEdge of the reference's DatasetMapper (data/dataset_mapper.py:148-158 ->
+        detection_utils.py:563-595) runs on the device, Pillow-exact, and writes the normalised pixels straight into the
+        batch slot: 1 byte per sample crosses PCIe and no float CHW copy is formed."""
+        from ...data import ResizeShortestEdge
+
+        aug = self.__dict__.get("_test_resize")
+        if aug is None:
+            aug = self.__dict__["_test_resize"] = ResizeShortestEdge.from_config(self._input_cfg, is_train=False)
+        raws = [x["raw"].to(self.device, non_blocking=True) for x in batched_inputs]
+        tfms = [aug.get_transform(r) for r in raws]
+        sizes = [(t.new_h, t.new_w) if t is not None else (int(r.shape[0]), int(r.shape[1])) for t, r in zip(tfms, raws)]
+        Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
+        buf = torch.empty(len(raws), Hp, Wp, 4, device=self.device, dtype=torch.float32)
+        for i, (r, t) in enumerate(zip(raws, tfms)):
+            if t is None:
+                K.preprocess_into(r.permute(2, 0, 1), buf[i], self.pixel_mean, self.pixel_std)
+            else:
+                t.apply_image(r, out_slot=buf[i], mean=self.pixel_mean, std=self.pixel_std)
         return ImageList(buf.permute(0, 3, 1, 2)[:, :3], sizes)
 
 
@@ -145,7 +170,8 @@ class GeneralizedRCNN(_RCNNBase):
         if do_postprocess:
             rows = []
             for inp, (h, w) in zip(batched_inputs, sizes):
-                oh, ow = inp.get("height", h), inp.get("width", w)
+                dh, dw = (int(inp["raw"].shape[0]), int(inp["raw"].shape[1])) if "image" not in inp else (h, w)
+                oh, ow = inp.get("height", dh), inp.get("width", dw)   # DatasetMapper: height/width = the file's size
                 rows.append([ow / w, oh / h, float(oh), float(ow)])
             post = self._dev_const(rows, torch.float32)
         status = K.new_status(dev)
@@ -164,8 +190,14 @@ class GeneralizedRCNN(_RCNNBase):
         ob, osc, ocl, cnt, status = self.inference_batched(batched_inputs, do_postprocess)
         out_sizes = []
         for inp in batched_inputs:
-            h, w = int(inp["image"].shape[-2]), int(inp["image"].shape[-1])
-            out_sizes.append((inp.get("height", h), inp.get("width", w)) if do_postprocess else (h, w))
+            if "image" in inp:
+                h, w = int(inp["image"].shape[-2]), int(inp["image"].shape[-1])
+                dh, dw = h, w
+            else:   # raw file pixels: the network saw the ResizeShortestEdge size, results default to the file's size
+                dh, dw = int(inp["raw"].shape[0]), int(inp["raw"].shape[1])
+                t = self._test_resize.get_transform(inp["raw"])
+                h, w = (t.new_h, t.new_w) if t is not None else (dh, dw)
+            out_sizes.append((inp.get("height", dh), inp.get("width", dw)) if do_postprocess else (h, w))
         insts = instances_from_batched(ob, osc, ocl, cnt, out_sizes, status)
         return [{"instances": r} for r in insts] if do_postprocess else insts
 

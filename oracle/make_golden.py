@@ -656,10 +656,35 @@ def gen_box_corrector_train_base():
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
 
 
+def gen_resize():
+    """Test-time input transform: the reference's ResizeShortestEdge.get_transform sizes and
+    ResizeTransform.apply_image (Pillow bilinear on uint8 HWC) on small random images covering up-scaling, anti-aliased
+    down-scaling, one unchanged dimension, and the max_size clamp."""
+    from detectron2.data.transforms import ResizeShortestEdge
+
+    rng = np.random.default_rng(7)
+    d = {}
+    cases = [(60, 80, 100, 1333), (90, 120, 64, 1333), (50, 200, 100, 333), (128, 96, 96, 1333), (37, 53, 80, 117),
+             (240, 160, 50, 1333)]
+    for i, (h, w, short, mx) in enumerate(cases):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        aug = ResizeShortestEdge([short, short], mx, "choice")
+        tfm = aug.get_transform(img)
+        out = tfm.apply_image(img)
+        d["in%d" % i], d["out%d" % i] = img, out
+        d["cfg%d" % i] = np.array([short, mx, tfm.new_h, tfm.new_w], np.int64)
+        boxes = np.array([[1.5, 2.0, w - 3.0, h - 1.0], [0.0, 0.0, 10.0, 12.5]], np.float32)
+        d["box_in%d" % i] = boxes
+        d["box_out%d" % i] = tfm.apply_box(boxes.copy()).astype(np.float32)
+        print("  case", i, (h, w), "->", out.shape[:2])
+    d["n"] = np.int64(len(cases))
+    save("resize", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

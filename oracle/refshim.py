@@ -183,6 +183,40 @@ def _fvcore(m):
     m.__version__ = "0.1.5"
 
 
+def _fv_transform(m):
+    """fvcore.transforms.transform (third-party, not under /root/reference): the base-class behaviour the reference's
+    ResizeTransform relies on, from fvcore's published source -- `_set_attributes` stores the constructor arguments,
+    `apply_box` maps the 4 corners through `apply_coords` and takes their min/max."""
+    import numpy as np
+
+    class Transform:
+        def _set_attributes(self, params=None):
+            if params:
+                for k, v in params.items():
+                    if k != "self" and not k.startswith("_"):
+                        setattr(self, k, v)
+
+        def apply_box(self, box):
+            idxs = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+            coords = np.asarray(box).reshape(-1, 4)[:, idxs].reshape(-1, 2)
+            coords = self.apply_coords(coords).reshape((-1, 4, 2))
+            return np.concatenate((coords.min(axis=1), coords.max(axis=1)), axis=1)
+
+        @classmethod
+        def register_type(cls, *a, **k):
+            return (lambda f: f) if not (len(a) == 2 and callable(a[1])) else None
+
+    class NoOpTransform(Transform):
+        def apply_image(self, img):
+            return img
+
+        def apply_coords(self, coords):
+            return coords
+
+    m.Transform = Transform
+    m.NoOpTransform = NoOpTransform
+
+
 def _termcolor(m):
     m.colored = lambda s, *a, **k: s
 
@@ -213,6 +247,7 @@ _REAL = {
     "fvcore.common.config": _fv_config,
     "fvcore.nn.weight_init": _fv_weight_init,
     "fvcore.nn": _fv_nn,
+    "fvcore.transforms.transform": _fv_transform,
     "termcolor": _termcolor,
     "torchvision": _torchvision,
     "torchvision.ops": _tv_ops,

@@ -469,3 +469,28 @@ def test_rbg_reproduces_reference_jitter_on_cpu():
         assert o.proposal_boxes.tensor.shape == ref.shape
         assert (o.proposal_boxes.tensor - ref).abs().max() <= 1e-4
         assert torch.equal(o.objectness_logits, g["rbg_logits%d" % i])
+
+
+def test_resize_host_tables_match_oracle():
+    """Host side of the device resize (lvc_amd/data/transforms.py): the vectorised coefficient tables equal the
+    oracle's scalar restatement of Pillow's precompute_coeffs entry for entry; ResizeShortestEdge sizes and
+    ResizeTransform.apply_box equal the reference's (tests/golden/resize.npz)."""
+    import numpy as np
+    from lvc_amd.data import ResizeShortestEdge, ResizeTransform, resample_coeffs
+    from oracle import resize as orz
+
+    for a, b in [(480, 800), (640, 1067), (1200, 800), (3000, 1200), (333, 888), (500, 1333), (70, 35), (64, 128), (7, 3)]:
+        b1, k1, s1 = resample_coeffs(a, b)
+        b2, k2, s2 = orz.coeffs(a, b)
+        assert s1 == s2 and np.array_equal(b1, b2) and np.array_equal(k1, k2), (a, b)
+    g = gold("resize")
+    for i in range(int(g["n"])):
+        h, w = g["in%d" % i].shape[:2]
+        short, mx, nh, nw = [int(v) for v in g["cfg%d" % i]]
+        aug = ResizeShortestEdge([short, short], mx, "choice")
+        tfm = aug.get_transform(g["in%d" % i])
+        assert (tfm.new_h, tfm.new_w) == (nh, nw)
+        assert torch.allclose(tfm.apply_box(g["box_in%d" % i]), g["box_out%d" % i], atol=0, rtol=0) or \
+            float((tfm.apply_box(g["box_in%d" % i]) - g["box_out%d" % i]).abs().max()) <= 1e-5
+    with pytest.raises(RuntimeError):
+        ResizeTransform(4, 4, 8, 8).apply_image(torch.zeros(4, 4, 3, dtype=torch.uint8))   # no CPU path

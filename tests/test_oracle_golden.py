@@ -131,3 +131,28 @@ def test_e2e_800x1333():
     g, mid = _check_e2e("e2e_r50_fpn_800x1333", inputs)
     for k in ("p2", "p3", "p4", "p5", "p6"):
         assert torch.allclose(mid["feats"][k][:, ::16, ::8, ::8], g["feat_" + k], rtol=0, atol=2e-4)
+
+
+def test_resize_oracle_matches_reference_transform_and_pillow():
+    """the numpy restatement of Pillow's fixed-point bilinear resample (oracle/resize.py) against the
+    reference's ResizeShortestEdge / ResizeTransform outputs (tests/golden/resize.npz) -- bit-exact -- and, where
+    Pillow is importable, against Pillow itself on a fresh image."""
+    import numpy as np
+    from oracle import resize as orz
+
+    g = gold("resize")
+    for i in range(int(g["n"])):
+        img = g["in%d" % i].numpy()
+        short, mx, nh, nw = [int(v) for v in g["cfg%d" % i]]
+        assert orz.shortest_edge_size(img.shape[0], img.shape[1], short, mx) == (nh, nw)
+        out = orz.resize_bilinear_u8(img, nh, nw)
+        assert np.array_equal(out, g["out%d" % i].numpy()), i
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (97, 131, 3), dtype=np.uint8)
+    for nh, nw in [(160, 216), (40, 54), (97, 200), (30, 131)]:
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+        assert np.array_equal(orz.resize_bilinear_u8(img, nh, nw), ref), (nh, nw)
