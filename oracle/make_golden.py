@@ -656,6 +656,92 @@ def gen_box_corrector_train_base():
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
 
 
+def gen_r101():
+    """R101-FPN (the depth BASELINE config 5 names): FrozenBN calibration of the seed-0 conditioned weights on a small
+    image, an end-to-end detection golden on the 2-image small batch (faster_rcnn base yaml, DEPTH 101, 80 classes), and
+    one box-corrector training step (cascade_ubbr base yaml with DEPTH 101: res3..res5 incl. res4's 23 blocks train)."""
+    from detectron2.layers import FrozenBatchNorm2d
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/faster_rcnn_R_50_FPN_base.yaml",
+                                 ["MODEL.ROI_HEADS.NUM_CLASSES", 80, "MODEL.RESNETS.DEPTH", 101])
+    model.load_state_dict(syn.conditioned_state_dict(model.state_dict(), seed=0), strict=True)
+    a = syn.synthetic_image(3, 240, 320)
+    b = syn.synthetic_image(4, 200, 352)
+    calib = syn.calibrate_frozen_bn_(model, lambda: model([{"image": a, "height": 240, "width": 320}]), FrozenBatchNorm2d)
+    save("r101_bn_calibration", **calib)
+    sd = model.state_dict()
+    save("r101_fpn_state_dict_keys", keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+    inputs = [{"image": a, "height": 480, "width": 640}, {"image": b, "height": 200, "width": 352}]
+    with torch.no_grad():
+        images = model.preprocess_image(inputs)
+        feats = model.backbone(images.tensor)
+        props, _ = model.proposal_generator(images, feats, None)
+        out = model(inputs)
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k] = v[:, ::8].contiguous()
+    for i in range(2):
+        d["prop_boxes%d" % i] = props[i].proposal_boxes.tensor
+        d["prop_logits%d" % i] = props[i].objectness_logits
+        inst = out[i]["instances"]
+        d["det_boxes%d" % i] = inst.pred_boxes.tensor
+        d["det_scores%d" % i] = inst.scores
+        d["det_classes%d" % i] = inst.pred_classes
+        print("  small image", i, "proposals", len(props[i]), "detections", len(inst))
+    save("e2e_r101_fpn_small", **d)
+
+    # ---- box-corrector training step, R101 (BASELINE config 5)
+    cfg, model = build_ref_model("COCO-detection/cascade_ubbr_R_50_FPN_base.yaml", ["MODEL.RESNETS.DEPTH", 101])
+    model.load_state_dict(syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib), strict=True)
+    model.train()
+    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "box_corrector_train_base.npz")).items()
+         if not k.startswith("frozen")}
+    batch, d = [], {}
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
+        inst.gt_classes = t["gt_classes%d" % i]
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(t["loaded_boxes%d" % i])
+        props.objectness_logits = t["loaded_logits%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+        for k in ("gt_boxes", "gt_classes", "loaded_boxes", "loaded_logits"):
+            d["%s%d" % (k, i)] = t["%s%d" % (k, i)]
+    rbg_out = []
+    orig = model.proposal_generator.forward
+
+    def recording(proposals, targets):
+        out, extra = orig(proposals, targets)
+        rbg_out.extend(out)
+        return out, extra
+
+    model.proposal_generator.forward = recording
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    torch.manual_seed(5)
+    try:
+        with EventStorage(0):
+            losses = model(batch)
+            sum(losses.values()).backward()
+    finally:
+        torch.randperm = real
+    for i, p in enumerate(rbg_out):
+        d["rbg_boxes%d" % i] = p.proposal_boxes.tensor
+        d["rbg_logits%d" % i] = p.objectness_logits
+    ntrain = 0
+    for n_, p_ in model.named_parameters():
+        if p_.requires_grad:
+            ntrain += 1
+            gflat = p_.grad.flatten()
+            stride = max(1, gflat.numel() // 1024)
+            d["grad_sample." + n_] = gflat[::stride][:1024].clone()
+            d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
+    print("  R101 corrector losses", {k: float(v.detach()) for k, v in losses.items()}, "trainable tensors", ntrain)
+    save("box_corrector_train_r101", **d, **{"loss." + k: v.detach() for k, v in losses.items()})
+
+
 def gen_resize():
     """Test-time input transform: the reference's ResizeShortestEdge.get_transform sizes and
     ResizeTransform.apply_image (Pillow bilinear on uint8 HWC) on small random images covering up-scaling, anti-aliased
@@ -684,7 +770,7 @@ def gen_resize():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "r101"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()
