@@ -57,3 +57,31 @@ def test_knn_large_vs_oracle_dense():
     # fp32 similarity ties between two shots of different classes can swap neighbours: allow 0.1 % of rows
     assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 1e-3
     assert (keep.cpu() != ref_keep).float().mean() <= 1e-3
+
+
+@pytest.mark.parametrize("S", [10, 63, 64, 700, 2400, 4096])
+def test_topk_vote_ties_and_sizes(S):
+    """knn_topk_vote_kernel against torch.topk semantics with the reference's tie rule made explicit (ties -> lower
+    shot index, i.e. a stable descending sort): rows with few distinct values (every candidate filter overflows into
+    the full-row path), ties exactly at the 10th place, constant rows, and every per-lane register bucket."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(S)
+    Q = 300
+    sims = torch.randn(Q, S, generator=g)
+    sims[0] = 0.25                                               # constant row
+    sims[1] = torch.randint(0, 3, (S,), generator=g).float()     # 3 distinct values
+    sims[2] = torch.randint(0, 12, (S,), generator=g).float()    # ties around the 10th place
+    sims[3, : min(S, 9)] = 5.0                                   # 9 clear winners, then a tie block
+    sims[4] = torch.arange(S).float()                            # winners at the END of the row
+    sims[5] = -torch.arange(S).float()
+    if S > 300:
+        sims[6, 100:400] = 7.0                                   # 300 tied candidates: beyond the LDS candidate list
+    shot_classes = torch.randint(0, 80, (S,), generator=g)
+    det = torch.randint(0, 80, (Q,), generator=g)
+    order = torch.sort(sims, dim=1, descending=True, stable=True)[1][:, :10]
+    ref_top = shot_classes[order]
+    ref_keep = (torch.mode(ref_top, dim=1)[0] == det).long()
+    top, keep = K.knn_topk_vote(sims.to(D), S, shot_classes.to(D), det.to(D), 10)
+    assert torch.equal(top.cpu(), ref_top)
+    assert torch.equal(keep.cpu(), ref_keep)
