@@ -241,3 +241,33 @@ def test_gradient_buckets_on_device_single_process():
     opt.step()
     assert not torch.equal(before, params[0])
     buckets.remove()
+
+
+def test_training_step_with_an_image_without_ground_truth():
+    """Edge case of the training rows (the reference handles it in Matcher / label_and_sample_*: rpn.py:296-300,
+    roi_heads.py:236-262): one image of the batch has no GT box.  Losses stay finite, every trainable tensor gets a
+    finite gradient, and the empty image contributes only background samples."""
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_base")
+    model = _base_model()
+    batch = _batch(g)
+    empty = Instances((200, 352))
+    empty.gt_boxes = Boxes(torch.zeros(0, 4))
+    empty.gt_classes = torch.zeros(0, dtype=torch.int64)
+    batch[1]["instances"] = empty
+    torch.manual_seed(1)
+    with EventStorage(0) as storage:
+        losses = model(batch)
+        sum(losses.values()).backward()
+    for k, v in losses.items():
+        assert torch.isfinite(v).all(), k
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    lat = storage.latest()
+    nfg = lat["roi_head/num_fg_samples"]
+    nfg = nfg[0] if isinstance(nfg, tuple) else nfg
+    assert 0 < float(nfg) <= 64     # only image 0 has foreground (at most 25 % of 512, halved by the empty image)
