@@ -377,6 +377,44 @@ def gen_train_base():
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
 
 
+def gen_train_base_steps():
+    """Three consecutive SGD steps (torch.optim.SGD, lr 2e-4 -- small enough that the trajectory is smooth and one step's fp32 noise is not amplified --, momentum 0.9, weight decay 1e-4) of
+    faster_rcnn_R_50_FPN_base.yaml on the gen_train batch: the four losses before every step.  Pins the optimizer step +
+    re-packing of every trainable weight (stale packed copies would freeze the losses)."""
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/faster_rcnn_R_50_FPN_base.yaml")
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    model.load_state_dict(syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib), strict=True)
+    model.train()
+    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "train_novel_ft.npz")).items()}
+    batch = []
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
+        inst.gt_classes = t["gt_classes%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "height": h, "width": w})
+    params = [p_ for p_ in model.parameters() if p_.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0002, momentum=0.9, weight_decay=1e-4)
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    rows = []
+    try:
+        with EventStorage(0):
+            for step in range(4):
+                losses = model(batch)
+                rows.append([float(losses[k].detach()) for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")])
+                print("  step", step, rows[-1])
+                opt.zero_grad()
+                sum(losses.values()).backward()
+                opt.step()
+    finally:
+        torch.randperm = real
+    save("train_base_steps", losses=np.array(rows, np.float64), gt_boxes0=t["gt_boxes0"], gt_boxes1=t["gt_boxes1"],
+         gt_classes0=t["gt_classes0"], gt_classes1=t["gt_classes1"])
+
+
 def gen_train_ft_all():
     """faster_rcnn_R_50_FPN_ft_all_30shot_aug_ftmore_dropout.yaml (the second fine-tune of BASELINE config 3: 80
     classes, BACKBONE.FREEZE only -- RPN head, 2-FC box head and the CosineSimOutputLayers predictor train), with
@@ -770,7 +808,7 @@ def gen_resize():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "r101"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "r101"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -271,3 +271,34 @@ def test_training_step_with_an_image_without_ground_truth():
     nfg = lat["roi_head/num_fg_samples"]
     nfg = nfg[0] if isinstance(nfg, tuple) else nfg
     assert 0 < float(nfg) <= 64     # only image 0 has foreground (at most 25 % of 512, halved by the empty image)
+
+
+def test_three_sgd_steps_follow_the_reference_trajectory(monkeypatch):
+    """Optimizer step + re-packing of every trainable weight (forward operand, split planes, data-gradient operand):
+    four forward passes with three torch SGD steps in between against the reference's CPU trajectory
+    (tests/golden/train_base_steps.npz).  A stale packed copy anywhere would freeze that layer; the classification
+    loss drops 5.43 -> 0.21 and the RPN losses by 2x per step, so following that trajectory pins the whole update path.  Later steps compound the
+    fp32 noise of earlier ones (and the proposals the updated RPN emits), hence the widening tolerance."""
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_base_steps")
+    model = _base_model()
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=0.0002, momentum=0.9, weight_decay=1e-4)
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    ref = g["losses"]
+    # ROI-head losses depend on WHICH proposals the (updated, fp32-noisy) RPN ranks first -- near-ties reorder the sampled
+    # set from the second update on (measured: 0.4 % / 0.8 % after one step, 6 % / 11 % after two); the RPN losses are
+    # evaluated on the fixed anchor set and stay within 2 %
+    tol_roi = [2e-4, 0.02, 0.25, 0.40]
+    tol_rpn = [2e-4, 0.005, 0.05, 0.10]
+    with EventStorage(0):
+        for step in range(4):
+            losses = model(_batch(g))
+            got = [float(losses[k].detach()) for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc")]
+            dev = [abs(a - float(b)) / max(abs(float(b)), 1e-3) for a, b in zip(got, ref[step])]
+            print("step", step, ["%.5f" % v for v in got], "relative deviation", ["%.1e" % d for d in dev])
+            assert max(dev[:2]) <= tol_roi[step] and max(dev[2:]) <= tol_rpn[step], (step, got, ref[step].tolist())
+            opt.zero_grad()
+            sum(losses.values()).backward()
+            opt.step()
