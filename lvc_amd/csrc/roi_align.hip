@@ -380,6 +380,171 @@ __global__ __launch_bounds__(256) void roi_align_bwd_kernel(RoiAlignArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// ROIAlign backward, separable form for the engine path (NHWC, 7x7 bins): the bilinear weight of sample (iy, ix) onto
+// pixel (y, x) is a product wy(iy, y) * wx(ix, x), and a sample is dropped when EITHER coordinate is out of range, so
+//     d feat[y][x][c] = 1/count * sum_ph sum_pw  G[ph][pw][c] * Wy[ph][y] * Wx[pw][x],
+//     Wy[ph][y] = sum over the bin's valid sample rows of their weight onto row y (likewise Wx).
+// One workgroup per (RoI, 256-channel slice), lane = channel: the two weight tables (7 x footprint rows / columns) are
+// built once in LDS, the RoI's 49 gradient vectors live in registers, and every pixel of the RoI's footprint receives ONE
+// atomic add per channel -- the sample-by-sample scatter of roi_align_bwd_kernel issues 4 * gh * gw atomics per bin,
+// ~3.3x as many (a 14 x 14 px RoI: 784 vs 225), and the L2 atomic rate is what bounds this kernel (6.6 ms of the 87 ms
+// batch-8 training step).  Same sample positions, clamps and weights as the reference (ROIAlign_cpu.cpp:219-406); the
+// products are associated differently (weights first), which moves the last bits as the atomics' order already does.
+// RoIs whose footprint or sample count exceeds the tables take the scatter loop below.
+#define RB_MAXF 192    // footprint rows / columns held in the tables
+#define RB_MAXS 448    // samples per axis (7 bins x 64)
+template <int PH, int PW>
+__global__ __launch_bounds__(256) void roi_align_bwd_rows_kernel(RoiAlignArgs p) {
+  __shared__ float s_w[2][PH][RB_MAXF];      // [axis][bin][footprint index]
+  __shared__ int s_lo[2][RB_MAXS];           // per sample: low pixel index (-1: dropped)
+  __shared__ float s_l[2][RB_MAXS];          // per sample: weight of the HIGH pixel (low gets 1 - l)
+  __shared__ int s_hi[2][RB_MAXS];
+  __shared__ int s_min[2], s_max[2];
+  const int k = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (p.num_valid && k >= *p.num_valid) return;
+  const bool c_ok = c < p.C;
+  const float* gk = p.out + (long long)k * p.so_k + (long long)(c_ok ? c : 0) * p.so_c;
+  const float* r = p.rois + (long long)k * 5;
+  const int lvl = p.levels ? p.levels[k] : 0;
+  const int H = p.H[lvl], W = p.W[lvl];
+  const float spatial_scale = p.scale[lvl];
+  const int b = (int)r[0];
+  const float offset = p.aligned ? 0.5f : 0.0f;
+  const float roi_start_w = r[1] * spatial_scale - offset;
+  const float roi_start_h = r[2] * spatial_scale - offset;
+  const float roi_end_w = r[3] * spatial_scale - offset;
+  const float roi_end_h = r[4] * spatial_scale - offset;
+  float roi_width = roi_end_w - roi_start_w;
+  float roi_height = roi_end_h - roi_start_h;
+  if (p.aligned) {
+    if (!(roi_width >= 0 && roi_height >= 0)) {
+      if (p.status && threadIdx.x == 0 && blockIdx.y == 0) atomicOr(p.status, 1);
+    }
+  } else {
+    roi_width = roi_width > 1.f ? roi_width : 1.f;
+    roi_height = roi_height > 1.f ? roi_height : 1.f;
+  }
+  const float bin_h = roi_height / (float)PH;
+  const float bin_w = roi_width / (float)PW;
+  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_height / (float)PH);
+  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_width / (float)PW);
+  const float count = (float)(gh * gw);
+  float* gin = const_cast<float*>(p.feat[lvl]) + (long long)b * p.sb[lvl] + (long long)(c_ok ? c : 0);
+
+  bool tables = gh >= 1 && gw >= 1 && PH * gh <= RB_MAXS && PW * gw <= RB_MAXS;
+  if (tables) {
+    if (threadIdx.x < 2) { s_min[threadIdx.x] = 0x7fffffff; s_max[threadIdx.x] = -1; }
+    __syncthreads();
+    // ---- per-sample records of both axes (thread = sample), footprint extent by LDS atomics
+    for (int axis = 0; axis < 2; ++axis) {
+      const int g = axis ? gw : gh, n = (axis ? PW : PH) * g, L = axis ? W : H;
+      const float start = axis ? roi_start_w : roi_start_h, bin = axis ? bin_w : bin_h;
+      for (int t = threadIdx.x; t < n; t += 256) {
+        const int pb = t / g, i = t - pb * g;
+        float v = start + pb * bin + (float)(i + .5f) * bin / (float)g;
+        int lo = -1, hi = -1;
+        float l = 0.f;
+        if (!(v < -1.0f || v > (float)L)) {
+          if (v <= 0) v = 0;
+          lo = (int)v;
+          if (lo >= L - 1) { hi = lo = L - 1; v = (float)lo; } else hi = lo + 1;
+          l = v - lo;
+          atomicMin(&s_min[axis], lo);
+          atomicMax(&s_max[axis], hi);
+        }
+        s_lo[axis][t] = lo; s_hi[axis][t] = hi; s_l[axis][t] = l;
+      }
+    }
+    __syncthreads();
+    tables = s_max[0] - s_min[0] < RB_MAXF && s_max[1] - s_min[1] < RB_MAXF;   // uniform over the workgroup
+  }
+  if (tables && s_max[0] >= 0 && s_max[1] >= 0) {
+    const int y0 = s_min[0], x0 = s_min[1];
+    const int FH = s_max[0] - y0 + 1, FW = s_max[1] - x0 + 1;
+    for (int i = threadIdx.x; i < 2 * PH * RB_MAXF; i += 256) (&s_w[0][0][0])[i] = 0.f;
+    __syncthreads();
+    // ---- weight tables: one thread per (axis, bin) walks that bin's samples in order (deterministic sums)
+    if (threadIdx.x < 2 * PH) {
+      const int axis = threadIdx.x / PH, pb = threadIdx.x % PH;
+      const int g = axis ? gw : gh, base = axis ? x0 : y0;
+      for (int i = 0; i < g; ++i) {
+        const int t = pb * g + i;
+        const int lo = s_lo[axis][t];
+        if (lo < 0) continue;
+        const float l = s_l[axis][t];
+        s_w[axis][pb][lo - base] += 1.f - l;
+        s_w[axis][pb][s_hi[axis][t] - base] += l;
+      }
+    }
+    __syncthreads();
+    if (c_ok) {
+      float g[PH][PW];
+#pragma unroll
+      for (int a = 0; a < PH; ++a)
+#pragma unroll
+        for (int bb = 0; bb < PW; ++bb) g[a][bb] = gk[a * p.so_h + bb * p.so_w] / count;
+      for (int fy = 0; fy < FH; ++fy) {
+        float row[PW];
+#pragma unroll
+        for (int bb = 0; bb < PW; ++bb) row[bb] = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int a = 0; a < PH; ++a) {
+          const float wy = s_w[0][a][fy];
+          if (wy != 0.f) {
+            any = true;
+#pragma unroll
+            for (int bb = 0; bb < PW; ++bb) row[bb] += g[a][bb] * wy;
+          }
+        }
+        if (!any) continue;
+        float* grow = gin + ((long long)(y0 + fy) * W + x0) * p.C;
+        for (int fx = 0; fx < FW; ++fx) {
+          float v = 0.f;
+          bool hit = false;
+#pragma unroll
+          for (int bb = 0; bb < PW; ++bb) {
+            const float wx = s_w[1][bb][fx];
+            if (wx != 0.f) { hit = true; v += row[bb] * wx; }
+          }
+          if (hit) unsafeAtomicAdd(grow + (long long)fx * p.C, v);
+        }
+      }
+    }
+    return;
+  }
+  if (tables) return;   // every sample of one axis is out of range: no gradient
+  // ---- scatter loop (roi_align_bwd_kernel) for RoIs beyond the tables
+  for (int ph = 0; ph < PH; ++ph) {
+    for (int pw = 0; pw < PW; ++pw) {
+      const float g = c_ok ? gk[ph * p.so_h + pw * p.so_w] : 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int y_low = (int)y, x_low = (int)x, y_high, x_high;
+          if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+          if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+          const float ly = y - y_low, lx = x - x_low;
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          if (c_ok) {
+            unsafeAtomicAdd(gin + (long long)(y_low * W + x_low) * p.C, g * (hy * hx) / count);
+            unsafeAtomicAdd(gin + (long long)(y_low * W + x_high) * p.C, g * (hy * lx) / count);
+            unsafeAtomicAdd(gin + (long long)(y_high * W + x_low) * p.C, g * (ly * hx) / count);
+            unsafeAtomicAdd(gin + (long long)(y_high * W + x_high) * p.C, g * (ly * lx) / count);
+          }
+        }
+      }
+    }
+  }
+}
+
 // Reference-shaped op (csrc/vision.cpp:97, ROIAlign.h:88-128): grad [K,C,ph,pw] contiguous -> grad_input [B,C,H,W],
 // zeroed here (the reference returns a fresh at::zeros tensor, ROIAlign_cuda.cu:392).
 extern "C" int lvc_roi_align_backward_nchw(const float* grad, const float* rois, float* grad_input, int B, int C,
@@ -437,7 +602,12 @@ extern "C" int lvc_roi_align_fpn_backward_nhwc(const float* grad, float* const* 
   a.so_k = (long long)C * pooled_h * pooled_w; a.so_c = 1;
   a.so_h = (long long)pooled_w * C; a.so_w = C;
   a.status = d_status;
-  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  static int rows_form = -1;
+  if (rows_form < 0) { const char* e = getenv("LVC_ROI_BWD_ROWS"); rows_form = e ? atoi(e) : 1; }
+  if (rows_form && pooled_h == 7 && pooled_w == 7)
+    hipLaunchKernelGGL((roi_align_bwd_rows_kernel<7, 7>), dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

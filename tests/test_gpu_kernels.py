@@ -376,6 +376,35 @@ def test_roi_align_fpn_backward_nhwc_matches_oracle():
         assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("sr", [0, 2])
+def test_roi_align_fpn_backward_edge_rois(sr):
+    """The separable backward (weight tables per axis, one atomic per footprint pixel) on the RoIs that stress its
+    bookkeeping: boxes hanging over every edge of the map (dropped samples, clamped rows), degenerate and one-pixel boxes,
+    boxes covering the whole map on the coarsest level, and RoIs too large for the tables (scatter path)."""
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    B, C = 2, 64
+    scales = [1 / 4, 1 / 32]
+    shapes = [(B, 60, 84, C), (B, 8, 11, C)]
+    rois = torch.tensor([
+        [0, -40.0, -30.0, 50.0, 60.0], [1, 300.0, 200.0, 400.0, 300.0], [0, 330.0, 10.0, 336.0, 239.0],
+        [1, 10.0, 10.0, 10.0, 10.0], [0, 100.0, 100.0, 101.0, 101.5], [1, -500.0, -500.0, -300.0, -300.0],
+        [0, 0.0, 0.0, 336.0, 240.0], [1, 5.0, 5.0, 330.0, 20.0], [0, 2.0, 3.0, 9.0, 230.0], [1, 0.0, 0.0, 336.0, 240.0],
+    ])
+    levels = torch.tensor([0, 0, 0, 0, 0, 0, 1, 0, 0, 0], dtype=torch.int32)
+    g = torch.Generator().manual_seed(5)
+    grad = torch.randn(rois.shape[0], 7, 7, C, generator=g)
+    d = _dev()
+    outs = k.roi_align_fpn_backward_nhwc(grad.to(d), shapes, scales, rois.to(d), levels.to(d), sr, True)
+    for l in range(2):
+        sel = (levels == l).nonzero().view(-1)
+        ref = oops.roi_align_backward(grad[sel].permute(0, 3, 1, 2), rois[sel], scales[l], 7, 7, B, C,
+                                      shapes[l][1], shapes[l][2], sr, True)
+        got = outs[l].cpu().permute(0, 3, 1, 2)
+        assert (got - ref).abs().max() <= 1e-5 * max(1.0, float(ref.abs().max())), l
+
+
 def _nms_case(g, n, nidx, jitter):
     base = _rand_rois(g, max(4, n // 6), 1, 1333, 800, 8, 300)[:, 1:]
     pick = torch.randint(0, base.shape[0], (n,), generator=g)
