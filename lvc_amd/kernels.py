@@ -206,6 +206,7 @@ _PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
 # operand split of the split-precision kernels that have both forms: "f16x2" = two fp16 planes, 3 MFMAs per block
 # (Ootomo & Yokota; csrc/conv3x3_halo_h2.hip), "bf16x3" = three bf16 planes, 6 MFMAs per block (no range limit)
 CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
+_H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "128"))
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -235,8 +236,8 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else 4 if pw_narrow else _BF16X3_MIN_K)
             and pc.K % 4 == 0 and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
         h2_halo = halo and (split or CONV_SPLIT) == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES
-        h2_pw = (not halo and (split or CONV_SPLIT) == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128
-                 and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3
+        h2_pw = (not halo and (split or CONV_SPLIT) == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= _H2_PW_MIN_C
+                 and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3 (f16x2 there: 0.312 vs 0.335 ms alone, no gain end to end)
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
     timer = CONV_TIMER
     if timer is not None and timer.only is not None and engine not in timer.only:

@@ -366,7 +366,7 @@ def gen_train_base():
         if p_.requires_grad:
             ntrain += 1
             gflat = p_.grad.flatten()
-            stride = max(1, gflat.numel() // 2048)
+            stride = max(1, gflat.numel() // 2048) | 1   # odd: never a whole number of rows of a 2^k-wide matrix
             d["grad_sample." + n_] = gflat[::stride][:2048].clone()
             d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
         else:
@@ -451,7 +451,7 @@ def gen_train_ft_all():
         if p_.requires_grad:
             ntrain += 1
             gflat = p_.grad.flatten()
-            stride = max(1, gflat.numel() // 2048)
+            stride = max(1, gflat.numel() // 2048) | 1   # odd: never a whole number of rows of a 2^k-wide matrix
             d["grad_sample." + n_] = gflat[::stride][:2048].clone()
             d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
         else:
@@ -568,7 +568,7 @@ def gen_box_corrector_train():
         if p_.requires_grad:
             ntrain += 1
             gflat = p_.grad.flatten()
-            stride = max(1, gflat.numel() // 4096)
+            stride = max(1, gflat.numel() // 4096) | 1   # odd: never a whole number of rows of a 2^k-wide matrix
             d["grad_sample." + n_] = gflat[::stride][:4096].clone()
             d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
     print("  losses", {k: float(v) for k, v in losses.items()}, "trainable tensors", ntrain,
@@ -682,7 +682,7 @@ def gen_box_corrector_train_base():
         if p_.requires_grad:
             ntrain += 1
             gflat = p_.grad.flatten()
-            stride = max(1, gflat.numel() // 2048)
+            stride = max(1, gflat.numel() // 2048) | 1   # odd: never a whole number of rows of a 2^k-wide matrix
             d["grad_sample." + n_] = gflat[::stride][:2048].clone()
             d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
         else:
@@ -773,7 +773,7 @@ def gen_r101():
         if p_.requires_grad:
             ntrain += 1
             gflat = p_.grad.flatten()
-            stride = max(1, gflat.numel() // 1024)
+            stride = max(1, gflat.numel() // 1024) | 1   # odd: never a whole number of rows of a 2^k-wide matrix
             d["grad_sample." + n_] = gflat[::stride][:1024].clone()
             d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
     print("  R101 corrector losses", {k: float(v.detach()) for k, v in losses.items()}, "trainable tensors", ntrain)
