@@ -1,0 +1,33 @@
+"""Batches in flight on several HIP streams (lvc_amd/evaluation.py) give the detections of the one-stream loop, bit for
+bit, in submission order -- including with the stream-K conv workers of two launches sharing the chip."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pipelined_inference_equals_sequential():
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.evaluation import inference_on_dataset
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+
+    model = build_model(base_rcnn_fpn()).eval()
+    syn.conditioned_r50_fpn_(model)
+    dev = torch.device("cuda:0")
+    loader = []
+    for b in range(6):
+        h, w = (416, 608) if b % 2 else (384, 640)
+        loader.append([{"image": syn.synthetic_image(10 + 2 * b + i, h, w).to(dev), "height": 2 * h, "width": 2 * w} for i in range(2)])
+    with torch.no_grad():
+        seq = [model(batch) for batch in loader]
+    for depth in (2, 3):
+        got = list(inference_on_dataset(model, loader, depth=depth))
+        assert len(got) == len(loader)
+        for (inputs, outs), ref, batch in zip(got, seq, loader):
+            assert inputs is batch
+            for o, r in zip(outs, ref):
+                a, b = o["instances"], r["instances"]
+                assert a.image_size == b.image_size and len(a) == len(b) > 0
+                assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
+                assert torch.equal(a.scores, b.scores) and torch.equal(a.pred_classes, b.pred_classes)
