@@ -412,6 +412,115 @@ __global__ __launch_bounds__(1024) void rpn_decode_kernel(RpnLevels lv, const fl
   if (tid == 0) ccount[b] = base;
 }
 
+// RPN steps 2-4, per-level form.  `batched_nms` with the level as group id (proposal_utils.py:104) never lets boxes of
+// different levels suppress each other, so NMS is L independent problems per image: one segment per (image, level) --
+// B*L chains of <= pre_nms_topk / 64 chunks instead of B chains over the concatenation (40 x 16 instead of 8 x 76 chunks,
+// and 136 instead of 2 926 mask blocks per image), then a merge of the L kept lists by (score desc, level asc, position
+// asc) = exactly the order the concatenated formulation keeps, first post_nms_topk.
+__global__ __launch_bounds__(1024) void rpn_decode_seg_kernel(RpnLevels lv, const float* __restrict__ cand_score,
+                                                              const int* __restrict__ cand_idx, int Ntot,
+                                                              const int* __restrict__ image_sizes, float scale_clamp,
+                                                              float min_box_size, int SN, float* __restrict__ sboxes,
+                                                              float* __restrict__ sscores, int* __restrict__ scount) {
+  __shared__ int sh[20];
+  const int l = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int seg = b * lv.L + l;
+  const float img_h = (float)image_sizes[b * 2 + 0], img_w = (float)image_sizes[b * 2 + 1];
+  const int c_begin = lv.cand_off[l], c_end = lv.cand_off[l + 1];
+  const int A = lv.A, W = lv.W[l], HW = lv.H[l] * W;
+  int base = 0;
+  for (int c0 = c_begin; c0 < c_end; c0 += 1024) {
+    const int c = c0 + tid;
+    bool ok = false;
+    float box[4] = {0, 0, 0, 0};
+    float score = 0.f;
+    if (c < c_end) {
+      const int i = cand_idx[(size_t)b * Ntot + c];
+      score = cand_score[(size_t)b * Ntot + c];
+      const int p = i / A, a = i - p * A;
+      const int y = p / W, x = p - y * W;
+      const float sx = (float)(x * lv.stride[l]), sy = (float)(y * lv.stride[l]);
+      const float* ca = lv.cell_anchors[l] + a * 4;
+      const float ax1 = sx + ca[0], ay1 = sy + ca[1], ax2 = sx + ca[2], ay2 = sy + ca[3];
+      const float* d = lv.deltas[l] + ((size_t)b * HW + p) * lv.ld_delta[l] + a * 4;
+      apply_deltas(ax1, ay1, ax2, ay2, d[0], d[1], d[2], d[3], 1.f, 1.f, 1.f, 1.f, scale_clamp, box);
+      ok = isfinite(box[0]) && isfinite(box[1]) && isfinite(box[2]) && isfinite(box[3]) && isfinite(score);
+      box[0] = clampf(box[0], 0.f, img_w); box[1] = clampf(box[1], 0.f, img_h);
+      box[2] = clampf(box[2], 0.f, img_w); box[3] = clampf(box[3], 0.f, img_h);
+      ok = ok && (box[2] - box[0] > min_box_size) && (box[3] - box[1] > min_box_size);
+    }
+    int tot;
+    const int pos = base + block_excl_scan_1024(ok ? 1 : 0, sh, &tot);
+    if (ok) {
+      float* o = sboxes + ((size_t)seg * SN + pos) * 4;
+      o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3];
+      sscores[(size_t)seg * SN + pos] = score;
+    }
+    base += tot;
+  }
+  if (tid == 0) scount[seg] = base;
+}
+
+#define MERGE_LDS_SCORES 8192
+__global__ __launch_bounds__(1024) void rpn_merge_levels_kernel(const float* __restrict__ sboxes,
+                                                                const float* __restrict__ sscores,
+                                                                const int* __restrict__ keep,
+                                                                const int* __restrict__ num_keep, int L, int SN,
+                                                                int post_topk, float* __restrict__ pboxes,
+                                                                float* __restrict__ plogits, int* __restrict__ out_count) {
+  __shared__ int s_nk[MAXL + 1];            // prefix of the kept counts
+  __shared__ float s_sc[MERGE_LDS_SCORES];  // kept scores of all levels, list after list (when they fit)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0;
+    for (int l = 0; l < L; ++l) { s_nk[l] = acc; acc += num_keep[b * L + l]; }
+    s_nk[L] = acc;
+  }
+  __syncthreads();
+  const int total = s_nk[L];
+  const int nout = total < post_topk ? total : post_topk;
+  const bool in_lds = total <= MERGE_LDS_SCORES;
+  if (in_lds) {
+    for (int e = tid; e < total; e += 1024) {
+      int l = 0;
+      while (e >= s_nk[l + 1]) ++l;
+      const int seg = b * L + l;
+      s_sc[e] = sscores[(size_t)seg * SN + keep[(size_t)seg * SN + (e - s_nk[l])]];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < total; e += 1024) {
+    int l = 0;
+    while (e >= s_nk[l + 1]) ++l;
+    const int t = e - s_nk[l];
+    const int seg = b * L + l;
+    const int j = keep[(size_t)seg * SN + t];
+    const float s = sscores[(size_t)seg * SN + j];
+    int rank = t;
+    for (int m = 0; m < L; ++m) {
+      if (m == l) continue;
+      const int segm = b * L + m, n = s_nk[m + 1] - s_nk[m];
+      int lo = 0, hi = n;   // first u whose element does NOT precede (s, l)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float sm = in_lds ? s_sc[s_nk[m] + mid] : sscores[(size_t)segm * SN + keep[(size_t)segm * SN + mid]];
+        if (sm > s || (sm == s && m < l)) lo = mid + 1; else hi = mid;
+      }
+      rank += lo;
+    }
+    if (rank < post_topk) {
+      *reinterpret_cast<float4*>(pboxes + ((size_t)b * post_topk + rank) * 4) =
+          *reinterpret_cast<const float4*>(sboxes + ((size_t)seg * SN + j) * 4);
+      plogits[(size_t)b * post_topk + rank] = s;
+    }
+  }
+  for (int r = nout + tid; r < post_topk; r += 1024) {   // rows past count = 0
+    *reinterpret_cast<float4*>(pboxes + ((size_t)b * post_topk + r) * 4) = float4{0.f, 0.f, 0.f, 0.f};
+    plogits[(size_t)b * post_topk + r] = 0.f;
+  }
+  if (tid == 0) out_count[b] = nout;
+}
+
 // RPN step 4: gather the kept candidates into the fixed-size proposal arrays (rows past count = 0)
 __global__ void gather_proposals_kernel(const float* __restrict__ cboxes, const float* __restrict__ cscores,
                                         const int* __restrict__ keep, const int* __restrict__ num_keep,
@@ -436,7 +545,8 @@ struct RpnPlan {
   int Ntot;
   long long nkeys;  // per image
   long long off_keys, off_cscore, off_cidx, off_cboxes, off_cscores2, off_clevels, off_ccount, off_keep, off_hist, off_ckeys, off_ties, off_nms, total;
-  int max_slices;
+  long long off_sboxes, off_sscores, off_scount, off_skeep, off_snk, off_snms, snms_bytes;   // per-(image, level) segments
+  int max_slices, SN;
 };
 static RpnPlan rpn_plan(int B, int L, int A, const int* Hs, const int* Ws, int pre_topk) {
   RpnPlan p;
@@ -460,6 +570,20 @@ static RpnPlan rpn_plan(int B, int L, int A, const int* Hs, const int* Ws, int p
   p.off_ckeys = o; o = align16(o + (long long)B * p.Ntot * 8);
   p.off_ties = o; o = align16(o + (long long)B * L * TOPK_PAD * 4);
   p.off_nms = o; o = align16(o + lvc_batched_nms_workspace_bytes(B, p.Ntot));
+  p.SN = 0;
+  for (int l = 0; l < L; ++l) {
+    long long n = (long long)Hs[l] * Ws[l] * A;
+    const int c = (int)(n < pre_topk ? n : pre_topk);
+    if (c > p.SN) p.SN = c;
+  }
+  const long long segs = (long long)B * L;
+  p.off_sboxes = o; o = align16(o + segs * p.SN * 16);
+  p.off_sscores = o; o = align16(o + segs * p.SN * 4);
+  p.off_scount = o; o = align16(o + segs * 4);
+  p.off_skeep = o; o = align16(o + segs * p.SN * 4);
+  p.off_snk = o; o = align16(o + segs * 4);
+  p.snms_bytes = lvc_batched_nms_workspace_bytes((int)segs, p.SN);
+  p.off_snms = o; o = align16(o + p.snms_bytes);
   p.total = o;
   return p;
 }
@@ -528,6 +652,26 @@ extern "C" int lvc_rpn_proposals(const float* const* logits, const int* ld_logit
   hipLaunchKernelGGL(rpn_topk_kernel, dim3(L, B), dim3(1024), 0, st, lv, pre_nms_topk, keys, cand_score,
                      cand_idx, p.Ntot, multi ? TK_SLICE : 0x7FFFFFFF);
   LVC_CHECK_LAUNCH();
+  static int seg_nms = -1;   // LVC_RPN_NMS_SEG=0: NMS over the concatenated levels with level ids (the reference's shape)
+  if (seg_nms < 0) { const char* e = getenv("LVC_RPN_NMS_SEG"); seg_nms = e ? atoi(e) : 1; }
+  if (seg_nms) {
+    float* sboxes = (float*)(ws + p.off_sboxes);
+    float* sscores = (float*)(ws + p.off_sscores);
+    int* scount = (int*)(ws + p.off_scount);
+    int* skeep = (int*)(ws + p.off_skeep);
+    int* snk = (int*)(ws + p.off_snk);
+    hipLaunchKernelGGL(rpn_decode_seg_kernel, dim3(L, B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
+                       d_image_sizes, scale_clamp, min_box_size, p.SN, sboxes, sscores, scount);
+    LVC_CHECK_LAUNCH();
+    const int keep_per_level = post_nms_topk < p.SN ? post_nms_topk : p.SN;
+    int rc = lvc_batched_nms(sboxes, sscores, nullptr, scount, B * L, p.SN, nms_thresh, keep_per_level, skeep, snk,
+                             ws + p.off_snms, p.snms_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rpn_merge_levels_kernel, dim3(B), dim3(1024), 0, st, sboxes, sscores, skeep, snk, L, p.SN,
+                       post_nms_topk, out_boxes, out_logits, d_out_count);
+    LVC_CHECK_LAUNCH();
+    return LVC_OK;
+  }
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
                      d_image_sizes, scale_clamp, min_box_size, cboxes, cscores, clevels, ccount);
   LVC_CHECK_LAUNCH();
