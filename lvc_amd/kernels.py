@@ -206,6 +206,11 @@ _PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
 # operand split of the split-precision kernels that have both forms: "f16x2" = two fp16 planes, 3 MFMAs per block
 # (Ootomo & Yokota; csrc/conv3x3_halo_h2.hip), "bf16x3" = three bf16 planes, 6 MFMAs per block (no range limit)
 CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
+# Operand split of the DATA-gradient convolutions.  "bf16x3" keeps fp32's exponent range (raw gradients of a mean-reduced
+# loss sit around 1e-6 .. 1e-3, below fp16's normal range); "f16x2" is the faster two-way fp16 split and needs the
+# gradients scaled into fp16's range first -- lvc_amd.solver.LossScaler does that with a power of two (exact) and switches
+# this on for the backward pass it wraps.
+DGRAD_SPLIT = _os.environ.get("LVC_DGRAD_SPLIT", "bf16x3")
 _H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "128"))
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
@@ -816,7 +821,7 @@ def conv_dgrad(dy, pcd, x_shape, stride):
     N, H, W, C = x_shape
     if dy.shape[3] != pcd.C:   # contraction padded to 32 channels
         dy = torch.nn.functional.pad(dy, (0, pcd.C - dy.shape[3]))
-    dxs = conv2d_nhwc(dy.contiguous(), pcd, split="bf16x3")
+    dxs = conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT)
     if stride == 1:
         assert tuple(dxs.shape) == (N, H, W, C), (dxs.shape, x_shape)
         return dxs

@@ -14,6 +14,7 @@ from lvc_amd.utils.events import EventStorage
 which = sys.argv[1] if len(sys.argv) > 1 else "detector"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+loss_scale = float(os.environ.get("LOSS_SCALE", "0"))    # > 0: lvc_amd.solver.LossScaler (data gradients on the f16x2 kernels)
 cfg = base_rcnn_fpn(num_classes=60)
 M = cfg.MODEL
 if which == "corrector":
@@ -45,6 +46,10 @@ for i in range(B):
     batch.append(d)
 params = [p for p in model.parameters() if p.requires_grad]
 opt = torch.optim.SGD(params, lr=1e-4, momentum=0.9, weight_decay=1e-4)
+scaler = None
+if loss_scale > 0:
+    from lvc_amd.solver import LossScaler
+    scaler = LossScaler(init_scale=loss_scale)
 times = []
 with EventStorage(0):
     for it in range(steps + 2):
@@ -52,9 +57,15 @@ with EventStorage(0):
         losses = model(batch)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
-        sum(losses.values()).backward()
+        if scaler is not None:
+            scaler.backward(sum(losses.values()))
+        else:
+            sum(losses.values()).backward()
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        opt.step()
+        if scaler is not None:
+            scaler.step(opt)
+        else:
+            opt.step()
         torch.cuda.synchronize(); t3 = time.perf_counter()
         if it >= 2:
             times.append((t1 - t0, t2 - t1, t3 - t2))

@@ -302,3 +302,47 @@ def test_three_sgd_steps_follow_the_reference_trajectory(monkeypatch):
             opt.zero_grad()
             sum(losses.values()).backward()
             opt.step()
+
+
+def test_loss_scaler_backward_matches_plain_backward(monkeypatch):
+    """lvc_amd.solver.LossScaler: loss x 2^10, data gradients on the two-way fp16 kernels, gradients x 2^-10 -- the
+    parameter gradients must equal the plain (bf16x3 data-gradient) backward to the fp32 noise of the step, the scale
+    factors being exact; an absurd scale must be caught by the kernels' range word, skip the step and halve the scale."""
+    from lvc_amd import kernels as K
+    from lvc_amd.solver import LossScaler
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_base")
+    model = _base_model()
+    params = [p for p in model.parameters() if p.requires_grad]
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with EventStorage(0):
+        sum(model(_batch(g)).values()).backward()
+    plain = [p.grad.detach().clone() for p in params]
+    for p in params:
+        p.grad = None
+    opt = torch.optim.SGD(params, lr=0.0)
+    scaler = LossScaler(init_scale=2.0 ** 10)
+    with EventStorage(0):
+        scaler.backward(sum(model(_batch(g)).values()))
+    assert K.DGRAD_SPLIT == "bf16x3"
+    assert scaler.step(opt) is True
+    worst = 0.0
+    for p, ref in zip(params, plain):
+        if float(ref.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0
+            continue
+        rel = float((p.grad - ref).norm() / ref.norm())
+        worst = max(worst, rel)
+    print("worst relative gradient difference, scaled f16x2 vs plain bf16x3 backward: %.2e" % worst)
+    assert worst <= 2e-3
+    # overflow: 2^40 x (gradients of order 1e-4..1) leaves fp16's range inside the data-gradient kernels
+    for p in params:
+        p.grad = None
+    big = LossScaler(init_scale=2.0 ** 40, max_scale=2.0 ** 40)
+    before = params[0].detach().clone()
+    with EventStorage(0):
+        big.backward(sum(model(_batch(g)).values()))
+    assert big.step(torch.optim.SGD(params, lr=0.1)) is False
+    assert big.scale_value == 2.0 ** 39 and big.skipped_steps == 1 and torch.equal(before, params[0])
+    assert K.conv_error_word(params[0].device) == 0
