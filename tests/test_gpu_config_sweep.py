@@ -1,0 +1,54 @@
+"""The detector under configurations other than the benchmark's, end to end against the CPU oracle on the same seeded
+inputs: batch sizes 1 / 3 / 5, image sizes that are not multiples of 32 (and differ inside a batch), fewer / more proposals,
+other NMS and score thresholds, 20 and 60 classes, detections-per-image 10 / 300.  The routing of every layer (kernel
+shapes, patch sizes, small-map fall-backs), the per-level NMS merge and the candidate stage all depend on these."""
+import pytest
+import torch
+
+from helpers import match_fraction
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # sizes of the batch images, num_classes, pre_topk, post_topk, rpn_nms, score_thresh, det_nms, dets_per_image
+    ([(97, 131)], 80, 1000, 1000, 0.7, 0.05, 0.5, 100),
+    ([(224, 200), (160, 333), (250, 90)], 20, 600, 300, 0.6, 0.02, 0.4, 10),
+    ([(333, 500), (320, 480)], 60, 2000, 1500, 0.8, 0.1, 0.6, 300),
+    ([(64, 64), (65, 63), (33, 200), (200, 33), (128, 128)], 80, 1000, 50, 0.7, 0.05, 0.5, 100),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_detector_configuration_sweep_matches_oracle(case):
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+
+    sizes, ncls, pre, post, rpn_nms, thr, det_nms, dets = CASES[case]
+    cfg = base_rcnn_fpn(num_classes=ncls)
+    cfg.MODEL.RPN.PRE_NMS_TOPK_TEST, cfg.MODEL.RPN.POST_NMS_TOPK_TEST, cfg.MODEL.RPN.NMS_THRESH = pre, post, rpn_nms
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST, cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = thr, det_nms
+    cfg.TEST.DETECTIONS_PER_IMAGE = dets
+    model = build_model(cfg).eval()
+    syn.conditioned_r50_fpn_(model)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    inputs = [{"image": syn.synthetic_image(20 + 7 * case + i, h, w), "height": h + 3 * i, "width": 2 * w} for i, (h, w) in enumerate(sizes)]
+    spec = orc.RCNNSpec(num_classes=ncls, pre_topk=pre, post_topk=post, rpn_nms=rpn_nms, score_thresh=thr, det_nms=det_nms,
+                        dets_per_image=dets)
+    with torch.no_grad():
+        ref = orc.generalized_rcnn_inference(sd, spec, inputs)
+        out = model(inputs)
+    assert len(out) == len(ref)
+    for i, (o, r) in enumerate(zip(out, ref)):
+        inst = o["instances"].to("cpu")
+        assert inst.image_size == (inputs[i]["height"], inputs[i]["width"])
+        n_ref = len(r["scores"])
+        assert abs(len(inst) - n_ref) <= max(2, n_ref // 20), (len(inst), n_ref)
+        if n_ref == 0:
+            continue
+        frac, wb, ws = match_fraction(inst.pred_boxes.tensor, inst.scores, inst.pred_classes, r["pred_boxes"], r["scores"],
+                                      r["pred_classes"], box_tol=0.1, score_tol=2e-3)
+        print("case %d image %d: %d detections, %.0f%% of the oracle's reproduced (worst box %.1e px, score %.1e)"
+              % (case, i, len(inst), 100 * frac, wb, ws))
+        assert frac >= 0.9, (case, i, frac)
