@@ -85,3 +85,26 @@ def test_topk_vote_ties_and_sizes(S):
     top, keep = K.knn_topk_vote(sims.to(D), S, shot_classes.to(D), det.to(D), 10)
     assert torch.equal(top.cpu(), ref_top)
     assert torch.equal(keep.cpu(), ref_keep)
+
+
+@pytest.mark.parametrize("Q,S,Dm,cosine", [(37, 300, 384, True), (2500, 600, 384, True), (5000, 1801, 96, True),
+                                            (1000, 330, 384, False), (40000, 2400, 384, True)])
+def test_knn_sweep_shapes(Q, S, Dm, cosine):
+    """Descriptor widths and set sizes other than the benchmark's -- 384 is the ViT-S/8 width the reference's DINO
+    descriptors have (tools/run_nearest_neighbours.py:292-293) -- including query counts below the 256-row GEMM tile, shot
+    counts that are not multiples of 64, more than one 32 768-query chunk, and the L2 branch (:155-159)."""
+    from lvc_amd.label_verification import knn_sweep
+    from oracle import knn as oknn
+
+    g = torch.Generator().manual_seed(Q + S)
+    ncls = max(2, S // 30)
+    classes = torch.sort(torch.randint(0, ncls, (S,), generator=g))[0]
+    centers = torch.randn(ncls, Dm, generator=g)
+    shots = centers[classes] + 1.5 * torch.randn(S, Dm, generator=g) + 0.3
+    qcls = torch.randint(0, ncls, (Q,), generator=g)
+    q = centers[qcls] + 2.0 * torch.randn(Q, Dm, generator=g) + 0.3
+    top, keep = knn_sweep(classes.to(D), shots.to(D), q.to(D), qcls.to(D), 10, cosine)
+    ref_top = oknn.dense(classes, shots, q, cosine)
+    ref_keep = oknn.get_nn_class_confirmatory(ref_top, qcls, 10)
+    assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 2e-3
+    assert (keep.cpu() != ref_keep).float().mean() <= 2e-3
