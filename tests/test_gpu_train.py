@@ -346,3 +346,42 @@ def test_loss_scaler_backward_matches_plain_backward(monkeypatch):
     assert big.step(torch.optim.SGD(params, lr=0.1)) is False
     assert big.scale_value == 2.0 ** 39 and big.skipped_steps == 1 and torch.equal(before, params[0])
     assert K.conv_error_word(params[0].device) == 0
+
+
+@pytest.mark.parametrize("sizes", [[(333, 500), (320, 480)], [(97, 131)], [(224, 200), (160, 333), (250, 90)]])
+def test_training_step_on_ragged_image_sizes(sizes):
+    """Backward through the trunk on maps whose sizes are odd at some level (the stride-2 scatter, the 2x2 down-sum of
+    the FPN and LastLevelMaxPool's scatter all depend on them) and on batches of 1 and 3 images: finite losses, a finite
+    gradient for every trainable tensor, and the same gradients again from a second identical step (only the atomics'
+    summation order may differ)."""
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    model = _base_model()
+    g = torch.Generator().manual_seed(len(sizes))
+    batch = []
+    for i, (h, w) in enumerate(sizes):
+        n = 3
+        x1 = torch.rand(n, generator=g) * (w * 0.5)
+        y1 = torch.rand(n, generator=g) * (h * 0.5)
+        boxes = torch.stack([x1, y1, x1 + 20 + torch.rand(n, generator=g) * (w * 0.4), y1 + 20 + torch.rand(n, generator=g) * (h * 0.4)], 1)
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(boxes)
+        inst.gt_classes = torch.randint(0, 60, (n,), generator=g)
+        batch.append({"image": syn.synthetic_image(40 + i, h, w), "instances": inst, "height": h, "width": w})
+    params = [p for p in model.parameters() if p.requires_grad]
+    grads = []
+    for rep in range(2):
+        for p in params:
+            p.grad = None
+        torch.manual_seed(3)
+        with EventStorage(0):
+            losses = model(batch)
+            sum(losses.values()).backward()
+        assert all(torch.isfinite(v).all() for v in losses.values())
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        grads.append([p.grad.detach().clone() for p in params])
+    for a, b in zip(*grads):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-12
