@@ -296,6 +296,11 @@ int lvc_pack_conv_weights(const float* w, const float* scale, float* wp, int K, 
 int lvc_split_weights(const float* wp, long long n, int planes, void* out, int* err_word, void* stream);
 int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                         int K, int R, int S, int stride, int pad, int lddy, void* stream);
+/* lvc_conv_wgrad_nhwc on the two-way fp16 split MFMA path (gfx950 LDS transpose reads for the pixel-major operands).
+ * dy and x must lie inside fp16's range -- gradients scaled by a power of two (lvc_amd.solver.LossScaler); a value beyond
+ * 65504 raises bit 1 (value 2) of *err_word (the conv error word of lvc_conv_workspace; may be NULL). */
+int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
+                              int K, int R, int S, int stride, int pad, int lddy, int* err_word, void* stream);
 int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int lvc_downsum2x2_nhwc(const float* x, float* y, int N, int Hs, int Ws, int C, void* stream);
 int lvc_colsum_atomic(const float* x, int M, int N, int ldx, float* out, void* stream);

@@ -261,3 +261,197 @@ extern "C" int lvc_colsum_atomic(const float* x, int M, int Ncol, int ldx, float
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-way fp16 split form of the weight gradient (used when lvc_amd.solver.LossScaler has scaled the upstream gradients
+// into fp16's range): the same pixel-contraction GEMM on v_mfma_f32_32x32x16_f16, three MFMAs per 32x32x16 block into a
+// main (a1 b1) and a cross (a1 b2 + a2 b1, weight 2^-11) accumulator as in the forward kernels -- 833 TF/s effective peak
+// instead of the 157 TF/s of the fp32 MFMA form.
+// The obstacle is the operand layout: a 16-bit MFMA wants 8 consecutive k values (= PIXELS here) per lane, but NHWC keeps a
+// pixel's channels contiguous and pixels 2*C bytes apart.  gfx950's LDS transpose read solves it without a transposing
+// store: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4 x 16 tile whose rows the group's lanes address
+// (lane t supplies row t/4, columns 4(t%4)..+3; scripts/micro/tr_read.hip prints the mapping).  With the LDS image kept
+// [pixel][channel] exactly as it arrives from HBM, two such reads per lane yield pixels {0..3, 4..7} (lanes 0-31) and
+// {8..11, 12..15} (lanes 32-63) of channels lane % 32 -- the 32x32x16 operand.  Both operands (dY^T and X) are read this way.
+typedef _Float16 wg_f16;
+typedef _Float16 wg_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+#define WG_PITCH 144                    // fp16 elements per LDS row: 128 + 16 (288 B: 4 consecutive rows on distinct banks)
+#define WG_PLANE (32 * WG_PITCH)        // one operand plane of a 32-pixel chunk
+
+__device__ __forceinline__ wg_f16x4 wg_tr_read(unsigned addr) {
+  wg_f16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradParams p, int* __restrict__ err_word) {
+  __shared__ __attribute__((aligned(16))) wg_f16 lds[2 * 4 * WG_PLANE];   // [buffer][dY1, dY2, X1, X2][32][WG_PITCH]
+  typedef __attribute__((address_space(3))) wg_f16 lds_f16;
+  const unsigned lds_base = (unsigned)(uintptr_t)(lds_f16*)lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lid = lvc_xcd_remap(blockIdx.x, gridDim.x);
+  int t = lid % p.tiles;
+  const int split = lid / p.tiles;
+  const int ct = t % p.c_tiles; t /= p.c_tiles;
+  const int kt = t % p.k_tiles; t /= p.k_tiles;
+  const int tap = t, r = tap / p.S, s = tap % p.S;
+  const int k0 = kt * 128, c0 = ct * 128;
+  const int nchunks = (p.M + 31) >> 5;
+  const int chunk0 = split * p.chunks_per_split;
+  int chunk1 = chunk0 + p.chunks_per_split;
+  if (chunk1 > nchunks) chunk1 = nchunks;
+  if (chunk0 >= chunk1) return;
+
+  const int lrow = tid >> 5;
+  const int lcol = (tid & 31) * 4;
+  const bool k_ok = k0 + lcol < p.K, c_ok = c0 + lcol < p.C;
+  f32x4 ra[4], rb[4];
+  int range_err = 0;
+  auto load = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = chunk * 32 + lrow + 8 * i;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+      if (m < p.M) {
+        if (k_ok) a = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + k0 + lcol);
+        const int ox = m % p.Wo, q = m / p.Wo, oy = q % p.Ho, n = q / p.Ho;
+        const int iy = oy * p.stride + r - p.pad, ix = ox * p.stride + s - p.pad;
+        if (c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          b = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H + iy) * p.W + ix) * p.C + c0 + lcol);
+      }
+      ra[i] = a;
+      rb[i] = b;
+    }
+  };
+  auto split4 = [&](const f32x4& v, wg_f16x4& h, wg_f16x4& m) {
+    float big = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const wg_f16 hh = (wg_f16)v[e];
+      h[e] = hh;
+      m[e] = (wg_f16)((v[e] - (float)hh) * 2048.f);
+      big = fmaxf(big, fabsf(v[e]));
+    }
+    if (!(big <= 65504.f)) range_err = 1;
+  };
+  auto store = [&](int buf) {
+    wg_f16* base = lds + buf * 4 * WG_PLANE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = (lrow + 8 * i) * WG_PITCH + lcol;
+      wg_f16x4 h, m;
+      split4(ra[i], h, m);
+      *reinterpret_cast<wg_f16x4*>(base + o) = h;
+      *reinterpret_cast<wg_f16x4*>(base + WG_PLANE + o) = m;
+      split4(rb[i], h, m);
+      *reinterpret_cast<wg_f16x4*>(base + 2 * WG_PLANE + o) = h;
+      *reinterpret_cast<wg_f16x4*>(base + 3 * WG_PLANE + o) = m;
+    }
+  };
+
+  const int wk = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  // transpose-read address of this lane inside a 32-channel block at pixel row 0: group g = lane / 16, t = lane % 16
+  const int g = lane >> 4, tt = lane & 15;
+  const unsigned tr_off = (unsigned)(((8 * (g >> 1) + (tt >> 2)) * WG_PITCH + 16 * (g & 1) + 4 * (tt & 3)) * 2);
+  f32x16 acc[2][2], accx[2][2];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { acc[mi][ni][j] = 0.f; accx[mi][ni][j] = 0.f; }
+
+  load(chunk0);
+  store(0);
+  __syncthreads();
+  int cur = 0;
+  for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+    const bool more = chunk + 1 < chunk1;
+    if (more) load(chunk + 1);
+    const unsigned bufb = lds_base + (unsigned)(cur * 4 * WG_PLANE * 2);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const unsigned rowb = bufb + (unsigned)(ks * 16 * WG_PITCH * 2) + tr_off;
+      wg_f16x8 fa[2][2], fb[2][2];   // [32-channel block][plane]
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const unsigned aa = rowb + (unsigned)((pl * WG_PLANE + wk + blk * 32) * 2);
+          const unsigned bb = rowb + (unsigned)(((2 + pl) * WG_PLANE + wc + blk * 32) * 2);
+          const wg_f16x4 a_lo = wg_tr_read(aa), a_hi = wg_tr_read(aa + 4 * WG_PITCH * 2);
+          const wg_f16x4 b_lo = wg_tr_read(bb), b_hi = wg_tr_read(bb + 4 * WG_PITCH * 2);
+          fa[blk][pl] = wg_f16x8{a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+          fb[blk][pl] = wg_f16x8{b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], accx[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], accx[mi][ni], 0, 0, 0);
+        }
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int RS = p.R * p.S;
+  const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int k = k0 + wk + mi * 32 + 8 * (e >> 2) + 4 * half + (e & 3);
+      if (k >= p.K) continue;
+      const float sc = p.scale ? p.scale[k] : 1.f;
+      float* row = p.dw + ((size_t)k * RS + tap) * p.C;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int c = c0 + wc + ni * 32 + l31;
+        if (c < p.C) unsafeAtomicAdd(row + c, (acc[mi][ni][e] + accx[mi][ni][e] * (1.f / 2048.f)) * sc);
+      }
+    }
+  if (range_err && err_word) atomicOr(err_word, 2);
+}
+
+// lvc_conv_wgrad_nhwc on the two-way fp16 split kernel.  dy (and x) must lie inside fp16's range (|v| <= 65504; gradients
+// scaled by lvc_amd.solver.LossScaler); a value outside raises bit 1 (value 2) of *err_word (the conv error word).
+extern "C" int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W,
+                                         int C, int K, int R, int S, int stride, int pad, int lddy, int* err_word,
+                                         void* stream) {
+  LVC_CHECK_ARG(x && dy && dw, "null pointer");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "bad shape");
+  LVC_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && lddy >= K, "C, K and lddy must be multiples of 4");
+  LVC_CHECK_ARG((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) == 0, "pointers must be 16-byte aligned");
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output map");
+  const long long M64 = (long long)N * Ho * Wo;
+  LVC_CHECK_ARG(M64 < (1ll << 31) - 64, "too many output pixels");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dw, 0, (size_t)K * R * S * C * sizeof(float), st) != hipSuccess) {
+    lvc_set_error("%s: hipMemsetAsync failed", __func__);
+    return LVC_ERR_HIP;
+  }
+  WgradParams p;
+  p.x = x; p.dy = dy; p.scale = scale; p.dw = dw;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.K = K; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.lddy = lddy; p.M = (int)M64;
+  p.k_tiles = lvc_cdiv(K, 128); p.c_tiles = lvc_cdiv(C, 128);
+  const int tiles = p.k_tiles * p.c_tiles * R * S;
+  p.tiles = tiles;
+  const int nchunks = lvc_cdiv(p.M, 32);
+  int splits = lvc_cdiv(1024, tiles);
+  const int max_splits = lvc_cdiv(nchunks, 16);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.chunks_per_split = lvc_cdiv(nchunks, splits);
+  splits = lvc_cdiv(nchunks, p.chunks_per_split);
+  hipLaunchKernelGGL(conv_wgrad_f16x2_kernel, dim3(tiles * splits), dim3(256), 0, st, p, err_word);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

@@ -765,7 +765,7 @@ def colsum_rows(x2d):
     return out
 
 
-def conv_wgrad(x, dy, scale, R, S, stride, pad):
+def conv_wgrad(x, dy, scale, R, S, stride, pad, split=None):
     """dW of y = conv(x, W) (* scale per output channel): x [N,H,W,C], dy [N,Ho,Wo,K] -> [K,R,S,C] fp32."""
     _req_cuda(x, dy, scale)
     assert x.dim() == 4 and dy.dim() == 4 and x.is_contiguous() and dy.is_contiguous()
@@ -774,6 +774,12 @@ def conv_wgrad(x, dy, scale, R, S, stride, pad):
     K = dy.shape[3]
     assert dy.shape[0] == N and dy.shape[1] == (H + 2 * pad - R) // stride + 1 and dy.shape[2] == (W + 2 * pad - S) // stride + 1
     dw = torch.empty(K, R, S, C, device=x.device, dtype=torch.float32)
+    if (split or DGRAD_SPLIT) == "f16x2":   # gradients scaled into fp16's range (solver.LossScaler): fp16 MFMA path
+        check(_lib.lib().lvc_conv_wgrad_nhwc_f16x2(ptr(x), ptr(dy), ptr(scale), ptr(dw), c_int(N), c_int(H), c_int(W),
+                                                   c_int(C), c_int(K), c_int(R), c_int(S), c_int(stride), c_int(pad),
+                                                   c_int(K), ptr(_conv_error_view(x.device)), _stream(x)),
+              "lvc_conv_wgrad_nhwc_f16x2")
+        return dw
     check(_lib.lib().lvc_conv_wgrad_nhwc(ptr(x), ptr(dy), ptr(scale), ptr(dw), c_int(N), c_int(H), c_int(W), c_int(C),
                                          c_int(K), c_int(R), c_int(S), c_int(stride), c_int(pad), c_int(K), _stream(x)),
           "lvc_conv_wgrad_nhwc")

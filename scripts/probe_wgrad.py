@@ -6,6 +6,7 @@ import torch
 from lvc_amd import kernels as K
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+SPLIT = os.environ.get("WGRAD_SPLIT")   # f16x2: the fp16 MFMA form
 L = [  # name, H, W (input), C, K, R, stride
     ("res3.0.conv1 s2", 200, 336, 256, 128, 1, 2), ("res3.conv2", 100, 168, 128, 128, 3, 1), ("res3.conv3", 100, 168, 128, 512, 1, 1),
     ("res3.conv1", 100, 168, 512, 128, 1, 1), ("res4.conv2", 50, 84, 256, 256, 3, 1), ("res4.conv3", 50, 84, 256, 1024, 1, 1),
@@ -21,11 +22,11 @@ for name, H, W, C, Kc, R, st in L:
     x = torch.randn(n, H, W, C, device=dev)
     dy = torch.randn(n, Ho, Wo, Kc, device=dev)
     for _ in range(2):
-        K.conv_wgrad(x, dy, None, R, R, st, pad)
+        K.conv_wgrad(x, dy, None, R, R, st, pad, split=SPLIT)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        K.conv_wgrad(x, dy, None, R, R, st, pad)
+        K.conv_wgrad(x, dy, None, R, R, st, pad, split=SPLIT)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     fl = 2.0 * n * Ho * Wo * Kc * C * R * R

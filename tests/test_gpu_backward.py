@@ -127,3 +127,45 @@ def test_conv2d_module_backward(C, K, R, stride, pad, bn, bias, relu, res_mode, 
         assert _rel(conv.bias.grad, br.grad) < TOL
     if res is not None:
         assert _rel(rd.grad.permute(0, 3, 1, 2), rr.grad) < TOL
+
+
+@pytest.mark.parametrize("N,H,W,C,K,R,stride,pad,scaled", [
+    (2, 25, 42, 64, 64, 3, 1, 1, True),
+    (2, 51, 35, 256, 128, 1, 2, 0, True),
+    (1, 50, 84, 256, 16, 1, 1, 0, False),
+    (1, 13, 21, 256, 256, 3, 1, 1, False),
+    (300, 1, 1, 1024, 1024, 1, 1, 0, False),
+    (2, 100, 168, 128, 512, 1, 1, 0, True),
+    (1, 37, 29, 96, 36, 3, 1, 1, False),       # channel tails inside the 128-wide tiles
+])
+def test_conv_wgrad_f16x2_matches_torch(N, H, W, C, K, R, stride, pad, scaled):
+    """The fp16 MFMA form of the weight gradient (two-way operand split, LDS transpose reads) on gradients that a loss
+    scale has brought into fp16's range: same fp64 reference and the same 2e-5 bar as the fp32 MFMA form."""
+    from lvc_amd import kernels as Kn
+    g = torch.Generator().manual_seed(H * 131 + C)
+    x = torch.randn(N, C, H, W, generator=g)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    dy = torch.randn(N, K, Ho, Wo, generator=g) * 0.05 * torch.exp(2.0 * torch.randn(N, K, Ho, Wo, generator=g))   # wide range
+    scale = torch.rand(K, generator=g) + 0.5 if scaled else None
+    w = torch.zeros(K, C, R, R, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), w, stride=stride, padding=pad)
+    if scaled:
+        y = y * scale.double().view(1, -1, 1, 1)
+    (y * dy.double()).sum().backward()
+    dev = torch.device("cuda:0")
+    dw = Kn.conv_wgrad(x.permute(0, 2, 3, 1).contiguous().to(dev), dy.permute(0, 2, 3, 1).contiguous().to(dev),
+                       scale.to(dev) if scaled else None, R, R, stride, pad, split="f16x2")
+    Kn.check_conv_error_word(dev)
+    assert _rel(dw.permute(0, 3, 1, 2), w.grad) < TOL
+
+
+def test_conv_wgrad_f16x2_reports_out_of_range_gradients():
+    from lvc_amd import kernels as Kn
+    dev = torch.device("cuda:0")
+    x = torch.randn(1, 8, 8, 64, device=dev)
+    dy = torch.randn(1, 8, 8, 64, device=dev)
+    dy[0, 3, 3, 5] = 1e6
+    Kn.clear_conv_error_word(dev)
+    Kn.conv_wgrad(x, dy, None, 1, 1, 1, 0, split="f16x2")
+    assert Kn.conv_error_word(dev) & 2
+    Kn.clear_conv_error_word(dev)
