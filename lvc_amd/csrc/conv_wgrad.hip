@@ -370,30 +370,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
     const bool more = chunk + 1 < chunk1;
     if (more) load(chunk + 1);
     const unsigned bufb = lds_base + (unsigned)(cur * 4 * WG_PLANE * 2);
+    // Transpose reads are inline asm: the compiler does not know that their results arrive late.  The wait is therefore an
+    // asm that takes every fragment register as a read-write operand -- nothing that consumes a fragment (an MFMA, even a
+    // register copy) can be scheduled above it.  At most 8 reads are in flight (the LGKM counter is 4 bits wide and is
+    // shared with scalar loads, so partial counts are not usable).
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const unsigned rowb = bufb + (unsigned)(ks * 16 * WG_PITCH * 2) + tr_off;
-      wg_f16x8 fa[2][2], fb[2][2];   // [32-channel block][plane]
+      wg_f16x4 a_lo[2][2], a_hi[2][2], b_lo[2][2], b_hi[2][2];   // [32-channel block][plane]
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
           const unsigned aa = rowb + (unsigned)((pl * WG_PLANE + wk + blk * 32) * 2);
-          const unsigned bb = rowb + (unsigned)(((2 + pl) * WG_PLANE + wc + blk * 32) * 2);
-          const wg_f16x4 a_lo = wg_tr_read(aa), a_hi = wg_tr_read(aa + 4 * WG_PITCH * 2);
-          const wg_f16x4 b_lo = wg_tr_read(bb), b_hi = wg_tr_read(bb + 4 * WG_PITCH * 2);
-          fa[blk][pl] = wg_f16x8{a_lo[0], a_lo[1], a_lo[2], a_lo[3], a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
-          fb[blk][pl] = wg_f16x8{b_lo[0], b_lo[1], b_lo[2], b_lo[3], b_hi[0], b_hi[1], b_hi[2], b_hi[3]};
+          a_lo[blk][pl] = wg_tr_read(aa);
+          a_hi[blk][pl] = wg_tr_read(aa + 4 * WG_PITCH * 2);
         }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(a_lo[0][0]), "+v"(a_hi[0][0]), "+v"(a_lo[0][1]), "+v"(a_hi[0][1]), "+v"(a_lo[1][0]), "+v"(a_hi[1][0]),
+                     "+v"(a_lo[1][1]), "+v"(a_hi[1][1])
+                   :
+                   : "memory");
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          const unsigned bb = rowb + (unsigned)(((2 + pl) * WG_PLANE + wc + blk * 32) * 2);
+          b_lo[blk][pl] = wg_tr_read(bb);
+          b_hi[blk][pl] = wg_tr_read(bb + 4 * WG_PITCH * 2);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(b_lo[0][0]), "+v"(b_hi[0][0]), "+v"(b_lo[0][1]), "+v"(b_hi[0][1]), "+v"(b_lo[1][0]), "+v"(b_hi[1][0]),
+                     "+v"(b_lo[1][1]), "+v"(b_hi[1][1])
+                   :
+                   : "memory");
+      auto cat = [](const wg_f16x4& lo, const wg_f16x4& hi) { return wg_f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        const wg_f16x8 a1 = cat(a_lo[mi][0], a_hi[mi][0]), a2 = cat(a_lo[mi][1], a_hi[mi][1]);
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], accx[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
-          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], accx[mi][ni], 0, 0, 0);
+          const wg_f16x8 b1 = cat(b_lo[ni][0], b_hi[ni][0]), b2 = cat(b_lo[ni][1], b_hi[ni][1]);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, accx[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[mi][ni], 0, 0, 0);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, accx[mi][ni], 0, 0, 0);
         }
+      }
     }
     if (more) store(cur ^ 1);
     __syncthreads();
