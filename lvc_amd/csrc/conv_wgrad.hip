@@ -276,7 +276,10 @@ extern "C" int lvc_colsum_atomic(const float* x, int M, int Ncol, int ldx, float
 typedef _Float16 wg_f16;
 typedef _Float16 wg_f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
-#define WG_PITCH 144                    // fp16 elements per LDS row: 128 + 16 (288 B: 4 consecutive rows on distinct banks)
+#define WG_PITCH 128                    // fp16 elements per LDS row, unpadded: the 32-byte channel groups of row r are XOR-
+                                        // swizzled by 2 * (r & 3), so the 4 rows x 2 channel groups a 32-lane half of a transpose
+                                        // read touches fall on 8 different 8-bank groups (the padded 288-byte pitch had the two
+                                        // groups of a half collide: SQ_LDS_BANK_CONFLICT = 79 % of the LDS cycles)
 #define WG_PLANE (32 * WG_PITCH)        // one operand plane of a 32-pixel chunk
 
 __device__ __forceinline__ wg_f16x4 wg_tr_read(unsigned addr) {
@@ -308,6 +311,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
   const bool k_ok = k0 + lcol < p.K, c_ok = c0 + lcol < p.C;
   f32x4 ra[4], rb[4];
   int range_err = 0;
+  // pixel coordinates of this thread's four rows, advanced by 32 pixels per chunk (two integer divisions per row and
+  // chunk were 60 % of the kernel's VALU instructions: 22 VALU per MFMA under the counters)
+  int pn[4], py[4], px[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = chunk0 * 32 + lrow + 8 * i;
+    px[i] = m % p.Wo;
+    const int q = m / p.Wo;
+    py[i] = q % p.Ho;
+    pn[i] = q / p.Ho;
+  }
   auto load = [&](int chunk) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -315,13 +329,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
       if (m < p.M) {
         if (k_ok) a = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + k0 + lcol);
-        const int ox = m % p.Wo, q = m / p.Wo, oy = q % p.Ho, n = q / p.Ho;
-        const int iy = oy * p.stride + r - p.pad, ix = ox * p.stride + s - p.pad;
+        const int iy = py[i] * p.stride + r - p.pad, ix = px[i] * p.stride + s - p.pad;
         if (c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          b = *reinterpret_cast<const f32x4*>(p.x + (((size_t)n * p.H + iy) * p.W + ix) * p.C + c0 + lcol);
+          b = *reinterpret_cast<const f32x4*>(p.x + (((size_t)pn[i] * p.H + iy) * p.W + ix) * p.C + c0 + lcol);
       }
       ra[i] = a;
       rb[i] = b;
+      if (p.Wo >= 32) {                    // the next chunk's row: at most one wrap
+        px[i] += 32;
+        if (px[i] >= p.Wo) {
+          px[i] -= p.Wo;
+          if (++py[i] == p.Ho) { py[i] = 0; ++pn[i]; }
+        }
+      } else {                             // narrow maps (and the Linear case, Wo = 1): divide
+        const int m2 = m + 32;
+        px[i] = m2 % p.Wo;
+        const int q2 = m2 / p.Wo;
+        py[i] = q2 % p.Ho;
+        pn[i] = q2 / p.Ho;
+      }
     }
   };
   auto split4 = [&](const f32x4& v, wg_f16x4& h, wg_f16x4& m) {
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
     wg_f16* base = lds + buf * 4 * WG_PLANE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int o = (lrow + 8 * i) * WG_PITCH + lcol;
+      const int o = (lrow + 8 * i) * WG_PITCH + (lcol ^ ((lrow & 3) << 5));   // (lrow + 8 i) & 3 == lrow & 3
       wg_f16x4 h, m;
       split4(ra[i], h, m);
       *reinterpret_cast<wg_f16x4*>(base + o) = h;
@@ -353,7 +379,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
   const int wk = (wave >> 1) * 64, wc = (wave & 1) * 64;
   // transpose-read address of this lane inside a 32-channel block at pixel row 0: group g = lane / 16, t = lane % 16
   const int g = lane >> 4, tt = lane & 15;
-  const unsigned tr_off = (unsigned)(((8 * (g >> 1) + (tt >> 2)) * WG_PITCH + 16 * (g & 1) + 4 * (tt & 3)) * 2);
+  // row of the tile this lane addresses: 8 * (g / 2) + tt / 4 (+4, +16 for the other reads: row & 3 == tt / 4 throughout)
+  const unsigned tr_row = (unsigned)((8 * (g >> 1) + (tt >> 2)) * WG_PITCH * 2);
+  unsigned tr_a[2], tr_b[2];   // byte offsets of the lane's swizzled column inside a row, per 32-channel block
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    tr_a[blk] = (unsigned)(((wk + blk * 32 + 16 * (g & 1) + 4 * (tt & 3)) ^ ((tt >> 2) << 5)) * 2);
+    tr_b[blk] = (unsigned)(((wc + blk * 32 + 16 * (g & 1) + 4 * (tt & 3)) ^ ((tt >> 2) << 5)) * 2);
+  }
   f32x16 acc[2][2], accx[2][2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
@@ -376,13 +409,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
     // shared with scalar loads, so partial counts are not usable).
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const unsigned rowb = bufb + (unsigned)(ks * 16 * WG_PITCH * 2) + tr_off;
+      const unsigned rowb = bufb + (unsigned)(ks * 16 * WG_PITCH * 2) + tr_row;
       wg_f16x4 a_lo[2][2], a_hi[2][2], b_lo[2][2], b_hi[2][2];   // [32-channel block][plane]
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-          const unsigned aa = rowb + (unsigned)((pl * WG_PLANE + wk + blk * 32) * 2);
+          const unsigned aa = rowb + (unsigned)(pl * WG_PLANE * 2) + tr_a[blk];
           a_lo[blk][pl] = wg_tr_read(aa);
           a_hi[blk][pl] = wg_tr_read(aa + 4 * WG_PITCH * 2);
         }
@@ -395,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-          const unsigned bb = rowb + (unsigned)(((2 + pl) * WG_PLANE + wc + blk * 32) * 2);
+          const unsigned bb = rowb + (unsigned)((2 + pl) * WG_PLANE * 2) + tr_b[blk];
           b_lo[blk][pl] = wg_tr_read(bb);
           b_hi[blk][pl] = wg_tr_read(bb + 4 * WG_PITCH * 2);
         }
