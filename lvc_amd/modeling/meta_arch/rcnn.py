@@ -249,12 +249,23 @@ class ProposalNetwork(_RCNNBase):
         self.proposal_generator = build_proposal_generator(cfg, self.backbone.output_shape())
         self.to(self.device)
 
-    def forward(self, batched_inputs):
-        if self.training:
-            raise NotImplementedError("ProposalNetwork training is not implemented in lvc_amd round 1")
+    def forward(self, batched_inputs, no_post=False):
+        """reference rcnn.py:433-480: training -> the RPN losses; `no_post` -> (proposals, images) as they are."""
         images = self.preprocess_image(batched_inputs)
-        features = self.backbone(images.tensor)
-        proposals, _ = self.proposal_generator(images, features, None)
+        with torch.set_grad_enabled(self.training and torch.is_grad_enabled()
+                                    and any(p.requires_grad for p in self.backbone.parameters())):
+            features = self.backbone(images.tensor)
+        if "instances" in batched_inputs[0]:
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        elif "targets" in batched_inputs[0]:
+            gt_instances = [x["targets"].to(self.device) for x in batched_inputs]
+        else:
+            gt_instances = None
+        proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
+        if no_post:
+            return proposals, images
+        if self.training:
+            return proposal_losses
         processed = []
         for r, inp, size in zip(proposals, batched_inputs, images.image_sizes):
             processed.append({"proposals": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))})

@@ -385,3 +385,38 @@ def test_training_step_on_ragged_image_sizes(sizes):
     for a, b in zip(*grads):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * scale + 1e-12
+
+
+def test_proposal_network_training_equals_rpn_part_of_the_detector(monkeypatch):
+    """ProposalNetwork (reference rcnn.py:413-488) in training returns the RPN losses; with the detector's weights they and
+    the gradients of the RPN head / FPN / trunk they induce equal the detector's RPN terms (golden: train_base.npz holds
+    the full detector's step, whose RPN losses do not depend on the RoI heads)."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_base")
+    det = _base_model()
+    cfg = base_rcnn_fpn(num_classes=60)
+    cfg.MODEL.META_ARCHITECTURE = "ProposalNetwork"
+    net = build_model(cfg).train()
+    own = net.state_dict()
+    net.load_state_dict({k: v for k, v in det.state_dict().items() if k in own}, strict=True)
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with EventStorage(0):
+        losses = net(_batch(g))
+        assert set(losses) == {"loss_rpn_cls", "loss_rpn_loc"}
+        sum(losses.values()).backward()
+    for k in ("loss_rpn_cls", "loss_rpn_loc"):
+        assert abs(float(losses[k].detach()) - float(g["loss." + k])) <= 2e-4 * max(1.0, abs(float(g["loss." + k])))
+    for name in ("proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.objectness_logits.bias",
+                 "proposal_generator.rpn_head.anchor_deltas.weight"):
+        p = dict(net.named_parameters())[name]
+        s, nrm, stride = [float(v) for v in g["grad_stats." + name]]
+        assert abs(float(p.grad.double().norm()) - nrm) <= 1e-3 * nrm, name     # the RPN head sees only the RPN losses
+    assert dict(net.named_parameters())["backbone.fpn_output2.weight"].grad is not None
+    net.eval()
+    with torch.no_grad():
+        out = net([{"image": _batch(g)[0]["image"], "height": 240, "width": 320}])
+    assert "proposals" in out[0] and len(out[0]["proposals"]) > 0
