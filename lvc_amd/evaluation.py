@@ -45,6 +45,12 @@ class PipelinedInference:
         (ob, osc, ocl, cnt, status), s, sizes = ticket
         with torch.cuda.stream(s):
             insts = instances_from_batched(ob, osc, ocl, cnt, sizes, status)   # one D2H read on that stream
+        # the results were allocated and written on the side stream: order the caller's stream behind it and tell the
+        # caching allocator that the caller's stream uses them too
+        cur = torch.cuda.current_stream(self.model.device)
+        cur.wait_stream(s)
+        for t in (ob, osc, ocl, cnt):
+            t.record_stream(cur)
         return [{"instances": r} for r in insts]
 
     def synchronize(self):

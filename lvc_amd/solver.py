@@ -55,6 +55,12 @@ class LossScaler:
         word = K.conv_error_word(device) if device is not None else 0
         if word & 1:
             K.check_conv_error_word(device)        # stream-K timeout: not a scaling matter
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # data parallel: every rank must take the same decision (one rank's overflow skips the step everywhere)
+            flag = torch.tensor([float(word & 2)], device=device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if float(flag.item()) > 0:
+                word |= 2
         if word & 2:
             K.clear_conv_error_word(device)
             for p in params:

@@ -494,3 +494,45 @@ def test_resize_host_tables_match_oracle():
             float((tfm.apply_box(g["box_in%d" % i]) - g["box_out%d" % i]).abs().max()) <= 1e-5
     with pytest.raises(RuntimeError):
         ResizeTransform(4, 4, 8, 8).apply_image(torch.zeros(4, 4, 3, dtype=torch.uint8))   # no CPU path
+
+
+def _scaler_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from lvc_amd import kernels as K
+    from lvc_amd.solver import LossScaler
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # the kernels' error word lives on the device; on CPU the two accessors are stubbed so that only rank 1 "overflows"
+        K.conv_error_word = lambda device: 2 if rank == 1 else 0
+        K.clear_conv_error_word = lambda device: None
+        w = torch.nn.Parameter(torch.ones(3))
+        opt = torch.optim.SGD([w], lr=1.0)
+        sc = LossScaler(init_scale=2.0 ** 4)
+        (w.sum() * sc.scale_value).backward()
+        took = sc.step(opt, params=[w], device=torch.device("cpu"))
+        q.put((rank, took, sc.scale_value, w.detach().tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_loss_scaler_overflow_decision_is_shared_across_ranks():
+    """Data parallel: an out-of-range operand seen by ONE rank must skip the optimizer step and halve the scale on EVERY
+    rank (otherwise the replicas diverge)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_scaler_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, took, scale, w in res:
+        assert took is False and scale == 8.0 and w == [1.0, 1.0, 1.0], (rank, took, scale, w)
