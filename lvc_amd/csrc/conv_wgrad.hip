@@ -288,7 +288,11 @@ __device__ __forceinline__ wg_f16x4 wg_tr_read(unsigned addr) {
   return v;
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradParams p, int* __restrict__ err_word) {
+// BUF: both tensors are smaller than 2 GiB, so the loader uses buffer loads whose out-of-range offset returns zeros: no
+// divergent branch around each of the eight requests of a chunk and 32-bit address arithmetic.
+template <bool BUF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradParams p, int* __restrict__ err_word,
+                                                                  unsigned x_bytes, unsigned dy_bytes) {
   __shared__ __attribute__((aligned(16))) wg_f16 lds[2 * 4 * WG_PLANE];   // [buffer][dY1, dY2, X1, X2][32][WG_PITCH]
   typedef __attribute__((address_space(3))) wg_f16 lds_f16;
   const unsigned lds_base = (unsigned)(uintptr_t)(lds_f16*)lds;
@@ -311,6 +315,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
   const bool k_ok = k0 + lcol < p.K, c_ok = c0 + lcol < p.C;
   f32x4 ra[4], rb[4];
   int range_err = 0;
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, BUF ? x_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, BUF ? dy_bytes : 0, 0x00020000);
   // pixel coordinates of this thread's four rows, advanced by 32 pixels per chunk (two integer divisions per row and
   // chunk were 60 % of the kernel's VALU instructions: 22 VALU per MFMA under the counters)
   int pn[4], py[4], px[4];
@@ -327,7 +333,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
     for (int i = 0; i < 4; ++i) {
       const int m = chunk * 32 + lrow + 8 * i;
       f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) {
+      if constexpr (BUF) {
+        const int iy = py[i] * p.stride + r - p.pad, ix = px[i] * p.stride + s - p.pad;
+        const bool okm = m < p.M;
+        const bool okx = okm && c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const unsigned ao = (okm && k_ok) ? (unsigned)(m * p.lddy + k0 + lcol) * 4u : 0x80000000u;
+        const unsigned bo = okx ? (unsigned)(((pn[i] * p.H + iy) * p.W + ix) * p.C + c0 + lcol) * 4u : 0x80000000u;
+        a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, ao, 0, 0));
+        b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bo, 0, 0));
+      } else if (m < p.M) {
         if (k_ok) a = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + k0 + lcol);
         const int iy = py[i] * p.stride + r - p.pad, ix = px[i] * p.stride + s - p.pad;
         if (c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
@@ -506,7 +520,12 @@ extern "C" int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const 
   if (splits < 1) splits = 1;
   p.chunks_per_split = lvc_cdiv(nchunks, splits);
   splits = lvc_cdiv(nchunks, p.chunks_per_split);
-  hipLaunchKernelGGL(conv_wgrad_f16x2_kernel, dim3(tiles * splits), dim3(256), 0, st, p, err_word);
+  const long long xb = (long long)N * H * W * C * 4, dyb = M64 * lddy * 4;
+  if (xb < (1ll << 31) && dyb < (1ll << 31))
+    hipLaunchKernelGGL(conv_wgrad_f16x2_kernel<true>, dim3(tiles * splits), dim3(256), 0, st, p, err_word, (unsigned)xb,
+                       (unsigned)dyb);
+  else
+    hipLaunchKernelGGL(conv_wgrad_f16x2_kernel<false>, dim3(tiles * splits), dim3(256), 0, st, p, err_word, 0u, 0u);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
