@@ -270,7 +270,8 @@ extern "C" int lvc_colsum_atomic(const float* x, int M, int Ncol, int ldx, float
 // The obstacle is the operand layout: a 16-bit MFMA wants 8 consecutive k values (= PIXELS here) per lane, but NHWC keeps a
 // pixel's channels contiguous and pixels 2*C bytes apart.  gfx950's LDS transpose read solves it without a transposing
 // store: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4 x 16 tile whose rows the group's lanes address
-// (lane t supplies row t/4, columns 4(t%4)..+3; scripts/micro/tr_read.hip prints the mapping).  With the LDS image kept
+// (lane t supplies row t/4, columns 4(t%4)..+3; scripts/micro/tr_read.hip prints the mapping; the kernel uses the compiler
+// builtin __builtin_amdgcn_ds_read_tr16_b64_v4f16, so waits and scheduling are the compiler's).  With the LDS image kept
 // [pixel][channel] exactly as it arrives from HBM, two such reads per lane yield pixels {0..3, 4..7} (lanes 0-31) and
 // {8..11, 12..15} (lanes 32-63) of channels lane % 32 -- the 32x32x16 operand.  Both operands (dY^T and X) are read this way.
 typedef _Float16 wg_f16;
@@ -282,10 +283,12 @@ typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
                                         // groups of a half collide: SQ_LDS_BANK_CONFLICT = 79 % of the LDS cycles)
 #define WG_PLANE (32 * WG_PITCH)        // one operand plane of a 32-pixel chunk
 
-__device__ __forceinline__ wg_f16x4 wg_tr_read(unsigned addr) {
-  wg_f16x4 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-  return v;
+// the compiler's own builtin for the transpose read: it tracks the read like any LDS load (waits, scheduling under MFMAs)
+typedef __fp16 wg_fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) wg_fp16x4 wg_lds_fp16x4;
+typedef __attribute__((address_space(3))) char wg_lds_char;
+__device__ __forceinline__ wg_f16x4 wg_tr_read(const wg_lds_char* base, unsigned byte_off) {
+  return __builtin_bit_cast(wg_f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((wg_lds_fp16x4*)(base + byte_off)));
 }
 
 // BUF: both tensors are smaller than 2 GiB, so the loader uses buffer loads whose out-of-range offset returns zeros: no
@@ -294,8 +297,7 @@ template <bool BUF>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradParams p, int* __restrict__ err_word,
                                                                   unsigned x_bytes, unsigned dy_bytes) {
   __shared__ __attribute__((aligned(16))) wg_f16 lds[2 * 4 * WG_PLANE];   // [buffer][dY1, dY2, X1, X2][32][WG_PITCH]
-  typedef __attribute__((address_space(3))) wg_f16 lds_f16;
-  const unsigned lds_base = (unsigned)(uintptr_t)(lds_f16*)lds;
+  const wg_lds_char* lds3 = (const wg_lds_char*)lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lid = lvc_xcd_remap(blockIdx.x, gridDim.x);
   int t = lid % p.tiles;
@@ -416,53 +418,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
   for (int chunk = chunk0; chunk < chunk1; ++chunk) {
     const bool more = chunk + 1 < chunk1;
     if (more) load(chunk + 1);
-    const unsigned bufb = lds_base + (unsigned)(cur * 4 * WG_PLANE * 2);
-    // Transpose reads are inline asm: the compiler does not know that their results arrive late.  The wait is therefore an
-    // asm that takes every fragment register as a read-write operand -- nothing that consumes a fragment (an MFMA, even a
-    // register copy) can be scheduled above it.  At most 8 reads are in flight (the LGKM counter is 4 bits wide and is
-    // shared with scalar loads, so partial counts are not usable).
+    const unsigned bufb = (unsigned)(cur * 4 * WG_PLANE * 2);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const unsigned rowb = bufb + (unsigned)(ks * 16 * WG_PITCH * 2) + tr_row;
-      wg_f16x4 a_lo[2][2], a_hi[2][2], b_lo[2][2], b_hi[2][2];   // [32-channel block][plane]
+      wg_f16x8 fa[2][2], fb[2][2];   // [32-channel block][plane]
+      auto cat = [](const wg_f16x4& lo, const wg_f16x4& hi) { return wg_f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
           const unsigned aa = rowb + (unsigned)(pl * WG_PLANE * 2) + tr_a[blk];
-          a_lo[blk][pl] = wg_tr_read(aa);
-          a_hi[blk][pl] = wg_tr_read(aa + 4 * WG_PITCH * 2);
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(a_lo[0][0]), "+v"(a_hi[0][0]), "+v"(a_lo[0][1]), "+v"(a_hi[0][1]), "+v"(a_lo[1][0]), "+v"(a_hi[1][0]),
-                     "+v"(a_lo[1][1]), "+v"(a_hi[1][1])
-                   :
-                   : "memory");
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
           const unsigned bb = rowb + (unsigned)((2 + pl) * WG_PLANE * 2) + tr_b[blk];
-          b_lo[blk][pl] = wg_tr_read(bb);
-          b_hi[blk][pl] = wg_tr_read(bb + 4 * WG_PITCH * 2);
+          fa[blk][pl] = cat(wg_tr_read(lds3, aa), wg_tr_read(lds3, aa + 4 * WG_PITCH * 2));
+          fb[blk][pl] = cat(wg_tr_read(lds3, bb), wg_tr_read(lds3, bb + 4 * WG_PITCH * 2));
         }
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(b_lo[0][0]), "+v"(b_hi[0][0]), "+v"(b_lo[0][1]), "+v"(b_hi[0][1]), "+v"(b_lo[1][0]), "+v"(b_hi[1][0]),
-                     "+v"(b_lo[1][1]), "+v"(b_hi[1][1])
-                   :
-                   : "memory");
-      auto cat = [](const wg_f16x4& lo, const wg_f16x4& hi) { return wg_f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]}; };
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const wg_f16x8 a1 = cat(a_lo[mi][0], a_hi[mi][0]), a2 = cat(a_lo[mi][1], a_hi[mi][1]);
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const wg_f16x8 b1 = cat(b_lo[ni][0], b_hi[ni][0]), b2 = cat(b_lo[ni][1], b_hi[ni][1]);
-          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, accx[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[mi][ni], 0, 0, 0);
-          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, accx[mi][ni], 0, 0, 0);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], accx[mi][ni], 0, 0, 0);
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+          accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], accx[mi][ni], 0, 0, 0);
         }
-      }
     }
     if (more) store(cur ^ 1);
     __syncthreads();
