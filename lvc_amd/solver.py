@@ -78,3 +78,129 @@ class LossScaler:
             self.scale_value *= 2.0
             self._good_steps = 0
         return True
+
+
+# ---- optimizer / learning-rate schedule (host side; reference detectron2/solver/build.py, lr_scheduler.py) -----------
+_NORM_TYPES = (torch.nn.modules.batchnorm._BatchNorm, torch.nn.GroupNorm, torch.nn.modules.instancenorm._InstanceNorm,
+               torch.nn.LayerNorm, torch.nn.LocalResponseNorm)
+
+
+def parameter_groups(cfg, model):
+    """One group per trainable parameter, as the reference builds them (detectron2/solver/build.py:110-131): weights
+    of normalisation modules decay by WEIGHT_DECAY_NORM, parameters NAMED "bias" train at BASE_LR * BIAS_LR_FACTOR and
+    decay by WEIGHT_DECAY_BIAS, everything else at BASE_LR / WEIGHT_DECAY.  A parameter shared by two modules is
+    listed once, under the first module that owns it."""
+    s = cfg.SOLVER
+    groups, seen = [], set()
+    for module in model.modules():
+        is_norm = isinstance(module, _NORM_TYPES)
+        for name, p in module.named_parameters(recurse=False):
+            if not p.requires_grad or id(p) in seen:
+                continue
+            seen.add(id(p))
+            lr, wd = s.BASE_LR, s.WEIGHT_DECAY
+            if is_norm:
+                wd = s.WEIGHT_DECAY_NORM
+            elif name == "bias":
+                lr, wd = s.BASE_LR * s.BIAS_LR_FACTOR, s.WEIGHT_DECAY_BIAS
+            groups.append({"params": [p], "lr": lr, "weight_decay": wd})
+    return groups
+
+
+class _ClippedSGD(torch.optim.SGD):
+    """SGD whose step first clips every parameter's gradient on its own (the reference clips per parameter, not over
+    the whole model: detectron2/solver/build.py:46-51)."""
+    clip_type, clip_value, norm_type = "value", 1.0, 2.0
+
+    def step(self, closure=None):
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if self.clip_type == "value":
+                    p.grad.clamp_(-self.clip_value, self.clip_value)
+                else:
+                    torch.nn.utils.clip_grad_norm_(p, self.clip_value, self.norm_type)
+        return super().step(closure)
+
+
+def build_optimizer(cfg, model):
+    """torch SGD over `parameter_groups` (detectron2/solver/build.py:93-136); SOLVER.CLIP_GRADIENTS.ENABLED adds the
+    per-parameter clip in front of every step (ibid. 59-91)."""
+    s = cfg.SOLVER
+    clip = s.CLIP_GRADIENTS
+    if clip.ENABLED:
+        if clip.CLIP_TYPE not in ("value", "norm"):
+            raise ValueError("'{}' is not a valid GradientClipType".format(clip.CLIP_TYPE))
+        opt = _ClippedSGD(parameter_groups(cfg, model), s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV)
+        opt.clip_type, opt.clip_value, opt.norm_type = clip.CLIP_TYPE, float(clip.CLIP_VALUE), float(clip.NORM_TYPE)
+        return opt
+    return torch.optim.SGD(parameter_groups(cfg, model), s.BASE_LR, momentum=s.MOMENTUM, nesterov=s.NESTEROV)
+
+
+def warmup_factor_at_iter(method, it, warmup_iters, warmup_factor):
+    """detectron2/solver/lr_scheduler.py:90-116: 1 after the warmup; during it `warmup_factor` ("constant") or the
+    line from `warmup_factor` at iteration 0 to 1 at `warmup_iters` ("linear")."""
+    if it >= warmup_iters:
+        return 1.0
+    if method == "constant":
+        return warmup_factor
+    if method == "linear":
+        a = it / warmup_iters
+        return warmup_factor * (1 - a) + a
+    raise ValueError("Unknown warmup method: {}".format(method))
+
+
+class _WarmupLR(torch.optim.lr_scheduler._LRScheduler):
+    def __init__(self, optimizer, warmup_factor, warmup_iters, warmup_method, last_epoch=-1):
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        super().__init__(optimizer, last_epoch)
+
+    def _decay(self, it):
+        raise NotImplementedError
+
+    def get_lr(self):
+        f = warmup_factor_at_iter(self.warmup_method, self.last_epoch, self.warmup_iters, self.warmup_factor)
+        d = self._decay(self.last_epoch)
+        return [base * f * d for base in self.base_lrs]
+
+    _compute_values = get_lr
+
+
+class WarmupMultiStepLR(_WarmupLR):
+    """lr = base * warmup * gamma^(number of milestones <= iteration) (detectron2/solver/lr_scheduler.py:15-48)."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=0.001, warmup_iters=1000,
+                 warmup_method="linear", last_epoch=-1):
+        milestones = list(milestones)
+        if milestones != sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+        self.milestones, self.gamma = milestones, gamma
+        super().__init__(optimizer, warmup_factor, warmup_iters, warmup_method, last_epoch)
+
+    def _decay(self, it):
+        return self.gamma ** sum(1 for m in self.milestones if m <= it)
+
+
+class WarmupCosineLR(_WarmupLR):
+    """lr = base * warmup * (1 + cos(pi * iteration / max_iters)) / 2 (detectron2/solver/lr_scheduler.py:51-87)."""
+
+    def __init__(self, optimizer, max_iters, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear",
+                 last_epoch=-1):
+        self.max_iters = max_iters
+        super().__init__(optimizer, warmup_factor, warmup_iters, warmup_method, last_epoch)
+
+    def _decay(self, it):
+        import math
+        return 0.5 * (1.0 + math.cos(math.pi * it / self.max_iters))
+
+
+def build_lr_scheduler(cfg, optimizer):
+    """detectron2/solver/build.py:139-165."""
+    s = cfg.SOLVER
+    kw = dict(warmup_factor=s.WARMUP_FACTOR, warmup_iters=s.WARMUP_ITERS, warmup_method=s.WARMUP_METHOD)
+    if s.LR_SCHEDULER_NAME == "WarmupMultiStepLR":
+        return WarmupMultiStepLR(optimizer, s.STEPS, s.GAMMA, **kw)
+    if s.LR_SCHEDULER_NAME == "WarmupCosineLR":
+        return WarmupCosineLR(optimizer, s.MAX_ITER, **kw)
+    raise ValueError("Unknown LR scheduler: {}".format(s.LR_SCHEDULER_NAME))

@@ -805,10 +805,90 @@ def gen_resize():
     save("resize", **d)
 
 
+def gen_solver():
+    """Optimizer parameter groups and learning-rate schedules (SURVEY 8 rows 19/20's host side): the reference's
+    build_optimizer on a toy model holding every parameter kind the rules distinguish (conv weight, conv bias, norm
+    weight/bias, a frozen parameter, a shared parameter), three SGD steps with value and norm clipping, and the
+    per-iteration lr of build_lr_scheduler for the shipped schedules."""
+    from detectron2.config import get_cfg
+    from detectron2.solver import build_lr_scheduler, build_optimizer
+
+    def toy():
+        torch.manual_seed(3)
+        m = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.BatchNorm2d(4), torch.nn.ReLU(),
+                                torch.nn.Conv2d(4, 4, 1, bias=False), torch.nn.GroupNorm(2, 4), torch.nn.Flatten(),
+                                torch.nn.Linear(4 * 6 * 6, 5), torch.nn.Linear(5, 5),
+                                torch.nn.Linear(5, 5, bias=False))
+        m[8].weight = m[7].weight            # shared: listed once
+        m[7].bias.requires_grad_(False)      # frozen: not listed
+        return m
+
+    d = {}
+    solver_cases = [
+        dict(BASE_LR=0.02, WEIGHT_DECAY=1e-4, WEIGHT_DECAY_NORM=0.0, BIAS_LR_FACTOR=2.0, WEIGHT_DECAY_BIAS=0.0,
+             MOMENTUM=0.9, NESTEROV=False, clip=None),
+        dict(BASE_LR=0.01, WEIGHT_DECAY=5e-4, WEIGHT_DECAY_NORM=1e-5, BIAS_LR_FACTOR=1.0, WEIGHT_DECAY_BIAS=5e-4,
+             MOMENTUM=0.8, NESTEROV=True, clip=("value", 0.01, 2.0)),
+        dict(BASE_LR=0.05, WEIGHT_DECAY=1e-4, WEIGHT_DECAY_NORM=0.0, BIAS_LR_FACTOR=1.0, WEIGHT_DECAY_BIAS=1e-4,
+             MOMENTUM=0.9, NESTEROV=False, clip=("norm", 0.05, 2.0)),
+    ]
+    x = torch.randn(2, 3, 6, 6, generator=torch.Generator().manual_seed(1))
+    for i, c in enumerate(solver_cases):
+        cfg = get_cfg()
+        for k, v in c.items():
+            if k != "clip":
+                setattr(cfg.SOLVER, k, v)
+        if c["clip"]:
+            cfg.SOLVER.CLIP_GRADIENTS.ENABLED = True
+            cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE, cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE, cfg.SOLVER.CLIP_GRADIENTS.NORM_TYPE = c["clip"]
+        m = toy()
+        opt = build_optimizer(cfg, m)
+        d["groups%d" % i] = np.array([[g["lr"], g["weight_decay"], g["momentum"], float(g["nesterov"]),
+                                       g["params"][0].numel()] for g in opt.param_groups], np.float64)
+        for _ in range(3):
+            opt.zero_grad()
+            (m(x) ** 2).sum().backward()
+            opt.step()
+        d["after%d" % i] = np.concatenate([p.detach().reshape(-1).numpy() for p in m.parameters()]).astype(np.float32)
+        d["case%d" % i] = np.array([c[k] for k in ("BASE_LR", "WEIGHT_DECAY", "WEIGHT_DECAY_NORM", "BIAS_LR_FACTOR",
+                                                   "WEIGHT_DECAY_BIAS", "MOMENTUM")] + [float(c["NESTEROV"])]
+                                   + ([{"value": 1.0, "norm": 2.0}[c["clip"][0]], c["clip"][1], c["clip"][2]]
+                                      if c["clip"] else [0.0, 0.0, 0.0]), np.float64)
+    d["x"] = x.numpy()
+    d["n_solver"] = np.int64(len(solver_cases))
+
+    sched_cases = [
+        ("WarmupMultiStepLR", 0.02, (60, 80), 0.1, 90, 0.001, 20, "linear"),
+        ("WarmupMultiStepLR", 0.001, (30,), 0.5, 50, 0.1, 10, "constant"),
+        ("WarmupMultiStepLR", 0.01, (5, 7), 0.1, 30, 0.001, 10, "linear"),      # a milestone inside the warmup
+        ("WarmupMultiStepLR", 0.01, (20,), 0.1, 30, 0.001, 0, "linear"),        # no warmup
+        ("WarmupCosineLR", 0.04, (30,), 0.1, 64, 0.01, 16, "linear"),
+    ]
+    for i, (name, lr, steps, gamma, max_iter, wf, wi, wm) in enumerate(sched_cases):
+        cfg = get_cfg()
+        cfg.SOLVER.LR_SCHEDULER_NAME, cfg.SOLVER.BASE_LR, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA = name, lr, steps, gamma
+        cfg.SOLVER.MAX_ITER, cfg.SOLVER.WARMUP_FACTOR, cfg.SOLVER.WARMUP_ITERS, cfg.SOLVER.WARMUP_METHOD = max_iter, wf, wi, wm
+        cfg.SOLVER.BIAS_LR_FACTOR = 2.0
+        m = torch.nn.Linear(3, 2)
+        opt = build_optimizer(cfg, m)
+        sch = build_lr_scheduler(cfg, opt)
+        lrs = []
+        for _ in range(max_iter):
+            lrs.append([g["lr"] for g in opt.param_groups])
+            opt.step()
+            sch.step()
+        d["lrs%d" % i] = np.array(lrs, np.float64)
+        d["sched%d" % i] = np.array([{"WarmupMultiStepLR": 0.0, "WarmupCosineLR": 1.0}[name], lr, gamma, max_iter, wf, wi,
+                                     {"linear": 0.0, "constant": 1.0}[wm]], np.float64)
+        d["steps%d" % i] = np.array(steps, np.int64)
+    d["n_sched"] = np.int64(len(sched_cases))
+    save("solver", **d)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "r101"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()
