@@ -46,6 +46,8 @@ struct HaloArgsH {
   int N, H, W, C, K, relu, res_mode, ldy, ldr;
   int PH, PW, HW, HP, MP;    // patch rows / cols, halo row pitch (PW + 2), halo pixels, patch pixels
   int tiles_x, tiles_y, tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
+  int ngroup;   // > 1: workers lw, lw+1, .., lw+ngroup-1 (neighbours on one XCD) walk the SAME pixel tiles, one output-channel
+                // tile each, so a halo patch is fetched from the fabric once and served to the others by that XCD's L2
   int x_bytes, w_plane_bytes;
 };
 
@@ -88,7 +90,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_h2_kernel(HaloArgsH p) {
   const int b_pl0 = NI == 2 ? 0 : (tid >> 8);         // plane of piece i: b_pl0 + i
 
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
-  int u = lw * p.units_per_worker;
+  const int wq = p.ngroup > 1 ? lw / p.ngroup : lw;          // position in the unit space
+  const int wsel = p.ngroup > 1 ? lw - wq * p.ngroup : 0;    // output-channel tile of a grouped worker
+  int u = wq * p.units_per_worker;
   const int u_end = min(u + p.units_per_worker, p.total_units);
 
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_h2_kernel(HaloArgsH p) {
     const int tile = u / p.nk;
     const int cc0 = u - tile * p.nk;
     const int cc1 = min(p.nk, cc0 + (u_end - u));
-    const int tile_n = tile % p.tiles_n;
-    const int tile_m = tile / p.tiles_n;
+    const int tile_n = p.ngroup > 1 ? wsel : tile % p.tiles_n;
+    const int tile_m = p.ngroup > 1 ? tile : tile / p.tiles_n;
     const int tx = tile_m % p.tiles_x;
     const int t2 = tile_m / p.tiles_x;
     const int ty = t2 % p.tiles_y;
@@ -289,8 +293,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_h2_kernel(HaloArgsH p) {
     }
     if (cc1 < p.nk) {
       const int last_unit = tile * p.nk + p.nk - 1;
-      const int last_worker = last_unit / p.units_per_worker;
-      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+      const int wstep = p.ngroup > 1 ? p.ngroup : 1;
+      const int last_worker = (last_unit / p.units_per_worker) * wstep + wsel;
+      for (int pw = lw + wstep; pw <= last_worker; pw += wstep) {
         if (tid == 0) {
           int spins = 0;
           while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -428,9 +433,19 @@ extern "C" int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_sp
   }
   int cap = g_cus_halo_h;  // one worker per CU: 150 KB of LDS per workgroup
   if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
+  // Two or four output-channel tiles: the workers of a group share their pixel tiles (see HaloArgsH::ngroup); the unit
+  // space is then pixel tiles x chunks only.  LVC_HALO_NGROUP=0 restores the one-worker-walks-all-channel-tiles order.
+  a.ngroup = 1;
+  static const int ngroup_on = [] { const char* e = getenv("LVC_HALO_NGROUP"); return e ? atoi(e) : 1; }();
+  if (ngroup_on && (a.tiles_n == 2 || a.tiles_n == 4) && cap % a.tiles_n == 0 && units / a.tiles_n >= cap / a.tiles_n) {
+    a.ngroup = a.tiles_n;
+    units /= a.tiles_n;
+    cap /= a.tiles_n;
+    a.total_units = (int)units;
+  }
   int workers = (int)(units < cap ? units : cap);
   a.units_per_worker = (int)((units + workers - 1) / workers);
-  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker);
+  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker) * a.ngroup;
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;

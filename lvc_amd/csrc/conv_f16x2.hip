@@ -34,6 +34,7 @@ struct ConvArgsH {
   int* flags;
   int N, H, W, C, K, R, S, stride, pad, Ho, Wo, M, Kg, relu, res_mode, ldy, ldr;
   int tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
+  int ngroup;                   // conv_pw256_f16x2_kernel: workers per row-tile group (1 = ungrouped)
   int x_bytes, w_plane_bytes;   // bytes of the input tensor / of ONE weight plane
 };
 
@@ -431,7 +432,13 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_f16x2_kernel(ConvArgsH p) {
   const int b_frag = (wn * NI * 32 + fi) * 32;
 
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
-  int u = lw * p.units_per_worker;
+  // ngroup > 1: the workers lw .. lw + ngroup - 1 (neighbours on one XCD) walk the same row tiles, one output-channel tile
+  // each, so an activation tile comes from the fabric once and from that XCD's L2 for the others
+  const int wq = p.ngroup > 1 ? lw / p.ngroup : lw;
+  const int wsel = p.ngroup > 1 ? lw - wq * p.ngroup : 0;
+  auto tile_n_of = [&](int tile) { return p.ngroup > 1 ? wsel : tile % p.tiles_n; };
+  auto tile_m_of = [&](int tile) { return p.ngroup > 1 ? tile : tile / p.tiles_n; };
+  int u = wq * p.units_per_worker;
   const int u_end = min(u + p.units_per_worker, p.total_units);
 
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -445,10 +452,10 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_f16x2_kernel(ConvArgsH p) {
   int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
   unsigned l_aoff[4];
   int lb = u, lb_kc = l_kc;
-  unsigned l_bbase = (unsigned)((l_tile % p.tiles_n) * GBN);   // first weight row of the loader's tile
+  unsigned l_bbase = (unsigned)(tile_n_of(l_tile) * GBN);   // first weight row of the loader's tile
   auto loader_enter = [&](int tile, int kc) {
     l_tile = tile; l_kc = kc;
-    const int m0 = (tile / p.tiles_n) * G_BM;
+    const int m0 = tile_m_of(tile) * G_BM;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = m0 + rslot + 64 * j;
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_f16x2_kernel(ConvArgsH p) {
     if (lb < u_end) {
       if (lb_kc == p.nk) {
         lb_kc = 0;
-        l_bbase = (unsigned)(((lb / p.nk) % p.tiles_n) * GBN);
+        l_bbase = (unsigned)(tile_n_of(lb / p.nk) * GBN);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i)
@@ -521,8 +528,8 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_f16x2_kernel(ConvArgsH p) {
     const int tile = u / p.nk;
     const int kc0 = u - tile * p.nk;
     const int kc1 = min(p.nk, kc0 + (u_end - u));
-    const int tile_n = tile % p.tiles_n;
-    const int tile_m = tile / p.tiles_n;
+    const int tile_n = tile_n_of(tile);
+    const int tile_m = tile_m_of(tile);
     const int m0 = tile_m * G_BM;
     const int n0 = tile_n * GBN;
 
@@ -628,8 +635,9 @@ __global__ __launch_bounds__(NT, 2) void conv_pw256_f16x2_kernel(ConvArgsH p) {
     }
     if (kc1 < p.nk) {
       const int last_unit = tile * p.nk + p.nk - 1;
-      const int last_worker = last_unit / p.units_per_worker;
-      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+      const int wstep = p.ngroup > 1 ? p.ngroup : 1;
+      const int last_worker = (last_unit / p.units_per_worker) * wstep + wsel;
+      for (int pw = lw + wstep; pw <= last_worker; pw += wstep) {
         if (tid == 0) {
           int spins = 0;
           while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
@@ -792,8 +800,20 @@ extern "C" int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_spl
   const int min_units = 4;
   int workers = (int)((units + min_units - 1) / min_units);
   if (workers > cap) workers = cap;
+  // 2, 4, 8 or 16 output-channel tiles on a chip-filling layer: group the workers (ConvArgsH::ngroup); the unit space is
+  // then row tiles x chunks.  LVC_PW_NGROUP=0: every worker walks all channel tiles of its row tiles.
+  a.ngroup = 1;
+  static const int ngroup_on = [] { const char* e = getenv("LVC_PW_NGROUP"); return e ? atoi(e) : 1; }();
+  const int tn = a.tiles_n;
+  if (ngroup_on && shape == 2 && workers == cap && tn >= 2 && tn <= 16 && (tn & (tn - 1)) == 0 && cap % tn == 0 &&
+      units / tn >= (long long)(cap / tn) * min_units) {
+    a.ngroup = tn;
+    units /= tn;
+    workers = cap / tn;
+    a.total_units = (int)units;
+  }
   a.units_per_worker = (int)((units + workers - 1) / workers);
-  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker);
+  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker) * a.ngroup;
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
