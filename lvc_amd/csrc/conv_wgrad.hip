@@ -312,58 +312,59 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
   if (chunk1 > nchunks) chunk1 = nchunks;
   if (chunk0 >= chunk1) return;
 
-  const int lrow = tid >> 5;
-  const int lcol = (tid & 31) * 4;
-  const bool k_ok = k0 + lcol < p.K, c_ok = c0 + lcol < p.C;
+  // loader: thread = (pixel row of the chunk, 16-byte slot): the eight lanes of a row fetch 128 contiguous bytes per
+  // request and four requests cover the row's 128 channels, so a thread follows ONE pixel (one set of coordinates and
+  // bounds per chunk; with four pixels per thread the address arithmetic was half of the kernel's VALU instructions)
+  const int lrow = tid >> 3;
+  const int lq = (tid & 7) * 4;            // channel of slot j: lq + 32 j
   f32x4 ra[4], rb[4];
   int range_err = 0;
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, BUF ? x_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t dyres = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, BUF ? dy_bytes : 0, 0x00020000);
-  // pixel coordinates of this thread's four rows, advanced by 32 pixels per chunk (two integer divisions per row and
-  // chunk were 60 % of the kernel's VALU instructions: 22 VALU per MFMA under the counters)
-  int pn[4], py[4], px[4];
+  // byte offsets of the four slots inside a pixel; a slot or a pixel out of range is 2^31, and the saturating sum of the
+  // two stays beyond the buffer (both tensors are < 2 GiB), so the load returns zeros
+  unsigned k_off[4], c_off[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = chunk0 * 32 + lrow + 8 * i;
-    px[i] = m % p.Wo;
-    const int q = m / p.Wo;
-    py[i] = q % p.Ho;
-    pn[i] = q / p.Ho;
+  for (int j = 0; j < 4; ++j) {
+    k_off[j] = k0 + lq + 32 * j < p.K ? (unsigned)(k0 + lq + 32 * j) * 4u : 0x80000000u;
+    c_off[j] = c0 + lq + 32 * j < p.C ? (unsigned)(c0 + lq + 32 * j) * 4u : 0x80000000u;
   }
-  auto load = [&](int chunk) {
+  int pm = chunk0 * 32 + lrow;             // this thread's pixel, advanced by 32 per chunk
+  int px = pm % p.Wo, py = (pm / p.Wo) % p.Ho, pn = pm / (p.Wo * p.Ho);
+  auto load = [&](int) {
+    const int iy = py * p.stride + r - p.pad, ix = px * p.stride + s - p.pad;
+    const bool okm = pm < p.M;
+    const bool okx = okm && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    if constexpr (BUF) {
+      const unsigned ab = okm ? (unsigned)(pm * p.lddy) * 4u : 0x80000000u;
+      const unsigned bb = okx ? (unsigned)(((pn * p.H + iy) * p.W + ix) * p.C) * 4u : 0x80000000u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = chunk * 32 + lrow + 8 * i;
-      f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (BUF) {
-        const int iy = py[i] * p.stride + r - p.pad, ix = px[i] * p.stride + s - p.pad;
-        const bool okm = m < p.M;
-        const bool okx = okm && c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const unsigned ao = (okm && k_ok) ? (unsigned)(m * p.lddy + k0 + lcol) * 4u : 0x80000000u;
-        const unsigned bo = okx ? (unsigned)(((pn[i] * p.H + iy) * p.W + ix) * p.C + c0 + lcol) * 4u : 0x80000000u;
-        a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, ao, 0, 0));
-        b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, bo, 0, 0));
-      } else if (m < p.M) {
-        if (k_ok) a = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.lddy + k0 + lcol);
-        const int iy = py[i] * p.stride + r - p.pad, ix = px[i] * p.stride + s - p.pad;
-        if (c_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          b = *reinterpret_cast<const f32x4*>(p.x + (((size_t)pn[i] * p.H + iy) * p.W + ix) * p.C + c0 + lcol);
+      for (int j = 0; j < 4; ++j) {
+        ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dyres, __builtin_elementwise_add_sat(ab, k_off[j]), 0, 0));
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, __builtin_elementwise_add_sat(bb, c_off[j]), 0, 0));
       }
-      ra[i] = a;
-      rb[i] = b;
-      if (p.Wo >= 32) {                    // the next chunk's row: at most one wrap
-        px[i] += 32;
-        if (px[i] >= p.Wo) {
-          px[i] -= p.Wo;
-          if (++py[i] == p.Ho) { py[i] = 0; ++pn[i]; }
-        }
-      } else {                             // narrow maps (and the Linear case, Wo = 1): divide
-        const int m2 = m + 32;
-        px[i] = m2 % p.Wo;
-        const int q2 = m2 / p.Wo;
-        py[i] = q2 % p.Ho;
-        pn[i] = q2 / p.Ho;
+    } else {
+      const float* ap = p.dy + (size_t)pm * p.lddy;
+      const float* bp = p.x + (((size_t)pn * p.H + iy) * p.W + ix) * p.C;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[j] = (okm && !(k_off[j] >> 31)) ? *reinterpret_cast<const f32x4*>(ap + (k_off[j] >> 2)) : z;
+        rb[j] = (okx && !(c_off[j] >> 31)) ? *reinterpret_cast<const f32x4*>(bp + (c_off[j] >> 2)) : z;
       }
+    }
+    pm += 32;
+    if (p.Wo >= 32) {                      // the next chunk's pixel: at most one wrap
+      px += 32;
+      if (px >= p.Wo) {
+        px -= p.Wo;
+        if (++py == p.Ho) { py = 0; ++pn; }
+      }
+    } else {                               // narrow maps (and the Linear case, Wo = 1): divide
+      px = pm % p.Wo;
+      const int q2 = pm / p.Wo;
+      py = q2 % p.Ho;
+      pn = q2 / p.Ho;
     }
   };
   auto split4 = [&](const f32x4& v, wg_f16x4& h, wg_f16x4& m) {
@@ -378,15 +379,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f16x2_kernel(const WgradPar
     if (!(big <= 65504.f)) range_err = 1;
   };
   auto store = [&](int buf) {
-    wg_f16* base = lds + buf * 4 * WG_PLANE;
+    wg_f16* base = lds + buf * 4 * WG_PLANE + lrow * WG_PITCH;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = (lrow + 8 * i) * WG_PITCH + (lcol ^ ((lrow & 3) << 5));   // (lrow + 8 i) & 3 == lrow & 3
+    for (int j = 0; j < 4; ++j) {
+      const int o = (lq + 32 * j) ^ ((lrow & 3) << 5);
       wg_f16x4 h, m;
-      split4(ra[i], h, m);
+      split4(ra[j], h, m);
       *reinterpret_cast<wg_f16x4*>(base + o) = h;
       *reinterpret_cast<wg_f16x4*>(base + WG_PLANE + o) = m;
-      split4(rb[i], h, m);
+      split4(rb[j], h, m);
       *reinterpret_cast<wg_f16x4*>(base + 2 * WG_PLANE + o) = h;
       *reinterpret_cast<wg_f16x4*>(base + 3 * WG_PLANE + o) = m;
     }
