@@ -142,10 +142,14 @@ def main():
     roofline = None
     if timer is not None:
         fl, ms, nlaunch = timer.flops_and_ms(dom)
-        traffic = None
+        traffic, pmc_busy = None, None
         pmc = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            traffic = pj.get("hbm_bytes_per_launch")
+            sq = pj.get("sq_counters_same_launch", {})
+            pmc_busy = {"mfma_busy_fraction": sq.get("mfma_busy_fraction"), "clock_GHz_under_load": sq.get("clock_GHz"),
+                        "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 4 SIMD x 256 CU) of the p2 3x3 launch, a separate rocprofv3 --pmc pass (profiles/r01_conv_pmc.json): the matrix pipes are busy this fraction of the cycles at the clock the 1.4 kW cap leaves"}
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_F16X2_TFLOPS if dom.startswith("f16x2") else PEAK_BF16X3_TFLOPS
         roofline = {
@@ -154,6 +158,7 @@ def main():
             "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split a = a1 + 2^-11 a2, main + cross fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once; the kernel runs at the 1.4 kW socket power cap (profiles/README.md)",
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic, "traffic_note": "fabric bytes (FETCH_SIZE x2 + WRITE_SIZE, gfx950 correction) of ONE p2 3x3 launch of this kernel vs 1.10 GB algorithmic; see profiles/r01_conv_pmc.json",
+            "mfma_utilisation_pmc": pmc_busy,
             "kernel_ms_per_step": round(ms / args.steps, 3), "launch_avg_ms": round(ms / nlaunch, 4)}
         other = {}
         for e in NAMES:
