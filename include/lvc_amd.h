@@ -237,6 +237,7 @@ int lvc_decode_boxes(const float* deltas, int ld, const float* boxes, int M, int
  *   outputs matches [N] int64 (first arg-max), labels [N] int8, matched_vals [N]; d_gt_best [G] uint32 scratch.
  * lvc_fast_rcnn_losses: FastRCNNOutputs.losses (lvc/modeling/roi_heads/fast_rcnn.py:267-279, 296-359): mean softmax CE
  *   and smooth-L1(sum)/R, plus d(loss)/d(logits) [R,K+1] and d(loss)/d(deltas) [R,4K|4].  gt_classes int64, K = bg.
+ *   One wave per row; the per-row terms are added in a fixed order from the fp64 scratch row_terms [2R].
  * lvc_rpn_losses: RPN.losses (proposal_generator/rpn.py:328-400) over S sampled anchors, forward only:
  *   out = (BCE-with-logits sum, smooth-L1 sum over positives) / normalizer.
  */
@@ -246,7 +247,7 @@ int lvc_match_boxes(const float* gt, int G, const float* boxes, int N, float t0,
 int lvc_fast_rcnn_losses(const float* logits, int ld_cls, const float* deltas, int ld_delta, int K, int cls_agnostic,
                          const float* proposals, const float* gt_boxes, const long long* gt_classes, int R, float wx,
                          float wy, float ww, float wh, float smooth_l1_beta, float* out_losses, float* dlogits,
-                         float* ddeltas, void* stream);
+                         float* ddeltas, double* row_terms /* [2R] scratch */, void* stream);
 int lvc_rpn_losses(const float* logits, const float* deltas, const float* anchors, const float* gt_boxes,
                    const signed char* labels, int S, float smooth_l1_beta, float normalizer, float* out_losses,
                    void* stream);
@@ -294,6 +295,10 @@ int lvc_colsum(const float* x, int M, int N, int ldx, float* out, void* stream);
 int lvc_pack_conv_weights(const float* w, const float* scale, float* wp, int K, int C, int R, int S, int rows_pad,
                           int cin_pad, int mode, void* stream);
 int lvc_split_weights(const float* wp, long long n, int planes, void* out, int* err_word, void* stream);
+/* lvc_pack_conv_weights and lvc_split_weights in one launch: planes_out [planes][rows_pad][R*S*cin_pad], planes = 2
+ * (fp16) or 3 (bf16); err_word as lvc_split_weights. */
+int lvc_pack_split_conv_weights(const float* w, const float* scale, float* wp, void* planes_out, int planes, int* err_word,
+                                int K, int C, int R, int S, int rows_pad, int cin_pad, int mode, void* stream);
 int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                         int K, int R, int S, int stride, int pad, int lddy, void* stream);
 /* lvc_conv_wgrad_nhwc on the two-way fp16 split MFMA path (gfx950 LDS transpose reads for the pixel-major operands).

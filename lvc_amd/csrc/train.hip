@@ -116,39 +116,59 @@ __device__ __forceinline__ float smooth_l1(float x, float t, float beta, float* 
   return n - 0.5f * beta;
 }
 
-// one workgroup; R rows (<= a few thousand): loss_cls = mean CE, loss_box = sum smooth-L1 over fg rows / R
-__global__ __launch_bounds__(1024) void fast_rcnn_losses_kernel(
+// One wave per row (lanes over the K+1 logits and the row's regression columns: coalesced), four rows per workgroup;
+// the per-row loss terms go to row_terms [2][R] (fp64) and fast_rcnn_losses_sum_kernel adds them in a fixed order, so
+// the losses do not depend on the launch geometry.  (As one 1024-thread workgroup walking strided rows: 0.71 ms for 4096
+// rows x 61 classes.)
+__global__ __launch_bounds__(256) void fast_rcnn_losses_rows_kernel(
     const float* __restrict__ logits, int ld_cls, const float* __restrict__ deltas, int ld_delta, int K,
     int cls_agnostic, const float* __restrict__ proposals, const float* __restrict__ gt_boxes,
     const long long* __restrict__ gt_classes, int R, float wx, float wy, float ww, float wh, float beta,
-    float* __restrict__ out_losses, float* __restrict__ dlogits, float* __restrict__ ddeltas) {
-  __shared__ double red[2][16];
-  double lc = 0.0, lb = 0.0;
-  for (int r = threadIdx.x; r < R; r += 1024) {
-    const float* lg = logits + (size_t)r * ld_cls;
-    const long long c = gt_classes[r];
-    float mx = -INFINITY;
-    for (int k = 0; k <= K; ++k) mx = fmaxf(mx, lg[k]);
-    float sum = 0.f;
-    for (int k = 0; k <= K; ++k) sum += expf(lg[k] - mx);
-    const float lse = mx + logf(sum);
-    lc += (double)(lse - lg[c]);
-    for (int k = 0; k <= K; ++k) dlogits[(size_t)r * (K + 1) + k] = (expf(lg[k] - lse) - (k == c ? 1.f : 0.f)) / (float)R;
-    const int nreg = cls_agnostic ? 4 : 4 * K;
-    for (int j = 0; j < nreg; ++j) ddeltas[(size_t)r * nreg + j] = 0.f;
-    if (c >= 0 && c < K) {
-      float t[4];
-      const float* p = proposals + (size_t)r * 4;
-      const float* g = gt_boxes + (size_t)r * 4;
-      get_deltas(p[0], p[1], p[2], p[3], g[0], g[1], g[2], g[3], wx, wy, ww, wh, t);
-      const int col = cls_agnostic ? 0 : 4 * (int)c;
-      for (int j = 0; j < 4; ++j) {
-        float gr;
-        lb += (double)smooth_l1(deltas[(size_t)r * ld_delta + col + j], t[j], beta, &gr);
-        ddeltas[(size_t)r * nreg + col + j] = gr / (float)R;
-      }
+    double* __restrict__ row_terms, float* __restrict__ dlogits, float* __restrict__ ddeltas) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* lg = logits + (size_t)r * ld_cls;
+  const long long c = gt_classes[r];
+  float mx = -INFINITY;
+  for (int k = lane; k <= K; k += 64) mx = fmaxf(mx, lg[k]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int k = lane; k <= K; k += 64) sum += expf(lg[k] - mx);
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float lse = mx + logf(sum);
+  for (int k = lane; k <= K; k += 64) dlogits[(size_t)r * (K + 1) + k] = (expf(lg[k] - lse) - (k == c ? 1.f : 0.f)) / (float)R;
+  const int nreg = cls_agnostic ? 4 : 4 * K;
+  const bool fg = c >= 0 && c < K;
+  const int col = cls_agnostic ? 0 : 4 * (int)c;
+  float gr[4] = {0.f, 0.f, 0.f, 0.f};
+  double lb = 0.0;
+  if (fg) {
+    float t[4];
+    const float* p = proposals + (size_t)r * 4;
+    const float* g = gt_boxes + (size_t)r * 4;
+    get_deltas(p[0], p[1], p[2], p[3], g[0], g[1], g[2], g[3], wx, wy, ww, wh, t);
+    for (int j = 0; j < 4; ++j) {
+      float gj;
+      lb += (double)smooth_l1(deltas[(size_t)r * ld_delta + col + j], t[j], beta, &gj);
+      gr[j] = gj / (float)R;
     }
   }
+  for (int j = lane; j < nreg; j += 64) {
+    const int q = j - col;
+    ddeltas[(size_t)r * nreg + j] = (fg && q >= 0 && q < 4) ? (q == 0 ? gr[0] : q == 1 ? gr[1] : q == 2 ? gr[2] : gr[3]) : 0.f;
+  }
+  if (lane == 0) {
+    row_terms[r] = (double)(lse - lg[c]);
+    row_terms[R + r] = lb;
+  }
+}
+
+__global__ __launch_bounds__(1024) void fast_rcnn_losses_sum_kernel(const double* __restrict__ row_terms, int R,
+                                                                     float* __restrict__ out_losses) {
+  __shared__ double red[2][16];
+  double lc = 0.0, lb = 0.0;
+  for (int r = threadIdx.x; r < R; r += 1024) { lc += row_terms[r]; lb += row_terms[R + r]; }
   for (int o = 32; o > 0; o >>= 1) { lc += __shfl_xor(lc, o); lb += __shfl_xor(lb, o); }
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lc; red[1][threadIdx.x >> 6] = lb; }
   __syncthreads();
@@ -161,17 +181,20 @@ __global__ __launch_bounds__(1024) void fast_rcnn_losses_kernel(
 }
 
 // logits [R, ld_cls] (K+1 used), deltas [R, ld_delta], proposals/gt_boxes [R,4], gt_classes [R] int64 (K = background)
-// out_losses [2] = (loss_cls, loss_box_reg) ; dlogits [R,K+1], ddeltas [R, 4K | 4] = d(loss)/d(input), dense.
+// out_losses [2] = (loss_cls, loss_box_reg) ; dlogits [R,K+1], ddeltas [R, 4K | 4] = d(loss)/d(input), dense;
+// row_terms [2R] fp64 scratch.
 extern "C" int lvc_fast_rcnn_losses(const float* logits, int ld_cls, const float* deltas, int ld_delta, int K,
                                     int cls_agnostic, const float* proposals, const float* gt_boxes,
                                     const long long* gt_classes, int R, float wx, float wy, float ww, float wh,
                                     float smooth_l1_beta, float* out_losses, float* dlogits, float* ddeltas,
-                                    void* stream) {
+                                    double* row_terms, void* stream) {
   LVC_CHECK_ARG(R > 0 && K > 0, "empty batch");
-  LVC_CHECK_ARG(logits && deltas && proposals && gt_boxes && gt_classes && out_losses && dlogits && ddeltas, "null pointer");
-  hipLaunchKernelGGL(fast_rcnn_losses_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, ld_cls, deltas,
-                     ld_delta, K, cls_agnostic, proposals, gt_boxes, gt_classes, R, wx, wy, ww, wh, smooth_l1_beta,
-                     out_losses, dlogits, ddeltas);
+  LVC_CHECK_ARG(logits && deltas && proposals && gt_boxes && gt_classes && out_losses && dlogits && ddeltas && row_terms, "null pointer");
+  hipLaunchKernelGGL(fast_rcnn_losses_rows_kernel, dim3(lvc_cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld_cls,
+                     deltas, ld_delta, K, cls_agnostic, proposals, gt_boxes, gt_classes, R, wx, wy, ww, wh, smooth_l1_beta,
+                     row_terms, dlogits, ddeltas);
+  LVC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(fast_rcnn_losses_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_terms, R, out_losses);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -84,16 +84,42 @@ def conv_affine(bias=None, bn=None, eps=1e-5):
     return scale, shift
 
 
-def _pack_weights(weight, scale, rows_pad, cin_pad, mode):
+def _pack_weights(weight, scale, rows_pad, cin_pad, mode, planes=0):
+    """Packed fp32 operand and, with planes = 2 / 3, its fp16 / bf16 split planes from the same launch (else None)."""
     K, C, R, S = weight.shape
     w = weight.detach()
     if w.dtype != torch.float32 or not w.is_contiguous():
         w = w.float().contiguous()
     wp = torch.empty(rows_pad, R * S * cin_pad, device=w.device, dtype=torch.float32)
+    if planes:
+        out = torch.empty((planes,) + tuple(wp.shape), device=w.device, dtype=torch.float16 if planes == 2 else torch.bfloat16)
+        err = _conv_error_view(w.device) if planes == 2 else None
+        check(_lib.lib().lvc_pack_split_conv_weights(ptr(w), ptr(scale), ptr(wp), ptr(out), c_int(planes), ptr(err), c_int(K),
+                                                     c_int(C), c_int(R), c_int(S), c_int(rows_pad), c_int(cin_pad),
+                                                     c_int(mode), _stream(w)), "lvc_pack_split_conv_weights")
+        return wp, out
     check(_lib.lib().lvc_pack_conv_weights(ptr(w), ptr(scale), ptr(wp), c_int(K), c_int(C), c_int(R), c_int(S),
                                            c_int(rows_pad), c_int(cin_pad), c_int(mode), _stream(w)),
           "lvc_pack_conv_weights")
-    return wp
+    return wp, None
+
+
+def _planes_hint(R, S, contraction, split):
+    """The split the conv routing will most likely ask of a layer (conv2d_nhwc: two-way fp16 for the 3x3 layers and the
+    1x1 layers with a long contraction, three-way bf16 otherwise); a wrong guess only costs the lazy split later."""
+    if CONV_ENGINE != "bf16x3":
+        return 0
+    if (split or CONV_SPLIT) == "f16x2" and ((R == 3 and S == 3) or (R == 1 and S == 1 and contraction >= _H2_PW_MIN_C)):
+        return 2
+    return 3
+
+
+def _with_planes(pc, planes, out):
+    if planes == 2:
+        pc._w2h = out
+    elif planes == 3:
+        pc._w3 = out
+    return pc
 
 
 def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False, affine=None):
@@ -119,8 +145,10 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False,
         assert C % BK == 0, "implicit-GEMM kernel needs in_channels % 32 == 0 (got {})".format(C)
         Kg = R * S * C
         # k = (c // 32, r, s, c % 32): the taps of one 32-channel chunk are consecutive gemm-k chunks
-        wp = _pack_weights(weight, None, Kpad, C, 0)
-        Cphys, mode = C, 0
+        planes = _planes_hint(R, S, C, None)
+        wp, pl = _pack_weights(weight, None, Kpad, C, 0, planes)
+        scale, shift = affine if affine is not None else conv_affine(bias, bn, eps)
+        return _with_planes(PackedConv(wp, scale, shift, K, C, R, S, stride, pad, Kg, 0), planes, pl)
     scale, shift = affine if affine is not None else conv_affine(bias, bn, eps)
     return PackedConv(wp, scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
 
@@ -709,12 +737,14 @@ def fast_rcnn_losses(logits, deltas, proposals, gt_boxes, gt_classes, num_classe
     out = torch.empty(2, device=dev, dtype=torch.float32)
     dl = torch.empty(R, K + 1, device=dev, dtype=torch.float32)
     dd = torch.empty(R, nreg, device=dev, dtype=torch.float32)
+    row_terms = torch.empty(2 * R, device=dev, dtype=torch.float64)
     wx, wy, ww, wh = box_weights
     assert logits.stride(1) == 1 and deltas.stride(1) == 1 and gt_classes.dtype == torch.int64
     rc = _lib.lib().lvc_fast_rcnn_losses(ptr(logits), c_int(logits.stride(0)), ptr(deltas), c_int(deltas.stride(0)), c_int(K),
                                          c_int(1 if nreg == 4 else 0), ptr(proposals.contiguous()), ptr(gt_boxes.contiguous()),
                                          ptr(gt_classes.contiguous()), c_int(R), c_float(wx), c_float(wy), c_float(ww),
-                                         c_float(wh), c_float(smooth_l1_beta), ptr(out), ptr(dl), ptr(dd), _stream(logits))
+                                         c_float(wh), c_float(smooth_l1_beta), ptr(out), ptr(dl), ptr(dd), ptr(row_terms),
+                                         _stream(logits))
     check(rc, "lvc_fast_rcnn_losses")
     return out, dl, dd
 
@@ -818,8 +848,9 @@ def pack_conv_dgrad(weight, scale, pad):
     Kout, C, R, S = weight.shape
     kin_pad = (Kout + 31) // 32 * 32
     rows_pad = (C + BN - 1) // BN * BN
-    wp = _pack_weights(weight, scale, rows_pad, kin_pad, 1)
-    return PackedConv(wp, None, None, C, kin_pad, R, S, 1, R - 1 - pad, R * S * kin_pad, 0)
+    planes = _planes_hint(R, S, kin_pad, DGRAD_SPLIT)
+    wp, pl = _pack_weights(weight, scale, rows_pad, kin_pad, 1, planes)
+    return _with_planes(PackedConv(wp, None, None, C, kin_pad, R, S, 1, R - 1 - pad, R * S * kin_pad, 0), planes, pl)
 
 
 def conv_dgrad(dy, pcd, x_shape, stride):

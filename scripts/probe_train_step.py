@@ -50,6 +50,21 @@ scaler = None
 if loss_scale > 0:
     from lvc_amd.solver import LossScaler
     scaler = LossScaler(init_scale=loss_scale)
+phase_ms = {}
+if os.environ.get("PHASES"):      # wall time of the forward's phases (synchronising hooks: use for attribution only)
+    def _hook(name, mod):
+        def pre(m, a, k=None):
+            torch.cuda.synchronize(); m._t0 = time.perf_counter()
+        def post(m, a, o):
+            torch.cuda.synchronize(); phase_ms.setdefault(name, []).append((time.perf_counter() - m._t0) * 1e3)
+        mod.register_forward_pre_hook(pre); mod.register_forward_hook(post)
+    for nm in ("backbone", "proposal_generator", "roi_heads"):
+        if getattr(model, nm, None) is not None:
+            _hook(nm, getattr(model, nm))
+    if hasattr(model.proposal_generator, "rpn_head"):
+        _hook("rpn_head", model.proposal_generator.rpn_head)
+    if hasattr(model.roi_heads, "box_pooler"):
+        _hook("box_pooler", model.roi_heads.box_pooler); _hook("box_head", model.roi_heads.box_head); _hook("box_predictor", model.roi_heads.box_predictor)
 times = []
 with EventStorage(0):
     for it in range(steps + 2):
@@ -72,3 +87,5 @@ with EventStorage(0):
         print(it, {k: round(float(v.detach()), 4) for k, v in losses.items()}, flush=True)
 f = sum(t[0] for t in times) / len(times); b = sum(t[1] for t in times) / len(times); o = sum(t[2] for t in times) / len(times)
 print("%s batch %d: forward %.1f ms  backward %.1f ms  sgd %.1f ms  -> %.2f img/s" % (which, B, f * 1e3, b * 1e3, o * 1e3, B / (f + b + o)))
+if phase_ms:
+    print({k: round(sum(v[2:]) / max(1, len(v[2:])), 2) for k, v in phase_ms.items()})
