@@ -301,6 +301,10 @@ int lvc_pack_split_conv_weights(const float* w, const float* scale, float* wp, v
                                 int K, int C, int R, int S, int rows_pad, int cin_pad, int mode, void* stream);
 int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                         int K, int R, int S, int stride, int pad, int lddy, void* stream);
+/* lvc_conv_wgrad_nhwc on the three-way bf16 split MFMA path (six bf16 MFMAs per fp32-accurate product, one fp32
+ * accumulator; gfx950 LDS transpose reads for the pixel-major operands).  No range restriction: the default. */
+int lvc_conv_wgrad_nhwc_bf16x3(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
+                               int K, int R, int S, int stride, int pad, int lddy, void* stream);
 /* lvc_conv_wgrad_nhwc on the two-way fp16 split MFMA path (gfx950 LDS transpose reads for the pixel-major operands).
  * dy and x must lie inside fp16's range -- gradients scaled by a power of two (lvc_amd.solver.LossScaler); a value beyond
  * 65504 raises bit 1 (value 2) of *err_word (the conv error word of lvc_conv_workspace; may be NULL). */

@@ -239,6 +239,8 @@ CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
 # gradients scaled into fp16's range first -- lvc_amd.solver.LossScaler does that with a power of two (exact) and switches
 # this on for the backward pass it wraps.
 DGRAD_SPLIT = _os.environ.get("LVC_DGRAD_SPLIT", "bf16x3")
+# weight gradients without a loss scale: "bf16x3" = three-way bf16 split on the bf16 matrix cores, "f32" = fp32 MFMA
+WGRAD_ENGINE = _os.environ.get("LVC_WGRAD_ENGINE", "bf16x3")
 _H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "128"))
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
@@ -810,9 +812,9 @@ def conv_wgrad(x, dy, scale, R, S, stride, pad, split=None):
                                                    c_int(K), ptr(_conv_error_view(x.device)), _stream(x)),
               "lvc_conv_wgrad_nhwc_f16x2")
         return dw
-    check(_lib.lib().lvc_conv_wgrad_nhwc(ptr(x), ptr(dy), ptr(scale), ptr(dw), c_int(N), c_int(H), c_int(W), c_int(C),
-                                         c_int(K), c_int(R), c_int(S), c_int(stride), c_int(pad), c_int(K), _stream(x)),
-          "lvc_conv_wgrad_nhwc")
+    fn = "lvc_conv_wgrad_nhwc_bf16x3" if WGRAD_ENGINE == "bf16x3" else "lvc_conv_wgrad_nhwc"
+    check(getattr(_lib.lib(), fn)(ptr(x), ptr(dy), ptr(scale), ptr(dw), c_int(N), c_int(H), c_int(W), c_int(C), c_int(K),
+                                  c_int(R), c_int(S), c_int(stride), c_int(pad), c_int(K), _stream(x)), fn)
     return dw
 
 
