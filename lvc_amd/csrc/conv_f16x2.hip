@@ -800,12 +800,15 @@ extern "C" int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_spl
   const int min_units = 4;
   int workers = (int)((units + min_units - 1) / min_units);
   if (workers > cap) workers = cap;
-  // 2, 4, 8 or 16 output-channel tiles on a chip-filling layer: group the workers (ConvArgsH::ngroup); the unit space is
-  // then row tiles x chunks.  LVC_PW_NGROUP=0: every worker walks all channel tiles of its row tiles.
+  // two output-channel tiles on a chip-filling layer: pair the workers (ConvArgsH::ngroup); the unit space is then row
+  // tiles x chunks.  Measured per layer (scripts/probe_layers_list.py): pairs gain 2 % on the 256-channel outputs (FPN
+  // laterals, res4 reductions); groups of 4 / 8 / 16 lose 1-7 % (sixteen workers in step on one row tile serialise on
+  // its loads), so wider layers keep the one-worker-walks-all-channel-tiles order.  LVC_PW_NGROUP=0: never group,
+  // =2: group every power-of-two tile count up to 16.
   a.ngroup = 1;
   static const int ngroup_on = [] { const char* e = getenv("LVC_PW_NGROUP"); return e ? atoi(e) : 1; }();
   const int tn = a.tiles_n;
-  if (ngroup_on && shape == 2 && workers == cap && tn >= 2 && tn <= 16 && (tn & (tn - 1)) == 0 && cap % tn == 0 &&
+  if (ngroup_on && shape == 2 && workers == cap && (tn == 2 || (ngroup_on > 1 && tn <= 16 && (tn & (tn - 1)) == 0)) && cap % tn == 0 &&
       units / tn >= (long long)(cap / tn) * min_units) {
     a.ngroup = tn;
     units /= tn;
