@@ -103,7 +103,8 @@ int lvc_stem_conv_pool_nhwc4(const float* x, const unsigned short* w_split, cons
 /* The same with the two-way fp16 operand split (csrc/stem_pool_h2.hip): w_split = [2][Kpad][224] fp16 planes;
  * d_error_word: device int whose bit 1 is set when an input beyond fp16's range is met (may be NULL). */
 int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                                   float* y, int N, int H, int W, int Kpad, int relu, int* d_error_word, void* stream);
+                                   float* y, int N, int H, int W, int Kpad, int relu, int* d_error_word,
+                                   float* y2 /* optional second copy of y, rows of ldy2 floats */, int ldy2, void* stream);
 
 /* GeneralizedRCNN.preprocess_image (lvc/modeling/meta_arch/rcnn.py:324-333) + ImageList.from_tensors
  * padding (detectron2/structures/image_list.py:95-119): out[y,x,:] = ((img[:,y,x]-mean)/std, 0), zero

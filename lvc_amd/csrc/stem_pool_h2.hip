@@ -53,6 +53,8 @@ struct StemArgsH {
   const float* scale;
   const float* shift;
   float* y;                  // [N, Hp, Wp, 64]
+  float* y2;                 // optional second copy of the output: rows of ldy2 floats (NULL: none)
+  int ldy2;
   int N, H, W, Ho, Wo, Hp, Wp, relu;
   int tiles_x, tiles_y, ntiles, nworkers;
   int x_bytes, w_plane_bytes;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
           }
         }
         *reinterpret_cast<f32x4*>(p.y + ((size_t)(img * p.Hp + py) * p.Wp + px) * 64 + c4 * 4) = best;
+        if (p.y2) *reinterpret_cast<f32x4*>(p.y2 + ((size_t)(img * p.Hp + py) * p.Wp + px) * p.ldy2 + c4 * 4) = best;
       }
     }
     __syncthreads();
@@ -270,13 +273,14 @@ static int g_cus_stem_h = 0;
 // plane stride = Kpad * 224), scale/shift [64] or NULL, y [N,Hp,Wp,64] with Ho = (H - 1) / 2 + 1, Hp = (Ho - 1) / 2 + 1.
 extern "C" int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned short* w_split, const float* scale,
                                               const float* shift, float* y, int N, int H, int W, int Kpad, int relu,
-                                              int* d_error_word, void* stream) {
+                                              int* d_error_word, float* y2, int ldy2, void* stream) {
   LVC_CHECK_ARG(x && w_split && y, "null pointer");
+  LVC_CHECK_ARG(!y2 || (ldy2 >= 64 && ldy2 % 4 == 0 && ((uintptr_t)y2 & 15) == 0), "bad second output");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && Kpad >= 64, "bad shape");
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0,
                 "pointers must be 16-byte aligned");
   StemArgsH a;
-  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.y = y;
+  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.y = y; a.y2 = y2; a.ldy2 = ldy2;
   a.N = N; a.H = H; a.W = W; a.relu = relu; a.err = d_error_word;
   a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1;
   a.Hp = (a.Ho + 2 - 3) / 2 + 1; a.Wp = (a.Wo + 2 - 3) / 2 + 1;

@@ -241,6 +241,8 @@ CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
 DGRAD_SPLIT = _os.environ.get("LVC_DGRAD_SPLIT", "bf16x3")
 # weight gradients without a loss scale: "bf16x3" = three-way bf16 split on the bf16 matrix cores, "f32" = fp32 MFMA
 WGRAD_ENGINE = _os.environ.get("LVC_WGRAD_ENGINE", "bf16x3")
+# inference: conv3 + stride-1 projection shortcut of res2.0 as one GEMM over [conv2 output | block input] (resnet.py)
+FUSE_PROJECTION = _os.environ.get("LVC_FUSE_PROJECTION", "1") != "0"
 _H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "128"))
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
@@ -321,7 +323,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
     return out
 
 
-def stem_conv_pool(x4, pc, relu=True):
+def stem_conv_pool(x4, pc, relu=True, second=None):
     """x4 [N,H,W,4] NHWC4, pc = pack_conv(stem weight 64x3x7x7, bn=..., stride=2, pad=3, stem=True) ->
     [N,Hp,Wp,64]: conv 7x7/2 + affine + ReLU + max-pool 3x3/2 in one launch."""
     _req_cuda(x4)
@@ -331,18 +333,24 @@ def stem_conv_pool(x4, pc, relu=True):
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
     out = torch.empty(N, Hp, Wp, 64, device=x4.device, dtype=torch.float32)
+    y2 = second(out.shape) if second is not None else None     # [N,Hp,Wp,64] view with a wider row stride
+    if y2 is not None:
+        assert y2.shape == out.shape and y2.stride(3) == 1 and y2.stride(1) == Wp * y2.stride(2) and y2.stride(0) == Hp * y2.stride(1)
     if CONV_SPLIT == "f16x2":
         ws = conv_workspace(x4.device)
         err = ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4]   # the conv error word
         st = _lib.lib().lvc_stem_conv_pool_nhwc4_f16x2(ptr(x4), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(out),
                                                        c_int(N), c_int(H), c_int(W), c_int(pc.w.shape[0]),
-                                                       c_int(1 if relu else 0), ptr(err), _stream(x4))
+                                                       c_int(1 if relu else 0), ptr(err), ptr(y2),
+                                                       c_int(y2.stride(2) if y2 is not None else 0), _stream(x4))
         check(st, "lvc_stem_conv_pool_nhwc4_f16x2")
         return out
     st = _lib.lib().lvc_stem_conv_pool_nhwc4(ptr(x4), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(out),
                                              c_int(N), c_int(H), c_int(W), c_int(pc.w.shape[0]), c_int(1 if relu else 0),
                                              _stream(x4))
     check(st, "lvc_stem_conv_pool_nhwc4")
+    if y2 is not None:
+        y2.copy_(out)
     return out
 
 

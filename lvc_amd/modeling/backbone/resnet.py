@@ -7,6 +7,7 @@ detectron2/modeling/backbone/resnet.py:101-211 (BottleneckBlock), :564-592 (Basi
 HBM between layers.  BasicBlock / DeepStem / Dropout / CLIP / Deform variants are not selected by any
 shipped config and are not provided (the builder raises for them).
 """
+import torch
 import torch.nn.functional as F
 from torch import nn
 
@@ -52,7 +53,40 @@ class BottleneckBlock(CNNBlockBase):
             if layer is not None:
                 weight_init.c2_msra_fill(layer)
 
-    def forward_nhwc(self, x):
+    def can_fuse_projection(self):
+        """Inference only: conv3 and a stride-1 projection shortcut (res2.0: both 64 -> 256 at 1/4 resolution, both
+        HBM streams) as ONE pointwise GEMM over the concatenated input [conv2 output | block input]."""
+        return (K.FUSE_PROJECTION and K.CONV_ENGINE == "bf16x3" and not torch.is_grad_enabled() and self.shortcut is not None
+                and self.shortcut.stride == 1 and self.conv2.stride == 1
+                and (self.conv2.out_channels + self.in_channels) % 32 == 0 and self.conv2.out_channels % 4 == 0)
+
+    def _fused_projection(self):
+        """relu(bn3(conv3(t)) + bn_s(shortcut(x))) = relu([s3 W3 | s_s W_s] [t | x] + (b3 + b_s)): the FrozenBN scales go
+        into the weights (one fp32 rounding per weight), the shifts add.  Saves writing the shortcut tensor and reading
+        it back as the residual (2 x 550 MB at batch 8)."""
+        a3, asc = self.conv3._affine(), self.shortcut._affine()
+
+        def build():
+            w3, ws = self.conv3.weight.detach().float(), self.shortcut.weight.detach().float()
+            if a3[0] is not None:
+                w3 = w3 * a3[0].view(-1, 1, 1, 1)
+            if asc[0] is not None:
+                ws = ws * asc[0].view(-1, 1, 1, 1)
+            shifts = [t for t in (a3[1], asc[1]) if t is not None]
+            shift = None if not shifts else shifts[0] if len(shifts) == 1 else shifts[0] + shifts[1]
+            return K.pack_conv(torch.cat([w3, ws], 1).contiguous(), affine=(None, shift))
+
+        if not hasattr(self, "_cache_fused"):
+            from ...layers.wrappers import _PackedCache
+            self._cache_fused = _PackedCache()
+        return self._cache_fused.get([self.conv3.weight, self.shortcut.weight, a3[0], a3[1], asc[0], asc[1]], build)
+
+    def forward_nhwc(self, x, concat=None):
+        """concat: [N,H,W, bottleneck + in] buffer whose LAST in_channels already hold x (`can_fuse_projection`)."""
+        if concat is not None:
+            out = self.conv1.forward_nhwc(x)
+            K.conv2d_nhwc(out, self.conv2.packed(), relu=True, out=concat)      # channels [0, bottleneck), row stride = buffer
+            return K.conv2d_nhwc(concat, self._fused_projection(), relu=True)
         out = self.conv1.forward_nhwc(x)
         out = self.conv2.forward_nhwc(out)
         shortcut = self.shortcut.forward_nhwc(x) if self.shortcut is not None else x
@@ -71,12 +105,16 @@ class BasicStem(CNNBlockBase):
                             norm=get_norm(norm, out_channels), activation=F.relu_)
         weight_init.c2_msra_fill(self.conv1)
 
-    def forward_nhwc(self, x4):
-        """x4: [N,H,W,4] (RGB + zero slot)."""
+    def forward_nhwc(self, x4, second=None):
+        """x4: [N,H,W,4] (RGB + zero slot).  second: optional callable shape -> [N,Hp,Wp,64] strided view that receives
+        a copy of the output (the concat buffer of a fused projection block)."""
         if K.CONV_ENGINE == "bf16x3" and K.STEM_FUSED and self.conv1.out_channels == 64 and self.conv1.norm is not None:
-            return K.stem_conv_pool(x4, self.conv1.packed(), relu=True)   # conv + FrozenBN + ReLU + max-pool, one launch
+            return K.stem_conv_pool(x4, self.conv1.packed(), relu=True, second=second)   # conv + FrozenBN + ReLU + max-pool, one launch
         y = self.conv1.forward_nhwc(x4)
-        return K.maxpool2d_nhwc(y, 3, 2, 1)
+        y = K.maxpool2d_nhwc(y, 3, 2, 1)
+        if second is not None:
+            second(y.shape).copy_(y)
+        return y
 
     def forward(self, x):
         return to_nchw_view(self.forward_nhwc(_as_nhwc4(x)))
@@ -124,11 +162,24 @@ class ResNet(Backbone):
 
     def forward_nhwc(self, x4):
         outputs = {}
-        x = self.stem.forward_nhwc(x4)
+        first = self.stages_and_names[0][0][0] if self.stages_and_names else None
+        concat = []
+        if isinstance(first, BottleneckBlock) and first.can_fuse_projection():
+            # the stem writes its output a second time, into the tail channels of res2.0's [conv2 output | x] buffer
+            def second(shape):
+                n, h, w, c = shape
+                concat.append(torch.empty(n, h, w, first.conv2.out_channels + c, device=x4.device, dtype=torch.float32))
+                return concat[0][..., first.conv2.out_channels:]
+            x = self.stem.forward_nhwc(x4, second=second)
+        else:
+            x = self.stem.forward_nhwc(x4)
         if "stem" in self._out_features:
             outputs["stem"] = x
         for stage, name in self.stages_and_names:
             for blk in stage:
+                if blk is first and concat:
+                    x = blk.forward_nhwc(x, concat=concat[0])
+                    continue
                 x = blk.forward_nhwc(x)
             if name in self._out_features:
                 outputs[name] = x
