@@ -54,9 +54,11 @@ class BottleneckBlock(CNNBlockBase):
                 weight_init.c2_msra_fill(layer)
 
     def can_fuse_projection(self):
-        """Inference only: conv3 and a stride-1 projection shortcut (res2.0: both 64 -> 256 at 1/4 resolution, both
-        HBM streams) as ONE pointwise GEMM over the concatenated input [conv2 output | block input]."""
-        return (K.FUSE_PROJECTION and K.CONV_ENGINE == "bf16x3" and not torch.is_grad_enabled() and self.shortcut is not None
+        """Gradient-free passes only (inference, or a frozen block in training -- res2 under FREEZE_AT 2): conv3 and a
+        stride-1 projection shortcut (res2.0: both 64 -> 256 at 1/4 resolution, both HBM streams) as ONE pointwise GEMM
+        over the concatenated input [conv2 output | block input]."""
+        grad_free = not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())
+        return (K.FUSE_PROJECTION and K.CONV_ENGINE == "bf16x3" and grad_free and self.shortcut is not None
                 and self.shortcut.stride == 1 and self.conv2.stride == 1
                 and (self.conv2.out_channels + self.in_channels) % 32 == 0 and self.conv2.out_channels % 4 == 0)
 
