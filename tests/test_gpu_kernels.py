@@ -488,3 +488,64 @@ def test_roi_align_negative_size_sets_status():
     k.roi_align_forward(torch.zeros(1, 4, 8, 8, device=d), torch.tensor([[0, 5, 5, 2, 2.0]], device=d), 1.0, 7, 7, 0, True, status=st)
     with pytest.raises(RuntimeError, match="non-negative size"):
         check_status(int(st.item()))
+
+
+@pytest.mark.gpu
+def test_pack_split_in_one_launch_equals_pack_then_split():
+    """lvc_pack_split_conv_weights (one launch) against lvc_pack_conv_weights + lvc_split_weights: same packed operand and
+    the same fp16 / bf16 planes bit for bit, forward (mode 0) and data-gradient (mode 1, flipped / transposed / scaled)."""
+    from lvc_amd import kernels as Kn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(96, 64, 3, 3, generator=g) * 0.05).to(dev)
+    scale = (torch.rand(96, generator=g) + 0.5).to(dev)
+    for mode, sc, rows, cin in ((0, None, 128, 64), (1, scale, 128, 96)):
+        wp0, none = Kn._pack_weights(w, sc, rows, cin, mode)
+        assert none is None
+        for planes, dt in ((2, torch.float16), (3, torch.bfloat16)):
+            wp1, pl = Kn._pack_weights(w, sc, rows, cin, mode, planes)
+            assert torch.equal(wp0, wp1) and pl.dtype == dt
+            pc = Kn.PackedConv(wp0, None, None, rows, cin, 3, 3, 1, 1, wp0.shape[1], 0)
+            ref = pc._split(planes)
+            assert torch.equal(pl.view(torch.int16), ref.view(torch.int16))
+    Kn.check_conv_error_word(dev)
+
+
+@pytest.mark.gpu
+def test_fused_projection_block_matches_two_launch_form(monkeypatch):
+    """res2.0 in inference: conv3 + projection shortcut as one GEMM over [conv2 output | block input] (FrozenBN scales
+    folded into the concatenated weights, the stem writing its output into the buffer's tail) against the two-launch
+    form of the reference graph (resnet.py:195-211); both against an fp64 torch evaluation of the same modules."""
+    from lvc_amd import kernels as Kn
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    dev = torch.device("cuda:0")
+    model = build_model(base_rcnn_fpn()).eval()
+    syn.conditioned_r50_fpn_(model)
+    body = model.backbone.bottom_up
+    blk = body.stages_and_names[0][0][0]
+    x = torch.randn(2, 3, 96, 160, generator=torch.Generator().manual_seed(2)).to(dev) * 50
+    outs = {}
+    with torch.no_grad():
+        for fused in (True, False):
+            monkeypatch.setattr(Kn, "FUSE_PROJECTION", fused)
+            assert blk.can_fuse_projection() == fused
+            outs[fused] = body(x)["res2"].double().cpu()
+        # fp64 evaluation of stem + res2 with torch ops on the same parameters
+        def bn(t, n):
+            s = n.weight.double() * (n.running_var.double() + n.eps).rsqrt()
+            return t * s.view(1, -1, 1, 1) + (n.bias.double() - n.running_mean.double() * s).view(1, -1, 1, 1)
+        def cv(t, c, relu):
+            y = bn(F.conv2d(t, c.weight.double(), stride=c.stride, padding=c.padding), c.norm)
+            return y.clamp_min(0) if relu else y
+        t = F.max_pool2d(cv(x.double(), body.stem.conv1, True), 3, 2, 1)
+        for b in body.stages_and_names[0][0]:
+            sc = cv(t, b.shortcut, False) if b.shortcut is not None else t
+            t = (cv(cv(cv(t, b.conv1, True), b.conv2, True), b.conv3, False) + sc).clamp_min(0)
+        ref = t.cpu()
+    scale = ref.abs().max().item()
+    e_f = (outs[True] - ref).abs().max().item() / scale
+    e_u = (outs[False] - ref).abs().max().item() / scale
+    assert e_f < 2e-6 and e_u < 2e-6, (e_f, e_u)
+    assert (outs[True] - outs[False]).abs().max().item() / scale < 2e-6
