@@ -23,9 +23,14 @@ def _rel(a, b):
     (1, 13, 21, 256, 256, 3, 1, 1, False),
     (300, 1, 1, 1024, 1024, 1, 1, 0, False),  # Linear as the 1x1 case
     (2, 100, 168, 128, 512, 1, 1, 0, True),   # 4 tiles, 33 600 pixels: split over the pixel range
+    (1, 37, 29, 96, 36, 3, 1, 1, False),      # channel tails inside the 128-wide tiles, rows narrower than a chunk
 ])
-def test_conv_wgrad_matches_torch(N, H, W, C, K, R, stride, pad, scaled):
+@pytest.mark.parametrize("engine", ["bf16x3", "f32"])
+def test_conv_wgrad_matches_torch(N, H, W, C, K, R, stride, pad, scaled, engine, monkeypatch):
+    """Both unscaled weight-gradient kernels (three-way bf16 split: the default; fp32 MFMA) on gradient-sized values
+    against an fp64 torch reference."""
     from lvc_amd import kernels as Kn
+    monkeypatch.setattr(Kn, "WGRAD_ENGINE", engine)
     g = torch.Generator().manual_seed(H * 131 + C)
     x = torch.randn(N, C, H, W, generator=g)
     Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
