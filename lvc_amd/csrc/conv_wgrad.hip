@@ -493,7 +493,8 @@ extern "C" int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const 
   const int tiles = p.k_tiles * p.c_tiles * R * S;
   p.tiles = tiles;
   const int nchunks = lvc_cdiv(p.M, 32);
-  int splits = lvc_cdiv(1024, tiles);
+  static const int target_h = [] { const char* e = getenv("LVC_WGRAD_F16_TARGET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  int splits = lvc_cdiv(target_h, tiles);
   const int max_splits = lvc_cdiv(nchunks, 16);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -717,8 +718,12 @@ extern "C" int lvc_conv_wgrad_nhwc_bf16x3(const float* x, const float* dy, const
   const int tiles = p.k_tiles * p.c_tiles * R * S;
   p.tiles = tiles;
   const int nchunks = lvc_cdiv(p.M, 16);
-  int splits = lvc_cdiv(1024, tiles);
-  const int max_splits = lvc_cdiv(nchunks, 32);           // at least 32 chunks (512 pixels) per slice
+  // three workgroups fit a CU (146 VGPRs, 48 KB of LDS): aim at three full rounds of them (2304 on 256 CUs; measured over
+  // the layer set: 1024 -> 12.4 ms, 1536 -> 12.1, 2304 -> 10.5, 3072 -> 11.0, 4608 -> 10.6)
+  static const int target_wgs = [] { const char* e = getenv("LVC_WGRAD_TARGET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 2304; }();
+  static const int min_chunks = [] { const char* e = getenv("LVC_WGRAD_BF16_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 32; }();
+  int splits = lvc_cdiv(target_wgs, tiles);
+  const int max_splits = lvc_cdiv(nchunks, min_chunks);   // at least 32 chunks (512 pixels) per slice
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   p.chunks_per_split = lvc_cdiv(nchunks, splits);
