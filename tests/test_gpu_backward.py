@@ -63,8 +63,11 @@ def test_scatter_downsum_colsum():
     d = Kn.downsum2x2(z)
     r = (z[:, ::2, ::2] + z[:, ::2, 1::2]) + (z[:, 1::2, ::2] + z[:, 1::2, 1::2])
     assert torch.equal(d, r)
-    m = torch.randn(70001, 100, device=dev)
+    m = torch.randn(70001, 100, device=dev)                 # float4 rows, one partial column block, ragged last slab
     assert _rel(Kn.colsum_rows(m), m.double().sum(0)) < 1e-6
+    for rows, cols in ((1, 256), (513, 260), (4099, 15), (777, 1024)):   # 15 columns: the 64-column scalar form
+        m = torch.randn(rows, cols, device=dev)
+        assert _rel(Kn.colsum_rows(m), m.double().sum(0)) < 1e-6
 
 
 def _ref_conv(x, w, b, bn, stride, pad, relu, residual, res_mode):
