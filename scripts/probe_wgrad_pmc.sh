@@ -2,7 +2,7 @@
 # MFMA duty, LDS conflicts and instruction mix of the fp16 weight-gradient kernel
 cd /tmp; export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/pmc_wgrad; mkdir -p $out
-export WGRAD_SPLIT=f16x2
+export WGRAD_SPLIT=${WGRAD_SPLIT-f16x2}   # WGRAD_SPLIT= (empty) profiles the default bf16x3 kernel
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $out -o g1 -- python $GRAFT_REPO_ROOT/scripts/probe_wgrad_one.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $out -o g2 -- python $GRAFT_REPO_ROOT/scripts/probe_wgrad_one.py > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d $out -o g3 -- python $GRAFT_REPO_ROOT/scripts/probe_wgrad_one.py > /dev/null 2>&1
