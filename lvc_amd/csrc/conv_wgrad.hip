@@ -524,7 +524,9 @@ extern "C" int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const 
   const int tiles = p.k_tiles * p.c_tiles * R * S;
   p.tiles = tiles;
   const int nchunks = lvc_cdiv(p.M, 32);
-  static const int target_h = [] { const char* e = getenv("LVC_WGRAD_F16_TARGET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();
+  // two workgroups fit a CU (250 VGPRs): four rounds of them (measured over the layer set on one box: 1024 -> 8.88 ms,
+  // 1536 -> 8.65, 2048 -> 8.54, 2560 -> 8.47, 3072 -> 8.40; the whole training step does not resolve 2048 from 3072)
+  static const int target_h = [] { const char* e = getenv("LVC_WGRAD_F16_TARGET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
   int splits = lvc_cdiv(target_h, tiles);
   const int max_splits = lvc_cdiv(nchunks, 16);
   if (splits > max_splits) splits = max_splits;
