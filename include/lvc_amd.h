@@ -36,8 +36,11 @@ const char* lvc_last_error(void);
 void lvc_set_error(const char* fmt, ...);
 
 /* ---------------------------------------------------------------------------------------------------
- * Convolution / linear layers: NHWC fp32 implicit GEMM on v_mfma_f32_32x32x2_f32, with the per-channel
- * affine (FrozenBN and/or bias), optional residual and ReLU fused into the epilogue.
+ * Convolution / linear layers: NHWC fp32 implicit GEMM with the per-channel affine (FrozenBN and/or bias),
+ * optional residual and ReLU fused into the epilogue.  This entry point is the exact-fp32 engine
+ * (v_mfma_f32_32x32x2_f32); the default engines of the detector are the fp32-accurate operand-split forms
+ * further down (lvc_conv*_f16x2: two-way fp16 split, 3 fp16 MFMAs per block; lvc_conv*_bf16x3: three-way
+ * bf16 split, 6 bf16 MFMAs per block), which take the same tensors and the same epilogue arguments.
  * Replaces: detectron2/layers/wrappers.py:41-99 (Conv2d+norm+activation), batch_norm.py:45-65 (FrozenBN),
  *   backbone/resnet.py:195-211 (residual add + ReLU), backbone/fpn.py:131-133 (nearest x2 upsample + add),
  *   lvc/modeling/roi_heads/box_head.py:82-91 and fast_rcnn.py:583-598 (Linear = 1x1 conv on [M,1,1,K]).
@@ -112,7 +115,6 @@ int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned short* w_split
 int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float* mean3, const float* std3,
                          float* out, int Hp, int Wp, void* stream);
 
-/* F.max_pool2d on NHWC (BasicStem resnet.py:591: k3 s2 p1; LastLevelMaxPool fpn.py:176: k1 s2 p0). */
 /* Test-time input pipeline: ResizeShortestEdge's Pillow bilinear resize of a uint8 HWC image
  * (detectron2/data/transforms/transform.py:101-109), bit-exact with Pillow's ImagingResample (22-bit fixed point,
  * horizontal then vertical pass, uint8 intermediate), optionally fused with preprocess_image's normalise + zero-pad
@@ -124,6 +126,7 @@ int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float
 int lvc_resize_bilinear_u8(const unsigned char* image, int H, int W, int new_h, int new_w, const int* xb, const int* xk,
                            int kxs, const int* yb, const int* yk, int kys, unsigned char* tmp, unsigned char* out_u8,
                            float* out_nhwc4, int Hp, int Wp, const float* mean3, const float* std3, void* stream);
+/* F.max_pool2d on NHWC (BasicStem resnet.py:591: k3 s2 p1; LastLevelMaxPool fpn.py:176: k1 s2 p0). */
 int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W, int C, int k, int stride, int pad,
                        void* stream);
 

@@ -3,8 +3,9 @@
 Same module tree / parameter names / config keys as reference
 detectron2/modeling/backbone/resnet.py:101-211 (BottleneckBlock), :564-592 (BasicStem),
 :648-763 (ResNet), :845-941 (builder), so reference checkpoints load unchanged.  Every conv+FrozenBN
-(+ReLU, +residual add) is one launch of the fp32-MFMA implicit-GEMM kernel; activations stay NHWC in
-HBM between layers.  BasicBlock / DeepStem / Dropout / CLIP / Deform variants are not selected by any
+(+ReLU, +residual add) is one launch of an implicit-GEMM MFMA kernel (fp32 operands split into fp16/bf16
+planes with fp32 accumulation, fp32-accurate: DESIGN.md section 3; `LVC_CONV_ENGINE=f32` selects the exact fp32
+MFMA form); activations stay NHWC fp32 in HBM between layers.  BasicBlock / DeepStem / Dropout / CLIP / Deform variants are not selected by any
 shipped config and are not provided (the builder raises for them).
 """
 import torch

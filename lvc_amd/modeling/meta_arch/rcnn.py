@@ -4,7 +4,7 @@
 (`image`, optional `height`/`width`/`proposals`) and the same freeze switches as the reference.
 
 The inference path is one uninterrupted stream of HIP launches with fixed shapes:
-  preprocess (normalise + pad + NHWC4)  ->  ResNet/FPN (fp32 MFMA implicit GEMM, fused epilogues)
+  preprocess (normalise + pad + NHWC4)  ->  ResNet/FPN (fp32-accurate split-operand MFMA implicit GEMM, fused epilogues)
   ->  RPN head + on-device proposal selection  ->  ROIAlign over all levels  ->  box head GEMMs
   ->  softmax / decode / per-class NMS / top-k / detector_postprocess
 with exactly ONE device->host read at the end (per-image detection counts + the status word), where

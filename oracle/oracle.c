@@ -7,7 +7,7 @@
  * Every function cites the reference code it restates (paths relative to
  * /root/reference).  Parity pins:
  *   - orc_roi_align_forward is checked against the reference's own
- *     ROIAlign_cpu.cpp compiled into oracle/_ref (tests/test_oracle_pins.py)
+ *     ROIAlign_cpu.cpp compiled into oracle/_ref (tests/test_oracle_golden.py)
  *     and against golden vectors produced by it (tests/golden/roi_align_*.npz);
  *     orc_roi_align_backward likewise (golden roi_align.npz keys bwd_*).
  *   - orc_nms restates torchvision 0.8.2's nms_cpu_kernel, a third-party

@@ -12,7 +12,6 @@ a few 1e-2 px on decoded boxes, i.e. the CPU path does not determine its own out
 tests therefore assert (a) trunk error vs fp64 no larger than 1.5x the CPU reference's own error vs fp64,
 (b) >= 90 % of the reference detections reproduced with identical class, |score| <= 2e-3, |box| <= 0.1 px, the
 remainder being near-tie reorderings in top-k/NMS, and print the exact statistics."""
-import os
 
 import pytest
 import torch
@@ -20,7 +19,6 @@ import torch
 from helpers import ROOT, gold, match_fraction, r50_state_dict
 
 pytestmark = pytest.mark.gpu
-CFG = os.path.join(ROOT, "tests", "golden", "configs", "faster_rcnn_R_50_FPN_base.yaml")
 
 
 def _model():
