@@ -15,10 +15,12 @@ def lib():
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
         src = os.path.join(_HERE, "oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        inc = os.path.join(_HERE, "roi_align_fwd.inc")
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(inc)):
             subprocess.check_call(["make", "-C", _HERE, "liboracle.so"])
         L = ctypes.CDLL(so)
         L.orc_roi_align_forward.restype = ctypes.c_int
+        L.orc_roi_align_forward_f64.restype = ctypes.c_int
         L.orc_roi_align_backward.restype = ctypes.c_int
         L.orc_nms.restype = ctypes.c_int64
         _LIB = L
@@ -31,6 +33,17 @@ def _p(t):
 
 def roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, aligned):
     """Same signature as the reference `_C.roi_align_forward` (csrc/vision.cpp:96)."""
+    if input.dtype == torch.float64:   # ROIAlignForward<double>: the fp64 evaluation of the path
+        input = input.contiguous()
+        rois = rois.contiguous().double()
+        K = rois.shape[0]
+        B, C, H, W = input.shape
+        out = torch.zeros(K, C, pooled_h, pooled_w, dtype=torch.float64)
+        rc = lib().orc_roi_align_forward_f64(_p(input), _p(rois), _p(out), K, C, H, W, pooled_h, pooled_w,
+                                             ctypes.c_double(spatial_scale), sampling_ratio, int(bool(aligned)))
+        if rc != 0:
+            raise RuntimeError("ROIs in ROIAlign cannot have non-negative size!")
+        return out
     input = input.contiguous().float()
     rois = rois.contiguous().float()
     K = rois.shape[0]

@@ -33,82 +33,26 @@
  * Returns 0, or -1 when aligned and an RoI has negative size
  * (ROIAlign_cpu.cpp:149-152 asserts there).
  */
-typedef struct {
-  int pos1, pos2, pos3, pos4;
-  float w1, w2, w3, w4;
-} orc_tap;
-
-int orc_roi_align_forward(const float* input, const float* rois, float* output, int K, int C,
-                          int H, int W, int pooled_h, int pooled_w, float spatial_scale,
-                          int sampling_ratio, int aligned) {
-  for (int n = 0; n < K; n++) {
-    const float* r = rois + (size_t)n * 5;
-    int b = (int)r[0];
-    float offset = aligned ? 0.5f : 0.0f;
-    float roi_start_w = r[1] * spatial_scale - offset;
-    float roi_start_h = r[2] * spatial_scale - offset;
-    float roi_end_w = r[3] * spatial_scale - offset;
-    float roi_end_h = r[4] * spatial_scale - offset;
-    float roi_width = roi_end_w - roi_start_w;
-    float roi_height = roi_end_h - roi_start_h;
-    if (aligned) {
-      if (!(roi_width >= 0 && roi_height >= 0)) return -1;
-    } else {
-      roi_width = roi_width > 1.f ? roi_width : 1.f;
-      roi_height = roi_height > 1.f ? roi_height : 1.f;
-    }
-    float bin_h = roi_height / (float)pooled_h;
-    float bin_w = roi_width / (float)pooled_w;
-    int gh = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_height / (float)pooled_h);
-    int gw = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(roi_width / (float)pooled_w);
-    int cnt = gh * gw > 1 ? gh * gw : 1;
-    float count = (float)cnt;
-    size_t ntap = (size_t)gh * gw * pooled_h * pooled_w;
-    orc_tap* taps = (orc_tap*)malloc((ntap ? ntap : 1) * sizeof(orc_tap));
-    size_t ti = 0;
-    for (int ph = 0; ph < pooled_h; ph++)
-      for (int pw = 0; pw < pooled_w; pw++)
-        for (int iy = 0; iy < gh; iy++) {
-          float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
-          for (int ix = 0; ix < gw; ix++) {
-            float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
-            float x = xx, y = yy;
-            orc_tap t;
-            if (y < -1.0 || y > H || x < -1.0 || x > W) {
-              memset(&t, 0, sizeof t);
-              taps[ti++] = t;
-              continue;
-            }
-            if (y <= 0) y = 0;
-            if (x <= 0) x = 0;
-            int y_low = (int)y, x_low = (int)x, y_high, x_high;
-            if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
-            if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
-            float ly = y - y_low, lx = x - x_low;
-            float hy = (float)(1. - ly), hx = (float)(1. - lx);
-            t.w1 = hy * hx; t.w2 = hy * lx; t.w3 = ly * hx; t.w4 = ly * lx;
-            t.pos1 = y_low * W + x_low; t.pos2 = y_low * W + x_high;
-            t.pos3 = y_high * W + x_low; t.pos4 = y_high * W + x_high;
-            taps[ti++] = t;
-          }
-        }
-    for (int c = 0; c < C; c++) {
-      const float* in = input + ((size_t)b * C + c) * H * W;
-      float* out = output + ((size_t)n * C + c) * pooled_h * pooled_w;
-      ti = 0;
-      for (int p = 0; p < pooled_h * pooled_w; p++) {
-        float acc = 0.f;
-        for (int s = 0; s < gh * gw; s++) {
-          orc_tap t = taps[ti++];
-          acc += t.w1 * in[t.pos1] + t.w2 * in[t.pos2] + t.w3 * in[t.pos3] + t.w4 * in[t.pos4];
-        }
-        out[p] = acc / count;
-      }
-    }
-    free(taps);
-  }
-  return 0;
-}
+#define ORC_T float
+#define ORC_FN orc_roi_align_forward
+#define ORC_TAP orc_tap
+#define ORC_CEIL ceilf
+#include "roi_align_fwd.inc"
+#undef ORC_T
+#undef ORC_FN
+#undef ORC_TAP
+#undef ORC_CEIL
+/* T = double: used by the fp64 evaluation of the whole path (tests/test_gpu_chain.py), which measures how far the
+ * reference's own fp32 CPU path and this build each are from the exact result. */
+#define ORC_T double
+#define ORC_FN orc_roi_align_forward_f64
+#define ORC_TAP orc_tap64
+#define ORC_CEIL ceil
+#include "roi_align_fwd.inc"
+#undef ORC_T
+#undef ORC_FN
+#undef ORC_TAP
+#undef ORC_CEIL
 
 /* ---- ROIAlign backward --------------------------------------------------
  * Restates ROIAlign_cpu.cpp:219-281 (bilinear_interpolate_gradient) and :288-406 (ROIAlignBackward), T=float:

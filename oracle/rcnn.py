@@ -18,12 +18,13 @@ SCALE_CLAMP = math.log(1000.0 / 16)  # detectron2/modeling/box_regression.py:11-
 
 
 # ------------------------------------------------------------------ preprocessing
-def preprocess(images, pixel_mean, pixel_std, size_divisibility):
+def preprocess(images, pixel_mean, pixel_std, size_divisibility, dtype=torch.float32):
     """lvc/modeling/meta_arch/rcnn.py:324-333 + detectron2/structures/image_list.py:57-119.
-    images: list of CHW float tensors.  Returns (padded [N,3,Hp,Wp], [(h,w),...])."""
-    mean = torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1)
-    std = torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1)
-    norm = [(im.float() - mean) / std for im in images]
+    images: list of CHW float tensors.  Returns (padded [N,3,Hp,Wp], [(h,w),...]).  dtype=float64 evaluates the
+    same formula in double (the "exact" run the fp32 paths are measured against)."""
+    mean = torch.tensor(pixel_mean, dtype=dtype).view(-1, 1, 1)
+    std = torch.tensor(pixel_std, dtype=dtype).view(-1, 1, 1)
+    norm = [(im.to(dtype) - mean) / std for im in images]
     sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in norm]
     mh = max(s[0] for s in sizes)
     mw = max(s[1] for s in sizes)
@@ -31,7 +32,7 @@ def preprocess(images, pixel_mean, pixel_std, size_divisibility):
         d = size_divisibility
         mh = (mh + d - 1) // d * d
         mw = (mw + d - 1) // d * d
-    out = torch.zeros(len(norm), norm[0].shape[0], mh, mw, dtype=torch.float32)
+    out = torch.zeros(len(norm), norm[0].shape[0], mh, mw, dtype=dtype)
     for o, im in zip(out, norm):
         o[..., : im.shape[-2], : im.shape[-1]].copy_(im)
     return out, sizes
@@ -121,8 +122,8 @@ def grid_anchors(cell_anchors, grid_sizes, strides, offset=0.0):
     """detectron2/modeling/anchor_generator.py:37-49, 157-178."""
     out = []
     for (gh, gw), stride, base in zip(grid_sizes, strides, cell_anchors):
-        sx = torch.arange(offset * stride, gw * stride, step=stride, dtype=torch.float32)
-        sy = torch.arange(offset * stride, gh * stride, step=stride, dtype=torch.float32)
+        sx = torch.arange(offset * stride, gw * stride, step=stride, dtype=base.dtype)
+        sy = torch.arange(offset * stride, gh * stride, step=stride, dtype=base.dtype)
         yy, xx = torch.meshgrid(sy, sx, indexing="ij")
         xx, yy = xx.reshape(-1), yy.reshape(-1)
         shifts = torch.stack((xx, yy, xx, yy), dim=1)
@@ -220,11 +221,12 @@ def assign_boxes_to_levels(boxes, min_level, max_level, canonical_box_size=224, 
 def roi_pool(feats, scales, box_lists, output_size=7, sampling_ratio=0, aligned=True, roi_align=None):
     """detectron2/modeling/poolers.py:191-246 with ROIAlignV2 (aligned=True)."""
     roi_align = roi_align or oops.roi_align_forward
-    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(box_lists)], 0)
+    dt = feats[0].dtype
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i), dtype=dt), b.to(dt)], 1) for i, b in enumerate(box_lists)], 0)
     min_level = int(round(-math.log2(scales[0])))
     max_level = int(round(-math.log2(scales[-1])))
     M, C = rois.shape[0], feats[0].shape[1]
-    out = torch.zeros(M, C, output_size, output_size)
+    out = torch.zeros(M, C, output_size, output_size, dtype=dt)
     if len(feats) == 1:
         return roi_align(feats[0], rois, scales[0], output_size, output_size, sampling_ratio, aligned)
     lv = assign_boxes_to_levels(rois[:, 1:], min_level, max_level)
@@ -276,7 +278,7 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
     return boxes[keep], scores[keep], inds[keep, 1], inds[keep, 0]
 
 
-def detector_postprocess(boxes, scores, classes, image_size, out_h, out_w):
+def detector_postprocess(boxes, scores, classes, image_size, out_h, out_w, return_keep=False):
     """detectron2/modeling/postprocessing.py:10-79 (box fields only)."""
     sx, sy = out_w / image_size[1], out_h / image_size[0]
     boxes = boxes.clone()
@@ -284,6 +286,8 @@ def detector_postprocess(boxes, scores, classes, image_size, out_h, out_w):
     boxes[:, 1::2] *= sy
     clip_boxes_(boxes, (out_h, out_w))
     keep = nonempty(boxes)
+    if return_keep:
+        return boxes[keep], scores[keep], classes[keep], keep
     return boxes[keep], scores[keep], classes[keep]
 
 
@@ -300,17 +304,22 @@ class RCNNSpec:
         del self.__dict__["self"]
 
 
-def generalized_rcnn_inference(sd, spec, batched_inputs, return_intermediates=False, roi_align=None):
+def generalized_rcnn_inference(sd, spec, batched_inputs, return_intermediates=False, roi_align=None, feats=None):
     """lvc/modeling/meta_arch/rcnn.py:177-322 (inference, do_postprocess=True), StandardROIHeads
-    (lvc/modeling/roi_heads/roi_heads.py:554-629).  batched_inputs: list of {"image","height","width"}."""
-    images, sizes = preprocess([b["image"] for b in batched_inputs], spec.pixel_mean, spec.pixel_std, 32)
-    feats = fpn(sd, resnet(sd, images, spec.depth))
+    (lvc/modeling/roi_heads/roi_heads.py:554-629).  batched_inputs: list of {"image","height","width"}.
+    The arithmetic type is the state_dict's (float32 = the reference's CPU path; a .double() state_dict gives the
+    fp64 evaluation; NMS decisions are taken on the float32-rounded boxes in both).  feats: precomputed {p2..p6}
+    (the post-trunk chain tests hand the SAME features to this function and to the HIP path)."""
+    dt = sd["backbone.fpn_lateral2.weight"].dtype
+    images, sizes = preprocess([b["image"] for b in batched_inputs], spec.pixel_mean, spec.pixel_std, 32, dtype=dt)
+    if feats is None:
+        feats = fpn(sd, resnet(sd, images, spec.depth))
     names = ["p2", "p3", "p4", "p5", "p6"]
     strides = [4, 8, 16, 32, 64]
     flist = [feats[n] for n in names]
     logits, deltas = rpn_head(sd, flist)
     ar = spec.aspect_ratios * len(names) if len(spec.aspect_ratios) == 1 else spec.aspect_ratios
-    cell = [sd.get("proposal_generator.anchor_generator.cell_anchors.%d" % i, generate_cell_anchors(s, a))
+    cell = [sd.get("proposal_generator.anchor_generator.cell_anchors.%d" % i, generate_cell_anchors(s, a)).to(dt)
             for i, (s, a) in enumerate(zip(spec.anchor_sizes, ar))]
     anchors = grid_anchors(cell, [f.shape[-2:] for f in flist], strides)
     lg, dl = flatten_rpn_outputs(logits, deltas)
@@ -331,8 +340,9 @@ def generalized_rcnn_inference(sd, spec, batched_inputs, return_intermediates=Fa
                                                          spec.dets_per_image)
         h = batched_inputs[bi].get("height", sizes[bi][0])
         w = batched_inputs[bi].get("width", sizes[bi][1])
-        b, s, c = detector_postprocess(b, s, c, sizes[bi], h, w)
-        results.append({"pred_boxes": b, "scores": s, "pred_classes": c})
+        b, s, c, kept = detector_postprocess(b, s, c, sizes[bi], h, w, return_keep=True)
+        # "rows": the proposal index each detection came from (fast_rcnn.py:131-137 returns it as the second value)
+        results.append({"pred_boxes": b, "scores": s, "pred_classes": c, "rows": rows[kept]})
     if return_intermediates:
         return results, {"images": images, "feats": feats, "rpn_logits": logits, "rpn_deltas": deltas,
                          "proposals": proposals, "pooled": pooled, "head": hfeat, "cls_logits": scores,
