@@ -1,0 +1,70 @@
+"""Data-parallel paths on the device: bench.py's launcher behaviour and RCCL initialisation, and 2-rank checks of the
+cfg-3 gradient average and of the sharded kNN sweep (RCCL when the box has >= 2 GPUs, otherwise two processes on the
+one GPU through gloo -- the code above the collective is the same)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "4"
+    return env
+
+
+def _torchrun(nproc, script, *args, timeout=900):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
+           "127.0.0.1", "--master-port", str(_port()), script] + list(args)
+    p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    return p.stdout
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=_env(), cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 3
+    assert "only" in json.loads(p.stdout.strip().splitlines()[-1])["error"]
+
+
+def test_bench_knn_leg_under_the_launcher_initialises_rccl():
+    """What the driver does for N > 1, at N = 1: torch.distributed.run + backend "nccl" (= RCCL)."""
+    out = _torchrun(1, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "knn")
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["rccl"] == {"backend": "nccl", "world_size": 1, "allreduce_of_ones": 1.0}
+    assert line["n_gpus"] == 1 and line["unit"] == "queries/s" and line["value"] > 1e6
+
+
+def _worker(mode):
+    out = _torchrun(2, os.path.join(ROOT, "tests", "_dp_worker.py"), mode)
+    line = [l for l in out.splitlines() if l.startswith("DP_WORKER_RESULT ")][-1]
+    return json.loads(line[len("DP_WORKER_RESULT "):])
+
+
+def test_two_rank_gradient_average_equals_the_concatenated_batch():
+    r = _worker("train")
+    print(r)
+    assert r["world"] == 2 and r["bytes"] == 103525 * 4
+    # fp32 atomics in the weight-gradient kernel: summation order differs between the two evaluations
+    assert max(r["rel_err_vs_concatenated_batch"]) <= 2e-4, r
+
+
+def test_two_rank_sharded_knn_equals_the_single_process_sweep():
+    r = _worker("knn")
+    print(r)
+    assert r["world"] == 2 and r["rows"] == 4096 and r["top_equal"] and r["keep_equal"]
