@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void knn_topk_vote_kernel(const float* __restr
   for (int j = 0; j < PER; ++j) {
     const int i = j * 64 + lane;
     v[j] = i < S ? sr[i] : -INFINITY;
+    if (v[j] != v[j]) v[j] = INFINITY;   // NaN similarity: torch.topk ranks NaN above every number; ties -> lower index
     lmax = fmaxf(lmax, v[j]);
   }
   // ---- 1. T = the lane maximum of rank KTOP-1

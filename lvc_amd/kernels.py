@@ -122,7 +122,7 @@ def _with_planes(pc, planes, out):
     return pc
 
 
-def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False, affine=None):
+def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False, affine=None, split=None):
     """weight: [K, C, R, S] (OIHW, the reference's state_dict layout) on the target device.
     bn: None or (weight, bias, running_mean, running_var) of a FrozenBatchNorm2d; affine: a precomputed
     `conv_affine(bias, bn, eps)` (the fold only changes when those tensors do, the weights change every step).
@@ -145,7 +145,7 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False,
         assert C % BK == 0, "implicit-GEMM kernel needs in_channels % 32 == 0 (got {})".format(C)
         Kg = R * S * C
         # k = (c // 32, r, s, c % 32): the taps of one 32-channel chunk are consecutive gemm-k chunks
-        planes = _planes_hint(R, S, C, None)
+        planes = _planes_hint(R, S, C, split)
         wp, pl = _pack_weights(weight, None, Kpad, C, 0, planes)
         scale, shift = affine if affine is not None else conv_affine(bias, bn, eps)
         return _with_planes(PackedConv(wp, scale, shift, K, C, R, S, stride, pad, Kg, 0), planes, pl)
@@ -153,9 +153,10 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False,
     return PackedConv(wp, scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
 
 
-def pack_linear(weight, bias=None):
-    """weight [K_out, K_in] -> a 1x1 'conv' over M x 1 x 1 x K_in rows."""
-    return pack_conv(weight[:, :, None, None], bias=bias)
+def pack_linear(weight, bias=None, split=None):
+    """weight [K_out, K_in] -> a 1x1 'conv' over M x 1 x 1 x K_in rows.  split: the operand split the GEMM will be
+    asked for (None = LVC_CONV_SPLIT), so that the matching planes are produced by the packing launch."""
+    return pack_conv(weight[:, :, None, None], bias=bias, split=split)
 
 
 _CONV_WS = {}
@@ -354,10 +355,11 @@ def stem_conv_pool(x4, pc, relu=True, second=None):
     return out
 
 
-def linear(x, pc, relu=False):
-    """x: [M, K_in] -> [M, K_out] through the same MFMA kernel."""
+def linear(x, pc, relu=False, split=None):
+    """x: [M, K_in] -> [M, K_out] through the same MFMA kernel.  split: as conv2d_nhwc (gradient GEMMs pass
+    DGRAD_SPLIT: unscaled gradients sit below fp16's normal range, and the fp16 split's range word only sees overflow)."""
     M, Kin = x.shape
-    y = conv2d_nhwc(x.view(M, 1, 1, Kin), pc, relu=relu)
+    y = conv2d_nhwc(x.view(M, 1, 1, Kin), pc, relu=relu, split=split)
     return y.view(M, pc.K)
 
 
@@ -892,7 +894,7 @@ def linear_backward(x, weight, dz, need_dx=True, need_dw=True):
         if pk:
             dzp = torch.zeros(M, Kout + pk, device=dev)
             dzp[:, :Kout] = dz
-        dx = linear(dzp.contiguous(), pack_linear(wt))
+        dx = linear(dzp.contiguous(), pack_linear(wt, split=DGRAD_SPLIT), split=DGRAD_SPLIT)
     if need_dw and Kout % 4 == 0 and Kin % 4 == 0:   # dw = dz^T @ x on the pixel-contraction kernel (no transposes)
         dw = conv_wgrad(x.detach().contiguous().view(M, 1, 1, Kin), dz.contiguous().view(M, 1, 1, Kout), None, 1, 1, 1, 0)
         dw = dw.view(Kout, Kin)
@@ -902,7 +904,7 @@ def linear_backward(x, weight, dz, need_dx=True, need_dw=True):
         xt[:, :M] = x.detach().t()
         dzt = torch.zeros(Kout, M + pm, device=dev)
         dzt[:, :M] = dz.t()
-        dw = linear(dzt, pack_linear(xt))
+        dw = linear(dzt, pack_linear(xt, split=DGRAD_SPLIT), split=DGRAD_SPLIT)
     return dx, dw
 
 

@@ -133,7 +133,7 @@ class GeneralizedRCNN(_RCNNBase):
         else:
             gt_instances = None
         # frozen trunk (the fine-tune yamls): no graph; otherwise the fused Conv2d autograd records res3.. / FPN
-        with torch.set_grad_enabled(any(p.requires_grad for p in self.backbone.parameters())):
+        with torch.set_grad_enabled(torch.is_grad_enabled() and any(p.requires_grad for p in self.backbone.parameters())):
             features = self.backbone(images.tensor)
         from ..proposal_generator.rbg import RBG
 

@@ -43,6 +43,8 @@ class _ScaleGradient(torch.autograd.Function):
 
 @ROI_HEADS_REGISTRY.register()
 class CascadeROIHeads(ROIHeads):
+    relabel_ignored_gt = False   # detectron2's label_and_sample_proposals: no gt_ignores toggle
+
     def __init__(self, cfg, input_shape):
         super().__init__(cfg, input_shape)
         BH = cfg.MODEL.ROI_BOX_HEAD

@@ -197,12 +197,12 @@ class _PredictorLoss(torch.autograd.Function):
         pad = (-R) % 32  # the GEMM contracts over R: multiple of the 32-wide k chunk
         xt = torch.zeros(x.shape[1], R + pad, device=x.device)
         xt[:, :R] = x.t()
-        pc = K.pack_linear(xt)
+        pc = K.pack_linear(xt, split=K.DGRAD_SPLIT)
 
         def dweight(dy, g):
             dyt = torch.zeros(dy.shape[1], R + pad, device=x.device)
             dyt[:, :R] = (dy * g).t()
-            return K.linear(dyt, pc)  # [K_out, K_in]
+            return K.linear(dyt, pc, split=K.DGRAD_SPLIT)  # [K_out, K_in]; gradients: range-free split
 
         dwc, dwb = dweight(dl, g_cls), dweight(dd, g_box)
         dbc = (dl * g_cls).sum(0) if ctx.has_bias[0] else None

@@ -64,6 +64,8 @@ class ROIHeads(nn.Module):
         sampled = torch.cat([fg, bg], dim=0)
         return sampled, gt_classes[sampled]
 
+    relabel_ignored_gt = True
+
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets, inference=False, log=None):
         """reference lvc roi_heads.py:173-278: append GT, match (IoU kernel), gt_ignores toggle, subsample.
@@ -80,16 +82,21 @@ class ROIHeads(nn.Module):
                 pboxes = torch.cat([pboxes, gt], 0)
                 plogits = torch.cat([plogits, gt_logit * torch.ones(len(gt), device=gt.device)], 0)
             matched_idxs, matched_labels = self.proposal_matcher.match(gt, pboxes)
-            if tgt.has("gt_ignores") and bool(tgt.gt_ignores.bool().sum()):
+            # lvc's ROIHeads only (roi_heads.py:222-228); CascadeROIHeads derives from detectron2's StandardROIHeads,
+            # whose label_and_sample_proposals (detectron2/modeling/roi_heads/roi_heads.py:220-306) has no such toggle
+            if self.relabel_ignored_gt and tgt.has("gt_ignores") and bool(tgt.gt_ignores.bool().sum()):
                 from ...structures import pairwise_iou
 
                 ig = tgt.gt_ignores.bool()
                 max_ig = pairwise_iou(Boxes(gt[ig]), Boxes(pboxes)).max(dim=0)[0]
                 matched_labels[max_ig > self.proposal_matcher.thresholds[1]] = -1
             sampled, gt_classes = self._sample_proposals(matched_idxs, matched_labels, tgt.gt_classes, inference)
-            inst = Instances(prop.image_size)
-            inst.proposal_boxes = Boxes(pboxes[sampled])
-            inst.objectness_logits = plogits[sampled]
+            if self.proposal_append_gt:
+                inst = Instances(prop.image_size)
+                inst.proposal_boxes = Boxes(pboxes[sampled])
+                inst.objectness_logits = plogits[sampled]
+            else:   # reference: proposals_per_image[sampled_idxs] -- every field the proposals carry is kept
+                inst = prop[sampled]
             inst.gt_classes = gt_classes
             if len(gt) > 0:
                 st = matched_idxs[sampled]

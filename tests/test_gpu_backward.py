@@ -177,3 +177,24 @@ def test_conv_wgrad_f16x2_reports_out_of_range_gradients():
     Kn.conv_wgrad(x, dy, None, 1, 1, 1, 0, split="f16x2")
     assert Kn.conv_error_word(dev) & 2
     Kn.clear_conv_error_word(dev)
+
+
+def test_linear_backward_keeps_tiny_gradients():
+    """Unscaled gradients of a mean-reduced loss (1e-8 and below) through the FC backward at M >= 2048 rows and a
+    contraction >= 128: the data-gradient GEMM must take the range-free split (DGRAD_SPLIT), not the two-way fp16 one,
+    whose residual plane flushes below 2^-35 (its range word only sees overflow).  fp64 reference."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(11)
+    M, Kin, Kout = 2560, 256, 192
+    x = torch.randn(M, Kin, generator=g)
+    w = torch.randn(Kout, Kin, generator=g) * 0.05
+    for mag in (1e-6, 1e-8, 1e-10):
+        dz = torch.randn(M, Kout, generator=g) * mag
+        dx, dw = K.linear_backward(x.cuda(), w.cuda(), dz.cuda())
+        rx = dz.double() @ w.double()
+        rw = dz.double().t() @ x.double()
+        ex = float((dx.cpu().double() - rx).norm() / rx.norm())
+        ew = float((dw.cpu().double() - rw).norm() / rw.norm())
+        print("gradient scale %.0e: dx rel %.2e, dw rel %.2e" % (mag, ex, ew))
+        assert ex <= 5e-6 and ew <= 5e-6, mag

@@ -613,3 +613,22 @@ def test_lr_scheduler_rejects_unknown_names():
         warmup_factor_at_iter("exp", 1, 10, 0.1)
     with pytest.raises(ValueError, match="increasing"):
         WarmupMultiStepLR(opt, [30, 20])
+
+
+def test_custom_ops_are_registered_with_the_reference_schemas():
+    """torch.ops.lvc_amd.* exist after `import lvc_amd` with the positional schemas of the reference's native seam
+    (detectron2/layers/csrc/vision.cpp:96-97, torchvision nms / batched_nms), and refuse CPU tensors loudly."""
+    import lvc_amd  # noqa: F401
+
+    S = {n: str(getattr(torch.ops.lvc_amd, n).default._schema) for n in ("roi_align_forward", "roi_align_backward", "nms", "batched_nms")}
+    assert S["roi_align_forward"] == ("lvc_amd::roi_align_forward(Tensor input, Tensor rois, float spatial_scale, int pooled_height, "
+                                      "int pooled_width, int sampling_ratio, bool aligned) -> Tensor")
+    assert S["roi_align_backward"] == ("lvc_amd::roi_align_backward(Tensor grad, Tensor rois, float spatial_scale, int pooled_height, "
+                                       "int pooled_width, int batch_size, int channels, int height, int width, int sampling_ratio, "
+                                       "bool aligned) -> Tensor")
+    assert S["nms"] == "lvc_amd::nms(Tensor boxes, Tensor scores, float iou_threshold) -> Tensor"
+    assert S["batched_nms"] == "lvc_amd::batched_nms(Tensor boxes, Tensor scores, Tensor idxs, float iou_threshold) -> Tensor"
+    with pytest.raises(RuntimeError):
+        torch.ops.lvc_amd.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+    with pytest.raises(RuntimeError):
+        torch.ops.lvc_amd.roi_align_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 0.25, 7, 7, 0, True)
