@@ -181,7 +181,9 @@ int lvc_roi_align_fpn_backward_nhwc(const float* grad, float* const* grad_feats,
  * threshold, score ties -> lower index).
  *   boxes [B,Nmax,4], scores [B,Nmax], idxs [B,Nmax] int32 or NULL, d_counts [B] int32 or NULL (= Nmax)
  *   keep [B,Nmax] int32 (indices into the image's rows, score-descending), d_num_keep [B] int32
- *   max_keep <= 0: unlimited.  Nmax <= 16384.
+ *   max_keep <= 0: unlimited.  Any Nmax: up to 16384 rows per image run as one LDS sort + one mask + one reduce launch;
+ *   beyond that (the reference switches to a per-class loop at 40000 boxes, nms.py:22-29, same result) a global bitonic
+ *   sort and the greedy pass in blocks of 16384 sorted rows.
  */
 long long lvc_batched_nms_workspace_bytes(int B, int Nmax);
 int lvc_batched_nms(const float* boxes, const float* scores, const int* idxs, const int* d_counts, int B,
@@ -196,7 +198,7 @@ int lvc_batched_nms(const float* boxes, const float* scores, const int* idxs, co
  *     deltas[l]  device ptr: delta c of anchor a                          = deltas[l][(b*H*W + p)*ld_delta[l] + a*4 + c]
  *     cell_anchors[l] device ptr [A,4]; Hs, Ws, strides
  *   d_image_sizes [B,2] int32 (h, w).  Outputs: out_boxes [B,post,4], out_logits [B,post] (zero rows past
- *   d_out_count[b]).  pre_nms_topk <= 2048; sum over levels of min(pre_nms_topk, H*W*A) <= 16384.
+ *   d_out_count[b]).  pre_nms_topk <= 2048.
  */
 long long lvc_rpn_proposals_workspace_bytes(int B, int L, int A, const int* Hs, const int* Ws, int pre_nms_topk);
 int lvc_rpn_proposals(const float* const* logits, const int* ld_logit, const float* const* deltas,
@@ -217,7 +219,8 @@ int lvc_assign_levels_rois(const float* boxes, int B, int R, int min_level, int 
  *   d_prop_count [B] or NULL, d_image_sizes [B,2] (h,w), (wx,wy,ww,wh) = ROI_BOX_HEAD.BBOX_REG_WEIGHTS,
  *   d_post [B,4] = (scale_x, scale_y, out_h, out_w) or NULL.
  *   Outputs [B,topk,*] + d_out_count [B]; out_rows = index of the proposal each detection came from.
- *   max_candidates <= 16384 (roi,class) pairs above score_thresh per image (overflow -> d_status bit 1).
+ *   max_candidates: capacity of the (roi,class) candidate list per image (pairs above score_thresh); R*K can never
+ *   overflow; a smaller capacity that does overflow sets d_status bit 1 (value 2) and the host re-runs with R*K.
  */
 long long lvc_fast_rcnn_inference_workspace_bytes(int B, int max_candidates);
 int lvc_fast_rcnn_inference(const float* cls_logits, int ld_cls, const float* deltas, int ld_delta, int K,

@@ -609,7 +609,6 @@ extern "C" int lvc_rpn_proposals(const float* const* logits, const int* ld_logit
                     out_logits && d_out_count && workspace, "null pointer");
   RpnPlan p = rpn_plan(B, L, A, Hs, Ws, pre_nms_topk);
   LVC_CHECK_ARG(workspace_bytes >= p.total, "workspace too small");
-  LVC_CHECK_ARG(p.Ntot <= 16384, "too many pre-NMS candidates per image (> 16384)");
   RpnLevels lv;
   memset(&lv, 0, sizeof lv);
   lv.L = L; lv.A = A;
@@ -910,7 +909,7 @@ extern "C" int lvc_fast_rcnn_inference(const float* cls_logits, int ld_cls, cons
                                        int* out_classes, int* out_rows, int* d_out_count, int* d_status,
                                        void* workspace, long long workspace_bytes, void* stream) {
   LVC_CHECK_ARG(B > 0 && R > 0 && K > 0 && topk > 0, "bad sizes");
-  LVC_CHECK_ARG(max_candidates > 0 && max_candidates <= 16384, "max_candidates must be in 1..16384");
+  LVC_CHECK_ARG(max_candidates > 0, "max_candidates must be positive");
   LVC_CHECK_ARG(cls_logits && deltas && proposals && d_image_sizes && out_boxes && out_scores && out_classes &&
                     out_rows && d_out_count && d_status && workspace, "null pointer");
   DetPlan p = det_plan(B, max_candidates);

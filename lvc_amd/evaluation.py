@@ -17,7 +17,7 @@ import collections
 import torch
 
 from . import kernels as K
-from .modeling.roi_heads.roi_heads import instances_from_batched
+from .modeling.roi_heads.roi_heads import CandidateOverflow, instances_from_batched, widen_limits
 
 
 class PipelinedInference:
@@ -38,13 +38,20 @@ class PipelinedInference:
         for inp in batched_inputs:
             ref = inp["image"].shape[-2:] if "image" in inp else inp["raw"].shape[:2]
             sizes.append((inp.get("height", int(ref[0])), inp.get("width", int(ref[1]))))
-        return (out, s, sizes)
+        return (out, s, sizes, batched_inputs, do_postprocess)
 
     def collect(self, ticket):
         """Wait for that batch only and build its `Instances` (the reference's per-image output dicts)."""
-        (ob, osc, ocl, cnt, status), s, sizes = ticket
+        (ob, osc, ocl, cnt, status), s, sizes, batched_inputs, do_postprocess = ticket
         with torch.cuda.stream(s):
-            insts = instances_from_batched(ob, osc, ocl, cnt, sizes, status)   # one D2H read on that stream
+            try:
+                insts = instances_from_batched(ob, osc, ocl, cnt, sizes, status)   # one D2H read on that stream
+            except (CandidateOverflow, K.Fp16RangeError) as e:
+                # a limit the reference does not have was hit by this batch: widen it and run the batch again, here
+                if not widen_limits(self.model, e):
+                    raise
+                with torch.no_grad():
+                    return self.model.inference(batched_inputs, do_postprocess=do_postprocess)
         # the results were allocated and written on the side stream: order the caller's stream behind it and tell the
         # caching allocator that the caller's stream uses them too
         cur = torch.cuda.current_stream(self.model.device)

@@ -190,16 +190,39 @@ def clear_conv_error_word(device):
     ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4].zero_()
 
 
+class Fp16RangeError(LvcNativeError):
+    """An operand beyond fp16's range (|a| > 65504, or NaN) reached a two-way fp16 split kernel: the results of that
+    pass are invalid.  The model entry points catch it, switch to the range-free three-way bf16 split
+    (`use_range_free_split`) and run the pass again."""
+
+
+_RANGE_FALLBACK_LOGGED = False
+
+
+def use_range_free_split(reason=""):
+    """Switch every conv/GEMM of this process from the two-way fp16 split to the exact three-way bf16 split (no range
+    limit, ~1.5x slower); logged once.  Packed layers keep both plane sets lazily, so this takes effect at the next call."""
+    global CONV_SPLIT, _RANGE_FALLBACK_LOGGED
+    CONV_SPLIT = "bf16x3"
+    if not _RANGE_FALLBACK_LOGGED:
+        _RANGE_FALLBACK_LOGGED = True
+        import logging
+
+        logging.getLogger("lvc_amd").warning(
+            "an operand beyond fp16's range (|a| > 65504 or NaN) reached the fp16x2 conv kernels%s; re-running on the "
+            "range-free bf16x3 kernels and keeping them for the rest of the process", (" (" + reason + ")") if reason else "")
+
+
 def check_conv_error_word(device):
     """Raise for a set bit of the conv workspace error word (bit 0: a stream-K worker timed out waiting for a partial
-    tile; bit 1: an operand beyond fp16's range reached a two-way fp16 split kernel).  Synchronises: call it where the
-    results are read anyway."""
+    tile; bit 1: an operand beyond fp16's range reached a two-way fp16 split kernel -> Fp16RangeError, which the model
+    entry points turn into a re-run on the bf16x3 kernels).  Synchronises: call it where the results are read anyway."""
     e = conv_error_word(device)
     if e & 1:
         raise LvcNativeError("conv/GEMM kernel: a stream-K worker timed out waiting for a partial tile")
     if e & 2:
         clear_conv_error_word(device)
-        raise LvcNativeError("conv/GEMM kernel: an operand with |a| > 65504 (or NaN) reached the fp16x2 split; "
+        raise Fp16RangeError("conv/GEMM kernel: an operand with |a| > 65504 (or NaN) reached the fp16x2 split; "
                              "set LVC_CONV_SPLIT=bf16x3 for range-free kernels")
 
 
@@ -567,6 +590,9 @@ def fast_rcnn_inference(cls_logits, deltas, proposals, prop_count, image_sizes, 
     cls_logits [B*R, >=K+1], deltas [B*R, 4K or 4] (row-contiguous, any row stride), proposals [B,R,4],
     prop_count [B] int32 or None, image_sizes [B,2] int32, post [B,4] fp32 = (scale_x, scale_y, out_h, out_w).
     Returns (boxes [B,topk,4], scores [B,topk], classes [B,topk] int32, rows [B,topk] int32, count [B] int32).
+    max_candidates: capacity of the per-image (roi, class) candidate list; None = R*K (cannot overflow).  The default
+    keeps the NMS in its one-block form; an overflow sets status bit 1 (value 2) -> `CandidateOverflow` where the status
+    is read, and the model entry points re-run with the full capacity.
     """
     _req_cuda(cls_logits, deltas, proposals, prop_count, image_sizes, post)
     B, R, _ = proposals.shape
@@ -578,7 +604,7 @@ def fast_rcnn_inference(cls_logits, deltas, proposals, prop_count, image_sizes, 
         status = new_status(dev)
     lib = _lib.lib()
     lib.lvc_fast_rcnn_inference_workspace_bytes.restype = c_longlong
-    max_candidates = min(max_candidates, max(1, R * K))
+    max_candidates = max(1, R * K) if max_candidates is None else min(max_candidates, max(1, R * K))
     nbytes = lib.lvc_fast_rcnn_inference_workspace_bytes(c_int(B), c_int(max_candidates))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ob = torch.empty(B, topk, 4, device=dev, dtype=torch.float32)

@@ -19,7 +19,7 @@ from ..backbone import build_backbone
 from ..postprocessing import detector_postprocess
 from ..proposal_generator import RPN, build_proposal_generator
 from ..roi_heads import StandardROIHeads, build_roi_heads
-from ..roi_heads.roi_heads import check_status, instances_from_batched
+from ..roi_heads.roi_heads import check_status, instances_from_batched, run_with_fallbacks
 from .build import META_ARCH_REGISTRY
 
 
@@ -124,6 +124,15 @@ class GeneralizedRCNN(_RCNNBase):
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
+
+        def once():
+            losses = self._forward_train(batched_inputs)
+            K.check_conv_error_word(self.device)   # fp16x2 range word of the forward kernels (the step syncs anyway)
+            return losses
+
+        return run_with_fallbacks(self, once)
+
+    def _forward_train(self, batched_inputs):
         # training forward (reference rcnn.py:127-175): losses of the RPN (logged; frozen) and of the box predictor
         images = self.preprocess_image(batched_inputs)
         if "instances" in batched_inputs[0]:
@@ -187,6 +196,9 @@ class GeneralizedRCNN(_RCNNBase):
             return self._inference_box_corrector(batched_inputs)
         if not (isinstance(self.proposal_generator, RPN) and isinstance(self.roi_heads, StandardROIHeads)):
             return self._inference_modular(batched_inputs, do_postprocess)
+        return run_with_fallbacks(self, lambda: self._inference_fast(batched_inputs, do_postprocess))
+
+    def _inference_fast(self, batched_inputs, do_postprocess):
         ob, osc, ocl, cnt, status = self.inference_batched(batched_inputs, do_postprocess)
         out_sizes = []
         for inp in batched_inputs:

@@ -117,6 +117,10 @@ class ROIHeads(nn.Module):
 
 @ROI_HEADS_REGISTRY.register()
 class StandardROIHeads(ROIHeads):
+    # capacity of the per-image (roi, class) candidate list of fast_rcnn_inference; None = R*K.  16 384 keeps the
+    # detection-stage NMS in its one-block form; `run_with_fallbacks` switches to None after the first overflow
+    det_max_candidates = 16384
+
     def __init__(self, cfg, input_shape):
         super().__init__(cfg, input_shape)
         self._init_box_head(cfg)
@@ -149,7 +153,8 @@ class StandardROIHeads(ROIHeads):
         scores, deltas = self.box_predictor(h)
         return K.fast_rcnn_inference(scores, deltas, prop_boxes, prop_count, image_sizes_dev, self.num_classes,
                                      self.box2box_transform.weights, self.test_score_thresh, self.test_nms_thresh,
-                                     self.test_detections_per_img, post=post, status=status)
+                                     self.test_detections_per_img, post=post, status=status,
+                                     max_candidates=self.det_max_candidates)
 
     def forward(self, images, features, proposals, targets=None):
         """Reference signature (roi_heads.py:554-572): -> (list[Instances], losses)."""
@@ -209,6 +214,40 @@ def _forward_train(self, features, proposals, targets):
 StandardROIHeads._forward_train = _forward_train
 
 
+def widen_limits(model, exc):
+    """React to a capacity / range condition the reference does not have: candidate list sized for R*K, or the range-free
+    bf16x3 split; logged once.  Returns False when the limit was already at its widest (the caller re-raises)."""
+    import logging
+
+    if isinstance(exc, CandidateOverflow):
+        heads = getattr(model, "roi_heads", None)
+        if heads is None or heads.det_max_candidates is None:
+            return False
+        logging.getLogger("lvc_amd").warning(
+            "more than %d (roi, class) candidates above SCORE_THRESH_TEST in one image: re-running with the list sized "
+            "for R*K and keeping that size", heads.det_max_candidates)
+        heads.det_max_candidates = None
+        return True
+    if isinstance(exc, K.Fp16RangeError):
+        if K.CONV_SPLIT == "bf16x3":
+            return False
+        K.use_range_free_split()
+        return True
+    return False
+
+
+def run_with_fallbacks(model, fn):
+    """Run fn() (one pass that ends by reading the status words); on CandidateOverflow / Fp16RangeError widen the limit
+    (`widen_limits`) and run again -- the pass degrades (one repeated batch, slower kernels) instead of failing."""
+    for _ in range(2):
+        try:
+            return fn()
+        except (CandidateOverflow, K.Fp16RangeError) as e:
+            if not widen_limits(model, e):
+                raise
+    return fn()
+
+
 def instances_from_batched(boxes, scores, classes, count, image_sizes, status=None):
     """One device->host read (counts + status), then per-image `Instances` of device tensors."""
     if status is not None:
@@ -229,10 +268,15 @@ def instances_from_batched(boxes, scores, classes, count, image_sizes, status=No
     return out
 
 
+class CandidateOverflow(RuntimeError):
+    """More (roi, class) pairs above SCORE_THRESH_TEST in one image than the candidate list was sized for.  The model
+    entry points catch it, size the list for R*K (`StandardROIHeads.det_max_candidates = None`) and run again."""
+
+
 def check_status(st):
     """Device status word written by the kernels (no sync on the hot path; read with the results)."""
     if st & 1:
         raise RuntimeError("ROIs in ROIAlign cannot have non-negative size!")  # reference ROIAlign_cpu.cpp:149-152
     if st & 2:
-        raise RuntimeError("lvc_fast_rcnn_inference: more than 16384 (roi, class) candidates above "
-                           "SCORE_THRESH_TEST in one image; raise the threshold")
+        raise CandidateOverflow("lvc_fast_rcnn_inference: more (roi, class) candidates above SCORE_THRESH_TEST in one "
+                                "image than the candidate list holds; re-run with max_candidates=None (= R*K)")

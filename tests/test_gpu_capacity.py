@@ -1,0 +1,129 @@
+"""Limits the reference does not have must degrade, not fail:
+  * batched NMS on more than 16 384 boxes per image (reference: per-class loop from 40 000 boxes, nms.py:22-29) --
+    global sort + blocked greedy pass, keep indices still bit-exact;
+  * SCORE_THRESH_TEST = 0: every (roi, class) pair is a candidate (1000 x 80 per image) -- the detector re-runs the
+    batch with the candidate list sized for R*K and keeps going;
+  * an activation beyond fp16's range -- the pass is repeated on the range-free bf16x3 kernels."""
+import logging
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _boxes(g, n, span=2000.0):
+    c = torch.rand(n, 2, generator=g) * span
+    wh = 8 + torch.rand(n, 2, generator=g) * 150
+    return torch.cat([c, c + wh], 1)
+
+
+@pytest.mark.parametrize("n,classes,thr", [(20000, 1, 0.5), (40000, 7, 0.7), (70001, 80, 0.5), (16385, 3, 0.3)])
+def test_large_nms_keep_indices_exact(n, classes, thr):
+    from lvc_amd import kernels as K
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(n)
+    boxes = _boxes(g, n)
+    scores = torch.rand(n, generator=g)
+    scores[500:520] = scores[500]                       # exact ties -> lower index first
+    idxs = torch.randint(0, classes, (n,), generator=g)
+    ref = oops.batched_nms(boxes, scores, idxs, thr)
+    keep, nk = K.batched_nms_batch(boxes[None].cuda(), scores[None].cuda(), idxs.to(torch.int32)[None].cuda(), None, thr)
+    got = keep[0, : int(nk.item())].cpu().long()
+    assert len(ref) > 16384 or n < 30000
+    assert torch.equal(got, ref)
+    # the drop-in op
+    got2 = torch.ops.lvc_amd.batched_nms(boxes.cuda(), scores.cuda(), idxs.cuda(), thr).cpu()
+    assert torch.equal(got2, ref)
+
+
+def test_large_nms_ragged_counts_and_max_keep():
+    """Two images in one call, capacity 50 000, real counts 33 000 and 9 000 (the second fits the first block and skips
+    every later stage), max_keep cuts the list where the reference's `keep[:k]` does."""
+    from lvc_amd import kernels as K
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(77)
+    Nmax, counts = 50000, [33000, 9000]
+    boxes = torch.zeros(2, Nmax, 4)
+    scores = torch.zeros(2, Nmax)
+    idxs = torch.zeros(2, Nmax, dtype=torch.int32)
+    refs = []
+    for b, n in enumerate(counts):
+        boxes[b, :n] = _boxes(g, n, 1200.0)
+        scores[b, :n] = torch.rand(n, generator=g)
+        idxs[b, :n] = torch.randint(0, 5, (n,), generator=g).int()
+        refs.append(oops.batched_nms(boxes[b, :n], scores[b, :n], idxs[b, :n], 0.6))
+    cnt = torch.tensor(counts, dtype=torch.int32).cuda()
+    keep, nk = K.batched_nms_batch(boxes.cuda(), scores.cuda(), idxs.cuda(), cnt, 0.6)
+    for b in range(2):
+        assert torch.equal(keep[b, : int(nk[b])].cpu().long(), refs[b]), b
+    keep, nk = K.batched_nms_batch(boxes.cuda(), scores.cuda(), idxs.cuda(), cnt, 0.6, max_keep=2500)
+    for b in range(2):
+        k = min(2500, len(refs[b]))
+        assert int(nk[b]) == k and torch.equal(keep[b, :k].cpu().long(), refs[b][:k]), b
+
+
+def test_score_thresh_zero_degrades_to_full_capacity(caplog):
+    """SCORE_THRESH_TEST = 0.0 (AP-style dumps): 1000 x 80 = 80 000 candidates per image.  The first pass overflows the
+    16 384-row list, the model re-runs the batch with R*K rows (logged once) and the detections equal the oracle's."""
+    from helpers import match_fraction, r50_state_dict
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+    from test_gpu_e2e import _model
+
+    model = _model()
+    model.roi_heads.test_score_thresh = 0.0
+    assert model.roi_heads.det_max_candidates == 16384
+    inputs = [{"image": syn.synthetic_image(3, 240, 320), "height": 240, "width": 320},
+              {"image": syn.synthetic_image(4, 200, 352), "height": 200, "width": 352}]
+    with caplog.at_level(logging.WARNING, logger="lvc_amd"), torch.no_grad():
+        out = model(inputs)
+    assert model.roi_heads.det_max_candidates is None
+    assert any("candidates" in r.getMessage() for r in caplog.records)
+    spec = orc.RCNNSpec(score_thresh=0.0)
+    with torch.no_grad():
+        ref = orc.generalized_rcnn_inference(r50_state_dict(), spec, inputs)
+    for o, r in zip(out, ref):
+        inst = o["instances"].to("cpu")
+        assert len(inst) == len(r["scores"]) == 100
+        frac, wb, ws = match_fraction(inst.pred_boxes.tensor, inst.scores, inst.pred_classes, r["pred_boxes"], r["scores"],
+                                      r["pred_classes"], box_tol=0.1, score_tol=2e-3)
+        print("thresh 0: matched %.0f%% (worst box %.1e px, score %.1e)" % (100 * frac, wb, ws))
+        assert frac >= 0.9
+    with torch.no_grad():     # second call: no further overflow, same answer
+        again = model(inputs)
+    assert torch.equal(again[0]["instances"].pred_boxes.tensor, out[0]["instances"].pred_boxes.tensor)
+
+
+def test_activation_beyond_fp16_range_falls_back_to_bf16x3(monkeypatch, caplog):
+    """An image scaled so that the normalised pixels exceed 65504: the fp16x2 stem raises the range word, the model
+    repeats the pass on the bf16x3 kernels (logged) and the trunk equals the fp32 oracle on that input."""
+    from helpers import r50_state_dict
+    from lvc_amd import kernels as K
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+    from test_gpu_e2e import _model
+
+    monkeypatch.setattr(K, "CONV_SPLIT", "f16x2")
+    monkeypatch.setattr(K, "_RANGE_FALLBACK_LOGGED", False)
+    model = _model()
+    img = syn.synthetic_image(3, 160, 192)
+    img[:, 40:60, 50:70] = 1.0e5
+    inputs = [{"image": img}]
+    with caplog.at_level(logging.WARNING, logger="lvc_amd"), torch.no_grad():
+        out = model(inputs)
+    assert K.CONV_SPLIT == "bf16x3"
+    assert any("fp16" in r.getMessage() for r in caplog.records)
+    sd = r50_state_dict()
+    spec = orc.RCNNSpec()
+    with torch.no_grad():
+        imgs, _ = orc.preprocess([img], spec.pixel_mean, spec.pixel_std, 32)
+        ref = orc.fpn(sd, orc.resnet(sd, imgs, 50))
+        got = model.backbone(model.preprocess_image(inputs).tensor)
+    for k in ref:
+        err = float((got[k].cpu() - ref[k]).abs().max()) / float(ref[k].abs().max())
+        print(k, "relative error on the bf16x3 fallback", err)
+        assert err <= 2e-4, k
+    assert len(out[0]["instances"]) >= 0

@@ -474,8 +474,8 @@ def test_c_abi_argument_errors_raise_runtime_error():
     pc = k.pack_conv(torch.randn(64, 64, 1, 1, device=d))
     with pytest.raises(AssertionError):
         k.conv2d_nhwc(torch.randn(1, 4, 4, 32, device=d), pc)   # channel mismatch
-    with pytest.raises(LvcNativeError, match="Nmax > 16384"):
-        k.batched_nms_batch(torch.zeros(1, 20000, 4, device=d), torch.zeros(1, 20000, device=d), None, None, 0.5)
+    with pytest.raises(LvcNativeError, match="k must be in 1..10"):
+        k.knn_topk_vote(torch.zeros(4, 64, device=d), 64, torch.zeros(64, dtype=torch.int64, device=d), None, 11)
     assert issubclass(LvcNativeError, RuntimeError)
 
 

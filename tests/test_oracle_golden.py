@@ -156,3 +156,33 @@ def test_resize_oracle_matches_reference_transform_and_pillow():
     for nh, nw in [(160, 216), (40, 54), (97, 200), (30, 131)]:
         ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
         assert np.array_equal(orz.resize_bilinear_u8(img, nh, nw), ref), (nh, nw)
+
+
+def test_nms_restatement_has_an_independent_witness_in_the_reference_rotated_kernel():
+    """torchvision is absent, so `orc_nms` (oracle.c) cannot be pinned against torchvision's own kernel.  The reference
+    does carry ONE greedy-NMS implementation of its own: nms_rotated_cpu.cpp (declared there as a structural copy of
+    torchvision's nms_cpu_kernel, :12), compiled unmodified into oracle/_ref/_C.so.  On axis-aligned boxes (angle 0) it
+    must keep exactly the same indices as the restatement, provided no pairwise IoU lies within 1e-3 of the threshold
+    (its polygon-clipping IoU differs from the closed form in the last bits, and it suppresses on `>=`, :54) and the
+    scores are distinct (its sort is unstable)."""
+    from oracle import refshim
+
+    C = refshim.ref_C()
+    if C is None:
+        pytest.skip("oracle/_ref/_C.so not built (needs /root/reference once)")
+    g = torch.Generator().manual_seed(123)
+    for thr, n in ((0.5, 700), (0.7, 700), (0.3, 400)):
+        c = torch.rand(n, 2, generator=g) * 300
+        wh = 20 + torch.rand(n, 2, generator=g) * 100
+        boxes = torch.cat([c, c + wh], 1)
+        scores = (torch.randperm(n, generator=g).float() + 0.5) / n      # distinct by construction
+        iou = oops.box_iou(boxes, boxes)
+        near = ((iou - thr).abs() < 1e-3).any(dim=1)
+        boxes, scores = boxes[~near], scores[~near]
+        assert len(boxes) > n // 2
+        keep = oops.nms(boxes, scores, thr)
+        dets = torch.stack([(boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2, boxes[:, 2] - boxes[:, 0],
+                            boxes[:, 3] - boxes[:, 1], torch.zeros(len(boxes))], 1).contiguous()
+        ref = C.nms_rotated(dets, scores.contiguous(), thr)
+        assert 10 < len(ref) < len(boxes)
+        assert keep.tolist() == ref.tolist(), thr
