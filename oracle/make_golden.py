@@ -885,10 +885,90 @@ def gen_solver():
     save("solver", **d)
 
 
+def gen_wire():
+    """SURVEY 8(f).2 wire formats: the reference's pseudo-label filter (tools/create_coco_dataset_from_dets_all.py:
+    get_ret_anns + save_coco, through the restated pycocotools index of the shim) and the verified-dataset writer
+    (tools/run_nearest_neighbours.py:230-249 save_coco) on a small synthetic detections file.  The fixture holds the input
+    json documents and the exact bytes of every file the reference wrote."""
+    import argparse
+    import json
+    import shutil
+    import tempfile
+    from collections import defaultdict
+
+    sys.argv = [sys.argv[0]]
+    import tools.create_coco_dataset_from_dets_all as T
+    import tools.run_nearest_neighbours as R
+
+    names = ["person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light",
+             "fire hydrant", "stop sign", "parking meter", "bench", "bird", "cat", "dog", "horse", "sheep", "cow"]
+    cats = [{"id": i + 1 + (i // 11), "name": n, "supercategory": "x"} for i, n in enumerate(names)]   # ids with a gap, like COCO's
+    g = torch.Generator().manual_seed(99)
+    images = [{"id": 1000 + 7 * i, "file_name": "img_%03d.jpg" % i, "height": 400 + 16 * (i % 5), "width": 600 + 8 * (i % 3)}
+              for i in range(14)]
+    gt = {"info": {"description": "synthetic"}, "licenses": [], "categories": cats, "images": images, "annotations": []}
+    dets = []
+    for k in range(260):
+        im = images[int(torch.randint(0, len(images), (1,), generator=g))]
+        c = cats[int(torch.randint(0, len(cats), (1,), generator=g))]
+        w = float(torch.rand(1, generator=g)) * 300 + 4
+        h = float(torch.rand(1, generator=g)) * 250 + 4
+        x = float(torch.rand(1, generator=g)) * (im["width"] - w)
+        y = float(torch.rand(1, generator=g)) * (im["height"] - h)
+        score = round(float(torch.rand(1, generator=g)) ** 0.5, 4)       # rounded: equal scores occur
+        row = {"image_id": im["id"], "category_id": c["id"], "bbox": [x, y, w, h], "score": score}
+        if k % 3 == 0:
+            row["top2_scores"] = [score, score / 2]
+            row["top2_inds"] = [c["id"], 1]
+        dets.append(row)
+    dets[17]["bbox"] = [0.0, 0.0, float(images[0]["width"]), float(images[0]["height"])]      # area_ratio 1.0 when it lands on image 0
+    dets[17]["image_id"] = images[0]["id"]
+    train_imgs = defaultdict(list)
+    for j, c in enumerate(cats):
+        train_imgs[c["id"]] = [images[(j + t) % len(images)]["id"] for t in range(3)]
+    cases = [dict(top=False, full=False, K_min=0.8, K_max=1.0, ar=0.0), dict(top=False, full=True, K_min=0.7, K_max=0.95, ar=0.0),
+             dict(top=True, full=False, K_min=6.0, K_max=1.0, ar=0.0), dict(top=True, full=True, K_min=4.0, K_max=0.0, ar=0.0),
+             dict(top=False, full=False, K_min=0.5, K_max=1.0, ar=0.05)]
+    out_dir = os.path.join(GOLD, "wire")
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump(gt, open(os.path.join(out_dir, "gt.json"), "w"))
+    json.dump(dets, open(os.path.join(out_dir, "dets.json"), "w"))
+    json.dump({str(k): v for k, v in train_imgs.items()}, open(os.path.join(out_dir, "train_imgs.json"), "w"))
+    tmp = tempfile.mkdtemp()
+    manifest = []
+    try:
+        gt_path = os.path.join(tmp, "gt.json")
+        json.dump(gt, open(gt_path, "w"))
+        for ci, case in enumerate(cases):
+            dt_path = os.path.join(tmp, "dets.json")
+            json.dump(dets, open(dt_path, "w"))
+            args = argparse.Namespace(dt_path=dt_path, full_dataset=False, all_cats=False, **case)
+            coco_gt = T.COCO_PK(gt_path)
+            ids = T.get_ids_names(coco_gt)
+            unseen_coco_ids = ids[3]
+            coco_dt = coco_gt.loadRes(dt_path, False)
+            anns = T.get_ret_anns(coco_dt, train_imgs, args, unseen_coco_ids)
+            img_ids = list(set(a["image_id"] for a in anns))
+            name = T.save_coco(args, coco_gt, coco_dt, anns, coco_gt.loadImgs(img_ids))
+            dst = "case%d__%s" % (ci, os.path.basename(name))
+            shutil.copy(name, os.path.join(out_dir, dst))
+            manifest.append({"case": case, "file": dst, "n_annotations": len(anns), "unseen_coco_ids": unseen_coco_ids})
+            print("  case", ci, case, "->", os.path.basename(name), len(anns), "annotations")
+            if ci == 0:   # the kNN step keeps a subset of those annotations: run_nearest_neighbours.save_coco
+                keep_ids = [a["id"] for a in anns][::2][::-1]
+                cfg = argparse.Namespace(QUERY_EXPAND=argparse.Namespace(NN_MODEL="dino_vits8/x", KNN=10, COSINE_SIM=True))
+                vname = R.save_coco(cfg, keep_ids, name)
+                shutil.copy(vname, os.path.join(out_dir, "verified__" + os.path.basename(vname)))
+                manifest.append({"verified": "verified__" + os.path.basename(vname), "from": dst, "keep_ids": keep_ids})
+    finally:
+        shutil.rmtree(tmp)
+    json.dump(manifest, open(os.path.join(out_dir, "manifest.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "wire"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -241,7 +241,118 @@ def _tv_ops_boxes(m):
     m.box_iou = oops.box_iou
 
 
+def _pycocotools_coco(m):
+    """pycocotools.coco.COCO (third-party, absent here; setup.py:186-188 asks pycocotools>=2.0.1): the index / query
+    subset the reference's pseudo-label tool uses (tools/create_coco_dataset_from_dets_all.py:14-54, 129-263), restated
+    from the published 2.0 source.  "parity unpinned" for these methods: nothing under /root/reference tests them."""
+    import copy
+    import itertools
+    import json
+    from collections import defaultdict
+
+    def _is_array_like(obj):
+        return hasattr(obj, "__iter__") and hasattr(obj, "__len__")
+
+    class COCO:
+        def __init__(self, annotation_file=None):
+            self.dataset, self.anns, self.cats, self.imgs = dict(), dict(), dict(), dict()
+            self.imgToAnns, self.catToImgs = defaultdict(list), defaultdict(list)
+            if annotation_file is not None:
+                with open(annotation_file, "r") as f:
+                    dataset = json.load(f)
+                assert type(dataset) == dict
+                self.dataset = dataset
+                self.createIndex()
+
+        def createIndex(self):
+            anns, cats, imgs = {}, {}, {}
+            imgToAnns, catToImgs = defaultdict(list), defaultdict(list)
+            if "annotations" in self.dataset:
+                for ann in self.dataset["annotations"]:
+                    imgToAnns[ann["image_id"]].append(ann)
+                    anns[ann["id"]] = ann
+            if "images" in self.dataset:
+                for img in self.dataset["images"]:
+                    imgs[img["id"]] = img
+            if "categories" in self.dataset:
+                for cat in self.dataset["categories"]:
+                    cats[cat["id"]] = cat
+            if "annotations" in self.dataset and "categories" in self.dataset:
+                for ann in self.dataset["annotations"]:
+                    catToImgs[ann["category_id"]].append(ann["image_id"])
+            self.anns, self.imgToAnns, self.catToImgs, self.imgs, self.cats = anns, imgToAnns, catToImgs, imgs, cats
+
+        def getAnnIds(self, imgIds=[], catIds=[], areaRng=[], iscrowd=None):
+            imgIds = imgIds if _is_array_like(imgIds) else [imgIds]
+            catIds = catIds if _is_array_like(catIds) else [catIds]
+            if len(imgIds) == len(catIds) == len(areaRng) == 0:
+                anns = self.dataset["annotations"]
+            else:
+                if not len(imgIds) == 0:
+                    lists = [self.imgToAnns[i] for i in imgIds if i in self.imgToAnns]
+                    anns = list(itertools.chain.from_iterable(lists))
+                else:
+                    anns = self.dataset["annotations"]
+                anns = anns if len(catIds) == 0 else [a for a in anns if a["category_id"] in catIds]
+                anns = anns if len(areaRng) == 0 else [a for a in anns if a["area"] > areaRng[0] and a["area"] < areaRng[1]]
+            if iscrowd is not None:
+                return [a["id"] for a in anns if a["iscrowd"] == iscrowd]
+            return [a["id"] for a in anns]
+
+        def getImgIds(self, imgIds=[], catIds=[]):
+            imgIds = imgIds if _is_array_like(imgIds) else [imgIds]
+            catIds = catIds if _is_array_like(catIds) else [catIds]
+            if len(imgIds) == len(catIds) == 0:
+                ids = self.imgs.keys()
+            else:
+                ids = set(imgIds)
+                for i, catId in enumerate(catIds):
+                    if i == 0 and len(ids) == 0:
+                        ids = set(self.catToImgs[catId])
+                    else:
+                        ids &= set(self.catToImgs[catId])
+            return list(ids)
+
+        def loadAnns(self, ids=[]):
+            if _is_array_like(ids):
+                return [self.anns[i] for i in ids]
+            return [self.anns[ids]]
+
+        def loadImgs(self, ids=[]):
+            if _is_array_like(ids):
+                return [self.imgs[i] for i in ids]
+            return [self.imgs[ids]]
+
+        def loadRes(self, resFile):
+            res = COCO()
+            res.dataset["images"] = [img for img in self.dataset["images"]]
+            if isinstance(resFile, str):
+                with open(resFile) as f:
+                    anns = json.load(f)
+            else:
+                anns = resFile
+            assert type(anns) == list, "results in not an array of objects"
+            annsImgIds = [ann["image_id"] for ann in anns]
+            assert set(annsImgIds) == (set(annsImgIds) & set(self.getImgIds()))
+            assert "bbox" in anns[0] and not anns[0]["bbox"] == []
+            res.dataset["categories"] = copy.deepcopy(self.dataset["categories"])
+            for id, ann in enumerate(anns):
+                bb = ann["bbox"]
+                x1, x2, y1, y2 = [bb[0], bb[0] + bb[2], bb[1], bb[1] + bb[3]]
+                if "segmentation" not in ann:
+                    ann["segmentation"] = [[x1, y1, x1, y2, x2, y2, x2, y1]]
+                ann["area"] = bb[2] * bb[3]
+                ann["id"] = id + 1
+                ann["iscrowd"] = 0
+            res.dataset["annotations"] = anns
+            res.createIndex()
+            return res
+
+    m.COCO = COCO
+
+
 _REAL = {
+    "pycocotools.coco": _pycocotools_coco,
     "fvcore": _fvcore,
     "fvcore.common.registry": _fv_registry,
     "fvcore.common.config": _fv_config,

@@ -632,3 +632,40 @@ def test_custom_ops_are_registered_with_the_reference_schemas():
         torch.ops.lvc_amd.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
     with pytest.raises(RuntimeError):
         torch.ops.lvc_amd.roi_align_forward(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 0.25, 7, 7, 0, True)
+
+
+def test_pseudo_label_files_are_byte_identical_to_the_reference(tmp_path):
+    """detections json -> score / rank filter -> pseudo-label dataset -> kNN-verified dataset.  The files
+    `lvc_amd.wire` writes equal, byte for byte, the ones the reference's tools wrote for the same inputs
+    (tests/golden/wire/, generated by oracle/make_golden.py gen_wire through the imported reference)."""
+    import json
+    import shutil
+
+    from helpers import GOLD
+    from lvc_amd import wire
+
+    W = os.path.join(GOLD, "wire")
+    manifest = json.load(open(os.path.join(W, "manifest.json")))
+    gt = json.load(open(os.path.join(W, "gt.json")))
+    train_imgs = {int(k): v for k, v in json.load(open(os.path.join(W, "train_imgs.json"))).items()}
+    n_cases = 0
+    for m in manifest:
+        if "case" not in m:
+            continue
+        n_cases += 1
+        rows = json.load(open(os.path.join(W, "dets.json")))
+        dt_path = str(tmp_path / "dets.json")
+        c = m["case"]
+        assert wire.novel_category_ids(gt["categories"]) == m["unseen_coco_ids"]
+        name, anns = wire.create_coco_dataset_from_dets(gt, gt, rows, train_imgs, dt_path, c["K_min"], c["K_max"], top=c["top"],
+                                                        full=c["full"], ar=c["ar"])
+        assert os.path.basename(name) == m["file"].split("__", 1)[1]
+        assert len(anns) == m["n_annotations"]
+        assert open(name, "rb").read() == open(os.path.join(W, m["file"]), "rb").read(), m["file"]
+    assert n_cases == 5
+    v = [m for m in manifest if "verified" in m][0]
+    src = str(tmp_path / v["from"].split("__", 1)[1])
+    shutil.copy(os.path.join(W, v["from"]), src)
+    out = wire.save_verified_dataset(src, v["keep_ids"], "dino_vits8/x", 10, True)
+    assert os.path.basename(out) == v["verified"].split("__", 1)[1]
+    assert open(out, "rb").read() == open(os.path.join(W, v["verified"]), "rb").read()
