@@ -95,6 +95,15 @@ int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_split, const f
                           const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
                           int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
                           void* stream);
+/* The same contract for pointwise layers (R = S = 1, pad 0, C % 32 == 0; y and residual below 2 GiB), operands streamed by
+ * LDS-DMA (csrc/conv_pw_dma.hip: raw fp32 activation rows and the fp16 weight planes go HBM/L2 -> LDS by
+ * global_load_lds_dwordx4 in a three-stage ring that runs across tile boundaries, the fp16 split happens in registers at
+ * fragment time, the epilogue stores from the accumulators).  Results equal lvc_conv2d_nhwc_f16x2's to fp32 rounding
+ * (same products, same accumulation order per tile).  LVC_ERR_INVALID for non-pointwise shapes. */
+int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                          const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
+                          void* stream);
 
 /* BasicStem in one launch (detectron2/modeling/backbone/resnet.py:588-592): conv 7x7 s2 p3 (3 -> 64) -> FrozenBN fold
  * (scale/shift, NULL = identity) -> ReLU -> max_pool2d 3x3 s2 p1, on the split-precision bf16 MFMA path

@@ -268,6 +268,8 @@ WGRAD_ENGINE = _os.environ.get("LVC_WGRAD_ENGINE", "bf16x3")
 # inference: conv3 + stride-1 projection shortcut of res2.0 as one GEMM over [conv2 output | block input] (resnet.py)
 FUSE_PROJECTION = _os.environ.get("LVC_FUSE_PROJECTION", "1") != "0"
 _H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "128"))
+# pointwise fp16x2 layers on the LDS-DMA kernel (csrc/conv_pw_dma.hip); 0 = the register-staged conv_pw256_f16x2_kernel
+PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -320,7 +322,8 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
         elif engine == "f16x2_pw":
-            st = _lib.lib().lvc_conv2d_nhwc_f16x2(
+            fn = "lvc_conv2d_nhwc_f16x2_dma" if PW_DMA and out.numel() < (1 << 29) and (residual is None or residual.numel() < (1 << 29)) else "lvc_conv2d_nhwc_f16x2"
+            st = getattr(_lib.lib(), fn)(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
                 c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),

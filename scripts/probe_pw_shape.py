@@ -1,0 +1,19 @@
+"""One pointwise layer shape, a few launches (for rocprofv3 --pmc passes): probe_pw_shape.py N H W C K stride res_mode"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lvc_amd import kernels as k
+N, H, W, C, K, st, rm = [int(v) for v in sys.argv[1:8]]
+d = torch.device("cuda:0")
+torch.manual_seed(0)
+x = torch.randn(N, H, W, C, device=d)
+w = torch.randn(K, C, 1, 1, device=d) * (2.0 / C) ** 0.5
+pc = k.pack_conv(w, stride=st)
+Ho, Wo = (H - 1) // st + 1, (W - 1) // st + 1
+res = None
+if rm == 1: res = torch.randn(N, Ho, Wo, K, device=d)
+if rm == 2: res = torch.randn(N, Ho // 2, Wo // 2, K, device=d)
+y = torch.empty(N, Ho, Wo, K, device=d)
+for _ in range(6):
+    k.conv2d_nhwc(x, pc, relu=True, residual=res, res_mode=rm, out=y)
+torch.cuda.synchronize()
