@@ -342,6 +342,25 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
                       const long long* det_classes, int kvote, long long* top_classes, long long* keep,
                       void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Descriptor network of the label-verification step: DINO ViT-S/8 as loaded by
+ * tools/run_nearest_neighbours.py:292-293 (torch.hub 'facebookresearch/dino', a third-party model: published
+ * architecture, restated for the tests in oracle/vit.py).  The linear layers run on the conv/GEMM entry points
+ * above; these are the remaining pieces.  All tensors fp32, row-major.
+ *   lvc_vit_patchify : img [B,C,H,W] -> [B*(H/ps)*(W/ps), C*ps*ps], column = c*ps*ps + r*ps + s (so that the ps x ps
+ *                      stride-ps convolution of patch_embed is one GEMM with proj.weight.reshape(D, C*ps*ps))
+ *   lvc_vit_tokens   : out[b][0] = cls + pos[0], out[b][1+p] = emb[b*P+p] + pos[1+p]   (out [B*(P+1), D], D % 4 == 0)
+ *   lvc_layernorm    : torch.nn.LayerNorm over rows of D <= 2048 elements (biased variance, eps inside the sqrt)
+ *   lvc_gelu         : torch.nn.GELU() exact (erf) form, n % 4 == 0
+ *   lvc_mha          : qkv [B*N, 3*H*64] (column = which*H*64 + h*64 + d) -> out [B*N, H*64] =
+ *                      softmax(q k^T * scale) v per (image, head); head_dim must be 64 */
+int lvc_vit_patchify(const float* img, float* out, int B, int C, int H, int W, int ps, void* stream);
+int lvc_vit_tokens(const float* emb, const float* cls, const float* pos, float* out, int B, int P, int D, void* stream);
+int lvc_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int D, float eps,
+                  void* stream);
+int lvc_gelu(const float* x, float* y, long long n, void* stream);
+int lvc_mha(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,14 +55,15 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
 }
 
-template <int NI, int NW, int D_NS>
-__global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
-  constexpr int D_BM = NW * 32, D_NT = NW * 64, D_A_BYTES = D_BM * 128;
+template <int NI, int NW, int D_NS, int MI>
+__global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(ConvArgsD p) {
+  constexpr int WR = 32 * MI;                  // rows of a wave
+  constexpr int D_BM = NW * WR, D_NT = NW * 64, D_A_BYTES = D_BM * 128;
   constexpr int GBN = 32 * NI;                 // output channels per tile
   constexpr int B_PLANE = GBN * 64;            // bytes of one weight plane chunk (GBN rows x 32 halves)
   constexpr int STAGE = D_A_BYTES + 2 * B_PLANE;
   constexpr int NBW = (4 * NI + NW - 1) / NW;  // weight DMA instructions per wave and chunk (4 * NI pieces over NW waves)
-  constexpr int NPER = 4 + NBW;                // DMA instructions per wave and chunk
+  constexpr int NPER = 4 * MI + NBW;           // DMA instructions per wave and chunk
   __shared__ __attribute__((aligned(1024))) unsigned char smem[D_NS * STAGE];
 
   const int tid = threadIdx.x;
@@ -87,8 +88,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
   // when the layer has a residual and the worker owns the tile's epilogue (its segment starts at chunk 0) -- one chunk per
   // 32-channel block of the residual rows: they take the activation slot of a stage and reach the accumulators as a product
   // with the identity (see the epilogue), so they are prefetched like any operand instead of being waited for per tile.
-  const float* asrc[4];
-  const float* rsrc[4];
+  const float* asrc[4 * MI];
+  const float* rsrc[4 * MI];
   const unsigned short* bsrc[NBW];
   int lu = u, l_tile = u / p.nk, l_kc = u - l_tile * p.nk;
   int l_seg0 = l_kc, l_phase = 0, l_j = 0, l_nj = 0;
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
     if (tm != l_tm) {
       l_tm = tm;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = wave * 32 + i * 8 + (lane >> 3);
+      for (int i = 0; i < 4 * MI; ++i) {
+        const int r = wave * WR + i * 8 + (lane >> 3);
         int m = tm * D_BM + r;
         m = m < p.M ? m : p.M - 1;          // rows past the end read a valid row; their outputs are never stored
         const int n = m / (p.Ho * p.Wo);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
     if (l_phase == 0) {
       if (dma) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(asrc[i] + l_kc * 32, st + (wave * 32 + i * 8) * 128);
+        for (int i = 0; i < 4 * MI; ++i) glds16(asrc[i] + l_kc * 32, st + (wave * WR + i * 8) * 128);
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {
           const int idx = (wave * NBW + j) % (4 * NI);
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
       if (dma) {
         const int c0 = tile_n_of(l_tile) * GBN + l_j * 32;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(rsrc[i] + c0, st + (wave * 32 + i * 8) * 128);
+        for (int i = 0; i < 4 * MI; ++i) glds16(rsrc[i] + c0, st + (wave * WR + i * 8) * 128);
 #pragma unroll
         for (int j = 0; j < NBW; ++j) {   // same instruction count as a K chunk (the counted waits rely on it); data unused
           const int idx = (wave * NBW + j) % (4 * NI);
@@ -188,72 +189,147 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
 
   float big = 0.f;   // largest |operand| met: beyond fp16 -> workspace error word
 
+#pragma unroll 1
   while (u < u_end) {
     const int tile = u / p.nk;
     const int kc0 = u - tile * p.nk;
     const int kc1 = min(p.nk, kc0 + (u_end - u));
     const int tile_n = tile_n_of(tile);
     const int tile_m = tile_m_of(tile);
-    const int m0 = tile_m * D_BM + wave * 32;   // first row of this wave
+    const int m0 = tile_m * D_BM + wave * WR;   // first row of this wave
     const int n0 = tile_n * GBN;
 
-    f32x16 acc[NI], accx[NI];   // main (a1 b1) and cross (a1 b2 + a2 b1, weight 2^-11) accumulators
+    // main (a1 b1) and cross (a1 b2 + a2 b1, weight 2^-11) accumulators.  The wide shape (MI == 2) has no room for 256
+    // cross registers next to 256 main ones: there the cross terms of ONE chunk go to a scratch accumulator per block and are
+    // folded into the main one right away (one fma per element and chunk)
+    constexpr bool WIDE = MI == 2;
+    f32x16 acc[MI][NI], accx[WIDE ? 1 : MI][WIDE ? 1 : NI];
 #pragma unroll
-    for (int b = 0; b < NI; ++b)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { acc[b][e] = 0.f; accx[b][e] = 0.f; }
+      for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    if (!WIDE) {
+#pragma unroll
+      for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) accx[WIDE ? 0 : a][WIDE ? 0 : b][e] = 0.f;
+    }
 
+#pragma unroll 1
     for (int kc = kc0; kc < kc1; ++kc) {
       chunk_top();
       const unsigned char* st = smem + (consumed % D_NS) * STAGE;
-      const unsigned char* sa = st + (wave * 32 + fi) * 128;
+      const unsigned char* sa = st + (wave * WR + fi) * 128;
       const unsigned char* sb = st + D_A_BYTES + fi * 64;
-      if (!(p.ablate & 2))
+      if (!(p.ablate & 2)) {
+        if constexpr (WIDE) {
+          // both k16 steps of the chunk at once: 8 activation fragments (split in registers), then per 32-channel block the
+          // four weight fragments, 2 main MFMAs per row block and a 4-MFMA cross chain into a scratch accumulator
+          f16x8 ha[MI][2], la[MI][2];
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const int G0 = s * 4 + fh * 2;
+              const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + ((G0 ^ fx7) * 16));
+              const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + (((G0 + 1) ^ fx7) * 16));
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f16 h0 = (f16)a0[e], h1 = (f16)a1[e];
+                ha[mi][s][e] = h0; ha[mi][s][4 + e] = h1;
+                la[mi][s][e] = (f16)((a0[e] - (float)h0) * 2048.f);
+                la[mi][s][4 + e] = (f16)((a1[e] - (float)h1) * 2048.f);
+                big = fmaxf(big, fmaxf(fabsf(a0[e]), fabsf(a1[e])));
+              }
+            }
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) {
+            f16x8 hb[2], lb[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+              const int bo = ((s * 2 + fh) ^ fx3) * 16;
+              hb[s] = *reinterpret_cast<const f16x8*>(sb + ni * 32 * 64 + bo);
+              lb[s] = *reinterpret_cast<const f16x8*>(sb + B_PLANE + ni * 32 * 64 + bo);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              f32x16 t;
+#pragma unroll
+              for (int e = 0; e < 16; ++e) t[e] = 0.f;
+              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][0], lb[0], t, 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][0], hb[0], acc[mi][ni], 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi][0], hb[0], t, 0, 0, 0);
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][1], hb[1], acc[mi][ni], 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][1], lb[1], t, 0, 0, 0);
+              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi][1], hb[1], t, 0, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[mi][ni][e] += t[e] * (1.f / 2048.f);
+            }
+          }
+        } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int G0 = s * 4 + fh * 2;
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + ((G0 ^ fx7) * 16));
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + (((G0 + 1) ^ fx7) * 16));
         const int bo = ((s * 2 + fh) ^ fx3) * 16;
-        f16x8 ha, la;
+        f16x8 ha[MI], la[MI];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const f16 h0 = (f16)a0[e], h1 = (f16)a1[e];
-          ha[e] = h0; ha[4 + e] = h1;
-          la[e] = (f16)((a0[e] - (float)h0) * 2048.f);
-          la[4 + e] = (f16)((a1[e] - (float)h1) * 2048.f);
-          big = fmaxf(big, fmaxf(fabsf(a0[e]), fabsf(a1[e])));
+        for (int mi = 0; mi < MI; ++mi) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + ((G0 ^ fx7) * 16));
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + (((G0 + 1) ^ fx7) * 16));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f16 h0 = (f16)a0[e], h1 = (f16)a1[e];
+            ha[mi][e] = h0; ha[mi][4 + e] = h1;
+            la[mi][e] = (f16)((a0[e] - (float)h0) * 2048.f);
+            la[mi][4 + e] = (f16)((a1[e] - (float)h1) * 2048.f);
+            big = fmaxf(big, fmaxf(fabsf(a0[e]), fabsf(a1[e])));
+          }
         }
-        // weight fragments one 32-channel block at a time (8 VGPRs live instead of 32); the two updates of accx[ni] are an
-        // accumulate chain (D -> C of the next MFMA: no wait states)
+        // weight fragments one 32-channel block at a time; the two updates of accx are an accumulate chain (D -> C of the
+        // next MFMA on that accumulator: no wait states)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
           const f16x8 hb = *reinterpret_cast<const f16x8*>(sb + ni * 32 * 64 + bo);
           const f16x8 lb = *reinterpret_cast<const f16x8*>(sb + B_PLANE + ni * 32 * 64 + bo);
-          accx[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, lb, accx[ni], 0, 0, 0);
-          acc[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, acc[ni], 0, 0, 0);
-          accx[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(la, hb, accx[ni], 0, 0, 0);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) accx[WIDE ? 0 : mi][WIDE ? 0 : ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi], lb, accx[WIDE ? 0 : mi][WIDE ? 0 : ni], 0, 0, 0);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi], hb, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) accx[WIDE ? 0 : mi][WIDE ? 0 : ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi], hb, accx[WIDE ? 0 : mi][WIDE ? 0 : ni], 0, 0, 0);
+        }
+      }
         }
       }
       ++consumed;
     }
     u += kc1 - kc0;
+    if (!WIDE) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[ni][e] += accx[ni][e] * (1.f / 2048.f);
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += accx[WIDE ? 0 : mi][WIDE ? 0 : ni][e] * (1.f / 2048.f);
+    }
 
     // ---- split tiles (same protocol as conv_f16x2.hip / conv_igemm.hip): a worker that starts inside a tile hands its
     // partial sums to the worker that owns the tile's first chunk
     if (kc0 != 0) {
-      float* dst = p.partials + (size_t)lw * (D_NT * 16 * NI);
+      float* dst = p.partials + (size_t)lw * (D_NT * 16 * MI * NI);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-          f32x4 v = {acc[ni][e4 * 4 + 0], acc[ni][e4 * 4 + 1], acc[ni][e4 * 4 + 2], acc[ni][e4 * 4 + 3]};
-          *reinterpret_cast<f32x4*>(dst + ((size_t)(ni * 4 + e4) * D_NT + tid) * 4) = v;
-        }
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * D_NT + tid) * 4) = v;
+          }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       landed = issued;
       __syncthreads();
@@ -278,15 +354,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        const float* src = p.partials + (size_t)pw * (D_NT * 16 * NI);
+        const float* src = p.partials + (size_t)pw * (D_NT * 16 * MI * NI);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int e4 = 0; e4 < 4; ++e4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(ni * 4 + e4) * D_NT + tid) * 4);
-            acc[ni][e4 * 4 + 0] += v[0]; acc[ni][e4 * 4 + 1] += v[1];
-            acc[ni][e4 * 4 + 2] += v[2]; acc[ni][e4 * 4 + 3] += v[3];
-          }
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * NI + ni) * 4 + e4) * D_NT + tid) * 4);
+              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
+              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
+            }
         __syncthreads();
         if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -300,7 +378,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
       const float sc = p.scale ? p.scale[colc] : 1.f;
       const float sh = p.shift ? p.shift[colc] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[ni][e] = acc[ni][e] * sc + sh;
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = acc[mi][ni][e] * sc + sh;
     }
     // Residual rows of block j sit in the activation slot of the next ring stage as raw fp32 [32 rows x 32 channels] per wave.
     // They join the accumulator as the product with the 32 x 32 identity on the same split operands (res = r1 + 2^-11 r2 to
@@ -312,32 +392,35 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
       for (int j = 0; j < NI; ++j) {
         if (j < nj) {
           chunk_top();
-          const unsigned char* sa = smem + (consumed % D_NS) * STAGE + (wave * 32 + fi) * 128;
-          f32x16 rx;
+          const unsigned char* sa = smem + (consumed % D_NS) * STAGE + (wave * WR + fi) * 128;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) rx[e] = 0.f;
+          for (int mi = 0; mi < MI; ++mi) {
+            f32x16 rx;
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const int G0 = s * 4 + fh * 2;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + ((G0 ^ fx7) * 16));
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + (((G0 + 1) ^ fx7) * 16));
-            f16x8 ha, la, ib;
+            for (int e = 0; e < 16; ++e) rx[e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const f16 h0 = (f16)a0[e], h1 = (f16)a1[e];
-              ha[e] = h0; ha[4 + e] = h1;
-              la[e] = (f16)((a0[e] - (float)h0) * 2048.f);
-              la[4 + e] = (f16)((a1[e] - (float)h1) * 2048.f);
-              big = fmaxf(big, fmaxf(fabsf(a0[e]), fabsf(a1[e])));
+            for (int s = 0; s < 2; ++s) {
+              const int G0 = s * 4 + fh * 2;
+              const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + ((G0 ^ fx7) * 16));
+              const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + (((G0 + 1) ^ fx7) * 16));
+              f16x8 ha, la, ib;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const f16 h0 = (f16)a0[e], h1 = (f16)a1[e];
+                ha[e] = h0; ha[4 + e] = h1;
+                la[e] = (f16)((a0[e] - (float)h0) * 2048.f);
+                la[4 + e] = (f16)((a1[e] - (float)h1) * 2048.f);
+                big = fmaxf(big, fmaxf(fabsf(a0[e]), fabsf(a1[e])));
+              }
+              const bool mine = (fi >> 3) == s * 2 + fh;
+#pragma unroll
+              for (int t = 0; t < 8; ++t) ib[t] = (mine && (fi & 7) == t) ? (f16)1.f : (f16)0.f;
+              acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, ib, acc[mi][j], 0, 0, 0);
+              rx = __builtin_amdgcn_mfma_f32_32x32x16_f16(la, ib, rx, 0, 0, 0);
             }
-            const bool mine = (fi >> 3) == s * 2 + fh;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) ib[t] = (mine && (fi & 7) == t) ? (f16)1.f : (f16)0.f;
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, ib, acc[j], 0, 0, 0);
-            rx = __builtin_amdgcn_mfma_f32_32x32x16_f16(la, ib, rx, 0, 0, 0);
+            for (int e = 0; e < 16; ++e) acc[mi][j][e] += rx[e] * (1.f / 2048.f);
           }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[j][e] += rx[e] * (1.f / 2048.f);
           ++consumed;
         }
       }
@@ -353,15 +436,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_dma_kernel(ConvArgsD p) {
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
     const float lo = p.relu ? 0.f : -INFINITY;
     const unsigned ldy4 = (unsigned)p.ldy * 4u;
-    const unsigned rbase = (unsigned)(m0 + 4 * fh) * ldy4;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int col = n0 + ni * 32 + fi;
-      const unsigned cbase = col < p.K ? rbase + (unsigned)col * 4u : 0x80000000u;
+    for (int mi = 0; mi < MI; ++mi) {
+      const unsigned rbase = (unsigned)(m0 + mi * 32 + 4 * fh) * ldy4;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const float v = fmaxf(acc[ni][e], lo);
-        if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = n0 + ni * 32 + fi;
+        const unsigned cbase = col < p.K ? rbase + (unsigned)col * 4u : 0x80000000u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = fmaxf(acc[mi][ni][e], lo);
+          if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
+        }
       }
     }
   }
@@ -404,8 +490,11 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   // per CU (measured 0 - 12 % slower on every layer of the R50-FPN set, profiles/README.md round 2: the weight planes are
   // delivered twice as often per row and the exposed latencies per CU stay the same)
   static const int shape_env = [] { const char* e = getenv("LVC_PW_DMA_SHAPE"); return e ? atoi(e) : 0; }();
-  const int nw = shape_env == 4 ? 4 : 8;
-  const int bm = nw * 32;
+  // LVC_PW_DMA_SHAPE=64: 4 waves with 64-row x 128-channel wave tiles, one wave per SIMD (512 registers each): a weight
+  // fragment feeds two row blocks, so LDS reads per MFMA drop from 1.08 KB to 0.75 KB
+  const bool wide = shape_env == 64 && K > 64;
+  const int nw = wide || shape_env == 4 ? 4 : 8;
+  const int bm = wide ? 256 : nw * 32;
   const int tiles_m = lvc_cdiv(a.M, bm);
   long long units = (long long)tiles_m * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
@@ -417,7 +506,7 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
       cus = 256;
     g_cus_d = cus;
   }
-  int cap = g_cus_d * (nw == 4 ? 2 : 1);   // resident workgroups: 8 waves of <= 256 VGPRs per CU either way
+  int cap = g_cus_d * (nw == 4 && !wide ? 2 : 1);   // resident workgroups per CU
   if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
   const int min_units = 4;
   int workers = (int)((units + min_units - 1) / min_units);
@@ -440,8 +529,10 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   static const int ablate = [] { const char* e = getenv("LVC_PW_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
   hipStream_t st = (hipStream_t)stream;
-#define PW_LAUNCH(NI_, NW_, NS_) hipLaunchKernelGGL((conv_pw_dma_kernel<NI_, NW_, NS_>), dim3(a.nworkers), dim3(NW_ * 64), 0, st, a)
-  if (nw == 8) {
+#define PW_LAUNCH(NI_, NW_, NS_) hipLaunchKernelGGL((conv_pw_dma_kernel<NI_, NW_, NS_, 1>), dim3(a.nworkers), dim3(NW_ * 64), 0, st, a)
+  if (wide) {
+    hipLaunchKernelGGL((conv_pw_dma_kernel<4, 4, 3, 2>), dim3(a.nworkers), dim3(256), 0, st, a);
+  } else if (nw == 8) {
     if (gbn == 32) PW_LAUNCH(1, 8, 3); else if (gbn == 64) PW_LAUNCH(2, 8, 3); else PW_LAUNCH(4, 8, 3);
   } else {
     if (gbn == 32) PW_LAUNCH(1, 4, 2); else if (gbn == 64) PW_LAUNCH(2, 4, 2); else PW_LAUNCH(4, 4, 2);

@@ -987,3 +987,60 @@ def crop_resize_nearest(image, windows, out_size=224):
                                             ptr(out), _stream(image))
     check(rc, "lvc_crop_resize_nearest")
     return out
+
+
+# --------------------------------------------------------------------------- descriptor network (ViT) pieces
+def vit_patchify(img, patch_size, kpad=None):
+    """img [B,C,H,W] fp32 -> [B*P, kpad] rows (column c*ps*ps + r*ps + s; zero columns up to kpad, a multiple of 32)."""
+    _req_cuda(img)
+    B, C, H, W = img.shape
+    kc = C * patch_size * patch_size
+    kpad = kpad or kc
+    P = (H // patch_size) * (W // patch_size)
+    if kpad == kc:
+        out = torch.empty(B * P, kc, device=img.device, dtype=torch.float32)
+        check(_lib.lib().lvc_vit_patchify(ptr(img), ptr(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(patch_size), _stream(img)),
+              "lvc_vit_patchify")
+        return out
+    tmp = vit_patchify(img, patch_size)
+    out = torch.zeros(B * P, kpad, device=img.device, dtype=torch.float32)
+    out[:, :kc] = tmp
+    return out
+
+
+def vit_tokens(emb, cls, pos, B):
+    _req_cuda(emb, cls, pos)
+    D = emb.shape[1]
+    P = emb.shape[0] // B
+    out = torch.empty(B * (P + 1), D, device=emb.device, dtype=torch.float32)
+    check(_lib.lib().lvc_vit_tokens(ptr(emb.contiguous()), ptr(cls.detach().contiguous()), ptr(pos.detach().contiguous()), ptr(out),
+                                    c_int(B), c_int(P), c_int(D), _stream(emb)), "lvc_vit_tokens")
+    return out
+
+
+def layernorm(x, weight, bias, eps):
+    _req_cuda(x, weight, bias)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    M, D = x.shape
+    y = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lvc_layernorm(ptr(x), c_int(x.stride(0)), ptr(weight.detach()), ptr(bias.detach()), ptr(y), c_int(D), c_int(M),
+                                   c_int(D), c_float(eps), _stream(x)), "lvc_layernorm")
+    return y
+
+
+def gelu(x):
+    _req_cuda(x)
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    check(_lib.lib().lvc_gelu(ptr(x), ptr(y), c_longlong(x.numel()), _stream(x)), "lvc_gelu")
+    return y
+
+
+def mha(qkv, B, N, num_heads, head_dim, scale):
+    """qkv [B*N, 3*H*head_dim] -> [B*N, H*head_dim] (softmax(q k^T scale) v per image and head)."""
+    _req_cuda(qkv)
+    qkv = qkv.contiguous()
+    out = torch.empty(B * N, num_heads * head_dim, device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().lvc_mha(ptr(qkv), ptr(out), c_int(B), c_int(N), c_int(num_heads), c_int(head_dim), c_float(scale), _stream(qkv)),
+          "lvc_mha")
+    return out

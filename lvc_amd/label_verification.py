@@ -13,6 +13,32 @@ from . import kernels as K
 QUERY_CHUNK = 32768  # rows of the similarity matrix materialised at once (x S x 4 bytes)
 
 
+def preprocess_crops(data, mean, std):
+    """reference tools/run_nearest_neighbours.py:95-99: concatenate the items' crops, (x - mean) / std per channel."""
+    crops = torch.cat([x["instances"].crops for x in data])
+    mean = torch.as_tensor(mean, dtype=torch.float32, device=crops.device).view(1, -1, 1, 1)
+    std = torch.as_tensor(std, dtype=torch.float32, device=crops.device).view(1, -1, 1, 1)
+    return (crops.float() - mean) / std
+
+
+def get_descriptors(model, data_loader, pixel_mean, pixel_std):
+    """reference get_descriptors (:102-128) over an iterable of one-image batches whose Instances carry `crops`
+    ([n,3,224,224], lvc_amd.wire.get_crops_qe): normalise, run the descriptor network on the device, replace `crops` by
+    `crop_feats` on the CPU, drop `image`.  Returns the list of items (deep copies are not needed: nothing else holds them)."""
+    out = []
+    with torch.no_grad():
+        for data in data_loader:
+            crops = preprocess_crops(data, pixel_mean, pixel_std).to(model.device)
+            feats = model(crops) if len(crops) else torch.zeros(0, model.embed_dim)
+            item = data[0]
+            item.pop("image", None)
+            item["instances"].remove("crops")
+            item["instances"].set("crop_feats", feats)
+            item["instances"] = item["instances"].to("cpu")
+            out.append(item)
+    return out
+
+
 def assemble_tensors(shot_features):
     """reference :131-139: concatenate shot classes/descriptors, sorted by class."""
     classes = torch.cat([x["instances"].gt_classes for x in shot_features])

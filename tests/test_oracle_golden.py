@@ -186,3 +186,43 @@ def test_nms_restatement_has_an_independent_witness_in_the_reference_rotated_ker
         ref = C.nms_rotated(dets, scores.contiguous(), thr)
         assert 10 < len(ref) < len(boxes)
         assert keep.tolist() == ref.tolist(), thr
+
+
+def test_vit_restatement_against_torch_modules():
+    """oracle/vit.py restates a third-party network (DINO ViT-S/8, absent here).  Independent witness of its arithmetic:
+    the same weights run through torch's own nn.MultiheadAttention / nn.LayerNorm / nn.GELU modules wired as a pre-norm
+    transformer block must give the same class token."""
+    from oracle import vit as ovit
+
+    g = torch.Generator().manual_seed(2)
+    D, H, depth, P = 384, 6, 2, 8
+    sd = {"patch_embed.proj.weight": torch.randn(D, 3, P, P, generator=g) * 0.05, "patch_embed.proj.bias": torch.randn(D, generator=g) * 0.1,
+          "cls_token": torch.randn(1, 1, D, generator=g) * 0.1, "pos_embed": torch.randn(1, 1 + 16, D, generator=g) * 0.1,
+          "norm.weight": 1 + 0.1 * torch.randn(D, generator=g), "norm.bias": 0.1 * torch.randn(D, generator=g)}
+    for i in range(depth):
+        p = "blocks.%d." % i
+        for n, shp, s in (("norm1.weight", (D,), None), ("norm1.bias", (D,), 0.1), ("attn.qkv.weight", (3 * D, D), 0.05),
+                          ("attn.qkv.bias", (3 * D,), 0.1), ("attn.proj.weight", (D, D), 0.05), ("attn.proj.bias", (D,), 0.1),
+                          ("norm2.weight", (D,), None), ("norm2.bias", (D,), 0.1), ("mlp.fc1.weight", (4 * D, D), 0.05),
+                          ("mlp.fc1.bias", (4 * D,), 0.1), ("mlp.fc2.weight", (D, 4 * D), 0.03), ("mlp.fc2.bias", (D,), 0.1)):
+            sd[p + n] = (1 + 0.1 * torch.randn(shp, generator=g)) if s is None else torch.randn(shp, generator=g) * s
+    x = torch.randn(2, 3, 32, 32, generator=g)
+    got = ovit.vit_forward(sd, x, patch_size=P, num_heads=H)
+    with torch.no_grad():
+        t = torch.nn.functional.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=P).flatten(2).transpose(1, 2)
+        t = torch.cat([sd["cls_token"].expand(2, -1, -1), t], 1) + sd["pos_embed"]
+        for i in range(depth):
+            p = "blocks.%d." % i
+            mha = torch.nn.MultiheadAttention(D, H, bias=True, batch_first=True)
+            mha.in_proj_weight.copy_(sd[p + "attn.qkv.weight"]); mha.in_proj_bias.copy_(sd[p + "attn.qkv.bias"])
+            mha.out_proj.weight.copy_(sd[p + "attn.proj.weight"]); mha.out_proj.bias.copy_(sd[p + "attn.proj.bias"])
+            ln1 = torch.nn.LayerNorm(D, eps=1e-6); ln1.weight.copy_(sd[p + "norm1.weight"]); ln1.bias.copy_(sd[p + "norm1.bias"])
+            ln2 = torch.nn.LayerNorm(D, eps=1e-6); ln2.weight.copy_(sd[p + "norm2.weight"]); ln2.bias.copy_(sd[p + "norm2.bias"])
+            y = ln1(t)
+            t = t + mha(y, y, y, need_weights=False)[0]
+            y = torch.nn.functional.linear(torch.nn.GELU()(torch.nn.functional.linear(ln2(t), sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])),
+                                           sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+            t = t + y
+        lnf = torch.nn.LayerNorm(D, eps=1e-6); lnf.weight.copy_(sd["norm.weight"]); lnf.bias.copy_(sd["norm.bias"])
+        ref = lnf(t)[:, 0]
+    assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
