@@ -255,6 +255,7 @@ CONV_HALO = _os.environ.get("LVC_CONV_HALO", "1") != "0"
 # BasicStem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2) as one fused split-precision kernel (csrc/stem_pool.hip)
 STEM_FUSED = _os.environ.get("LVC_STEM_FUSED", "1") != "0"
 _PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
+_PW_NARROW_MIN_C = int(_os.environ.get("LVC_PW_NARROW_MIN_C", "64"))
 # operand split of the split-precision kernels that have both forms: "f16x2" = two fp16 planes, 3 MFMAs per block
 # (Ootomo & Yokota; csrc/conv3x3_halo_h2.hip), "bf16x3" = three bf16 planes, 6 MFMAs per block (no range limit)
 CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
@@ -267,7 +268,7 @@ DGRAD_SPLIT = _os.environ.get("LVC_DGRAD_SPLIT", "bf16x3")
 WGRAD_ENGINE = _os.environ.get("LVC_WGRAD_ENGINE", "bf16x3")
 # inference: conv3 + stride-1 projection shortcut of res2.0 as one GEMM over [conv2 output | block input] (resnet.py)
 FUSE_PROJECTION = _os.environ.get("LVC_FUSE_PROJECTION", "1") != "0"
-_H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "128"))
+_H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "64"))   # 64-channel streams too since the LDS-DMA kernel (0.32 -> 0.27 ms on res2 conv3)
 # pointwise fp16x2 layers on the LDS-DMA kernel (csrc/conv_pw_dma.hip); 0 = the register-staged conv_pw256_f16x2_kernel
 PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
@@ -295,7 +296,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
     halo = CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0
     # narrow 1x1 layers (256 -> 64 reductions, the 15-channel RPN predictors) go to the 64- / 32-channel tiles of the
     # 256-row pointwise shape
-    pw_narrow = _PW_NARROW and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= 128 and pc.C % 32 == 0 and N * Ho * Wo >= 2048
+    pw_narrow = _PW_NARROW and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= _PW_NARROW_MIN_C and pc.C % 32 == 0 and N * Ho * Wo >= 2048
     if (CONV_ENGINE == "bf16x3" and pc.mode == 0 and pc.K >= (64 if halo else 4 if pw_narrow else _BF16X3_MIN_K)
             and pc.K % 4 == 0 and out.shape[-1] % 4 == 0 and ldr % 4 == 0):
         h2_halo = halo and (split or CONV_SPLIT) == "f16x2" and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES
