@@ -97,7 +97,16 @@ class GradientBuckets:
     ranks whose autograd engines finish gradients in a different order still agree on the sequence.  Parameters that
     receive no gradient in a step contribute zeros (DDP's find_unused_parameters behaviour, without the graph walk)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, average=True):
+    def __init__(self, params, bucket_bytes=64 << 20, average=True, mode=None):
+        """mode "all_reduce" (default; env LVC_GRAD_EXCHANGE overrides): one ring all-reduce per bucket.  mode "rs_ag": a
+        reduce-scatter launched from the hook plus an all-gather in finish() -- the same bytes per link as the ring
+        (2 (N-1)/N of the bucket) but as two collectives RCCL can spread over all seven xGMI links of a GPU, and the
+        all-gather half moves out of the backward's shadow only when it has to (SURVEY.md section 5 sizes cfg 5's 361.5 MB
+        for it).  No 8-GPU curve exists yet for either, so the default stays the plain ring."""
+        import os
+
+        self.mode = mode or os.environ.get("LVC_GRAD_EXCHANGE", "all_reduce")
+        assert self.mode in ("all_reduce", "rs_ag"), self.mode
         self.params = [p for p in params if p.requires_grad]
         self.average = average
         self.buckets = []
@@ -118,8 +127,10 @@ class GradientBuckets:
 
     def _close(self, plist):
         total = sum(p.numel() for p in plist)
-        flat = torch.zeros(total, device=plist[0].device, dtype=plist[0].dtype)
-        b = {"params": plist, "flat": flat, "pending": len(plist), "work": None, "launched": False, "seen": set()}
+        world = get_world_size()
+        padded = (total + world - 1) // world * world if self.mode == "rs_ag" else total   # equal shards per rank
+        flat = torch.zeros(padded, device=plist[0].device, dtype=plist[0].dtype)
+        b = {"params": plist, "flat": flat, "pending": len(plist), "work": None, "launched": False, "seen": set(), "shard": None}
         o = 0
         for p in plist:
             self._where[id(p)] = (len(self.buckets), o)
@@ -149,8 +160,14 @@ class GradientBuckets:
                         bi, off = self._where[id(p)]
                         b["flat"][off: off + p.numel()].zero_()
                         p.grad = b["flat"][off: off + p.numel()].view_as(p)
-            if get_world_size() > 1:
-                b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+            if get_world_size() > 1 or (self.mode == "rs_ag" and dist.is_available() and dist.is_initialized()):
+                if self.mode == "rs_ag" and dist.get_backend() != "gloo":
+                    world = get_world_size()
+                    if b["shard"] is None:
+                        b["shard"] = torch.empty(b["flat"].numel() // world, device=b["flat"].device, dtype=b["flat"].dtype)
+                    b["work"] = dist.reduce_scatter_tensor(b["shard"], b["flat"], op=dist.ReduceOp.SUM, async_op=True)
+                else:   # gloo (CPU tests) has no reduce_scatter_tensor: same result through the all-reduce
+                    b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
             b["launched"] = True
             self.bytes_reduced += b["flat"].numel() * b["flat"].element_size()
             self._next += 1
@@ -163,6 +180,8 @@ class GradientBuckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
+                if self.mode == "rs_ag" and dist.get_backend() != "gloo":
+                    dist.all_gather_into_tensor(b["flat"], b["shard"])
             if self.average and world > 1:
                 b["flat"] /= world
             b["pending"], b["launched"] = len(b["params"]), False

@@ -75,6 +75,13 @@ def main():
         nbytes = D.allreduce_gradients_(params)
         avg = [p.grad.detach().clone() for p in params]
         out["bytes"] = nbytes
+        # the bucketed, backward-overlapped exchange (cfg 5's path) in both forms must give the same averaged gradient
+        for mode in ("all_reduce", "rs_ag"):
+            buckets = D.GradientBuckets(params, bucket_bytes=1 << 18, mode=mode)   # several buckets
+            grads([image(rank * per + i) for i in range(per)])
+            buckets.finish()
+            out["buckets_" + mode] = max(float((a - p.grad).abs().max() / a.abs().max()) for a, p in zip(avg, params))
+            buckets.remove()
         if rank == 0:
             grads([image(i) for i in range(per * world)])
             rel = [float((a - p.grad).norm() / p.grad.norm()) for a, p in zip(avg, params)]

@@ -62,6 +62,28 @@ def test_two_rank_gradient_average_equals_the_concatenated_batch():
     assert r["world"] == 2 and r["bytes"] == 103525 * 4
     # fp32 atomics in the weight-gradient kernel: summation order differs between the two evaluations
     assert max(r["rel_err_vs_concatenated_batch"]) <= 2e-4, r
+    assert r["buckets_all_reduce"] <= 2e-4 and r["buckets_rs_ag"] <= 2e-4, r
+
+
+def test_gradient_buckets_reduce_scatter_all_gather_over_rccl_world_1():
+    """RCCL's reduce_scatter_tensor / all_gather_into_tensor path of GradientBuckets (mode "rs_ag"), at the world size this
+    box has (1): the collectives run through RCCL and leave the gradients unchanged."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from lvc_amd import distributed as D\n"
+        "torch.cuda.set_device(0); dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "ps = [torch.nn.Parameter(torch.randn(n, device='cuda')) for n in (1000, 33, 70001)]\n"
+        "b = D.GradientBuckets(ps, bucket_bytes=1 << 12, mode='rs_ag')\n"
+        "loss = sum((p * p).sum() for p in ps); loss.backward(); n = b.finish()\n"
+        "ok = all(torch.equal(p.grad, 2 * p.detach()) for p in ps)\n"
+        "print('RSAG', ok, n, len(b.buckets), dist.get_backend()); dist.destroy_process_group()\n" % ROOT)
+    path = os.path.join(ROOT, "gpurun_out", "_rsag_worker.py")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    open(path, "w").write(code)
+    out = _torchrun(1, path)
+    line = [l for l in out.splitlines() if l.startswith("RSAG")][-1].split()
+    assert line[1] == "True" and int(line[2]) == (1000 + 33 + 70001) * 4 and int(line[3]) >= 2 and line[4] == "nccl", line
 
 
 def test_two_rank_sharded_knn_equals_the_single_process_sweep():

@@ -549,3 +549,26 @@ def test_fused_projection_block_matches_two_launch_form(monkeypatch):
     e_u = (outs[False] - ref).abs().max().item() / scale
     assert e_f < 2e-6 and e_u < 2e-6, (e_f, e_u)
     assert (outs[True] - outs[False]).abs().max().item() / scale < 2e-6
+
+
+@pytest.mark.parametrize("h,w,dtype", [(37, 61, "f32"), (800, 1333, "u8"), (224, 224, "f32"), (33, 64, "u8")])
+def test_preprocess_kernel_bit_exact(h, w, dtype):
+    """GeneralizedRCNN.preprocess_image + ImageList padding in isolation (reference lvc/modeling/meta_arch/rcnn.py:324-333,
+    structures/image_list.py:95-119): (x - mean) / std per channel, zero padding, a zero 4th channel slot -- bit for bit
+    against the oracle's torch-CPU evaluation of the same two fp32 operations."""
+    from lvc_amd import kernels as k
+    from oracle import rcnn as orc
+
+    g = torch.Generator().manual_seed(h * 1000 + w)
+    img = torch.rand(3, h, w, generator=g) * 255.0
+    if dtype == "u8":
+        img = img.round().to(torch.uint8)
+    for mean, std in (((103.53, 116.28, 123.675), (1.0, 1.0, 1.0)), ((123.675, 116.28, 103.53), (58.395, 57.12, 57.375))):
+        Hp, Wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        buf = torch.full((Hp, Wp, 4), 7.0, device=_dev())
+        k.preprocess_into(img.to(_dev()), buf, mean, std)
+        ref, sizes = orc.preprocess([img], mean, std, 32)
+        assert sizes == [(h, w)] and tuple(ref.shape) == (1, 3, Hp, Wp)
+        got = buf.cpu()
+        assert torch.equal(got[..., :3].permute(2, 0, 1), ref[0])
+        assert float(got[..., 3].abs().max()) == 0.0
