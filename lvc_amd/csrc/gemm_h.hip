@@ -1,0 +1,198 @@
+// gemm_h.hip -- y [M, N] (fp32) = A [M, C] . B [N, C]^T on fp16 operands: the pre-filter GEMM of the two-stage kNN sweep
+// (tools/run_nearest_neighbours.py:146-151 computes these similarities in fp32; here they only select the shots whose exact
+// fp32 similarity lvc_knn_verify_topk_vote re-evaluates, see knn.hip).
+//
+// Shape of the kernel (one workgroup of 8 waves per CU, persistent over its tile list):
+//   * 256 x 256 output tiles, wave grid 4 x 2, a wave owns 64 rows x 128 columns = 2 x 4 MFMA blocks of 32 x 32 (128
+//     accumulator registers): per 32-deep chunk a wave reads 4 KB of A and 8 KB of B fragments for 16 MFMAs -- 96 KB of LDS
+//     reads per chunk and workgroup against 2 x 512 matrix-pipe cycles per SIMD, the LDS port and the matrix pipe are about
+//     level (the 8 x 1 wave grid of conv_pw_dma.hip reads 160 KB for the same work and is LDS-bound with one MFMA per block);
+//   * operands arrive by `global_load_lds_dwordx4` into a ring of four 32 KB stages (A rows 0..255 then B rows 0..255, 64 bytes
+//     per row and chunk), three chunks ahead, across tile boundaries; one s_barrier per chunk;
+//   * LDS images are lane-linear; the four 16-byte granules of a row are permuted with slot = G ^ ((row >> 2) & 3) on the
+//     source side and on the fragment-read side, so that a 16-lane group of a ds_read_b128 covers the 64 banks once;
+//   * row tiles are dealt to XCDs (tile_m % 8 == blockIdx % 8) and a workgroup walks (row tile, column tile) pairs of its XCD
+//     with the column tile fastest: an A tile leaves HBM once and is shared through that XCD's L2;
+//   * the epilogue stores from the accumulators through a buffer descriptor (rows >= M, columns >= N dropped by the bounds
+//     check) while the ring keeps the next tile's first chunks in flight.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define GH_NS 4
+#define GH_A_BYTES (256 * 64)
+#define GH_STAGE (2 * GH_A_BYTES)
+
+struct GemmHArgs {
+  const unsigned short* a;
+  const unsigned short* b;
+  float* y;
+  int M, N, C, ldy, nk, tiles_m, tiles_n, nworkers;
+  unsigned y_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* gh_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gh_glb_ptr_t;
+
+__device__ __forceinline__ void gh_glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((gh_glb_ptr_t)g, (gh_lds_ptr_t)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[GH_NS * GH_STAGE];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int fx3 = (fi >> 2) & 3;
+
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per_xcd = p.nworkers >> 3;
+  const int ntl = ((p.tiles_m - xcd + 7) >> 3) * p.tiles_n;   // tiles of this XCD: row tiles xcd, xcd + 8, ... x all column tiles
+  if (local >= ntl) return;
+
+  // ---- loader: this wave DMAs rows [wave*32, wave*32 + 32) of the A image and of the B image of every chunk (2 + 2 instructions
+  // of 16 rows x 64 bytes); lane -> row lane / 4, LDS slot lane % 4, source granule slot ^ ((row >> 2) & 3)
+  const unsigned short* asrc[2];
+  const unsigned short* bsrc[2];
+  int l_u = local, l_kc = 0;
+  bool l_done = false;
+  auto loader_enter = [&](int u) {
+    const int tm = (u / p.tiles_n) * 8 + xcd, tn = u % p.tiles_n;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = wave * 32 + j * 16 + (lane >> 2);
+      const int G = (lane & 3) ^ ((r >> 2) & 3);
+      int ra = tm * 256 + r, rb = tn * 256 + r;
+      ra = ra < p.M ? ra : p.M - 1;      // rows past the end read a valid row; their outputs are never stored
+      rb = rb < p.N ? rb : p.N - 1;
+      asrc[j] = p.a + (size_t)ra * p.C + G * 8;
+      bsrc[j] = p.b + (size_t)rb * p.C + G * 8;
+    }
+  };
+  int issued = 0, consumed = 0, landed = 0;
+  auto issue_chunk = [&]() {
+    if (l_done) return;
+    unsigned char* st = smem + (issued % GH_NS) * GH_STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gh_glds16(asrc[j] + l_kc * 32, st + (wave * 32 + j * 16) * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) gh_glds16(bsrc[j] + l_kc * 32, st + GH_A_BYTES + (wave * 32 + j * 16) * 64);
+    ++issued;
+    if (++l_kc == p.nk) {
+      l_kc = 0;
+      l_u += per_xcd;
+      if (l_u < ntl) loader_enter(l_u);
+      else l_done = true;
+    }
+  };
+  // top of a chunk: chunk `consumed` has landed once this wave's pieces of it are done (loads retire in order: only the 4
+  // pieces of each younger chunk may still be outstanding) and every wave has said so at the barrier; past the barrier every
+  // wave is done with chunk consumed - 1, whose slot takes chunk consumed + 3
+  auto chunk_top = [&]() {
+    if (consumed >= landed) {
+      const int ahead = issued - consumed - 1;
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    issue_chunk();
+  };
+  loader_enter(l_u);
+  issue_chunk();
+  issue_chunk();
+  issue_chunk();
+
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+  const unsigned ldy4 = (unsigned)p.ldy * 4u;
+
+#pragma unroll 1
+  for (int u = local; u < ntl; u += per_xcd) {
+    const int tile_m = (u / p.tiles_n) * 8 + xcd, tile_n = u % p.tiles_n;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+#pragma unroll 1
+    for (int kc = 0; kc < p.nk; ++kc) {
+      chunk_top();
+      const unsigned char* st = smem + (consumed % GH_NS) * GH_STAGE;
+      const unsigned char* sa = st + (wm * 64 + fi) * 64;
+      const unsigned char* sb = st + GH_A_BYTES + (wn * 128 + fi) * 64;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const int bo = ((s * 2 + fh) ^ fx3) * 16;
+        f16x8 fa[2], fb[4];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const f16x8*>(sa + mi * 32 * 64 + bo);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const f16x8*>(sb + ni * 32 * 64 + bo);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+      }
+      ++consumed;
+    }
+
+    // ---- epilogue.  The chunks prefetched so far are drained first and remembered as landed: the counted waits of the next
+    // chunks would otherwise also wait for these 128 stores (one vmcnt queue).  A store writes 2 rows x 32 consecutive columns.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed = issued;
+    const int m0 = tile_m * 256 + wm * 64, n0 = tile_n * 256 + wn * 128;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const unsigned rbase = (unsigned)(m0 + mi * 32 + 4 * fh) * ldy4;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = n0 + ni * 32 + fi;
+        const unsigned cbase = col < p.N ? rbase + (unsigned)col * 4u : 0x80000000u;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = acc[mi][ni][e];   // a scalar copy: __builtin_bit_cast on the vector element itself reads element 0
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+static int g_cus_h = 0;
+
+// a [M, C], b [N, C]: fp16 bit patterns, rows contiguous, 16-byte aligned, C % 32 == 0; y [M, ldy] fp32 (ldy >= N), smaller
+// than 2 GiB.  y[m][n] = sum_c a[m][c] * b[n][c] accumulated in fp32 (chunks of 32 in order, 16-wide MFMA steps inside).
+extern "C" int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, float* y, int M, int N, int C, int ldy,
+                            void* stream) {
+  LVC_CHECK_ARG(M >= 0 && N > 0 && C > 0, "bad shape");
+  if (M == 0) return LVC_OK;
+  LVC_CHECK_ARG(a && b && y, "null pointer");
+  LVC_CHECK_ARG(C % 32 == 0, "needs C % 32 == 0");
+  LVC_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "operands must be 16-byte aligned");
+  GemmHArgs g;
+  g.a = a; g.b = b; g.y = y; g.M = M; g.N = N; g.C = C;
+  g.ldy = ldy > 0 ? ldy : N;
+  LVC_CHECK_ARG(g.ldy >= N, "ldy < N");
+  const long long yb = (long long)M * g.ldy * 4;
+  LVC_CHECK_ARG(yb < (1ll << 31), "output must be smaller than 2 GiB");
+  g.y_bytes = (unsigned)yb;
+  g.nk = C / 32;
+  g.tiles_m = lvc_cdiv(M, 256);
+  g.tiles_n = lvc_cdiv(N, 256);
+  if (g_cus_h == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    g_cus_h = cus;
+  }
+  g.nworkers = g_cus_h / 8 * 8;
+  if (g.nworkers < 8) g.nworkers = 8;
+  hipLaunchKernelGGL(gemm_f16_dma_kernel, dim3(g.nworkers), dim3(512), 0, (hipStream_t)stream, g);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

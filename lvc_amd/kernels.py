@@ -744,6 +744,48 @@ def knn_topk_vote(sims, num_shots, shot_classes, det_classes, k):
     return top, keep
 
 
+def rownorm_h(x, mu=None, eps=1e-5, mode=0):
+    """`rownorm` plus the same rows rounded to fp16: (y fp32 [M,D], yh fp16 [M,D])."""
+    _req_cuda(x, mu)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    M, D = x.shape
+    y = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    yh = torch.empty(M, D, device=x.device, dtype=torch.float16)
+    rc = _lib.lib().lvc_rownorm_h(ptr(x), ptr(mu), ptr(y), ptr(yh), c_int(M), c_int(D), c_int(x.stride(0)), c_float(eps),
+                                  c_int(mode), _stream(x))
+    check(rc, "lvc_rownorm_h")
+    return y, yh
+
+
+def gemm_f16(a, b):
+    """a [M,C] . b [N,C]^T on fp16 operands with fp32 accumulation -> [M,N] fp32 (lvc_gemm_f16): the pre-filter of the
+    two-stage kNN sweep."""
+    _req_cuda(a, b)
+    M, C = a.shape
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float16 and b.dtype == torch.float16 and b.shape[1] == C
+    y = torch.empty(M, b.shape[0], device=a.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_gemm_f16(ptr(a), ptr(b), ptr(y), c_int(M), c_int(b.shape[0]), c_int(C), c_int(b.shape[0]), _stream(a))
+    check(rc, "lvc_gemm_f16")
+    return y
+
+
+def knn_verify_topk_vote(approx, qn, sn, margin, shot_classes, det_classes, k):
+    """approx [Q,S] from gemm_f16_hi over the same normalised rows qn [Q,D], sn [S,D]: exact top-10 classes + vote."""
+    _req_cuda(approx, qn, sn, shot_classes, det_classes)
+    Q, S = approx.shape[0], sn.shape[0]
+    assert approx.stride(1) == 1 and qn.is_contiguous() and sn.is_contiguous() and shot_classes.dtype == torch.int64
+    top = torch.empty(Q, 10, dtype=torch.int64, device=approx.device)
+    keep = torch.empty(Q, dtype=torch.int64, device=approx.device) if det_classes is not None else None
+    if det_classes is not None:
+        det_classes = det_classes.contiguous()
+        assert det_classes.dtype == torch.int64
+    rc = _lib.lib().lvc_knn_verify_topk_vote(ptr(approx), c_int(approx.stride(0)), c_int(Q), c_int(S), ptr(qn), ptr(sn),
+                                             c_int(qn.shape[1]), c_float(margin), ptr(shot_classes), ptr(det_classes), c_int(k),
+                                             ptr(top), ptr(keep), _stream(approx))
+    check(rc, "lvc_knn_verify_topk_vote")
+    return top, keep
+
+
 # --------------------------------------------------------------------------- training-time kernels
 def match_boxes(gt_boxes, boxes, thresholds, labels, allow_low_quality_matches):
     """pairwise_iou + Matcher on device.  gt_boxes [G,4] (G >= 1), boxes [N,4].

@@ -6,10 +6,18 @@
 per-image Python loop and its [q_i,S,D] broadcast disappear.  `run_nearest_neighbours` /
 `get_nn_class_confirmatory` keep the reference's list-of-dicts signatures on top of it.
 """
+import os
+
 import torch
 
 from . import kernels as K
 
+# LVC_KNN_TWO_STAGE=0: materialise the full-precision similarity matrix (three MFMAs per block) and rank it directly
+KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
+# unit-norm rows: |fp16 dot - exact| <= 2^-11 (|q| rounding) + 2^-11 (|s| rounding) + 2^-22 + fp32 accumulation
+# < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
+VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16
+TWO_STAGE_CHUNK = 1 << 18
 QUERY_CHUNK = 32768  # rows of the similarity matrix materialised at once (x S x 4 bytes)
 
 
@@ -57,23 +65,35 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
     if D % 32 != 0:
         raise RuntimeError("descriptor dimension must be a multiple of 32 (got {})".format(D))
     shot_classes = shot_classes.to(torch.int64).contiguous()
+    two_stage = KNN_TWO_STAGE and cosine and D <= 2048 and S >= 10
     if cosine:
         mu = K.colmean(shots)
-        sn = K.rownorm(shots, mu=mu, eps=1e-8, mode=1)
-        pc = K.pack_linear(sn)
+        if two_stage:
+            sn, sh = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
+        else:
+            sn = K.rownorm(shots, mu=mu, eps=1e-8, mode=1)
+            pc = K.pack_linear(sn)
     else:
         # ranking by -cdist(q, s) == ranking by q.s - |s|^2/2 (|q| is constant per row)
         pc = K.pack_linear(shots)
         pc.shift = (-0.5 * (shots * shots).sum(1)).contiguous()
     tops, keeps = [], []
-    for s0 in range(0, max(Q, 1), QUERY_CHUNK):
-        qc = q[s0: s0 + QUERY_CHUNK]
+    # the two-stage path keeps only transient fp16 / fp32 copies per chunk: take as many rows as the GEMM's 2 GiB output allows
+    chunk = min(TWO_STAGE_CHUNK, (2 ** 31 - 1) // (4 * S)) if two_stage else QUERY_CHUNK
+    for s0 in range(0, max(Q, 1), chunk):
+        qc = q[s0: s0 + chunk]
         if qc.shape[0] == 0:
             break
-        qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
-        sims = K.linear(qn, pc)
-        dc = detector_classes[s0: s0 + QUERY_CHUNK].to(torch.int64) if detector_classes is not None else None
-        t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
+        dc = detector_classes[s0: s0 + chunk].to(torch.int64) if detector_classes is not None else None
+        if two_stage:
+            # fp16 similarities (one MFMA per block instead of three) as a pre-filter, exact fp32 re-evaluation of the few shots
+            # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
+            qn, qh = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1)
+            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qn, sn, VERIFY_MARGIN, shot_classes, dc, k)
+        else:
+            qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
+            sims = K.linear(qn, pc)
+            t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
         tops.append(t)
         keeps.append(kp)
     if not tops:

@@ -108,3 +108,92 @@ def test_knn_sweep_shapes(Q, S, Dm, cosine):
     ref_keep = oknn.get_nn_class_confirmatory(ref_top, qcls, 10)
     assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 2e-3
     assert (keep.cpu() != ref_keep).float().mean() <= 2e-3
+
+
+def _unit_rows(n, d, g):
+    x = torch.randn(n, d, generator=g, dtype=torch.float64)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+@pytest.mark.parametrize("Dm", [64, 384, 1024, 2048])
+def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm):
+    """knn_verify_topk_vote_kernel with a pre-filter matrix perturbed by the WORST noise its contract allows (+-2^-10,
+    uniformly random per entry -- far rougher than the fp16 hi-plane GEMM): the exact ten best (fp64 ranking of the same
+    rows) must come back wherever fp32 can tell them apart; a block of 300 identical shots drives rows through the
+    all-shots path and the tie rule (lower shot index)."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(Dm)
+    Q, S = 500, 1500
+    sn = _unit_rows(S, Dm, g)
+    sn[200:500] = sn[200]                       # 300 identical shots
+    qn = _unit_rows(Q, Dm, g)
+    qn[:20] = sn[200] * 0.8 + 0.6 * qn[:20]      # queries next to the block: > KV_MAX_CAND candidates
+    qn = qn / qn.norm(dim=1, keepdim=True)
+    sims = qn @ sn.t()
+    approx = (sims + (torch.rand(Q, S, generator=g, dtype=torch.float64) * 2 - 1) * 2.0 ** -10).float()
+    shot_classes = torch.randint(0, 80, (S,), generator=g)
+    det = torch.randint(0, 80, (Q,), generator=g)
+    top, keep = K.knn_verify_topk_vote(approx.to(D), qn.float().contiguous().to(D), sn.float().contiguous().to(D),
+                                       2.0 ** -9 + 2.0 ** -16, shot_classes.to(D), det.to(D), 10)
+    qs, ss = qn.float().double(), sn.float().double()      # the fp32 rows the kernel reads, evaluated in fp64
+    s64 = qs @ ss.t()
+    val, order = torch.sort(s64, dim=1, descending=True, stable=True)
+    ref_top = shot_classes[order[:, :10]]
+    clear = ((val[:, :10] - val[:, 1:11]) > 2e-6).all(dim=1)     # rows whose top 11 are separated beyond fp32 summation noise
+    clear[:20] = True                                            # block rows: identical shots tie exactly in any precision ...
+    assert clear.float().mean() > 0.9
+    got = top.cpu()
+    assert torch.equal(got[20:][clear[20:]], ref_top[20:][clear[20:]])
+    # ... so their winners are the block's lowest indices (one class) unless a non-block shot beats them
+    blk = (order[:20, :10] >= 200) & (order[:20, :10] < 500)
+    assert blk.all(), "test construction: the block should own the top ten of the first 20 rows"
+    assert torch.equal(got[:20], shot_classes[200:210].expand(20, 10))
+    ref_keep = (torch.mode(got, dim=1)[0] == det).long()
+    assert torch.equal(keep.cpu(), ref_keep)
+
+
+def test_two_stage_equals_single_stage(monkeypatch):
+    """The fp16 pre-filter + exact verification and the full-precision similarity matrix pick the same neighbours (both rank
+    fp32 evaluations of the same dot products; rows where two shots tie to fp32 rounding may swap)."""
+    from lvc_amd import label_verification as LV
+
+    g = torch.Generator().manual_seed(5)
+    S, Dm, Q = 2400, 1024, 20000
+    classes = torch.arange(80).repeat_interleave(30)
+    centers = torch.randn(80, Dm, generator=g)
+    shots = (centers[classes] + 2.0 * torch.randn(S, Dm, generator=g) + 0.3).to(D)
+    qcls = torch.randint(0, 80, (Q,), generator=g)
+    q = (centers[qcls] + 2.5 * torch.randn(Q, Dm, generator=g) + 0.3).to(D)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(LV, "KNN_TWO_STAGE", flag)
+        out[flag] = LV.knn_sweep(classes.to(D), shots, q, qcls.to(D), 10, True)
+    assert (out[True][0] != out[False][0]).any(dim=1).float().mean() <= 5e-4
+    assert (out[True][1] != out[False][1]).float().mean() <= 5e-4
+
+
+def test_fp16_gemm_error_bound_and_exactness():
+    """lvc_gemm_f16: (a) on operands that are exactly representable products (small integers) the result is exact for every
+    tile-edge shape; (b) on unit-norm rows rounded to fp16 by lvc_rownorm_h the distance to the fp64 product of the fp32 rows
+    stays inside the bound the verification margin is derived from (2^-10)."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(11)
+    for M, S, Dm in [(700, 333, 96), (257, 64, 64), (1, 10, 32), (5000, 2400, 384), (513, 257, 1024)]:
+        a = torch.randint(-4, 5, (M, Dm), generator=g).half()
+        b = torch.randint(-4, 5, (S, Dm), generator=g).half()
+        y = K.gemm_f16(a.to(D), b.to(D))
+        assert torch.equal(y.cpu(), a.float() @ b.float().t())
+    for M, S, Dm in [(3000, 2400, 1024), (700, 333, 384)]:
+        a, b = torch.randn(M, Dm, generator=g) + 0.2, torch.randn(S, Dm, generator=g) + 0.2
+        a[0] = 0
+        a[0, 3] = 5.0                                       # one-hot rows: the largest single-term products
+        b[1] = 0
+        b[1, 3] = -7.0
+        an, ah = K.rownorm_h(a.to(D), eps=1e-8, mode=1)
+        bn, bh = K.rownorm_h(b.to(D), eps=1e-8, mode=1)
+        assert torch.equal(an, K.rownorm(a.to(D), eps=1e-8, mode=1)) and torch.equal(ah, an.half())
+        y = K.gemm_f16(ah, bh)
+        exact = an.double() @ bn.double().t()
+        assert (y.double() - exact).abs().max().item() <= 2.0 ** -10
