@@ -342,18 +342,23 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
                       const long long* det_classes, int kvote, long long* top_classes, long long* keep,
                       void* stream);
 /* Two-stage form of the same sweep (cosine branch; the similarities of run_nearest_neighbours.py:146-151 are never
- * materialised in full precision).  lvc_rownorm_h: lvc_rownorm (contiguous y) that also writes the rows rounded to fp16.
+ * materialised in full precision).
+ * lvc_rownorm_h: lvc_rownorm that writes the rows rounded to fp16 (yh [M,D]), the denominators (den [M] or NULL) and, if
+ *   y is not NULL, the fp32 rows (contiguous, bit-identical to lvc_rownorm).
  * lvc_gemm_f16: y [M,ldy] fp32 = a [M,C] . b [N,C]^T on fp16 operands (csrc/gemm_h.hip; C % 32 == 0, y below 2 GiB) -- for
- * unit-norm rows |y - exact| < 2^-10.  lvc_knn_verify_topk_vote: per query row, every shot whose approximate similarity
- * is within `margin` (>= 2 x that bound) of the 10th largest approximate value is re-evaluated in fp32 from the
- * normalised rows qn [Q,D] / sn [S,D] (D % 4 == 0, D <= 2048) and ranked exactly (ties -> lower shot index); that set
- * provably contains the exact ten best.  Outputs as lvc_knn_topk_vote. */
-int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, int M, int D, int ldx, float eps, int mode,
-                  void* stream);
+ *   unit-norm rows |y - exact| < 2^-10.
+ * lvc_knn_verify_topk_vote: per query row, the shots whose approximate similarity is within `margin` (>= 2 x that bound)
+ *   of the 10th largest approximate value provably contain the exact ten best; those of them that have a shot of another
+ *   class within margin are re-evaluated in fp32 from q [Q,ldq] (raw descriptors; (q - mu) / den[row] is redone exactly as
+ *   lvc_rownorm_h did it; mu / den may be NULL: q then already holds the rows) and sn [S,D] (normalised shots), and the
+ *   candidates are ranked so that the class sequence equals the exact ranking's (ties -> lower shot index; csrc/knn.hip
+ *   states the argument).  D % 4 == 0, D <= 2048.  Outputs as lvc_knn_topk_vote. */
+int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, int M, int D, int ldx, float eps,
+                  int mode, void* stream);
 int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, float* y, int M, int N, int C, int ldy, void* stream);
-int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* qn, const float* sn, int D,
-                             float margin, const long long* shot_classes, const long long* det_classes, int kvote,
-                             long long* top_classes, long long* keep, void* stream);
+int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
+                             const float* den, const float* sn, int D, float margin, const long long* shot_classes,
+                             const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Descriptor network of the label-verification step: DINO ViT-S/8 as loaded by

@@ -103,11 +103,12 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   for (int d = lane; d < D; d += 64) yr[d] = (xr[d] - (mu ? mu[d] : 0.f)) / den;
 }
 
-// The same rows twice: fp32 (bit-identical to rownorm_kernel: same summation order, same division) and rounded to fp16
-// (round to nearest even) for the pre-filter GEMM of the two-stage kNN sweep (gemm_h.hip).
+// lvc_rownorm for the two-stage kNN sweep: the normalised rows rounded to fp16 (round to nearest even; the operand of the
+// pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), and --
+// optionally -- the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
 __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict__ x, const float* __restrict__ mu,
-                                                        float* __restrict__ y, _Float16* __restrict__ yh, int M, int D,
-                                                        int ldx, float eps, int mode) {
+                                                        float* __restrict__ y, _Float16* __restrict__ yh, float* __restrict__ dens,
+                                                        int M, int D, int ldx, float eps, int mode) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* xr = x + (size_t)row * ldx;
@@ -119,21 +120,22 @@ __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict_
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float nrm = sqrtf(ss);
   const float den = mode == 0 ? nrm + eps : (nrm > eps ? nrm : eps);
-  float* yr = y + (size_t)row * D;
+  if (dens && lane == 0) dens[row] = den;
+  float* yr = y ? y + (size_t)row * D : nullptr;
   _Float16* hr = yh + (size_t)row * D;
   for (int d = lane; d < D; d += 64) {
     const float v = (xr[d] - (mu ? mu[d] : 0.f)) / den;
-    yr[d] = v;
+    if (yr) yr[d] = v;
     hr[d] = (_Float16)v;
   }
 }
 
-extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, int M, int D, int ldx, float eps,
-                             int mode, void* stream) {
+extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, int M, int D, int ldx,
+                             float eps, int mode, void* stream) {
   LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
   if (M == 0) return LVC_OK;
-  LVC_CHECK_ARG(x && y && yh, "null pointer");
-  hipLaunchKernelGGL(rownorm_h_kernel, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, M, D,
+  LVC_CHECK_ARG(x && yh, "null pointer");
+  hipLaunchKernelGGL(rownorm_h_kernel, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, M, D,
                      ldx > 0 ? ldx : D, eps, mode);
   LVC_CHECK_LAUNCH();
   return LVC_OK;

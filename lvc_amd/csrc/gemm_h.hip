@@ -16,6 +16,7 @@
 //   * the epilogue stores from the accumulators through a buffer descriptor (rows >= M, columns >= N dropped by the bounds
 //     check) while the ring keeps the next tile's first chunks in flight.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -30,6 +31,7 @@ struct GemmHArgs {
   float* y;
   int M, N, C, ldy, nk, tiles_m, tiles_n, nworkers;
   unsigned y_bytes;
+  int ablate;   // experiments (LVC_GH_ABLATE): 1 = no operand DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no stores
 };
 
 typedef __attribute__((address_space(3))) void* gh_lds_ptr_t;
@@ -75,10 +77,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   auto issue_chunk = [&]() {
     if (l_done) return;
     unsigned char* st = smem + (issued % GH_NS) * GH_STAGE;
+    if (!(p.ablate & 1) || issued < GH_NS - 1) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gh_glds16(asrc[j] + l_kc * 32, st + (wave * 32 + j * 16) * 64);
+      for (int j = 0; j < 2; ++j) gh_glds16(asrc[j] + l_kc * 32, st + (wave * 32 + j * 16) * 64);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) gh_glds16(bsrc[j] + l_kc * 32, st + GH_A_BYTES + (wave * 32 + j * 16) * 64);
+      for (int j = 0; j < 2; ++j) gh_glds16(bsrc[j] + l_kc * 32, st + GH_A_BYTES + (wave * 32 + j * 16) * 64);
+    }
     ++issued;
     if (++l_kc == p.nk) {
       l_kc = 0;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
       const unsigned char* st = smem + (consumed % GH_NS) * GH_STAGE;
       const unsigned char* sa = st + (wm * 64 + fi) * 64;
       const unsigned char* sb = st + GH_A_BYTES + (wn * 128 + fi) * 64;
+      if (!(p.ablate & 2))
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int bo = ((s * 2 + fh) ^ fx3) * 16;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const float v = acc[mi][ni][e];   // a scalar copy: __builtin_bit_cast on the vector element itself reads element 0
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
+          if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
         }
       }
     }
@@ -182,6 +187,8 @@ extern "C" int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, fl
   LVC_CHECK_ARG(yb < (1ll << 31), "output must be smaller than 2 GiB");
   g.y_bytes = (unsigned)yb;
   g.nk = C / 32;
+  static const int ablate = [] { const char* e = getenv("LVC_GH_ABLATE"); return e ? atoi(e) : 0; }();
+  g.ablate = ablate;
   g.tiles_m = lvc_cdiv(M, 256);
   g.tiles_n = lvc_cdiv(N, 256);
   if (g_cus_h == 0) {

@@ -10,6 +10,7 @@
 //      each other (ties -> lower shot index), no cross-lane reduction chains; shot_classes gather, majority vote
 //      with torch.mode's tie rule (smallest class id), keep = (vote == detector class).
 #include "common.h"
+#include <stdlib.h>
 
 // mu[d] = mean over rows.  One workgroup sums a 64-row slab for 256 columns; slabs are combined with fp32 atomics
 // into the zeroed mu, already divided by M (the serial one-thread-per-column form took 0.9 ms for 2400 x 1024).
@@ -181,26 +182,40 @@ extern "C" int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const 
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Two-stage exact top-10: the [Q, S] matrix handed in is an APPROXIMATION of the similarities (lvc_gemm_f16_hi_dma: every
+// Two-stage exact top-10: the [Q, S] matrix handed in is an APPROXIMATION of the similarities (lvc_gemm_f16, gemm_h.hip: every
 // operand rounded to fp16, one MFMA per block instead of three) with |approx - exact| <= eps for unit-norm rows
-// (eps = 2^-10 * sum |q_i s_i| <= 2^-10 by Cauchy-Schwarz, plus the fp32 accumulation, ~1e-6).  Let A10 be the 10th largest
-// approximate value of a row.  The ten best approximate shots have exact similarity >= A10 - eps, so the exact 10th best
-// x10 >= A10 - eps, and every shot of the exact top ten has approx >= x10 - eps >= A10 - 2 eps: the shots with
-// approx >= A10 - margin (margin >= 2 eps) CONTAIN the exact top ten.  Only those (a dozen or so on uncorrelated
-// descriptors) are re-evaluated in fp32 -- lane l sums elements l*4 .. l*4+3 of every 256-element slice in order, then a
-// butterfly over the lanes: a fixed order -- and ranked (value descending, ties -> lower shot index); classes and the vote as
-// in knn_topk_vote_kernel.  A row with more than KV_MAX_CAND candidates (a cloud of near-identical shots) evaluates ALL
-// shots exactly, KV_MAX_CAND at a time, keeping the running ten best.
+// (eps = 2^-10 * sum |q_i s_i| <= 2^-10 by Cauchy-Schwarz, plus the fp32 accumulation, ~1e-6).
+//   1. Containment.  Let A10 be the 10th largest approximate value of a row.  The ten best approximate shots have exact
+//      similarity >= A10 - eps, so the exact 10th best x10 >= A10 - eps, and every shot of the exact top ten has
+//      approx >= x10 - eps >= A10 - 2 eps: the candidates {approx >= A10 - margin}, margin >= 2 eps, contain the exact top ten
+//      (a dozen or so shots on uncorrelated descriptors).
+//   2. What has to be exact.  The outputs are CLASS ids in rank order.  Call a candidate flagged when another candidate of a
+//      DIFFERENT class lies within margin of it; flagged candidates are re-evaluated in fp32 (lane l sums elements l*4 .. l*4+3
+//      of every 256-element slice in order with fmas, then a butterfly over the lanes: a fixed order), and the candidates are
+//      sorted by key = exact value where flagged, approximate value otherwise (descending, ties -> lower shot index).  Two
+//      candidates of different classes are ordered as by the exact values: both flagged -> both keys exact; one of them
+//      unflagged -> their approximate values differ by more than margin >= 2 eps, and moving either value by eps cannot swap
+//      them.  Two total orders that agree on every cross-class pair put each class on the same set of positions, so the class
+//      sequence -- and with it top_classes and the vote -- equals the one of the exact ranking with the reference's tie rule.
+//   3. A row with more than KV_MAX_CAND candidates (a cloud of near-identical shots) evaluates ALL shots exactly,
+//      KV_MAX_CAND - 10 at a time next to the running ten best.
+// The query row is normalised on the fly from the raw descriptors exactly as lvc_rownorm does it ((q - mu) / den, den from
+// lvc_rownorm_h), and only for rows that have a flagged candidate.
 #define KV_MAX_CAND 192
 template <int KTOP, int PER>
 __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
-                                                                   const float* __restrict__ qn, const float* __restrict__ sn,
+                                                                   const float* __restrict__ q, int ldq, const float* __restrict__ mu,
+                                                                   const float* __restrict__ den, const float* __restrict__ sn,
                                                                    int D, float margin, const long long* __restrict__ shot_classes,
                                                                    const long long* __restrict__ det_classes, int kvote,
-                                                                   long long* __restrict__ top_classes, long long* __restrict__ keep) {
+                                                                   long long* __restrict__ top_classes, long long* __restrict__ keep,
+                                                                   int stop_after) {
   __shared__ float s_lmax[4][64];
-  __shared__ float s_val[4][KV_MAX_CAND + KTOP];     // exact similarity of the candidates (+ the running best of the slow path)
+  __shared__ float s_ap[4][KV_MAX_CAND];             // approximate value of a candidate
+  __shared__ float s_val[4][KV_MAX_CAND + KTOP];     // sort key: exact similarity where evaluated, else the approximate one
   __shared__ int s_idx[4][KV_MAX_CAND + KTOP];
+  __shared__ long long s_ccl[4][KV_MAX_CAND];        // class of a candidate
+  __shared__ short s_alist[4][KV_MAX_CAND];          // positions of the flagged candidates
   __shared__ float s_T[4];
   __shared__ long long s_cls[4][KTOP];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -216,6 +231,8 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     if (v[j] != v[j]) v[j] = INFINITY;
     lmax = fmaxf(lmax, v[j]);
   }
+  // (stop_after: timing experiments, LVC_KV_STOP; results are then meaningless)
+  if (stop_after == 1) { if (lmax == 123.f) top_classes[row] = 1; return; }
   // ---- A10: exact 10th largest approximate value.  First a lower bound T (the lane maximum of rank KTOP-1), then the rank of
   // every value >= T among those values
   s_lmax[w][lane] = lmax;
@@ -241,6 +258,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (stop_after == 2) { if (total == 12345) top_classes[row] = 1; return; }
   float A10 = T;      // more than KV_MAX_CAND values >= T (near-constant row): T itself is a valid lower bound of A10
   if (total <= KV_MAX_CAND) {
     for (int c0 = 0; c0 < total; c0 += 64) {
@@ -257,39 +275,80 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     A10 = s_T[w];
   }
   const float Tv = A10 - margin;
-  // the query row in registers: lane l holds elements s*256 + l*4 .. +3 of every 256-element slice
-  const float* qr = qn + (size_t)row * D;
+  if (stop_after == 3) { if (Tv == 123.f) top_classes[row] = 1; return; }
+  // the normalised query row in registers, loaded when the first exact similarity is needed: lane l holds elements
+  // sl*256 + l*4 .. +3 of every 256-element slice sl (where below D)
   float4 qv[8];
-  // D % 4 == 0, D <= 2048: lane l owns elements sl*256 + l*4 .. +3 of slice sl (where below D)
+  bool have_q = false;
+  auto load_q = [&]() {
+    if (have_q) return;
+    have_q = true;
+    const float* qr = q + (size_t)row * ldq;
+    const float dn = den ? den[row] : 1.f;
 #pragma unroll
-  for (int sl = 0; sl < 8; ++sl)
-    qv[sl] = sl * 256 + lane * 4 < D ? *reinterpret_cast<const float4*>(qr + sl * 256 + lane * 4) : float4{0.f, 0.f, 0.f, 0.f};
-  auto exact_dot = [&](int si) {
-    const float* sr = sn + (size_t)si * D;
-    float acc = 0.f;
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl)
-      if (sl * 256 + lane * 4 < D) {
-        const float4 sv = *reinterpret_cast<const float4*>(sr + sl * 256 + lane * 4);
-        acc += qv[sl].x * sv.x; acc += qv[sl].y * sv.y; acc += qv[sl].z * sv.z; acc += qv[sl].w * sv.w;
+    for (int sl = 0; sl < 8; ++sl) {
+      const int d = sl * 256 + lane * 4;
+      float4 x = {0.f, 0.f, 0.f, 0.f};
+      if (d < D) {
+        x = *reinterpret_cast<const float4*>(qr + d);
+        if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + d); x.x -= m4.x; x.y -= m4.y; x.z -= m4.z; x.w -= m4.w; }
+        if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
       }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    return acc;
+      qv[sl] = x;
+    }
   };
-  // rank the first n entries of (s_val, s_idx) (value descending, ties -> lower shot index) and keep the KTOP best in place
+  // exact similarities of the n shots listed through pos_of(k) -> position in (s_idx, s_val), four rows in flight
+  auto exact_dots = [&](int n, auto pos_of) {
+    load_q();
+    for (int k0 = 0; k0 < n; k0 += 4) {
+      const float* sr[4];
+      int pos[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        pos[t] = pos_of(min(k0 + t, n - 1));
+        sr[t] = sn + (size_t)s_idx[w][pos[t]] * D;
+      }
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl)
+        if (sl * 256 < D) {
+          const bool in = sl * 256 + lane * 4 < D;
+          float4 sv[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) sv[t] = in ? *reinterpret_cast<const float4*>(sr[t] + sl * 256 + lane * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            // explicit fmas: every row in flight must round the same way (identical shots tie exactly)
+            acc[t] = __builtin_fmaf(qv[sl].x, sv[t].x, acc[t]); acc[t] = __builtin_fmaf(qv[sl].y, sv[t].y, acc[t]);
+            acc[t] = __builtin_fmaf(qv[sl].z, sv[t].z, acc[t]); acc[t] = __builtin_fmaf(qv[sl].w, sv[t].w, acc[t]);
+          }
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], o);
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s_val[w][pos[t]] = acc[t];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+  // rank the first n entries by (s_val descending, s_idx ascending) and keep the KTOP best in place.  Winners park in the tail
+  // slots [KV_MAX_CAND + rank] (ranks are unique, the loops never read the tail) and move to the front afterwards.
   auto keep_best = [&](int n) {
     for (int c0 = 0; c0 < n; c0 += 64) {
       const int c = c0 + lane;
-      const float mv = c < n ? s_val[w][c] : -INFINITY;
-      const int mi = c < n ? s_idx[w][c] : 0x7fffffff;
-      int r = 0;
-      for (int l = 0; l < n; ++l) {
-        const float o = s_val[w][l];
-        const int oi = s_idx[w][l];
-        r += (o > mv || (o == mv && oi < mi)) ? 1 : 0;
+      if (c < n) {
+        const float mv = s_val[w][c];
+        const int mi = s_idx[w][c];
+        int r = 0;
+        for (int l = 0; l < n; ++l) {
+          const float o = s_val[w][l];
+          r += (o > mv || (o == mv && s_idx[w][l] < mi)) ? 1 : 0;
+        }
+        if (r < KTOP) { s_val[w][KV_MAX_CAND + r] = mv; s_idx[w][KV_MAX_CAND + r] = mi; }
       }
-      // winners park in the tail slots [KV_MAX_CAND + rank] (ranks are unique, the loops above never read the tail)
-      if (c < n && r < KTOP) { s_val[w][KV_MAX_CAND + r] = mv; s_idx[w][KV_MAX_CAND + r] = mi; }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const int kept = n < KTOP ? n : KTOP;
@@ -305,67 +364,96 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     const unsigned long long m = __ballot(is_c);
     if (m) {
       const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-      if (is_c && pos < KV_MAX_CAND) s_idx[w][pos] = j * 64 + lane;
+      if (is_c && pos < KV_MAX_CAND) { s_idx[w][pos] = j * 64 + lane; s_ap[w][pos] = v[j]; }
       ncand += __popcll(m);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (stop_after == 4) { if (ncand == 12345) top_classes[row] = 1; return; }
   int nbest;
   if (ncand <= KV_MAX_CAND) {
-    for (int c = 0; c < ncand; ++c) {
-      const float e = exact_dot(s_idx[w][c]);
-      if (lane == 0) s_val[w][c] = e;
+    for (int c = lane; c < ncand; c += 64) s_ccl[w][c] = shot_classes[s_idx[w][c]];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // flagged candidates (a candidate of another class within margin), their positions compacted; key = approx for the others
+    int nflag = 0;
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+      const int c = c0 + lane;
+      bool fl = false;
+      if (c < ncand) {
+        const float mv = s_ap[w][c];
+        const long long mc = s_ccl[w][c];
+        for (int l = 0; l < ncand; ++l) fl = fl || (s_ccl[w][l] != mc && !(fabsf(s_ap[w][l] - mv) > margin));
+        s_val[w][c] = mv;
+      }
+      const unsigned long long m = __ballot(fl);
+      if (fl) s_alist[w][nflag + __popcll(m & ((1ull << lane) - 1ull))] = (short)c;
+      nflag += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (stop_after == 5) { if (nflag == 12345) top_classes[row] = 1; return; }
+    if (nflag) exact_dots(nflag, [&](int k) { return (int)s_alist[w][k]; });
+    if (stop_after == 6) { if (s_val[w][0] == 99.f) top_classes[row] = 1; return; }
     nbest = keep_best(ncand);
   } else {
-    // slow path: every shot exactly, in blocks of KV_MAX_CAND - KTOP next to the running best
+    // every shot exactly, in blocks of KV_MAX_CAND - KTOP next to the running best
     nbest = 0;
     for (int s0 = 0; s0 < S; s0 += KV_MAX_CAND - KTOP) {
       const int nb = min(KV_MAX_CAND - KTOP, S - s0);
-      for (int c = 0; c < nb; ++c) {
-        const float e = exact_dot(s0 + c);
-        if (lane == 0) { s_val[w][nbest + c] = e; s_idx[w][nbest + c] = s0 + c; }
-      }
+      for (int c = lane; c < nb; c += 64) s_idx[w][nbest + c] = s0 + c;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const int base = nbest;
+      exact_dots(nb, [&](int k) { return base + k; });
       nbest = keep_best(nbest + nb);
     }
   }
+  long long mycl = -1;
   if (lane < KTOP) {
-    const long long cl = lane < nbest ? shot_classes[s_idx[w][lane]] : -1;
-    s_cls[w][lane] = cl;
-    top_classes[(size_t)row * KTOP + lane] = cl;
+    mycl = lane < nbest ? shot_classes[s_idx[w][lane]] : -1;
+    s_cls[w][lane] = mycl;
+    top_classes[(size_t)row * KTOP + lane] = mycl;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  if (lane == 0 && keep) {
-    long long mode = -1; int mcount = 0;
-    for (int a = 0; a < kvote; ++a) {
-      int c = 0;
-      for (int b = 0; b < kvote; ++b) c += (s_cls[w][b] == s_cls[w][a]);
-      if (c > mcount || (c == mcount && s_cls[w][a] < mode)) { mcount = c; mode = s_cls[w][a]; }
+  if (keep) {
+    // mode of the first kvote classes, ties -> smallest class id: lane a counts its class, then the best (count, -class)
+    int cnt = 0;
+    if (lane < kvote)
+      for (int b = 0; b < kvote; ++b) cnt += (s_cls[w][b] == mycl);
+    int best = cnt;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    long long cand = (lane < kvote && cnt == best) ? mycl : 0x7fffffffffffffffll;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const long long other = __shfl_xor(cand, o);
+      cand = other < cand ? other : cand;
     }
-    keep[row] = (det_classes && det_classes[row] == mode) ? 1 : 0;
+    if (lane == 0) keep[row] = (det_classes && det_classes[row] == cand) ? 1 : 0;
   }
 }
 
-// approx [Q, ld] (S used columns) from lvc_gemm_f16_hi_dma over the SAME normalised rows qn [Q, D] / sn [S, D] (fp32, D % 4 == 0,
-// D <= 2048); margin >= 2 x the approximation error bound (2^-9 for unit-norm rows is what the host passes).
-extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* qn, const float* sn, int D,
-                                        float margin, const long long* shot_classes, const long long* det_classes, int kvote,
-                                        long long* top_classes, long long* keep, void* stream) {
+// approx [Q, ld] (S used columns) from lvc_gemm_f16 over the fp16 roundings of the normalised rows; q [Q, ldq] the RAW query
+// descriptors with mu [D] (or NULL) and den [Q] (or NULL) as lvc_rownorm_h used them (NULL, NULL: q already holds the normalised
+// rows); sn [S, D] the normalised shots (fp32).  D % 4 == 0, D <= 2048; margin >= 2 x the approximation error bound (the host
+// passes 2^-9 for unit-norm rows).
+extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
+                                        const float* den, const float* sn, int D, float margin, const long long* shot_classes,
+                                        const long long* det_classes, int kvote, long long* top_classes, long long* keep,
+                                        void* stream) {
   LVC_CHECK_ARG(Q >= 0 && S >= 10, "need at least 10 shots");
   if (Q == 0) return LVC_OK;
-  LVC_CHECK_ARG(approx && qn && sn && shot_classes && top_classes, "null pointer");
+  LVC_CHECK_ARG(approx && q && sn && shot_classes && top_classes, "null pointer");
   LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
   LVC_CHECK_ARG(D % 4 == 0 && D <= 2048 && D > 0, "descriptor length must be a multiple of 4, at most 2048");
   LVC_CHECK_ARG(kvote >= 1 && kvote <= 10 && margin >= 0.f, "k must be in 1..10, margin >= 0");
-  LVC_CHECK_ARG((((uintptr_t)qn | (uintptr_t)sn) & 15) == 0, "descriptor rows must be 16-byte aligned");
+  const int ldqq = ldq > 0 ? ldq : D;
+  LVC_CHECK_ARG((((uintptr_t)q | (uintptr_t)sn | (uintptr_t)mu) & 15) == 0 && ldqq % 4 == 0, "descriptor rows must be 16-byte aligned");
   const int per = lvc_cdiv(S, 64);
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
-#define KV_LAUNCH(P) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P>), grid, block, 0, st, approx, ldd, Q, S, qn, sn, D, margin, \
-                                        shot_classes, det_classes, kvote, top_classes, keep)
+  static const int stop_after = [] { const char* e = getenv("LVC_KV_STOP"); return e ? atoi(e) : 0; }();
+#define KV_LAUNCH(P) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, sn, D, \
+                                        margin, shot_classes, det_classes, kvote, top_classes, keep, stop_after)
   if (per <= 8) KV_LAUNCH(8);
   else if (per <= 16) KV_LAUNCH(16);
   else if (per <= 24) KV_LAUNCH(24);

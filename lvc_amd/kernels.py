@@ -744,17 +744,19 @@ def knn_topk_vote(sims, num_shots, shot_classes, det_classes, k):
     return top, keep
 
 
-def rownorm_h(x, mu=None, eps=1e-5, mode=0):
-    """`rownorm` plus the same rows rounded to fp16: (y fp32 [M,D], yh fp16 [M,D])."""
+def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True):
+    """`rownorm` for the two-stage kNN sweep: (y fp32 [M,D] or None, yh fp16 [M,D], den [M]); y is bit-identical to
+    `rownorm`'s output and equals (x - mu) / den[:, None] exactly."""
     _req_cuda(x, mu)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
     M, D = x.shape
-    y = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    y = torch.empty(M, D, device=x.device, dtype=torch.float32) if want_rows else None
     yh = torch.empty(M, D, device=x.device, dtype=torch.float16)
-    rc = _lib.lib().lvc_rownorm_h(ptr(x), ptr(mu), ptr(y), ptr(yh), c_int(M), c_int(D), c_int(x.stride(0)), c_float(eps),
-                                  c_int(mode), _stream(x))
+    den = torch.empty(M, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_rownorm_h(ptr(x), ptr(mu), ptr(y), ptr(yh), ptr(den), c_int(M), c_int(D), c_int(x.stride(0)),
+                                  c_float(eps), c_int(mode), _stream(x))
     check(rc, "lvc_rownorm_h")
-    return y, yh
+    return y, yh, den
 
 
 def gemm_f16(a, b):
@@ -769,19 +771,22 @@ def gemm_f16(a, b):
     return y
 
 
-def knn_verify_topk_vote(approx, qn, sn, margin, shot_classes, det_classes, k):
-    """approx [Q,S] from gemm_f16_hi over the same normalised rows qn [Q,D], sn [S,D]: exact top-10 classes + vote."""
-    _req_cuda(approx, qn, sn, shot_classes, det_classes)
+def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None):
+    """approx [Q,S] from gemm_f16 over the fp16 roundings of the normalised rows; q [Q,D] the raw query descriptors with the
+    mu / den `rownorm_h` used (or the normalised rows themselves with mu = den = None); sn [S,D] normalised shots.
+    Exact top-10 classes + vote (csrc/knn.hip)."""
+    _req_cuda(approx, q, sn, shot_classes, det_classes, mu, den)
     Q, S = approx.shape[0], sn.shape[0]
-    assert approx.stride(1) == 1 and qn.is_contiguous() and sn.is_contiguous() and shot_classes.dtype == torch.int64
+    assert approx.stride(1) == 1 and q.stride(1) == 1 and sn.is_contiguous() and shot_classes.dtype == torch.int64
+    assert q.dtype == torch.float32 and sn.dtype == torch.float32 and q.shape[1] == sn.shape[1]
     top = torch.empty(Q, 10, dtype=torch.int64, device=approx.device)
     keep = torch.empty(Q, dtype=torch.int64, device=approx.device) if det_classes is not None else None
     if det_classes is not None:
         det_classes = det_classes.contiguous()
         assert det_classes.dtype == torch.int64
-    rc = _lib.lib().lvc_knn_verify_topk_vote(ptr(approx), c_int(approx.stride(0)), c_int(Q), c_int(S), ptr(qn), ptr(sn),
-                                             c_int(qn.shape[1]), c_float(margin), ptr(shot_classes), ptr(det_classes), c_int(k),
-                                             ptr(top), ptr(keep), _stream(approx))
+    rc = _lib.lib().lvc_knn_verify_topk_vote(ptr(approx), c_int(approx.stride(0)), c_int(Q), c_int(S), ptr(q), c_int(q.stride(0)),
+                                             ptr(mu), ptr(den), ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(shot_classes),
+                                             ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(approx))
     check(rc, "lvc_knn_verify_topk_vote")
     return top, keep
 

@@ -69,7 +69,7 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
     if cosine:
         mu = K.colmean(shots)
         if two_stage:
-            sn, sh = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
+            sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
         else:
             sn = K.rownorm(shots, mu=mu, eps=1e-8, mode=1)
             pc = K.pack_linear(sn)
@@ -88,8 +88,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
         if two_stage:
             # fp16 similarities (one MFMA per block instead of three) as a pre-filter, exact fp32 re-evaluation of the few shots
             # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
-            qn, qh = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1)
-            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qn, sn, VERIFY_MARGIN, shot_classes, dc, k)
+            _, qh, den = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False)
+            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
         else:
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)

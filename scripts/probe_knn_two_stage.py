@@ -37,17 +37,17 @@ for flag in (False, True, False, True):
     print("two_stage" if flag else "single   ", "%.3f ms" % timeit(lambda: LV.knn_sweep(classes, shots, q, qcls, 10, True)))
 print("rows differing", (res[True][0] != res[False][0]).any(dim=1).sum().item(), "keep differing", (res[True][1] != res[False][1]).sum().item())
 mu = K.colmean(shots)
-sn, sh = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
+sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
 pc = K.pack_linear(sn)
 N = min(Q, 120000)
-qn, qh = K.rownorm_h(q[:N], mu=mu, eps=1e-8, mode=1)
+qn, qh, den = K.rownorm_h(q[:N], mu=mu, eps=1e-8, mode=1)
 print("rows", N)
 print("rownorm   %.3f ms" % timeit(lambda: K.rownorm(q[:N], mu=mu, eps=1e-8, mode=1)))
-print("rownorm_h %.3f ms" % timeit(lambda: K.rownorm_h(q[:N], mu=mu, eps=1e-8, mode=1)))
+print("rownorm_h %.3f ms" % timeit(lambda: K.rownorm_h(q[:N], mu=mu, eps=1e-8, mode=1, want_rows=False)))
 t = timeit(lambda: K.gemm_f16(qh, sh))
 print("gemm f16  %.3f ms  %.0f TF/s" % (t, 2.0 * N * S * Dm / t / 1e9))
 ap = K.gemm_f16(qh, sh)
-print("verify    %.3f ms" % timeit(lambda: K.knn_verify_topk_vote(ap, qn, sn, LV.VERIFY_MARGIN, classes, qcls[:N], 10)))
+print("verify    %.3f ms" % timeit(lambda: K.knn_verify_topk_vote(ap, q[:N], sn, LV.VERIFY_MARGIN, classes, qcls[:N], 10, mu=mu, den=den)))
 n1 = min(N, 32768)
 t = timeit(lambda: K.linear(qn[:n1], pc))
 print("gemm x3   %.3f ms per %d rows  %.0f TF/s fp32-equivalent" % (t, n1, 2.0 * n1 * S * Dm / t / 1e9))

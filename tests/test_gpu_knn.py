@@ -115,25 +115,37 @@ def _unit_rows(n, d, g):
     return x / x.norm(dim=1, keepdim=True)
 
 
-@pytest.mark.parametrize("Dm", [64, 384, 1024, 2048])
-def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm):
+@pytest.mark.parametrize("Dm,clustered", [(64, False), (384, False), (1024, False), (2048, False), (384, True), (1024, True)])
+def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm, clustered):
     """knn_verify_topk_vote_kernel with a pre-filter matrix perturbed by the WORST noise its contract allows (+-2^-10,
-    uniformly random per entry -- far rougher than the fp16 hi-plane GEMM): the exact ten best (fp64 ranking of the same
-    rows) must come back wherever fp32 can tell them apart; a block of 300 identical shots drives rows through the
-    all-shots path and the tie rule (lower shot index)."""
+    uniformly random per entry -- far rougher than the fp16 GEMM): the class sequence of the exact ten best (fp64 ranking of
+    the same rows) must come back wherever fp32 can tell the shots apart.  Random classes make nearly every candidate
+    "flagged" (a shot of another class within margin: exact re-evaluation); `clustered` gives the shots of a class a common
+    direction, so that most neighbours share the class and are ranked by their approximate values alone.  A block of 300
+    identical shots drives rows through the all-shots path and the tie rule (lower shot index)."""
     from lvc_amd import kernels as K
 
-    g = torch.Generator().manual_seed(Dm)
+    g = torch.Generator().manual_seed(Dm + clustered)
     Q, S = 500, 1500
-    sn = _unit_rows(S, Dm, g)
+    if clustered:
+        shot_classes = torch.arange(S) // 30
+        centers = _unit_rows(S // 30, Dm, g)
+        sn = centers[shot_classes] * 0.5 + _unit_rows(S, Dm, g)
+        sn = sn / sn.norm(dim=1, keepdim=True)
+        qn = centers[torch.randint(0, S // 30, (Q,), generator=g)] * 0.5 + _unit_rows(Q, Dm, g)
+    else:
+        shot_classes = torch.randint(0, 80, (S,), generator=g)
+        sn = _unit_rows(S, Dm, g)
+        qn = _unit_rows(Q, Dm, g)
     sn[200:500] = sn[200]                       # 300 identical shots
-    qn = _unit_rows(Q, Dm, g)
     qn[:20] = sn[200] * 0.8 + 0.6 * qn[:20]      # queries next to the block: > KV_MAX_CAND candidates
     qn = qn / qn.norm(dim=1, keepdim=True)
+    if clustered:
+        shot_classes = shot_classes.clone()
+        shot_classes[200:500] = torch.randint(0, 50, (300,), generator=g)
     sims = qn @ sn.t()
     approx = (sims + (torch.rand(Q, S, generator=g, dtype=torch.float64) * 2 - 1) * 2.0 ** -10).float()
-    shot_classes = torch.randint(0, 80, (S,), generator=g)
-    det = torch.randint(0, 80, (Q,), generator=g)
+    det = torch.randint(0, 50, (Q,), generator=g)
     top, keep = K.knn_verify_topk_vote(approx.to(D), qn.float().contiguous().to(D), sn.float().contiguous().to(D),
                                        2.0 ** -9 + 2.0 ** -16, shot_classes.to(D), det.to(D), 10)
     qs, ss = qn.float().double(), sn.float().double()      # the fp32 rows the kernel reads, evaluated in fp64
@@ -145,12 +157,36 @@ def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm):
     assert clear.float().mean() > 0.9
     got = top.cpu()
     assert torch.equal(got[20:][clear[20:]], ref_top[20:][clear[20:]])
-    # ... so their winners are the block's lowest indices (one class) unless a non-block shot beats them
+    # ... so their winners are the block's lowest indices unless a non-block shot beats them
     blk = (order[:20, :10] >= 200) & (order[:20, :10] < 500)
     assert blk.all(), "test construction: the block should own the top ten of the first 20 rows"
     assert torch.equal(got[:20], shot_classes[200:210].expand(20, 10))
     ref_keep = (torch.mode(got, dim=1)[0] == det).long()
     assert torch.equal(keep.cpu(), ref_keep)
+
+
+def test_verify_kernel_normalises_raw_queries_like_rownorm():
+    """Raw descriptors + (mu, den) from rownorm_h give the same answer as the pre-normalised rows: the kernel redoes
+    (q - mu) / den bit for bit."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(3)
+    Q, S, Dm = 3000, 900, 384
+    shots = (torch.randn(S, Dm, generator=g) + 0.4).to(D)
+    q = (torch.randn(Q, Dm, generator=g) + 0.4).to(D)
+    classes = torch.randint(0, 20, (S,), generator=g).to(D)
+    det = torch.randint(0, 20, (Q,), generator=g).to(D)
+    mu = K.colmean(shots)
+    sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
+    qn, qh, den = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1)
+    assert torch.equal(qn, K.rownorm(q, mu=mu, eps=1e-8, mode=1)) and torch.equal(qn, (q - mu) / den[:, None])
+    _, qh2, den2 = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False)
+    assert torch.equal(qh, qh2) and torch.equal(den, den2) and torch.equal(qh, qn.half())
+    ap = K.gemm_f16(qh, sh)
+    m = 2.0 ** -9 + 2.0 ** -16
+    a = K.knn_verify_topk_vote(ap, qn, sn, m, classes, det, 10)
+    b = K.knn_verify_topk_vote(ap, q, sn, m, classes, det, 10, mu=mu, den=den)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_two_stage_equals_single_stage(monkeypatch):
@@ -191,8 +227,8 @@ def test_fp16_gemm_error_bound_and_exactness():
         a[0, 3] = 5.0                                       # one-hot rows: the largest single-term products
         b[1] = 0
         b[1, 3] = -7.0
-        an, ah = K.rownorm_h(a.to(D), eps=1e-8, mode=1)
-        bn, bh = K.rownorm_h(b.to(D), eps=1e-8, mode=1)
+        an, ah, _ = K.rownorm_h(a.to(D), eps=1e-8, mode=1)
+        bn, bh, _ = K.rownorm_h(b.to(D), eps=1e-8, mode=1)
         assert torch.equal(an, K.rownorm(a.to(D), eps=1e-8, mode=1)) and torch.equal(ah, an.half())
         y = K.gemm_f16(ah, bh)
         exact = an.double() @ bn.double().t()
