@@ -345,8 +345,13 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
  * materialised in full precision).
  * lvc_rownorm_h: lvc_rownorm that writes the rows rounded to fp16 (yh [M,D]), the denominators (den [M] or NULL) and, if
  *   y is not NULL, the fp32 rows (contiguous, bit-identical to lvc_rownorm).
- * lvc_gemm_f16: y [M,ldy] fp32 = a [M,C] . b [N,C]^T on fp16 operands (csrc/gemm_h.hip; C % 32 == 0, y below 2 GiB) -- for
- *   unit-norm rows |y - exact| < 2^-10.
+ * lvc_gemm_f16: y [M,ldy] fp32 = a [M,C] . b [N,ldb]^T on fp16 operands (csrc/gemm_h.hip; C % 32 == 0, ldb = elements
+ *   between rows of b, 0 = C; y below 2 GiB) -- for unit-norm rows |y - exact| < 2^-10.
+ * lvc_gemm_f16_emit: the same products without the matrix: every (m, n) with value >= lb[m] - margin is appended as the
+ *   pair (fp32 value, int32 n) to lists[m][0..256) at a slot reserved by an atomic add on counts[m] (zero on entry; list
+ *   order arbitrary; counts[m] > 256 = overflow, excess entries dropped).  lists: M * 256 * 8 bytes.
+ * lvc_knn_lower_bound: lb[m] <= the 10th largest of row m of sub [Q,ld] (10 <= n <= 256 columns: similarities to a
+ *   subset of the shots), hence <= the 10th largest over all shots.
  * lvc_knn_verify_topk_vote: per query row, the shots whose approximate similarity is within `margin` (>= 2 x that bound)
  *   of the 10th largest approximate value provably contain the exact ten best; those of them that have a shot of another
  *   class within margin are re-evaluated in fp32 from q [Q,ldq] (raw descriptors; (q - mu) / den[row] is redone exactly as
@@ -355,10 +360,18 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
  *   states the argument).  D % 4 == 0, D <= 2048.  Outputs as lvc_knn_topk_vote. */
 int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, int M, int D, int ldx, float eps,
                   int mode, void* stream);
-int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, float* y, int M, int N, int C, int ldy, void* stream);
+int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
+                 void* stream);
+int lvc_gemm_f16_emit(const unsigned short* a, const unsigned short* b, int ldb, int M, int N, int C, const float* lb,
+                      float margin, void* lists, int* counts, void* stream);
+int lvc_knn_lower_bound(const float* sub, int ld, int Q, int n, float* lb, void* stream);
 int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
                              const float* den, const float* sn, int D, float margin, const long long* shot_classes,
                              const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream);
+/* lvc_knn_verify_topk_vote on the candidate lists of lvc_gemm_f16_emit instead of the dense matrix. */
+int lvc_knn_verify_lists(const void* lists, const int* counts, int Q, int S, const float* q, int ldq, const float* mu,
+                         const float* den, const float* sn, int D, float margin, const long long* shot_classes,
+                         const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Descriptor network of the label-verification step: DINO ViT-S/8 as loaded by

@@ -202,80 +202,28 @@ extern "C" int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const 
 // The query row is normalised on the fly from the raw descriptors exactly as lvc_rownorm does it ((q - mu) / den, den from
 // lvc_rownorm_h), and only for rows that have a flagged candidate.
 #define KV_MAX_CAND 192
-template <int KTOP, int PER>
-__global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
-                                                                   const float* __restrict__ q, int ldq, const float* __restrict__ mu,
-                                                                   const float* __restrict__ den, const float* __restrict__ sn,
-                                                                   int D, float margin, const long long* __restrict__ shot_classes,
-                                                                   const long long* __restrict__ det_classes, int kvote,
-                                                                   long long* __restrict__ top_classes, long long* __restrict__ keep,
-                                                                   int stop_after) {
-  __shared__ float s_lmax[4][64];
-  __shared__ float s_ap[4][KV_MAX_CAND];             // approximate value of a candidate
-  __shared__ float s_val[4][KV_MAX_CAND + KTOP];     // sort key: exact similarity where evaluated, else the approximate one
-  __shared__ int s_idx[4][KV_MAX_CAND + KTOP];
-  __shared__ long long s_ccl[4][KV_MAX_CAND];        // class of a candidate
-  __shared__ short s_alist[4][KV_MAX_CAND];          // positions of the flagged candidates
-  __shared__ float s_T[4];
-  __shared__ long long s_cls[4][KTOP];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= Q) return;     // whole waves leave; nothing below synchronises across waves
-  const float* ar = approx + (size_t)row * ld;
-  float v[PER];
-  float lmax = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int i = j * 64 + lane;
-    v[j] = i < S ? ar[i] : -INFINITY;
-    if (v[j] != v[j]) v[j] = INFINITY;
-    lmax = fmaxf(lmax, v[j]);
-  }
-  // (stop_after: timing experiments, LVC_KV_STOP; results are then meaningless)
-  if (stop_after == 1) { if (lmax == 123.f) top_classes[row] = 1; return; }
-  // ---- A10: exact 10th largest approximate value.  First a lower bound T (the lane maximum of rank KTOP-1), then the rank of
-  // every value >= T among those values
-  s_lmax[w][lane] = lmax;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  int rank = 0;
-#pragma unroll 8
-  for (int l = 0; l < 64; ++l) {
-    const float o = s_lmax[w][l];
-    rank += (o > lmax || (o == lmax && l < lane)) ? 1 : 0;
-  }
-  if (rank == KTOP - 1) s_T[w] = lmax;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  const float T = s_T[w];
-  int total = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const bool is_c = v[j] >= T;
-    const unsigned long long m = __ballot(is_c);
-    if (m) {
-      const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-      if (is_c && pos < KV_MAX_CAND) s_val[w][pos] = v[j];
-      total += __popcll(m);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  if (stop_after == 2) { if (total == 12345) top_classes[row] = 1; return; }
-  float A10 = T;      // more than KV_MAX_CAND values >= T (near-constant row): T itself is a valid lower bound of A10
-  if (total <= KV_MAX_CAND) {
-    for (int c0 = 0; c0 < total; c0 += 64) {
-      const int c = c0 + lane;
-      const float mv = c < total ? s_val[w][c] : -INFINITY;
-      int r = 0;
-      for (int l = 0; l < total; ++l) {
-        const float o = s_val[w][l];
-        r += (o > mv || (o == mv && l < c)) ? 1 : 0;
-      }
-      if (c < total && r == KTOP - 1) s_T[w] = mv;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    A10 = s_T[w];
-  }
-  const float Tv = A10 - margin;
-  if (stop_after == 3) { if (Tv == 123.f) top_classes[row] = 1; return; }
+#define KV_LIST_CAP 256      // entries per row of the candidate lists the emitting GEMM writes (gemm_h.hip)
+
+template <int KTOP>
+struct KvLds {
+  float ap[KV_MAX_CAND];             // approximate value of a candidate
+  float val[KV_MAX_CAND + KTOP];     // sort key: exact similarity where evaluated, else the approximate one
+  int idx[KV_MAX_CAND + KTOP];
+  long long ccl[KV_MAX_CAND];        // class of a candidate
+  short alist[KV_MAX_CAND];          // positions of the flagged candidates
+  long long cls[KTOP];
+  float T;
+};
+
+// Steps 2 and 3 of the comment above for one row (one wave): the candidates sit in L.ap / L.idx [0, ncand) when
+// ncand <= KV_MAX_CAND; a larger ncand means "evaluate every shot".  Writes top_classes[row] and keep[row].
+template <int KTOP>
+__device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const int row, const int ncand, const int S,
+                                          const float* __restrict__ q, const int ldq, const float* __restrict__ mu,
+                                          const float* __restrict__ den, const float* __restrict__ sn, const int D, const float margin,
+                                          const long long* __restrict__ shot_classes, const long long* __restrict__ det_classes,
+                                          const int kvote, long long* __restrict__ top_classes, long long* __restrict__ keep,
+                                          const int stop_after) {
   // the normalised query row in registers, loaded when the first exact similarity is needed: lane l holds elements
   // sl*256 + l*4 .. +3 of every 256-element slice sl (where below D)
   float4 qv[8];
@@ -297,7 +245,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
       qv[sl] = x;
     }
   };
-  // exact similarities of the n shots listed through pos_of(k) -> position in (s_idx, s_val), four rows in flight
+  // exact similarities of the n shots listed through pos_of(k) -> position in (L.idx, L.val), four rows in flight
   auto exact_dots = [&](int n, auto pos_of) {
     load_q();
     for (int k0 = 0; k0 < n; k0 += 4) {
@@ -306,7 +254,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         pos[t] = pos_of(min(k0 + t, n - 1));
-        sr[t] = sn + (size_t)s_idx[w][pos[t]] * D;
+        sr[t] = sn + (size_t)L.idx[pos[t]] * D;
       }
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -329,50 +277,36 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
         for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], o);
       if (lane == 0) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s_val[w][pos[t]] = acc[t];
+        for (int t = 0; t < 4; ++t) L.val[pos[t]] = acc[t];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
-  // rank the first n entries by (s_val descending, s_idx ascending) and keep the KTOP best in place.  Winners park in the tail
+  // rank the first n entries by (val descending, idx ascending) and keep the KTOP best in place.  Winners park in the tail
   // slots [KV_MAX_CAND + rank] (ranks are unique, the loops never read the tail) and move to the front afterwards.
   auto keep_best = [&](int n) {
     for (int c0 = 0; c0 < n; c0 += 64) {
       const int c = c0 + lane;
       if (c < n) {
-        const float mv = s_val[w][c];
-        const int mi = s_idx[w][c];
+        const float mv = L.val[c];
+        const int mi = L.idx[c];
         int r = 0;
         for (int l = 0; l < n; ++l) {
-          const float o = s_val[w][l];
-          r += (o > mv || (o == mv && s_idx[w][l] < mi)) ? 1 : 0;
+          const float o = L.val[l];
+          r += (o > mv || (o == mv && L.idx[l] < mi)) ? 1 : 0;
         }
-        if (r < KTOP) { s_val[w][KV_MAX_CAND + r] = mv; s_idx[w][KV_MAX_CAND + r] = mi; }
+        if (r < KTOP) { L.val[KV_MAX_CAND + r] = mv; L.idx[KV_MAX_CAND + r] = mi; }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     const int kept = n < KTOP ? n : KTOP;
-    if (lane < kept) { s_val[w][lane] = s_val[w][KV_MAX_CAND + lane]; s_idx[w][lane] = s_idx[w][KV_MAX_CAND + lane]; }
+    if (lane < kept) { L.val[lane] = L.val[KV_MAX_CAND + lane]; L.idx[lane] = L.idx[KV_MAX_CAND + lane]; }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     return kept;
   };
-  // ---- candidates: approx >= A10 - margin
-  int ncand = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const bool is_c = v[j] >= Tv && v[j] > -INFINITY;
-    const unsigned long long m = __ballot(is_c);
-    if (m) {
-      const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-      if (is_c && pos < KV_MAX_CAND) { s_idx[w][pos] = j * 64 + lane; s_ap[w][pos] = v[j]; }
-      ncand += __popcll(m);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  if (stop_after == 4) { if (ncand == 12345) top_classes[row] = 1; return; }
   int nbest;
   if (ncand <= KV_MAX_CAND) {
-    for (int c = lane; c < ncand; c += 64) s_ccl[w][c] = shot_classes[s_idx[w][c]];
+    for (int c = lane; c < ncand; c += 64) L.ccl[c] = shot_classes[L.idx[c]];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     // flagged candidates (a candidate of another class within margin), their positions compacted; key = approx for the others
     int nflag = 0;
@@ -380,26 +314,26 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
       const int c = c0 + lane;
       bool fl = false;
       if (c < ncand) {
-        const float mv = s_ap[w][c];
-        const long long mc = s_ccl[w][c];
-        for (int l = 0; l < ncand; ++l) fl = fl || (s_ccl[w][l] != mc && !(fabsf(s_ap[w][l] - mv) > margin));
-        s_val[w][c] = mv;
+        const float mv = L.ap[c];
+        const long long mc = L.ccl[c];
+        for (int l = 0; l < ncand; ++l) fl = fl || (L.ccl[l] != mc && !(fabsf(L.ap[l] - mv) > margin));
+        L.val[c] = mv;
       }
       const unsigned long long m = __ballot(fl);
-      if (fl) s_alist[w][nflag + __popcll(m & ((1ull << lane) - 1ull))] = (short)c;
+      if (fl) L.alist[nflag + __popcll(m & ((1ull << lane) - 1ull))] = (short)c;
       nflag += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (stop_after == 5) { if (nflag == 12345) top_classes[row] = 1; return; }
-    if (nflag) exact_dots(nflag, [&](int k) { return (int)s_alist[w][k]; });
-    if (stop_after == 6) { if (s_val[w][0] == 99.f) top_classes[row] = 1; return; }
+    if (nflag) exact_dots(nflag, [&](int k) { return (int)L.alist[k]; });
+    if (stop_after == 6) { if (L.val[0] == 99.f) top_classes[row] = 1; return; }
     nbest = keep_best(ncand);
   } else {
     // every shot exactly, in blocks of KV_MAX_CAND - KTOP next to the running best
     nbest = 0;
     for (int s0 = 0; s0 < S; s0 += KV_MAX_CAND - KTOP) {
       const int nb = min(KV_MAX_CAND - KTOP, S - s0);
-      for (int c = lane; c < nb; c += 64) s_idx[w][nbest + c] = s0 + c;
+      for (int c = lane; c < nb; c += 64) L.idx[nbest + c] = s0 + c;
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       const int base = nbest;
       exact_dots(nb, [&](int k) { return base + k; });
@@ -408,8 +342,8 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
   }
   long long mycl = -1;
   if (lane < KTOP) {
-    mycl = lane < nbest ? shot_classes[s_idx[w][lane]] : -1;
-    s_cls[w][lane] = mycl;
+    mycl = lane < nbest ? shot_classes[L.idx[lane]] : -1;
+    L.cls[lane] = mycl;
     top_classes[(size_t)row * KTOP + lane] = mycl;
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -417,7 +351,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     // mode of the first kvote classes, ties -> smallest class id: lane a counts its class, then the best (count, -class)
     int cnt = 0;
     if (lane < kvote)
-      for (int b = 0; b < kvote; ++b) cnt += (s_cls[w][b] == mycl);
+      for (int b = 0; b < kvote; ++b) cnt += (L.cls[b] == mycl);
     int best = cnt;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
@@ -431,6 +365,205 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
   }
 }
 
+// Form A: the pre-filter similarities as a dense [Q, ld] matrix (lvc_gemm_f16).
+template <int KTOP, int PER>
+__global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
+                                                                   const float* __restrict__ q, int ldq, const float* __restrict__ mu,
+                                                                   const float* __restrict__ den, const float* __restrict__ sn,
+                                                                   int D, float margin, const long long* __restrict__ shot_classes,
+                                                                   const long long* __restrict__ det_classes, int kvote,
+                                                                   long long* __restrict__ top_classes, long long* __restrict__ keep,
+                                                                   int stop_after) {
+  __shared__ float s_lmax[4][64];
+  __shared__ KvLds<KTOP> s_L[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= Q) return;     // whole waves leave; nothing below synchronises across waves
+  KvLds<KTOP>& L = s_L[w];
+  const float* ar = approx + (size_t)row * ld;
+  float v[PER];
+  float lmax = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = j * 64 + lane;
+    v[j] = i < S ? ar[i] : -INFINITY;
+    if (v[j] != v[j]) v[j] = INFINITY;
+    lmax = fmaxf(lmax, v[j]);
+  }
+  // (stop_after: timing experiments, LVC_KV_STOP; results are then meaningless)
+  if (stop_after == 1) { if (lmax == 123.f) top_classes[row] = 1; return; }
+  // ---- A10: exact 10th largest approximate value.  First a lower bound T (the lane maximum of rank KTOP-1), then the rank of
+  // every value >= T among those values
+  s_lmax[w][lane] = lmax;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  int rank = 0;
+#pragma unroll 8
+  for (int l = 0; l < 64; ++l) {
+    const float o = s_lmax[w][l];
+    rank += (o > lmax || (o == lmax && l < lane)) ? 1 : 0;
+  }
+  if (rank == KTOP - 1) L.T = lmax;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  const float T = L.T;
+  int total = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const bool is_c = v[j] >= T;
+    const unsigned long long m = __ballot(is_c);
+    if (m) {
+      const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
+      if (is_c && pos < KV_MAX_CAND) L.val[pos] = v[j];
+      total += __popcll(m);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (stop_after == 2) { if (total == 12345) top_classes[row] = 1; return; }
+  float A10 = T;      // more than KV_MAX_CAND values >= T (near-constant row): T itself is a valid lower bound of A10
+  if (total <= KV_MAX_CAND) {
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int c = c0 + lane;
+      const float mv = c < total ? L.val[c] : -INFINITY;
+      int r = 0;
+      for (int l = 0; l < total; ++l) {
+        const float o = L.val[l];
+        r += (o > mv || (o == mv && l < c)) ? 1 : 0;
+      }
+      if (c < total && r == KTOP - 1) L.T = mv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    A10 = L.T;
+  }
+  const float Tv = A10 - margin;
+  if (stop_after == 3) { if (Tv == 123.f) top_classes[row] = 1; return; }
+  // ---- candidates: approx >= A10 - margin
+  int ncand = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const bool is_c = v[j] >= Tv && v[j] > -INFINITY;
+    const unsigned long long m = __ballot(is_c);
+    if (m) {
+      const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
+      if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = j * 64 + lane; L.ap[pos] = v[j]; }
+      ncand += __popcll(m);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (stop_after == 4) { if (ncand == 12345) top_classes[row] = 1; return; }
+  kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep, stop_after);
+}
+
+// Form B: per row a LIST of (approximate similarity, shot index) pairs, every entry >= lb[row] - margin where lb[row] <= A10
+// (lvc_gemm_f16_emit, gemm_h.hip: the similarity matrix is never written).  The list holds every candidate of step 1 (they are
+// >= A10 - margin >= lb - margin) in arbitrary order; count[row] > KV_LIST_CAP means the list overflowed: every shot is evaluated.
+template <int KTOP>
+__global__ __launch_bounds__(256) void knn_verify_list_kernel(const float2* __restrict__ lists, const int* __restrict__ counts,
+                                                              int Q, int S, const float* __restrict__ q, int ldq,
+                                                              const float* __restrict__ mu, const float* __restrict__ den,
+                                                              const float* __restrict__ sn, int D, float margin,
+                                                              const long long* __restrict__ shot_classes,
+                                                              const long long* __restrict__ det_classes, int kvote,
+                                                              long long* __restrict__ top_classes, long long* __restrict__ keep) {
+  __shared__ float s_lv[4][KV_LIST_CAP];
+  __shared__ int s_li[4][KV_LIST_CAP];
+  __shared__ KvLds<KTOP> s_L[4];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= Q) return;
+  KvLds<KTOP>& L = s_L[w];
+  const int n = counts[row];
+  int ncand = KV_MAX_CAND + 1;      // overflow (or a list too short to hold ten shots: cannot happen with a valid lb) -> all shots
+  if (n <= KV_LIST_CAP && n >= KTOP) {
+    const float2* lr = lists + (size_t)row * KV_LIST_CAP;
+    float mv[KV_LIST_CAP / 64];
+    int mi[KV_LIST_CAP / 64];
+#pragma unroll
+    for (int j = 0; j < KV_LIST_CAP / 64; ++j) {
+      const int c = j * 64 + lane;
+      float2 e = {-INFINITY, 0.f};
+      if (c < n) e = lr[c];
+      mv[j] = e.x != e.x ? INFINITY : e.x;
+      mi[j] = __builtin_bit_cast(int, e.y);
+      s_lv[w][c] = mv[j];
+      s_li[w][c] = mi[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // A10 = the entry of rank KTOP - 1 by (value descending, shot index ascending: the order of the matrix scan)
+#pragma unroll
+    for (int j = 0; j < KV_LIST_CAP / 64; ++j) {
+      if (j * 64 < n) {
+        const int c = j * 64 + lane;
+        int r = 0;
+        for (int l = 0; l < n; ++l) {
+          const float o = s_lv[w][l];
+          r += (o > mv[j] || (o == mv[j] && s_li[w][l] < mi[j])) ? 1 : 0;
+        }
+        if (c < n && r == KTOP - 1) L.T = mv[j];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const float Tv = L.T - margin;
+    ncand = 0;
+#pragma unroll
+    for (int j = 0; j < KV_LIST_CAP / 64; ++j) {
+      const bool is_c = j * 64 + lane < n && mv[j] >= Tv;
+      const unsigned long long m = __ballot(is_c);
+      if (m) {
+        const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
+        if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = mi[j]; L.ap[pos] = mv[j]; }
+        ncand += __popcll(m);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  }
+  kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep, 0);
+}
+
+// lb[row] = a lower bound of the 10th largest value of row `row` of sub [Q, ld] (n <= 256 used columns: the approximate
+// similarities to a SUBSET of the shots): the lane maximum of rank 9 -- ten distinct entries are >= it.  -inf when fewer than ten
+// lanes hold a value.
+__global__ __launch_bounds__(256) void knn_lower_bound_kernel(const float* __restrict__ sub, int ld, int Q, int n, float* __restrict__ lb) {
+  __shared__ float s_lmax[4][64];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= Q) return;
+  const float* ar = sub + (size_t)row * ld;
+  float lmax = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * 64 + lane;
+    float x = i < n ? ar[i] : -INFINITY;
+    if (x != x) x = -INFINITY;
+    lmax = fmaxf(lmax, x);
+  }
+  s_lmax[w][lane] = lmax;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  int rank = 0;
+#pragma unroll 8
+  for (int l = 0; l < 64; ++l) {
+    const float o = s_lmax[w][l];
+    rank += (o > lmax || (o == lmax && l < lane)) ? 1 : 0;
+  }
+  if (rank == 9) lb[row] = lmax;
+}
+
+extern "C" int lvc_knn_lower_bound(const float* sub, int ld, int Q, int n, float* lb, void* stream) {
+  LVC_CHECK_ARG(Q >= 0 && n >= 10 && n <= 256, "need 10..256 columns");
+  if (Q == 0) return LVC_OK;
+  LVC_CHECK_ARG(sub && lb, "null pointer");
+  hipLaunchKernelGGL(knn_lower_bound_kernel, dim3(lvc_cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, sub, ld > 0 ? ld : n, Q, n, lb);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+#define KV_CHECKS()                                                                                                              \
+  LVC_CHECK_ARG(Q >= 0 && S >= 10, "need at least 10 shots");                                                                    \
+  if (Q == 0) return LVC_OK;                                                                                                     \
+  LVC_CHECK_ARG(q && sn && shot_classes && top_classes, "null pointer");                                                         \
+  LVC_CHECK_ARG(D % 4 == 0 && D <= 2048 && D > 0, "descriptor length must be a multiple of 4, at most 2048");                    \
+  LVC_CHECK_ARG(kvote >= 1 && kvote <= 10 && margin >= 0.f, "k must be in 1..10, margin >= 0");                                  \
+  const int ldqq = ldq > 0 ? ldq : D;                                                                                            \
+  LVC_CHECK_ARG((((uintptr_t)q | (uintptr_t)sn | (uintptr_t)mu) & 15) == 0 && ldqq % 4 == 0, "descriptor rows must be 16-byte aligned")
+
 // approx [Q, ld] (S used columns) from lvc_gemm_f16 over the fp16 roundings of the normalised rows; q [Q, ldq] the RAW query
 // descriptors with mu [D] (or NULL) and den [Q] (or NULL) as lvc_rownorm_h used them (NULL, NULL: q already holds the normalised
 // rows); sn [S, D] the normalised shots (fp32).  D % 4 == 0, D <= 2048; margin >= 2 x the approximation error bound (the host
@@ -439,14 +572,9 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
                                         const float* den, const float* sn, int D, float margin, const long long* shot_classes,
                                         const long long* det_classes, int kvote, long long* top_classes, long long* keep,
                                         void* stream) {
-  LVC_CHECK_ARG(Q >= 0 && S >= 10, "need at least 10 shots");
-  if (Q == 0) return LVC_OK;
-  LVC_CHECK_ARG(approx && q && sn && shot_classes && top_classes, "null pointer");
+  KV_CHECKS();
+  LVC_CHECK_ARG(approx, "null pointer");
   LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
-  LVC_CHECK_ARG(D % 4 == 0 && D <= 2048 && D > 0, "descriptor length must be a multiple of 4, at most 2048");
-  LVC_CHECK_ARG(kvote >= 1 && kvote <= 10 && margin >= 0.f, "k must be in 1..10, margin >= 0");
-  const int ldqq = ldq > 0 ? ldq : D;
-  LVC_CHECK_ARG((((uintptr_t)q | (uintptr_t)sn | (uintptr_t)mu) & 15) == 0 && ldqq % 4 == 0, "descriptor rows must be 16-byte aligned");
   const int per = lvc_cdiv(S, 64);
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -462,6 +590,19 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   else if (per <= 48) KV_LAUNCH(48);
   else KV_LAUNCH(64);
 #undef KV_LAUNCH
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// The same on candidate lists: lists [Q][256] pairs (fp32 approximate similarity, int32 shot index) and counts [Q] as
+// lvc_gemm_f16_emit wrote them (every shot with approx >= lb[row] - margin, lb[row] <= the row's 10th largest approximate value).
+extern "C" int lvc_knn_verify_lists(const void* lists, const int* counts, int Q, int S, const float* q, int ldq, const float* mu,
+                                    const float* den, const float* sn, int D, float margin, const long long* shot_classes,
+                                    const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream) {
+  KV_CHECKS();
+  LVC_CHECK_ARG(lists && counts, "null pointer");
+  hipLaunchKernelGGL((knn_verify_list_kernel<10>), dim3(lvc_cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, (const float2*)lists, counts, Q,
+                     S, q, ldqq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

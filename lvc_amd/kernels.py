@@ -759,16 +759,65 @@ def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True):
     return y, yh, den
 
 
-def gemm_f16(a, b):
-    """a [M,C] . b [N,C]^T on fp16 operands with fp32 accumulation -> [M,N] fp32 (lvc_gemm_f16): the pre-filter of the
-    two-stage kNN sweep."""
+def gemm_f16(a, b, n=None, ldb=None):
+    """a [M,C] . b^T on fp16 operands with fp32 accumulation -> [M,N] fp32 (lvc_gemm_f16): the pre-filter of the two-stage
+    kNN sweep.  n / ldb: use n rows of b that lie ldb elements apart (a strided subset of a contiguous [*, C] tensor)."""
     _req_cuda(a, b)
     M, C = a.shape
     assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float16 and b.dtype == torch.float16 and b.shape[1] == C
-    y = torch.empty(M, b.shape[0], device=a.device, dtype=torch.float32)
-    rc = _lib.lib().lvc_gemm_f16(ptr(a), ptr(b), ptr(y), c_int(M), c_int(b.shape[0]), c_int(C), c_int(b.shape[0]), _stream(a))
+    N = b.shape[0] if n is None else n
+    ldb = C if ldb is None else ldb
+    assert (N - 1) * ldb + C <= b.numel()
+    y = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_gemm_f16(ptr(a), ptr(b), c_int(ldb), ptr(y), c_int(M), c_int(N), c_int(C), c_int(N), _stream(a))
     check(rc, "lvc_gemm_f16")
     return y
+
+
+KNN_LIST_CAP = 256
+
+
+def gemm_f16_emit(a, b, lb, margin):
+    """The products of `gemm_f16(a, b)` as per-row candidate lists: (lists [M,256,2] fp32 view of (value, int32 column bits),
+    counts [M] int32) holding every column with value >= lb[row] - margin (lvc_gemm_f16_emit)."""
+    _req_cuda(a, b, lb)
+    M, C = a.shape
+    assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float16 and b.dtype == torch.float16 and b.shape[1] == C
+    assert lb.dtype == torch.float32 and lb.is_contiguous() and lb.numel() == M
+    lists = torch.empty(M, KNN_LIST_CAP, 2, device=a.device, dtype=torch.float32)
+    counts = torch.zeros(M, device=a.device, dtype=torch.int32)
+    rc = _lib.lib().lvc_gemm_f16_emit(ptr(a), ptr(b), c_int(C), c_int(M), c_int(b.shape[0]), c_int(C), ptr(lb), c_float(margin),
+                                      ptr(lists), ptr(counts), _stream(a))
+    check(rc, "lvc_gemm_f16_emit")
+    return lists, counts
+
+
+def knn_lower_bound(sub):
+    """lb [Q]: a lower bound of the 10th largest entry of each row of sub [Q, 10..256] (lvc_knn_lower_bound)."""
+    _req_cuda(sub)
+    assert sub.dtype == torch.float32 and sub.stride(1) == 1
+    lb = torch.full((sub.shape[0],), float("-inf"), device=sub.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_knn_lower_bound(ptr(sub), c_int(sub.stride(0)), c_int(sub.shape[0]), c_int(sub.shape[1]), ptr(lb), _stream(sub))
+    check(rc, "lvc_knn_lower_bound")
+    return lb
+
+
+def knn_verify_lists(lists, counts, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None):
+    """`knn_verify_topk_vote` on the candidate lists of `gemm_f16_emit`."""
+    _req_cuda(lists, counts, q, sn, shot_classes, det_classes, mu, den)
+    Q, S = counts.shape[0], sn.shape[0]
+    assert lists.is_contiguous() and counts.dtype == torch.int32 and q.stride(1) == 1 and sn.is_contiguous()
+    assert q.dtype == torch.float32 and sn.dtype == torch.float32 and q.shape[1] == sn.shape[1] and shot_classes.dtype == torch.int64
+    top = torch.empty(Q, 10, dtype=torch.int64, device=q.device)
+    keep = torch.empty(Q, dtype=torch.int64, device=q.device) if det_classes is not None else None
+    if det_classes is not None:
+        det_classes = det_classes.contiguous()
+        assert det_classes.dtype == torch.int64
+    rc = _lib.lib().lvc_knn_verify_lists(ptr(lists), ptr(counts), c_int(Q), c_int(S), ptr(q), c_int(q.stride(0)), ptr(mu), ptr(den),
+                                         ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(shot_classes), ptr(det_classes), c_int(k),
+                                         ptr(top), ptr(keep), _stream(q))
+    check(rc, "lvc_knn_verify_lists")
+    return top, keep
 
 
 def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None):

@@ -14,6 +14,9 @@ from . import kernels as K
 
 # LVC_KNN_TWO_STAGE=0: materialise the full-precision similarity matrix (three MFMAs per block) and rank it directly
 KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
+# LVC_KNN_EMIT=1 (experiment, measured slower: profiles/README.md round 2): the pre-filter GEMM appends per-row candidate lists
+# from its epilogue instead of writing the [Q, S] matrix
+KNN_EMIT = os.environ.get("LVC_KNN_EMIT", "0") == "1"
 # unit-norm rows: |fp16 dot - exact| <= 2^-11 (|q| rounding) + 2^-11 (|s| rounding) + 2^-22 + fp32 accumulation
 # < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
 VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16
@@ -79,7 +82,7 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
         pc.shift = (-0.5 * (shots * shots).sum(1)).contiguous()
     tops, keeps = [], []
     # the two-stage path keeps only transient fp16 / fp32 copies per chunk: take as many rows as the GEMM's 2 GiB output allows
-    chunk = min(TWO_STAGE_CHUNK, (2 ** 31 - 1) // (4 * S)) if two_stage else QUERY_CHUNK
+    chunk = (TWO_STAGE_CHUNK if KNN_EMIT else min(TWO_STAGE_CHUNK, (2 ** 31 - 1) // (4 * S))) if two_stage else QUERY_CHUNK
     for s0 in range(0, max(Q, 1), chunk):
         qc = q[s0: s0 + chunk]
         if qc.shape[0] == 0:
@@ -89,7 +92,15 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             # fp16 similarities (one MFMA per block instead of three) as a pre-filter, exact fp32 re-evaluation of the few shots
             # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
             _, qh, den = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False)
-            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
+            if KNN_EMIT:
+                # a lower bound of each row's 10th best similarity from a strided subset of <= 256 shots, then the full product
+                # with an epilogue that keeps only what can still matter (csrc/gemm_h.hip): no Q x S matrix in HBM
+                nsub = min(256, S)
+                lb = K.knn_lower_bound(K.gemm_f16(qh, sh, n=nsub, ldb=(S // nsub) * D))
+                lists, counts = K.gemm_f16_emit(qh, sh, lb, VERIFY_MARGIN)
+                t, kp = K.knn_verify_lists(lists, counts, qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
+            else:
+                t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
         else:
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)

@@ -31,11 +31,11 @@ def timeit(f, n=10):
 
 
 res = {}
-for flag in (False, True, False, True):
-    LV.KNN_TWO_STAGE = flag
-    res[flag] = LV.knn_sweep(classes, shots, q, qcls, 10, True)
-    print("two_stage" if flag else "single   ", "%.3f ms" % timeit(lambda: LV.knn_sweep(classes, shots, q, qcls, 10, True)))
-print("rows differing", (res[True][0] != res[False][0]).any(dim=1).sum().item(), "keep differing", (res[True][1] != res[False][1]).sum().item())
+for name, two, emit in (("single", False, False), ("matrix", True, False), ("emit", True, True)) * 2:
+    LV.KNN_TWO_STAGE, LV.KNN_EMIT = two, emit
+    res[name] = LV.knn_sweep(classes, shots, q, qcls, 10, True)
+    print("%-7s %.3f ms" % (name, timeit(lambda: LV.knn_sweep(classes, shots, q, qcls, 10, True))))
+print("rows differing emit/single", (res["emit"][0] != res["single"][0]).any(dim=1).sum().item(), "emit/matrix", (res["emit"][0] != res["matrix"][0]).any(dim=1).sum().item())
 mu = K.colmean(shots)
 sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
 pc = K.pack_linear(sn)
@@ -54,3 +54,12 @@ print("gemm x3   %.3f ms per %d rows  %.0f TF/s fp32-equivalent" % (t, n1, 2.0 *
 sm = K.linear(qn[:n1], pc)
 print("topk      %.3f ms per %d rows" % (timeit(lambda: K.knn_topk_vote(sm, S, classes, qcls[:n1], 10)), n1))
 print("max |approx - x3|", (ap[:n1] - sm).abs().max().item())
+nsub = 256
+print("sub gemm  %.3f ms" % timeit(lambda: K.gemm_f16(qh, sh, n=nsub, ldb=(S // nsub) * Dm)))
+sub = K.gemm_f16(qh, sh, n=nsub, ldb=(S // nsub) * Dm)
+print("lb        %.3f ms" % timeit(lambda: K.knn_lower_bound(sub)))
+lb = K.knn_lower_bound(sub)
+print("emit gemm %.3f ms (incl. lists alloc + counts memset)" % timeit(lambda: K.gemm_f16_emit(qh, sh, lb, LV.VERIFY_MARGIN)))
+lists, counts = K.gemm_f16_emit(qh, sh, lb, LV.VERIFY_MARGIN)
+print("counts mean %.1f max %d" % (counts.float().mean().item(), counts.max().item()))
+print("verify l  %.3f ms" % timeit(lambda: K.knn_verify_lists(lists, counts, q[:N], sn, LV.VERIFY_MARGIN, classes, qcls[:N], 10, mu=mu, den=den)))
