@@ -137,56 +137,88 @@ def _max_and_all(c, dt):
 
 
 # ----------------------------------------------------------------------------------------------- kNN (cfg 4)
-def _knn_inputs(c, q_rows, seed):
+def _knn_inputs(c, rows, seed, classes=None, centers=None, spread=0.0):
+    """Synthetic descriptors.  `classes` given: class-structured rows centers[class] + spread * noise + 0.3 (what a descriptor
+    network produces for objects of 80 classes: the premise of a kNN vote); None: unstructured N(0, 1) rows."""
     import torch
 
     g = torch.Generator(device=c.dev).manual_seed(seed)
-    return torch.randn(q_rows, KNN_D, device=c.dev, generator=g)
+    x = torch.randn(rows, KNN_D, device=c.dev, generator=g)
+    if classes is None:
+        return x
+    return centers[classes] + spread * x + 0.3
 
 
 def knn_leg(c, steps, warmup, sample_check=2048):
     """BASELINE configs[3]: Q = 120 000 queries (sharded over the ranks: strong scaling), S = 2400 shots of 80 classes,
     D = 1024, cosine, k = 10.  Every rank contributes S / world shots to ONE RCCL all-gather, sweeps its own queries,
-    results are gathered to rank 0 (reference tools/run_nearest_neighbours.py:301-325)."""
+    results are gathered to rank 0 (reference tools/run_nearest_neighbours.py:301-325).
+    Inputs: class-structured descriptors (80 class directions, 30 shots each, queries of a random class, 30 % of the detector
+    labels wrong); the unstructured N(0,1) inputs of the earlier rounds are timed next to them (`unstructured`): the two-stage
+    sweep re-evaluates a neighbour in fp32 only where a shot of ANOTHER class is within the pre-filter's error margin, which
+    unstructured rows make the common case."""
     import torch
 
     from lvc_amd import distributed as D
+    from lvc_amd import label_verification as LV
     from lvc_amd.label_verification import knn_sweep, knn_sweep_distributed
 
     rng = D.shard_range(KNN_Q, c.rank, c.world)
-    q = _knn_inputs(c, len(rng), 100 + c.rank)
-    det = torch.randint(0, 80, (len(rng),), device=c.dev)
     srng = D.shard_range(KNN_S, c.rank, c.world)
     classes_all = torch.arange(80).repeat_interleave(30)
-    shots = _knn_inputs(c, len(srng), 7 + c.rank)
     cls = classes_all[srng.start: srng.stop].to(c.dev)
+    gc = torch.Generator(device=c.dev).manual_seed(5)
+    centers = torch.randn(80, KNN_D, device=c.dev, generator=gc)      # the same on every rank
+    gq = torch.Generator(device=c.dev).manual_seed(200 + c.rank)
+    qcls = torch.randint(0, 80, (len(rng),), device=c.dev, generator=gq)
+    det = torch.where(torch.rand(len(rng), device=c.dev, generator=gq) < 0.7, qcls, torch.randint(0, 80, (len(rng),), device=c.dev, generator=gq))
+    inputs = {"structured": (_knn_inputs(c, len(srng), 7 + c.rank, cls, centers, 2.0), _knn_inputs(c, len(rng), 100 + c.rank, qcls, centers, 2.5)),
+              "unstructured": (_knn_inputs(c, len(srng), 7 + c.rank), _knn_inputs(c, len(rng), 100 + c.rank))}
 
-    def step():
-        if c.use_dist:
-            return knn_sweep_distributed(cls, shots, q, det, 10, True)
-        return knn_sweep(cls, shots, q, det, 10, True)
+    def timed(shots, q, n):
+        def step():
+            if c.use_dist:
+                return knn_sweep_distributed(cls, shots, q, det, 10, True)
+            return knn_sweep(cls, shots, q, det, 10, True)
 
-    for _ in range(max(1, warmup)):
-        top, keep = step()
-    _barrier(c)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        top, keep = step()
-    _barrier(c)
-    dt, every = _max_and_all(c, time.perf_counter() - t0)
-    per = dt / steps
+        for _ in range(max(1, warmup)):
+            res = step()
+        _barrier(c)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            res = step()
+        _barrier(c)
+        dt, _ = _max_and_all(c, time.perf_counter() - t0)
+        return dt / n, res
+
+    per, (top, keep) = timed(*inputs["structured"], steps)
+    per_u, (top_u, _) = timed(*inputs["unstructured"], steps)
+    path = "two-stage (fp16 pre-filter GEMM + exact fp32 verification)" if LV.KNN_TWO_STAGE else "single-stage (fp32-accurate f16x2 GEMM + top-k)"
     out = {"workload": "kNN label verification: Q=%d (sharded %d/rank) x S=%d x D=%d, cosine, top-10 + vote" % (KNN_Q, len(rng), KNN_S, KNN_D),
+           "path": path, "inputs": "class-structured synthetic descriptors (80 classes x 30 shots, 30 % wrong detector labels)",
            "ms_per_sweep": round(per * 1e3, 3), "queries_per_s": round(KNN_Q / per),
            "algorithmic_tflops": round(2.0 * KNN_Q * KNN_S * KNN_D / per / 1e12, 1),
-           "algorithmic_bytes": KNN_Q * KNN_D * 4 + KNN_S * KNN_D * 4 + KNN_Q * 10 * 8}
+           "algorithmic_bytes": KNN_Q * KNN_D * 4 + KNN_S * KNN_D * 4 + KNN_Q * 10 * 8,
+           "kept_fraction": round(float(keep.float().mean()), 4)}
     out["algorithmic_GBps"] = round(out["algorithmic_bytes"] / per / 1e9, 1)
     out["frac_of_hbm_peak"] = round(out["algorithmic_bytes"] / per / 1e9 / PEAK_HBM_GBPS, 4)
-    out["frac_of_f16x2_mfma_peak"] = round(2.0 * KNN_Q * KNN_S * KNN_D / per / 1e12 / PEAK_F16X2_TFLOPS, 4)
+    # one fp16 MFMA per product in the pre-filter (dense fp16 peak); the single-stage path needs three (f16x2 peak)
+    peak = PEAK_F16X2_TFLOPS * 3 if LV.KNN_TWO_STAGE else PEAK_F16X2_TFLOPS
+    out["frac_of_mfma_peak"] = round(2.0 * KNN_Q * KNN_S * KNN_D / per / 1e12 / peak, 4)
+    out["mfma_peak_tflops"] = round(peak, 1)
+    out["unstructured"] = {"inputs": "N(0,1) rows (the earlier rounds' input)", "ms_per_sweep": round(per_u * 1e3, 3),
+                           "queries_per_s": round(KNN_Q / per_u)}
     if c.rank == 0 and not c.use_dist and sample_check:
         from oracle import knn as oknn
 
-        ref = oknn.dense(cls.cpu(), shots.cpu(), q[:sample_check].cpu(), True)
-        out["top10_rows_identical_to_oracle"] = "%d / %d" % (int((top[:sample_check].cpu() == ref).all(dim=1).sum()), sample_check)
+        for name, t in (("structured", top), ("unstructured", top_u)):
+            shots, q = inputs[name]
+            ref = oknn.dense(cls.cpu(), shots.cpu(), q[:sample_check].cpu(), True)
+            same = "%d / %d" % (int((t[:sample_check].cpu() == ref).all(dim=1).sum()), sample_check)
+            if name == "structured":
+                out["top10_rows_identical_to_oracle"] = same
+            else:
+                out["unstructured"]["top10_rows_identical_to_oracle"] = same
     return out
 
 
@@ -471,7 +503,7 @@ def infer_main(c, args):
                     extras["knn"] = knn_leg(c, 5, 2)
                     bk = extras.get("bandwidth_kernels")
                     if isinstance(bk, dict) and "error" not in bk:
-                        bk["knn_topk_vote"] = _knn_topk_alone(c)
+                        bk.update(_knn_kernels_alone(c))
             else:
                 extras["dp_legs"] = {"knn": knn_leg(c, 3, 1)}
                 extras["dp_legs"]["train_cfg3"] = train_leg(c, 3, 1)
@@ -501,20 +533,52 @@ def infer_main(c, args):
         print(json.dumps(line))
 
 
-def _knn_topk_alone(c):
-    """knn_topk_vote_kernel alone on a 32768 x 2400 similarity block (what one chunk of the sweep hands it)."""
+def _knn_kernels_alone(c):
+    """The kernels of the kNN sweep alone, event-timed: the fp16 pre-filter GEMM on the full 120k x 2400 x 1024 problem, the
+    verification kernel on its output (class-structured descriptors as in `knn_leg`), and the single-stage top-k kernel on a
+    32768 x 2400 block."""
     import torch
 
     from lvc_amd import kernels as K
+    from lvc_amd import label_verification as LV
 
+    out = {}
+    cls = torch.arange(80, device=c.dev).repeat_interleave(30)
+    g = torch.Generator(device=c.dev).manual_seed(5)
+    centers = torch.randn(80, KNN_D, device=c.dev, generator=g)
+    qcls = torch.randint(0, 80, (KNN_Q,), device=c.dev, generator=g)
+    shots = _knn_inputs(c, KNN_S, 7, cls, centers, 2.0)
+    q = _knn_inputs(c, KNN_Q, 100, qcls, centers, 2.5)
+    mu = K.colmean(shots)
+    sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
+    _, qh, den = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False)
+    nq = min(KNN_Q, (2 ** 31 - 1) // (4 * KNN_S))
+    ms = _event_ms(lambda: K.gemm_f16(qh[:nq], sh), 10)
+    fl = 2.0 * nq * KNN_S * KNN_D
+    out["knn_gemm_f16"] = {"kernel": "gemm_f16_dma_kernel, %d x %d x %d fp16 operands -> fp32" % (nq, KNN_S, KNN_D), "ms": round(ms, 4),
+                           "tflops": round(fl / ms / 1e9, 1), "frac_of_fp16_mfma_peak_2500": round(fl / ms / 1e9 / 2500.0, 4),
+                           "algorithmic_bytes": nq * KNN_D * 2 + KNN_S * KNN_D * 2 + nq * KNN_S * 4}
+    out["knn_gemm_f16"]["GBps"] = round(out["knn_gemm_f16"]["algorithmic_bytes"] / ms / 1e6, 1)
+    ap = K.gemm_f16(qh[:nq], sh)
+    ms = _event_ms(lambda: K.knn_verify_topk_vote(ap, q[:nq], sn, LV.VERIFY_MARGIN, cls, qcls[:nq], 10, mu=mu, den=den), 10)
+    alg = nq * KNN_S * 4 + nq * 10 * 8 + nq * 8
+    out["knn_verify_topk_vote"] = {"kernel": "knn_verify_topk_vote_kernel, %d x %d pre-filter similarities -> exact top-10 class ids + keep" % (nq, KNN_S),
+                                   "ms": round(ms, 4), "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1),
+                                   "frac_of_hbm_peak": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4)}
+    ms = _event_ms(lambda: K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False), 10)
+    alg = KNN_Q * KNN_D * 6 + KNN_Q * 4
+    out["knn_rownorm_h"] = {"kernel": "rownorm_h_kernel, %d x %d fp32 -> fp16 rows + denominators" % (KNN_Q, KNN_D), "ms": round(ms, 4),
+                            "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4)}
+    del ap
     Q = 32768
     sims = torch.randn(Q, KNN_S, device=c.dev)
-    cls = torch.arange(80, device=c.dev).repeat_interleave(30)
     det = torch.randint(0, 80, (Q,), device=c.dev)
     ms = _event_ms(lambda: K.knn_topk_vote(sims, KNN_S, cls, det, 10), 10)
     alg = Q * KNN_S * 4 + Q * 10 * 8 + Q * 8
-    return {"kernel": "knn_topk_vote_kernel, %d x %d similarities -> top-10 class ids + keep" % (Q, KNN_S), "ms": round(ms, 4),
-            "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1), "frac_of_hbm_peak": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4)}
+    out["knn_topk_vote"] = {"kernel": "knn_topk_vote_kernel (single-stage path), %d x %d similarities -> top-10 class ids + keep" % (Q, KNN_S),
+                            "ms": round(ms, 4), "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1),
+                            "frac_of_hbm_peak": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4)}
+    return out
 
 
 def _cpu_baseline(model, imgs):

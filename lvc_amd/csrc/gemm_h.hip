@@ -81,11 +81,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
       bsrc[j] = p.b + (size_t)rb * p.ldb + G * 8;
     }
   };
-  int issued = 0, consumed = 0, landed = 0;
+  int issued = 0, landed = 0;   // chunks [0, landed) are known to have landed (a full drain happened after their issue)
   auto issue_chunk = [&]() {
     if (l_done) return;
     unsigned char* st = smem + (issued % GH_NS) * GH_STAGE;
-    if (!(p.ablate & 1) || issued < GH_NS - 1) {
+    if (!(p.ablate & 1) || issued < GH_NS) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) gh_glds16(asrc[j] + l_kc * 32, st + (wave * 32 + j * 16) * 64);
 #pragma unroll
@@ -99,63 +99,58 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
       else l_done = true;
     }
   };
-  // top of a chunk: chunk `consumed` has landed once this wave's pieces of it are done (loads retire in order: only the 4
-  // pieces of each younger chunk may still be outstanding) and every wave has said so at the barrier; past the barrier every
-  // wave is done with chunk consumed - 1, whose slot takes chunk consumed + 3
-  auto chunk_top = [&]() {
-    if (consumed >= landed) {
-      const int ahead = issued - consumed - 1;
-      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    issue_chunk();
+  // this wave's pieces of chunk g have landed: loads retire in order, only the 4 pieces of each younger chunk may be outstanding
+  auto wait_landed = [&](int g) {
+    if (g < landed) return;
+    const int younger = issued - g - 1;
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
+  // the six fragments of a k16 step (2 row blocks of A + 4 column blocks of B).  They are read from LDS one step AHEAD of the
+  // MFMAs that use them: after a barrier every wave of the workgroup is at the same point, so reading and multiplying the same
+  // data would alternate "all waves on the LDS port" with "all waves on the matrix pipe"; one step ahead, the reads of the next
+  // step travel under the eight MFMAs of this one.  Written as asm so that the scheduler cannot move the reads; a wait carries
+  // the fragments (and the accumulator the preceding MFMAs end on) as operands, which pins the MFMAs on either side of it.
+  struct Half { f16x8 a[2]; f16x8 b[4]; };
+  const unsigned a_off = (unsigned)((wm * 64 + fi) * 64), b_off = (unsigned)(GH_A_BYTES + (wn * 128 + fi) * 64);
+  const unsigned bo0 = (unsigned)((fh ^ fx3) * 16), bo1 = (unsigned)(((2 + fh) ^ fx3) * 16);
+  const unsigned smem_lds = (unsigned)(size_t)(gh_lds_ptr_t)(void*)smem;
+  auto read_half = [&](Half& h, int g, unsigned bo) {
+    const unsigned st = smem_lds + (unsigned)(g % GH_NS) * GH_STAGE;
+    const unsigned a0 = st + a_off + bo, b0 = st + b_off + bo;
+#define GH_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+    GH_READ(h.a[0], a0, 0); GH_READ(h.a[1], a0, 2048);
+    GH_READ(h.b[0], b0, 0); GH_READ(h.b[1], b0, 2048); GH_READ(h.b[2], b0, 4096); GH_READ(h.b[3], b0, 6144);
+#undef GH_READ
+  };
+  auto wait_half = [&](Half& h, f32x16& last) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(h.a[0]), "+v"(h.a[1]), "+v"(h.b[0]), "+v"(h.b[1]), "+v"(h.b[2]), "+v"(h.b[3]), "+v"(last));
+  };
+
+  const int total = ((ntl - local + per_xcd - 1) / per_xcd) * p.nk;   // chunks of this workgroup
   loader_enter(l_u);
-  issue_chunk();
-  issue_chunk();
-  issue_chunk();
+  for (int i = 0; i < GH_NS; ++i) issue_chunk();
 
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
   const unsigned ldy4 = (unsigned)p.ldy * 4u;
 
-#pragma unroll 1
-  for (int u = local; u < ntl; u += per_xcd) {
-    const int tile_m = (u / p.tiles_n) * 8 + xcd, tile_n = u % p.tiles_n;
-    f32x16 acc[2][4];
+  f32x16 acc[2][4];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-#pragma unroll 1
-    for (int kc = 0; kc < p.nk; ++kc) {
-      chunk_top();
-      const unsigned char* st = smem + (consumed % GH_NS) * GH_STAGE;
-      const unsigned char* sa = st + (wm * 64 + fi) * 64;
-      const unsigned char* sb = st + GH_A_BYTES + (wn * 128 + fi) * 64;
-      if (!(p.ablate & 2))
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const int bo = ((s * 2 + fh) ^ fx3) * 16;
-        f16x8 fa[2], fb[4];
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) fa[mi] = *reinterpret_cast<const f16x8*>(sa + mi * 32 * 64 + bo);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fb[ni] = *reinterpret_cast<const f16x8*>(sb + ni * 32 * 64 + bo);
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
-      }
-      ++consumed;
-    }
-
-    // ---- epilogue.  The chunks prefetched so far are drained first and remembered as landed: the counted waits of the next
-    // chunks would otherwise also wait for these 128 stores (one vmcnt queue).  A store writes 2 rows x 32 consecutive columns.
+  };
+  zero_acc();
+  int u = local, kc = 0;
+  auto epilogue = [&]() {
+    const int tile_m = (u / p.tiles_n) * 8 + xcd, tile_n = u % p.tiles_n;
+    // The chunks prefetched so far are drained first and remembered as landed: the counted waits of the next chunks would
+    // otherwise also wait for these stores (one vmcnt queue).  A store writes 2 rows x 32 consecutive columns.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed = issued;
     const int m0 = tile_m * 256 + wm * 64, n0 = tile_n * 256 + wn * 128;
@@ -233,6 +228,39 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
             off += __popc(half);
           }
         }
+    }
+  };
+  Half H0, H1;
+  auto mfmas = [&](Half& h) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h.a[mi], h.b[ni], acc[mi][ni], 0, 0, 0);
+  };
+  wait_landed(0);
+  __builtin_amdgcn_s_barrier();
+  if (!(p.ablate & 2)) read_half(H0, 0, bo0);
+  // step g: H0 holds (or is about to receive) the first k16 step of chunk g.  Before the barrier every wave has finished its
+  // LDS reads of chunk g - 1 (so that slot can take chunk g - 1 + GH_NS) and its own DMA pieces of chunk g + 1 have landed.
+#pragma unroll 1
+  for (int g = 0; g < total; ++g) {
+    const bool more = g + 1 < total;
+    if (more) wait_landed(g + 1);
+    __builtin_amdgcn_s_barrier();
+    if (g > 0) issue_chunk();
+    if (!(p.ablate & 2)) {
+      wait_half(H0, acc[1][3]);
+      read_half(H1, g, bo1);
+      mfmas(H0);
+      wait_half(H1, acc[1][3]);
+      if (more) read_half(H0, g + 1, bo0);
+      mfmas(H1);
+    }
+    if (++kc == p.nk) {
+      epilogue();
+      zero_acc();
+      kc = 0;
+      u += per_xcd;
     }
   }
 }
