@@ -8,7 +8,8 @@
 //     reads per chunk and workgroup against 2 x 512 matrix-pipe cycles per SIMD, the LDS port and the matrix pipe are about
 //     level (the 8 x 1 wave grid of conv_pw_dma.hip reads 160 KB for the same work and is LDS-bound with one MFMA per block);
 //   * operands arrive by `global_load_lds_dwordx4` into a ring of four 32 KB stages (A rows 0..255 then B rows 0..255, 64 bytes
-//     per row and chunk), three chunks ahead, across tile boundaries; one s_barrier per chunk;
+//     per row and chunk), two to three chunks ahead, across tile boundaries; one s_barrier per chunk; fragments are read one
+//     k16 step ahead of the MFMAs that use them;
 //   * LDS images are lane-linear; the four 16-byte granules of a row are permuted with slot = G ^ ((row >> 2) & 3) on the
 //     source side and on the fragment-read side, so that a 16-lane group of a ds_read_b128 covers the 64 banks once;
 //   * row tiles are dealt to XCDs (tile_m % 8 == blockIdx % 8) and a workgroup walks (row tile, column tile) pairs of its XCD
@@ -113,6 +114,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   // data would alternate "all waves on the LDS port" with "all waves on the matrix pipe"; one step ahead, the reads of the next
   // step travel under the eight MFMAs of this one.  Written as asm so that the scheduler cannot move the reads; a wait carries
   // the fragments (and the accumulator the preceding MFMAs end on) as operands, which pins the MFMAs on either side of it.
+  // (Measured on the 120k x 2400 x 1024 sweep: the same 0.85 ms as the compiler-scheduled read-then-multiply loop; with DMA
+  // and stores ablated the loop runs at 1.06 PFLOP/s either way -- what the matrix pipe delivers at the ~1.5 GHz it is
+  // power-capped to; operand DMA and the output stores then add 0.13 ms each: LVC_GH_ABLATE, profiles/README.md round 2.)
   struct Half { f16x8 a[2]; f16x8 b[4]; };
   const unsigned a_off = (unsigned)((wm * 64 + fi) * 64), b_off = (unsigned)(GH_A_BYTES + (wn * 128 + fi) * 64);
   const unsigned bo0 = (unsigned)((fh ^ fx3) * 16), bo1 = (unsigned)(((2 + fh) ^ fx3) * 16);
