@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 // lvc_rownorm for the two-stage kNN sweep: the normalised rows rounded to fp16 (round to nearest even; the operand of the
 // pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), and --
 // optionally -- the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
+template <int NPER>   // NPER * 64 >= D: the centred row stays in registers between the two passes (NPER = 0: it is read twice)
 __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict__ x, const float* __restrict__ mu,
                                                         float* __restrict__ y, _Float16* __restrict__ yh, float* __restrict__ dens,
                                                         int M, int D, int ldx, float eps, int mode) {
@@ -113,9 +114,21 @@ __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict_
   if (row >= M) return;
   const float* xr = x + (size_t)row * ldx;
   float ss = 0.f;
-  for (int d = lane; d < D; d += 64) {
-    float v = xr[d] - (mu ? mu[d] : 0.f);
-    ss += v * v;
+  float c[NPER > 0 ? NPER : 1];
+  if constexpr (NPER > 0) {
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+      const int d = lane + 64 * i;
+      c[i] = d < D ? xr[d] - (mu ? mu[d] : 0.f) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NPER; ++i)
+      if (lane + 64 * i < D) ss += c[i] * c[i];     // the same order as the strided loop below
+  } else {
+    for (int d = lane; d < D; d += 64) {
+      float v = xr[d] - (mu ? mu[d] : 0.f);
+      ss += v * v;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
   const float nrm = sqrtf(ss);
@@ -123,10 +136,22 @@ __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict_
   if (dens && lane == 0) dens[row] = den;
   float* yr = y ? y + (size_t)row * D : nullptr;
   _Float16* hr = yh + (size_t)row * D;
-  for (int d = lane; d < D; d += 64) {
-    const float v = (xr[d] - (mu ? mu[d] : 0.f)) / den;
-    if (yr) yr[d] = v;
-    hr[d] = (_Float16)v;
+  if constexpr (NPER > 0) {
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+      const int d = lane + 64 * i;
+      if (d < D) {
+        const float v = c[i] / den;
+        if (yr) yr[d] = v;
+        hr[d] = (_Float16)v;
+      }
+    }
+  } else {
+    for (int d = lane; d < D; d += 64) {
+      const float v = (xr[d] - (mu ? mu[d] : 0.f)) / den;
+      if (yr) yr[d] = v;
+      hr[d] = (_Float16)v;
+    }
   }
 }
 
@@ -135,8 +160,14 @@ extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned
   LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
   if (M == 0) return LVC_OK;
   LVC_CHECK_ARG(x && yh, "null pointer");
-  hipLaunchKernelGGL(rownorm_h_kernel, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, M, D,
-                     ldx > 0 ? ldx : D, eps, mode);
+  const dim3 grid(lvc_cdiv(M, 4)), block(256);
+  const int ldxx = ldx > 0 ? ldx : D;
+#define RH_LAUNCH(N) hipLaunchKernelGGL(rownorm_h_kernel<N>, grid, block, 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, M, D, ldxx, eps, mode)
+  if (D <= 512) RH_LAUNCH(8);
+  else if (D <= 1024) RH_LAUNCH(16);
+  else if (D <= 2048) RH_LAUNCH(32);
+  else RH_LAUNCH(0);
+#undef RH_LAUNCH
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

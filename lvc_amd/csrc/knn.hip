@@ -224,30 +224,13 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
                                           const long long* __restrict__ shot_classes, const long long* __restrict__ det_classes,
                                           const int kvote, long long* __restrict__ top_classes, long long* __restrict__ keep,
                                           const int stop_after) {
-  // the normalised query row in registers, loaded when the first exact similarity is needed: lane l holds elements
-  // sl*256 + l*4 .. +3 of every 256-element slice sl (where below D)
-  float4 qv[8];
-  bool have_q = false;
-  auto load_q = [&]() {
-    if (have_q) return;
-    have_q = true;
-    const float* qr = q + (size_t)row * ldq;
-    const float dn = den ? den[row] : 1.f;
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-      const int d = sl * 256 + lane * 4;
-      float4 x = {0.f, 0.f, 0.f, 0.f};
-      if (d < D) {
-        x = *reinterpret_cast<const float4*>(qr + d);
-        if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + d); x.x -= m4.x; x.y -= m4.y; x.z -= m4.z; x.w -= m4.w; }
-        if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
-      }
-      qv[sl] = x;
-    }
-  };
-  // exact similarities of the n shots listed through pos_of(k) -> position in (L.idx, L.val), four rows in flight
+  // exact similarities of the n shots listed through pos_of(k) -> position in (L.idx, L.val), four shot rows in flight.  Lane l
+  // owns elements sl*256 + l*4 .. +3 of every 256-element slice sl (where below D); the query slice is fetched and normalised
+  // per slice (an L1 hit after the first group) instead of being held in registers: the rare exact path must not set the
+  // register count -- and with it the occupancy -- of the scan that every row runs
+  const float* qr = q + (size_t)row * ldq;
+  const float dn = den ? den[row] : 1.f;
   auto exact_dots = [&](int n, auto pos_of) {
-    load_q();
     for (int k0 = 0; k0 < n; k0 += 4) {
       const float* sr[4];
       int pos[4];
@@ -257,20 +240,26 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
         sr[t] = sn + (size_t)L.idx[pos[t]] * D;
       }
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int d0 = 0; d0 < D; d0 += 256) {
+        const int d = d0 + lane * 4;
+        const bool in = d < D;
+        float4 x = {0.f, 0.f, 0.f, 0.f};
+        float4 sv[4];
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl)
-        if (sl * 256 < D) {
-          const bool in = sl * 256 + lane * 4 < D;
-          float4 sv[4];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) sv[t] = in ? *reinterpret_cast<const float4*>(sr[t] + sl * 256 + lane * 4) : float4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            // explicit fmas: every row in flight must round the same way (identical shots tie exactly)
-            acc[t] = __builtin_fmaf(qv[sl].x, sv[t].x, acc[t]); acc[t] = __builtin_fmaf(qv[sl].y, sv[t].y, acc[t]);
-            acc[t] = __builtin_fmaf(qv[sl].z, sv[t].z, acc[t]); acc[t] = __builtin_fmaf(qv[sl].w, sv[t].w, acc[t]);
-          }
+        for (int t = 0; t < 4; ++t) sv[t] = in ? *reinterpret_cast<const float4*>(sr[t] + d) : float4{0.f, 0.f, 0.f, 0.f};
+        if (in) {
+          x = *reinterpret_cast<const float4*>(qr + d);
+          if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + d); x.x -= m4.x; x.y -= m4.y; x.z -= m4.z; x.w -= m4.w; }
+          if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          // explicit fmas: every row in flight must round the same way (identical shots tie exactly)
+          acc[t] = __builtin_fmaf(x.x, sv[t].x, acc[t]); acc[t] = __builtin_fmaf(x.y, sv[t].y, acc[t]);
+          acc[t] = __builtin_fmaf(x.z, sv[t].z, acc[t]); acc[t] = __builtin_fmaf(x.w, sv[t].w, acc[t]);
+        }
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1)
 #pragma unroll

