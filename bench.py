@@ -192,7 +192,11 @@ def knn_leg(c, steps, warmup, sample_check=2048):
         return dt / n, res
 
     per, (top, keep) = timed(*inputs["structured"], steps)
-    per_u, (top_u, _) = timed(*inputs["unstructured"], steps)
+    if os.environ.get("LVC_BENCH_KNN_STRUCTURED_ONLY") == "1":     # profiler runs: one kind of input per trace
+        per_u, top_u = per, top
+        inputs["unstructured"] = inputs["structured"]
+    else:
+        per_u, (top_u, _) = timed(*inputs["unstructured"], steps)
     path = "two-stage (fp16 pre-filter GEMM + exact fp32 verification)" if LV.KNN_TWO_STAGE else "single-stage (fp32-accurate f16x2 GEMM + top-k)"
     out = {"workload": "kNN label verification: Q=%d (sharded %d/rank) x S=%d x D=%d, cosine, top-10 + vote" % (KNN_Q, len(rng), KNN_S, KNN_D),
            "path": path, "inputs": "class-structured synthetic descriptors (80 classes x 30 shots, 30 % wrong detector labels)",

@@ -1,7 +1,7 @@
 """fp16 pre-filter GEMM alone (120000 x 2400 x 1024): time and TF/s; LVC_GH_ABLATE for the ablations."""
 import os, sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lvc_amd import kernels as K
 D = "cuda:0"
 M, N, C = 120000, 2400, 1024
