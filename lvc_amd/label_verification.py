@@ -21,6 +21,7 @@ KNN_EMIT = os.environ.get("LVC_KNN_EMIT", "0") == "1"
 # < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
 VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16
 TWO_STAGE_CHUNK = 1 << 18
+MAX_SHOTS_PER_LAUNCH = 4096   # knn_topk_vote_kernel / knn_verify_topk_vote_kernel: 64 values per lane
 QUERY_CHUNK = 32768  # rows of the similarity matrix materialised at once (x S x 4 bytes)
 
 
@@ -68,7 +69,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
     if D % 32 != 0:
         raise RuntimeError("descriptor dimension must be a multiple of 32 (got {})".format(D))
     shot_classes = shot_classes.to(torch.int64).contiguous()
-    two_stage = KNN_TWO_STAGE and cosine and D <= 2048 and S >= 10
+    large = S > MAX_SHOTS_PER_LAUNCH     # beyond the top-k kernels' row length (LVIS-sized shot sets): ranked by a stable torch sort
+    two_stage = KNN_TWO_STAGE and cosine and D <= 2048 and S >= 10 and not large
     if cosine:
         mu = K.colmean(shots)
         if two_stage:
@@ -83,6 +85,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
     tops, keeps = [], []
     # the two-stage path keeps only transient fp16 / fp32 copies per chunk: take as many rows as the GEMM's 2 GiB output allows
     chunk = (TWO_STAGE_CHUNK if KNN_EMIT else min(TWO_STAGE_CHUNK, (2 ** 31 - 1) // (4 * S))) if two_stage else QUERY_CHUNK
+    if large:
+        chunk = max(256, min(QUERY_CHUNK, (2 ** 31 - 1) // (4 * S)))
     for s0 in range(0, max(Q, 1), chunk):
         qc = q[s0: s0 + chunk]
         if qc.shape[0] == 0:
@@ -104,13 +108,21 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
         else:
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)
-            t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
+            if large:
+                # the same similarities (HIP GEMM), ranked with the reference's tie rule by a stable descending sort; the vote as
+                # torch.mode (smallest class id on ties), which is what get_nn_class_confirmatory does
+                t = shot_classes[torch.sort(sims, dim=1, descending=True, stable=True)[1][:, :10]]
+                kp = (torch.mode(t[:, :k], dim=1)[0] == dc).to(torch.int64) if dc is not None else None
+            else:
+                t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
         tops.append(t)
         keeps.append(kp)
     if not tops:
         dev = q.device
         return torch.empty(0, 10, dtype=torch.int64, device=dev), (
             torch.empty(0, dtype=torch.int64, device=dev) if detector_classes is not None else None)
+    if len(tops) == 1:     # the usual case: no copy of the results
+        return tops[0], (keeps[0] if detector_classes is not None else None)
     return torch.cat(tops), (torch.cat(keeps) if detector_classes is not None else None)
 
 

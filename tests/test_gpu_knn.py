@@ -287,3 +287,24 @@ def test_fp16_gemm_error_bound_and_exactness():
         y = K.gemm_f16(ah, bh)
         exact = an.double() @ bn.double().t()
         assert (y.double() - exact).abs().max().item() <= 2.0 ** -10
+
+
+@pytest.mark.parametrize("cosine", [True, False])
+def test_knn_sweep_more_shots_than_a_kernel_row(cosine):
+    """S > 4096 (an LVIS-sized shot set; the reference has no cap): the sweep ranks the HIP GEMM's similarities with a stable
+    sort instead of the 4096-wide top-k kernels; same answers as the oracle."""
+    from lvc_amd.label_verification import knn_sweep
+    from oracle import knn as oknn
+
+    g = torch.Generator().manual_seed(9)
+    S, Dm, Q = 5000, 128, 700
+    classes = torch.sort(torch.randint(0, 200, (S,), generator=g))[0]
+    centers = torch.randn(200, Dm, generator=g)
+    shots = centers[classes] + 1.5 * torch.randn(S, Dm, generator=g) + 0.3
+    qcls = torch.randint(0, 200, (Q,), generator=g)
+    q = centers[qcls] + 2.0 * torch.randn(Q, Dm, generator=g) + 0.3
+    top, keep = knn_sweep(classes.to(D), shots.to(D), q.to(D), qcls.to(D), 10, cosine)
+    ref_top = oknn.dense(classes, shots, q, cosine)
+    ref_keep = oknn.get_nn_class_confirmatory(ref_top, qcls, 10)
+    assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 3e-3
+    assert (keep.cpu() != ref_keep).float().mean() <= 3e-3
