@@ -109,10 +109,14 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)
             if large:
-                # the same similarities (HIP GEMM), ranked with the reference's tie rule by a stable descending sort; the vote as
-                # torch.mode (smallest class id on ties), which is what get_nn_class_confirmatory does
+                # the same similarities (HIP GEMM), ranked with the reference's tie rule by a stable descending sort
                 t = shot_classes[torch.sort(sims, dim=1, descending=True, stable=True)[1][:, :10]]
-                kp = (torch.mode(t[:, :k], dim=1)[0] == dc).to(torch.int64) if dc is not None else None
+                kp = None
+                if dc is not None:     # mode of the first k ids, the SMALLEST id among equally frequent ones (CPU torch.mode's rule)
+                    tk = t[:, :k]
+                    cnt = (tk[:, :, None] == tk[:, None, :]).sum(2)
+                    mode = torch.where(cnt == cnt.max(1, keepdim=True)[0], tk, torch.full_like(tk, 2 ** 62)).min(1)[0]
+                    kp = (mode == dc).to(torch.int64)
             else:
                 t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
         tops.append(t)
