@@ -1,0 +1,34 @@
+"""The pointwise layers of R50-FPN at batch 8 (800x1333 -> 200x336 at res2), each timed alone: ms per launch; env switches
+(LVC_PW_PF, ...) give the A/B.  Layers cycle through 3 distinct input buffers so that a layer does not find its input in L2."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from lvc_amd import kernels as k
+d = torch.device("cuda:0")
+torch.manual_seed(0)
+LAYERS = [("res2 c1 256>64", 8, 200, 336, 256, 64, 0), ("res2 c3 64>256+r", 8, 200, 336, 64, 256, 1),
+          ("res3 c1 512>128", 8, 100, 168, 512, 128, 0), ("res3 c3 128>512+r", 8, 100, 168, 128, 512, 1),
+          ("res4 c1 1024>256", 8, 50, 84, 1024, 256, 0), ("res4 c3 256>1024+r", 8, 50, 84, 256, 1024, 1),
+          ("res5 c1 2048>512", 8, 25, 42, 2048, 512, 0), ("res5 c3 512>2048+r", 8, 25, 42, 512, 2048, 1),
+          ("fpn lat2 256>256+up", 8, 200, 336, 256, 256, 2), ("fpn lat3 512>256+up", 8, 100, 168, 512, 256, 2),
+          ("fc1 12544>1024", 8000, 1, 1, 12544, 1024, 0), ("fc2 1024>1024", 8000, 1, 1, 1024, 1024, 0)]
+tot = 0.0
+for name, N, H, W, C, K, rm in LAYERS:
+    xs = [torch.randn(N, H, W, C, device=d) for _ in range(3)]
+    w = torch.randn(K, C, 1, 1, device=d) * (2.0 / C) ** 0.5
+    pc = k.pack_conv(w)
+    res = None
+    if rm == 1: res = [torch.randn(N, H, W, K, device=d) for _ in range(3)]
+    if rm == 2: res = [torch.randn(N, H // 2, W // 2, K, device=d) for _ in range(3)]
+    y = torch.empty(N, H, W, K, device=d)
+    f = lambda i: k.conv2d_nhwc(xs[i % 3], pc, relu=True, residual=res[i % 3] if res else None, res_mode=rm, out=y)
+    for i in range(6): f(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(30): f(i)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 30
+    tot += ms
+    print("%-22s %.4f ms  %6.1f TF/s" % (name, ms, 2.0 * N * H * W * C * K / ms / 1e9))
+print("sum %.4f ms  (LVC_PW_PF=%s)" % (tot, os.environ.get("LVC_PW_PF", "0")))
