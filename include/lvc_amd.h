@@ -123,6 +123,9 @@ int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned short* w_split
  * outside h x w.  image: CHW, dtype 0 = fp32, 1 = uint8.  mean3/std3 are [host] arrays of 3 floats. */
 int lvc_preprocess_nhwc4(const void* image, int dtype, int h, int w, const float* mean3, const float* std3,
                          float* out, int Hp, int Wp, void* stream);
+/* The same for B images in one launch (16 per launch): images[i] -> out[i] ([B,Hp,Wp,4]); all float32 or all uint8. */
+int lvc_preprocess_batch_nhwc4(const void* const* images, int dtype, const int* hs, const int* ws, int B, const float* mean3,
+                               const float* std3, float* out, int Hp, int Wp, void* stream);
 
 /* Test-time input pipeline: ResizeShortestEdge's Pillow bilinear resize of a uint8 HWC image
  * (detectron2/data/transforms/transform.py:101-109), bit-exact with Pillow's ImagingResample (22-bit fixed point,

@@ -230,9 +230,20 @@ class LaunchTimer:
     """Optional per-launch HIP-event bracket for the conv/GEMM kernel (bench.py's roofline leg).
     Events are recorded on the stream the kernel is launched on (torch's current stream)."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, every=1):
         self.records = []  # (algorithmic flops, start event, end event, engine)
         self.only = only   # None = bracket every launch; else the set of engine tags to bracket
+        self.every = max(1, int(every))   # bracket the launches of every `every`-th step only (`next_step` counts them): an
+        self.step = 0                     # event pair costs ~6 us of stream bubbles around a launch
+        self.active = True
+
+    def next_step(self):
+        """Call at the start of a step: launches are bracketed in steps 0, every, 2*every, ..."""
+        self.active = self.step % self.every == 0
+        self.step += 1
+
+    def steps_timed(self):
+        return (self.step + self.every - 1) // self.every
 
     def flops_and_ms(self, engine=None):
         torch.cuda.synchronize()
@@ -304,7 +315,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                  and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3 (f16x2 there: 0.312 vs 0.335 ms alone, no gain end to end)
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
     timer = CONV_TIMER
-    if timer is not None and timer.only is not None and engine not in timer.only:
+    if timer is not None and (not timer.active or (timer.only is not None and engine not in timer.only)):
         timer = None
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -646,6 +657,32 @@ def preprocess_into(image, out_slot, mean, std):
     rc = _lib.lib().lvc_preprocess_nhwc4(ptr(image), c_int(dt), c_int(image.shape[1]), c_int(image.shape[2]), m, s,
                                          ptr(out_slot), c_int(Hp), c_int(Wp), _stream(image))
     check(rc, "lvc_preprocess_nhwc4")
+
+
+def preprocess_batch_into(images, out, mean, std):
+    """images: list of CHW (3,h,w) device tensors (all float32 or all uint8); out: [B,Hp,Wp,4] batch tensor.  One launch per
+    16 images (lvc_preprocess_batch_nhwc4); the same values as `preprocess_into` image by image."""
+    _req_cuda(out, *images)
+    B = len(images)
+    assert out.dim() == 4 and out.shape[0] == B and out.shape[3] == 4 and out.is_contiguous() and out.dtype == torch.float32
+    u8 = images[0].dtype == torch.uint8
+    imgs = []
+    for im in images:
+        assert im.dim() == 3 and im.shape[0] == 3
+        if u8:
+            assert im.dtype == torch.uint8
+        else:
+            im = im.float()
+        imgs.append(im.contiguous())
+    P = (c_void_p * B)(*[im.data_ptr() for im in imgs])
+    hs = (c_int * B)(*[int(im.shape[1]) for im in imgs])
+    ws = (c_int * B)(*[int(im.shape[2]) for im in imgs])
+    m = (c_float * 3)(*[float(v) for v in mean])
+    s_ = (c_float * 3)(*[float(v) for v in std])
+    rc = _lib.lib().lvc_preprocess_batch_nhwc4(P, c_int(1 if u8 else 0), hs, ws, c_int(B), m, s_, ptr(out), c_int(out.shape[1]),
+                                               c_int(out.shape[2]), _stream(out))
+    check(rc, "lvc_preprocess_batch_nhwc4")
+    return imgs   # keeps converted copies alive until the caller drops them (the launch is asynchronous)
 
 
 def resize_bilinear_u8(img, new_h, new_w, coeffs_fn, out_slot=None, mean=None, std=None):

@@ -59,8 +59,11 @@ class _RCNNBase(nn.Module):
         sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         Hp, Wp = ImageList.padded_size(sizes, self.backbone.size_divisibility)
         buf = torch.empty(len(images), Hp, Wp, 4, device=self.device, dtype=torch.float32)
-        for i, im in enumerate(images):
-            K.preprocess_into(im, buf[i], self.pixel_mean, self.pixel_std)
+        if len({im.dtype for im in images}) == 1 and images[0].dtype in (torch.float32, torch.uint8):
+            K.preprocess_batch_into(images, buf, self.pixel_mean, self.pixel_std)     # the whole batch in one launch
+        else:
+            for i, im in enumerate(images):
+                K.preprocess_into(im, buf[i], self.pixel_mean, self.pixel_std)
         return ImageList(buf.permute(0, 3, 1, 2)[:, :3], sizes)
 
     def _preprocess_raw(self, batched_inputs):

@@ -572,3 +572,22 @@ def test_preprocess_kernel_bit_exact(h, w, dtype):
         got = buf.cpu()
         assert torch.equal(got[..., :3].permute(2, 0, 1), ref[0])
         assert float(got[..., 3].abs().max()) == 0.0
+
+
+def test_preprocess_batch_equals_per_image():
+    """lvc_preprocess_batch_nhwc4 (one launch for the batch) against lvc_preprocess_nhwc4 image by image: bit-identical, for
+    ragged sizes, float32 and uint8 inputs, and more than 16 images (two launches)."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(4)
+    mean, std = [103.53, 116.28, 123.675], [1.0, 57.375, 58.395]
+    for dtype in (torch.float32, torch.uint8):
+        sizes = [(37, 50), (64, 64), (1, 3), (50, 61)] * 5
+        imgs = [(torch.rand(3, h, w, generator=g) * 255).to(dtype).to("cuda:0") for h, w in sizes]
+        Hp, Wp = 64, 96
+        a = torch.full((len(imgs), Hp, Wp, 4), 7.0, device="cuda:0")
+        b = torch.full((len(imgs), Hp, Wp, 4), 9.0, device="cuda:0")
+        K.preprocess_batch_into(imgs, a, mean, std)
+        for i, im in enumerate(imgs):
+            K.preprocess_into(im, b[i], mean, std)
+        assert torch.equal(a, b)
