@@ -258,12 +258,13 @@ def instances_from_batched(boxes, scores, classes, count, image_sizes, status=No
     else:
         counts = count.tolist()
     out = []
+    classes64 = classes.to(torch.int64)     # one conversion for the batch; the per-image fields below are views
     for i, size in enumerate(image_sizes):
         n = counts[i]
         inst = Instances(tuple(size))
         inst.pred_boxes = Boxes(boxes[i, :n])
         inst.scores = scores[i, :n]
-        inst.pred_classes = classes[i, :n].to(torch.int64)
+        inst.pred_classes = classes64[i, :n]
         out.append(inst)
     return out
 
