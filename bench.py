@@ -203,7 +203,7 @@ def knn_leg(c, steps, warmup, sample_check=2048):
            "ms_per_sweep": round(per * 1e3, 3), "queries_per_s": round(KNN_Q / per),
            "algorithmic_tflops": round(2.0 * KNN_Q * KNN_S * KNN_D / per / 1e12, 1),
            "algorithmic_bytes": KNN_Q * KNN_D * 4 + KNN_S * KNN_D * 4 + KNN_Q * 10 * 8,
-           "kept_fraction": round(float(keep.float().mean()), 4)}
+           "kept_fraction": round(float(keep.float().mean()), 4) if keep is not None else None}   # gathered to rank 0 only
     out["algorithmic_GBps"] = round(out["algorithmic_bytes"] / per / 1e9, 1)
     out["frac_of_hbm_peak"] = round(out["algorithmic_bytes"] / per / 1e9 / PEAK_HBM_GBPS, 4)
     # one fp16 MFMA per product in the pre-filter (dense fp16 peak); the single-stage path needs three (f16x2 peak)
