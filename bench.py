@@ -466,21 +466,30 @@ def infer_main(c, args):
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_F16X2_TFLOPS if dom.startswith("f16x2") else PEAK_BF16X3_TFLOPS
         traffic = pmc = None
-        pmc_file = os.path.join(ROOT, "profiles", "r02_conv_pmc.json")
-        if not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")
-        if os.path.exists(pmc_file):
-            pj = json.load(open(pmc_file))
-            traffic = pj.get("hbm_bytes_per_launch")
-            sq = pj.get("sq_counters_same_launch", {})
-            pmc = {"source": os.path.relpath(pmc_file, ROOT) + " (a separate rocprofv3 --pmc pass of one p2 3x3 launch; counters cannot be read inside this run)",
-                   "mfma_busy_fraction": sq.get("mfma_busy_fraction"), "clock_GHz_under_load": sq.get("clock_GHz")}
+        live = None
+        if c.rank == 0 and c.world == 1 and not args.no_live_pmc:
+            live = _live_conv_pmc()
+        if live is not None:
+            traffic = live["hbm_bytes_per_launch"]
+            pmc = live
+        else:
+            pmc_file = os.path.join(ROOT, "profiles", "r02_conv_pmc.json")
+            if not os.path.exists(pmc_file):
+                pmc_file = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")
+            if os.path.exists(pmc_file):
+                pj = json.load(open(pmc_file))
+                traffic = pj.get("hbm_bytes_per_launch")
+                sq = pj.get("sq_counters_same_launch", {})
+                pmc = {"source": os.path.relpath(pmc_file, ROOT) + " (a separate rocprofv3 --pmc pass of one p2 3x3 launch; no live pass in this run)",
+                       "mfma_busy_fraction": sq.get("mfma_busy_fraction"), "clock_GHz_under_load": sq.get("clock_GHz")}
         roofline = {
             "kernel": "%s (%d launches/step; HIP-event brackets in %d of the %d timed steps)" % (NAMES[dom], nlaunch // max(1, timer.steps_timed()), timer.steps_timed(), args.steps),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split a = a1 + 2^-11 a2, main + cross fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once; the kernel runs at the 1.4 kW socket power cap (profiles/README.md)",
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": "profiles (fabric bytes FETCH_SIZE x2 + WRITE_SIZE of ONE p2 3x3 launch vs 1.10 GB algorithmic; not measured in this run)",
+            "traffic": traffic,
+            "traffic_source": ("live rocprofv3 --pmc passes in this run" if live is not None else "profiles (not measured in this run)")
+                              + ": fabric bytes FETCH_SIZE x2 + WRITE_SIZE of ONE p2 3x3 launch (the dominant kernel's largest, 2 of its 22 launches per step) vs 1.10 GB algorithmic",
             "mfma_utilisation_pmc": pmc,
             "kernel_ms_per_step": round(ms / max(1, timer.steps_timed()), 3), "launch_avg_ms": round(ms / nlaunch, 4)}
         other = {}
@@ -539,6 +548,59 @@ def infer_main(c, args):
         }
         line.update(extras)
         print(json.dumps(line))
+
+
+def _live_conv_pmc(timeout_s=150):
+    """HBM-side traffic and matrix-pipe occupancy of the dominant kernel's largest launch (3x3 256 -> 256 on the batch's p2 map:
+    fpn_output2 / rpn_head.conv), measured on THIS box: three rocprofv3 passes (--pmc FETCH_SIZE | --pmc WRITE_SIZE | the SQ
+    counters; each with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of scripts/probe_one.py in a subprocess.
+    Returns None when rocprofv3 is not there or a pass fails (the committed profile is quoted instead)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    probe = os.path.join(ROOT, "scripts", "probe_one.py")
+    if not os.path.exists(exe) or not os.path.exists(probe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="lvc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    agg, ms = {}, None
+    try:
+        passes = ["FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"]
+        for i, ctr in enumerate(passes):
+            cmd = [exe, "--pmc"] + ctr.split() + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t%d" % i, "--",
+                                                  sys.executable, probe, "8", "256", "200", "336", "256", "3", "1", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(tmp, "**", "t%d*counter_collection.csv" % i), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "halo" in row["Kernel_Name"]:
+                        agg[row["Counter_Name"]] = float(row["Counter_Value"])      # the last launch of the pass
+            if i == 2:
+                for f in glob.glob(os.path.join(tmp, "**", "t2*kernel_trace.csv"), recursive=True):
+                    d = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in csv.DictReader(open(f)) if "halo" in x["Kernel_Name"]]
+                    ms = d[-1] if d else None
+        if "FETCH_SIZE" not in agg or "WRITE_SIZE" not in agg:
+            return None
+        cyc = agg.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        alg = 8 * 200 * 336 * 256 * 4 * 2 + 256 * 2304 * 4      # the p2 activation tensor read once and written once + the weights
+        out = {"source": "live: rocprofv3 --pmc passes of scripts/probe_one.py 8 256 200 336 256 3 1 1 on this box, inside this bench run",
+               "launch": "conv3x3_halo_h2_kernel, 3x3 256 -> 256 on [8,200,336,256] (the largest launch of the dominant kernel, 2 per step)",
+               "hbm_bytes_per_launch": int(2 * agg["FETCH_SIZE"] * 1024 + agg["WRITE_SIZE"] * 1024),
+               "correction": "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM), WRITE_SIZE as is",
+               "algorithmic_bytes_per_launch": alg,
+               "traffic_over_algorithmic": round((2 * agg["FETCH_SIZE"] * 1024 + agg["WRITE_SIZE"] * 1024) / alg, 3),
+               "launch_ms_under_profiler": round(ms, 4) if ms else None,
+               "mfma_busy_fraction": round(agg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024), 4) if cyc else None,
+               "clock_GHz_under_load": round(cyc / ms / 1e6, 3) if (cyc and ms) else None}
+        return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _knn_kernels_alone(c):
@@ -630,6 +692,7 @@ def main():
     ap.add_argument("--workload", choices=("infer", "train", "knn"), default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bandwidth_kernels / knn / dp_legs objects")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc subprocess passes (the committed profile is quoted)")
     ap.add_argument("--no-launch-timer", action="store_true", help="skip the per-launch HIP events (A/B their cost)")
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="streams of the extra pipelined pass reported as `pipelined` (1 = skip it); the timed region is always one stream")
