@@ -346,8 +346,9 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
                       void* stream);
 /* Two-stage form of the same sweep (cosine branch; the similarities of run_nearest_neighbours.py:146-151 are never
  * materialised in full precision).
- * lvc_rownorm_h: lvc_rownorm that writes the rows rounded to fp16 (yh [M,D]), the denominators (den [M] or NULL) and, if
- *   y is not NULL, the fp32 rows (contiguous, bit-identical to lvc_rownorm).
+ * lvc_rownorm_h: lvc_rownorm that writes the rows rounded to fp16 (yh [M,D]), the denominators (den [M] or NULL), the
+ *   2-norm of each row's rounding residual row - fp16(row) (resid [M] or NULL) and, if y is not NULL, the fp32 rows
+ *   (contiguous, bit-identical to lvc_rownorm).
  * lvc_gemm_f16: y [M,ldy] fp32 = a [M,C] . b [N,ldb]^T on fp16 operands (csrc/gemm_h.hip; C % 32 == 0, ldb = elements
  *   between rows of b, 0 = C; y below 2 GiB) -- for unit-norm rows |y - exact| < 2^-10.
  * lvc_gemm_f16_emit: the same products without the matrix: every (m, n) with value >= lb[m] - margin is appended as the
@@ -360,17 +361,20 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
  *   class within margin are re-evaluated in fp32 from q [Q,ldq] (raw descriptors; (q - mu) / den[row] is redone exactly as
  *   lvc_rownorm_h did it; mu / den may be NULL: q then already holds the rows) and sn [S,D] (normalised shots), and the
  *   candidates are ranked so that the class sequence equals the exact ranking's (ties -> lower shot index; csrc/knn.hip
- *   states the argument).  D % 4 == 0, D <= 2048.  Outputs as lvc_knn_topk_vote. */
-int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, int M, int D, int ldx, float eps,
-                  int mode, void* stream);
+ *   states the argument).  margins [Q] (or NULL): a margin per row that replaces `margin` -- 2 x the row's own error bound
+ *   |resid_q| max|s_h| + |q| max resid_s + D 2^-24 (Cauchy-Schwarz on the two rounding residuals + fp32 accumulation), about
+ *   half the worst case.  D % 4 == 0, D <= 2048.  Outputs as lvc_knn_topk_vote. */
+int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, float* resid, int M, int D, int ldx,
+                  float eps, int mode, void* stream);
 int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
                  void* stream);
 int lvc_gemm_f16_emit(const unsigned short* a, const unsigned short* b, int ldb, int M, int N, int C, const float* lb,
                       float margin, void* lists, int* counts, void* stream);
 int lvc_knn_lower_bound(const float* sub, int ld, int Q, int n, float* lb, void* stream);
 int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
-                             const float* den, const float* sn, int D, float margin, const long long* shot_classes,
-                             const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream);
+                             const float* den, const float* sn, int D, float margin, const float* margins,
+                             const long long* shot_classes, const long long* det_classes, int kvote, long long* top_classes,
+                             long long* keep, void* stream);
 /* lvc_knn_verify_topk_vote on the candidate lists of lvc_gemm_f16_emit instead of the dense matrix. */
 int lvc_knn_verify_lists(const void* lists, const int* counts, int Q, int S, const float* q, int ldq, const float* mu,
                          const float* den, const float* sn, int D, float margin, const long long* shot_classes,

@@ -154,12 +154,13 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 }
 
 // lvc_rownorm for the two-stage kNN sweep: the normalised rows rounded to fp16 (round to nearest even; the operand of the
-// pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), and --
-// optionally -- the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
+// pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), the
+// 2-norm of each row's fp16 rounding residual resid [M] (what bounds the pre-filter's error for that row) and -- optionally --
+// the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
 template <int NPER>   // NPER * 64 >= D: the centred row stays in registers between the two passes (NPER = 0: it is read twice)
 __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict__ x, const float* __restrict__ mu,
                                                         float* __restrict__ y, _Float16* __restrict__ yh, float* __restrict__ dens,
-                                                        int M, int D, int ldx, float eps, int mode) {
+                                                        float* __restrict__ resid, int M, int D, int ldx, float eps, int mode) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
   const float* xr = x + (size_t)row * ldx;
@@ -186,33 +187,44 @@ __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict_
   if (dens && lane == 0) dens[row] = den;
   float* yr = y ? y + (size_t)row * D : nullptr;
   _Float16* hr = yh + (size_t)row * D;
+  float rs = 0.f;     // sum of squares of the fp16 rounding residuals v - fp16(v) (each residual is exact in fp32)
   if constexpr (NPER > 0) {
 #pragma unroll
     for (int i = 0; i < NPER; ++i) {
       const int d = lane + 64 * i;
       if (d < D) {
         const float v = c[i] / den;
+        const _Float16 h = (_Float16)v;
         if (yr) yr[d] = v;
-        hr[d] = (_Float16)v;
+        hr[d] = h;
+        const float r = v - (float)h;
+        rs += r * r;
       }
     }
   } else {
     for (int d = lane; d < D; d += 64) {
       const float v = (xr[d] - (mu ? mu[d] : 0.f)) / den;
+      const _Float16 h = (_Float16)v;
       if (yr) yr[d] = v;
-      hr[d] = (_Float16)v;
+      hr[d] = h;
+      const float r = v - (float)h;
+      rs += r * r;
     }
+  }
+  if (resid) {
+    for (int o = 32; o > 0; o >>= 1) rs += __shfl_xor(rs, o);
+    if (lane == 0) resid[row] = sqrtf(rs);
   }
 }
 
-extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, int M, int D, int ldx,
-                             float eps, int mode, void* stream) {
+extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, float* resid, int M, int D,
+                             int ldx, float eps, int mode, void* stream) {
   LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
   if (M == 0) return LVC_OK;
   LVC_CHECK_ARG(x && yh, "null pointer");
   const dim3 grid(lvc_cdiv(M, 4)), block(256);
   const int ldxx = ldx > 0 ? ldx : D;
-#define RH_LAUNCH(N) hipLaunchKernelGGL(rownorm_h_kernel<N>, grid, block, 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, M, D, ldxx, eps, mode)
+#define RH_LAUNCH(N) hipLaunchKernelGGL(rownorm_h_kernel<N>, grid, block, 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, resid, M, D, ldxx, eps, mode)
   if (D <= 512) RH_LAUNCH(8);
   else if (D <= 1024) RH_LAUNCH(16);
   else if (D <= 2048) RH_LAUNCH(32);

@@ -359,7 +359,8 @@ template <int KTOP, int PER>
 __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
                                                                    const float* __restrict__ q, int ldq, const float* __restrict__ mu,
                                                                    const float* __restrict__ den, const float* __restrict__ sn,
-                                                                   int D, float margin, const long long* __restrict__ shot_classes,
+                                                                   int D, float margin_all, const float* __restrict__ margins,
+                                                                   const long long* __restrict__ shot_classes,
                                                                    const long long* __restrict__ det_classes, int kvote,
                                                                    long long* __restrict__ top_classes, long long* __restrict__ keep,
                                                                    int stop_after) {
@@ -368,6 +369,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
   if (row >= Q) return;     // whole waves leave; nothing below synchronises across waves
+  const float margin = margins ? margins[row] : margin_all;
   KvLds<KTOP>& L = s_L[w];
   const float* ar = approx + (size_t)row * ld;
   float v[PER];
@@ -555,12 +557,13 @@ extern "C" int lvc_knn_lower_bound(const float* sub, int ld, int Q, int n, float
 
 // approx [Q, ld] (S used columns) from lvc_gemm_f16 over the fp16 roundings of the normalised rows; q [Q, ldq] the RAW query
 // descriptors with mu [D] (or NULL) and den [Q] (or NULL) as lvc_rownorm_h used them (NULL, NULL: q already holds the normalised
-// rows); sn [S, D] the normalised shots (fp32).  D % 4 == 0, D <= 2048; margin >= 2 x the approximation error bound (the host
-// passes 2^-9 for unit-norm rows).
+// rows); sn [S, D] the normalised shots (fp32).  D % 4 == 0, D <= 2048; margin >= 2 x the approximation error bound (2^-9 covers
+// unit-norm rows in the worst case); margins [Q] (or NULL) replaces it row by row (the host passes 2 x the row's own bound from
+// the rounding residual norms lvc_rownorm_h measures: about half the worst case, so fewer exact re-evaluations).
 extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
-                                        const float* den, const float* sn, int D, float margin, const long long* shot_classes,
-                                        const long long* det_classes, int kvote, long long* top_classes, long long* keep,
-                                        void* stream) {
+                                        const float* den, const float* sn, int D, float margin, const float* margins,
+                                        const long long* shot_classes, const long long* det_classes, int kvote,
+                                        long long* top_classes, long long* keep, void* stream) {
   KV_CHECKS();
   LVC_CHECK_ARG(approx, "null pointer");
   LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
@@ -570,7 +573,7 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   const int ldd = ld > 0 ? ld : S;
   static const int stop_after = [] { const char* e = getenv("LVC_KV_STOP"); return e ? atoi(e) : 0; }();
 #define KV_LAUNCH(P) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, sn, D, \
-                                        margin, shot_classes, det_classes, kvote, top_classes, keep, stop_after)
+                                        margin, margins, shot_classes, det_classes, kvote, top_classes, keep, stop_after)
   if (per <= 8) KV_LAUNCH(8);
   else if (per <= 16) KV_LAUNCH(16);
   else if (per <= 24) KV_LAUNCH(24);

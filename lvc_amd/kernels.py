@@ -781,19 +781,20 @@ def knn_topk_vote(sims, num_shots, shot_classes, det_classes, k):
     return top, keep
 
 
-def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True):
+def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True, want_resid=False):
     """`rownorm` for the two-stage kNN sweep: (y fp32 [M,D] or None, yh fp16 [M,D], den [M]); y is bit-identical to
-    `rownorm`'s output and equals (x - mu) / den[:, None] exactly."""
+    `rownorm`'s output and equals (x - mu) / den[:, None] exactly.  want_resid: also resid [M] = |row - fp16(row)|_2."""
     _req_cuda(x, mu)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
     M, D = x.shape
     y = torch.empty(M, D, device=x.device, dtype=torch.float32) if want_rows else None
     yh = torch.empty(M, D, device=x.device, dtype=torch.float16)
     den = torch.empty(M, device=x.device, dtype=torch.float32)
-    rc = _lib.lib().lvc_rownorm_h(ptr(x), ptr(mu), ptr(y), ptr(yh), ptr(den), c_int(M), c_int(D), c_int(x.stride(0)),
+    resid = torch.empty(M, device=x.device, dtype=torch.float32) if want_resid else None
+    rc = _lib.lib().lvc_rownorm_h(ptr(x), ptr(mu), ptr(y), ptr(yh), ptr(den), ptr(resid), c_int(M), c_int(D), c_int(x.stride(0)),
                                   c_float(eps), c_int(mode), _stream(x))
     check(rc, "lvc_rownorm_h")
-    return y, yh, den
+    return (y, yh, den, resid) if want_resid else (y, yh, den)
 
 
 def gemm_f16(a, b, n=None, ldb=None):
@@ -857,12 +858,13 @@ def knn_verify_lists(lists, counts, q, sn, margin, shot_classes, det_classes, k,
     return top, keep
 
 
-def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None):
+def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None, margins=None):
     """approx [Q,S] from gemm_f16 over the fp16 roundings of the normalised rows; q [Q,D] the raw query descriptors with the
     mu / den `rownorm_h` used (or the normalised rows themselves with mu = den = None); sn [S,D] normalised shots.
     Exact top-10 classes + vote (csrc/knn.hip)."""
-    _req_cuda(approx, q, sn, shot_classes, det_classes, mu, den)
+    _req_cuda(approx, q, sn, shot_classes, det_classes, mu, den, margins)
     Q, S = approx.shape[0], sn.shape[0]
+    assert margins is None or (margins.dtype == torch.float32 and margins.is_contiguous() and margins.numel() == Q)
     assert approx.stride(1) == 1 and q.stride(1) == 1 and sn.is_contiguous() and shot_classes.dtype == torch.int64
     assert q.dtype == torch.float32 and sn.dtype == torch.float32 and q.shape[1] == sn.shape[1]
     top = torch.empty(Q, 10, dtype=torch.int64, device=approx.device)
@@ -871,8 +873,8 @@ def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu
         det_classes = det_classes.contiguous()
         assert det_classes.dtype == torch.int64
     rc = _lib.lib().lvc_knn_verify_topk_vote(ptr(approx), c_int(approx.stride(0)), c_int(Q), c_int(S), ptr(q), c_int(q.stride(0)),
-                                             ptr(mu), ptr(den), ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(shot_classes),
-                                             ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(approx))
+                                             ptr(mu), ptr(den), ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(margins),
+                                             ptr(shot_classes), ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(approx))
     check(rc, "lvc_knn_verify_topk_vote")
     return top, keep
 

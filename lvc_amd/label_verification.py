@@ -14,6 +14,8 @@ from . import kernels as K
 
 # LVC_KNN_TWO_STAGE=0: materialise the full-precision similarity matrix (three MFMAs per block) and rank it directly
 KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
+# LVC_KNN_ROW_MARGINS=0: the worst-case margin 2^-9 for every row instead of the per-row bound from the measured rounding residuals
+KNN_ROW_MARGINS = os.environ.get("LVC_KNN_ROW_MARGINS", "1") != "0"
 # LVC_KNN_EMIT=1 (experiment, measured slower: profiles/README.md round 2): the pre-filter GEMM appends per-row candidate lists
 # from its epilogue instead of writing the [Q, S] matrix
 KNN_EMIT = os.environ.get("LVC_KNN_EMIT", "0") == "1"
@@ -59,6 +61,16 @@ def assemble_tensors(shot_features):
     return classes[sorter], desc[sorter]
 
 
+def pre_filter_margins(qres, sh_max, sres_max, D):
+    """margin [Q] = 2 x the error bound of the fp16 pre-filter for each query row against ANY shot:
+        |q.s - q_h.s_h| = |(q - q_h).s_h + q.(s - s_h)| <= |q - q_h| |s_h| + |q| |s - s_h|      (Cauchy-Schwarz, twice)
+    with the residual norms `rownorm_h` measured (qres per row, the shots' largest), |q| <= 1 + 1e-5, plus 2 D 2^-24 for the
+    fp32 accumulation of the pre-filter and of the exact re-evaluation (|sum of rounding errors| <= D u sum |q_i s_i| <= D u).
+    About half of the worst case 2^-9 (`VERIFY_MARGIN`) on real rows: fewer shots inside the window, fewer exact dot products."""
+    eps = qres * sh_max + sres_max * (1.0 + 1e-5) + 2.0 * D * 2.0 ** -24
+    return (2.0 * (1.0 + 1e-4)) * eps
+
+
 def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classes=None, k=10, cosine=True):
     """shot_descriptors [S,D], shot_classes [S] int64, query_descriptors [Q,D] (device, fp32, D % 32 == 0).
     Returns (top10_shots [Q,10] int64 class ids, keep [Q] int64 or None)."""
@@ -74,7 +86,11 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
     if cosine:
         mu = K.colmean(shots)
         if two_stage:
-            sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
+            sn, sh, _, sres = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1, want_resid=True)
+            # pieces of the per-row error bound of the fp16 pre-filter (pre_filter_margins): the largest fp16-row norm and the
+            # largest rounding-residual norm over the shots
+            sh_max = sh.float().norm(dim=1).max()
+            sres_max = sres.max()
         else:
             sn = K.rownorm(shots, mu=mu, eps=1e-8, mode=1)
             pc = K.pack_linear(sn)
@@ -95,7 +111,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
         if two_stage:
             # fp16 similarities (one MFMA per block instead of three) as a pre-filter, exact fp32 re-evaluation of the few shots
             # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
-            _, qh, den = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False)
+            _, qh, den, qres = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False, want_resid=True)
+            margins = pre_filter_margins(qres, sh_max, sres_max, D)
             if KNN_EMIT:
                 # a lower bound of each row's 10th best similarity from a strided subset of <= 256 shots, then the full product
                 # with an epilogue that keeps only what can still matter (csrc/gemm_h.hip): no Q x S matrix in HBM
@@ -104,7 +121,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
                 lists, counts = K.gemm_f16_emit(qh, sh, lb, VERIFY_MARGIN)
                 t, kp = K.knn_verify_lists(lists, counts, qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
             else:
-                t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
+                t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den,
+                                               margins=margins if KNN_ROW_MARGINS else None)
         else:
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)

@@ -308,3 +308,30 @@ def test_knn_sweep_more_shots_than_a_kernel_row(cosine):
     ref_keep = oknn.get_nn_class_confirmatory(ref_top, qcls, 10)
     assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 3e-3
     assert (keep.cpu() != ref_keep).float().mean() <= 3e-3
+
+
+@pytest.mark.parametrize("Dm", [64, 384, 1024])
+def test_per_row_margins_bound_the_pre_filter_error(Dm):
+    """`pre_filter_margins` (2 x the per-row bound from the rounding-residual norms `rownorm_h` measures) really bounds
+    2 |fp16 pre-filter - fp64 product of the fp32 rows| for every (query, shot) pair -- random rows, rows with a few huge
+    entries (the worst case of an fp16 rounding), and rows that are tiny after centring -- and is tighter than the worst case."""
+    from lvc_amd import kernels as K
+    from lvc_amd.label_verification import VERIFY_MARGIN, pre_filter_margins
+
+    g = torch.Generator().manual_seed(Dm)
+    S, Q = 700, 2000
+    shots = torch.randn(S, Dm, generator=g) + 0.3
+    q = torch.randn(Q, Dm, generator=g) + 0.3
+    q[:50] = 0.3
+    q[:50, :3] += 40.0 * torch.randn(50, 3, generator=g)          # three dominant coordinates
+    q[50:60] = 0.3 + 1e-6 * torch.randn(10, Dm, generator=g)        # nearly the mean
+    shots[:20, 5] += 30.0
+    shots, q = shots.to(D), q.to(D)
+    mu = K.colmean(shots)
+    sn, sh, _, sres = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1, want_resid=True)
+    qn, qh, _, qres = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_resid=True)
+    assert torch.allclose(qres, (qn - qh.float()).norm(dim=1), rtol=1e-5, atol=1e-12)
+    margins = pre_filter_margins(qres, sh.float().norm(dim=1).max(), sres.max(), Dm)
+    err = (K.gemm_f16(qh, sh).double() - qn.double() @ sn.double().t()).abs().max(dim=1)[0]
+    assert (2.0 * err <= margins.double()).all()
+    assert margins.max().item() < VERIFY_MARGIN and margins.median().item() < 0.7 * VERIFY_MARGIN
