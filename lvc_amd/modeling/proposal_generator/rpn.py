@@ -176,6 +176,7 @@ class RPN(nn.Module):
         """reference rpn.py:269-325.  anchors: [R,4] tensor of all anchors; returns (labels [N,R] int8 in {-1,0,1},
         matched gt boxes [N,R,4])."""
         gt_labels, matched_gt_boxes = [], []
+        batched = self.batched_sampling and anchors.is_cuda and len(gt_instances) > 0
         for inst in gt_instances:
             gt = inst.gt_boxes.tensor
             matched_idxs, labels = self.anchor_matcher.match(gt, anchors)
@@ -184,13 +185,46 @@ class RPN(nn.Module):
                 t = self.anchor_boundary_thresh
                 inside = (anchors[:, 0] >= -t) & (anchors[:, 1] >= -t) & (anchors[:, 2] < w + t) & (anchors[:, 3] < h + t)
                 labels[~inside] = -1
-            pos_idx, neg_idx = subsample_labels(labels, self.batch_size_per_image, self.positive_fraction, 0)
-            labels.fill_(-1)
-            labels.scatter_(0, pos_idx, 1)
-            labels.scatter_(0, neg_idx, 0)
+            if not batched:
+                pos_idx, neg_idx = subsample_labels(labels, self.batch_size_per_image, self.positive_fraction, 0)
+                labels.fill_(-1)
+                labels.scatter_(0, pos_idx, 1)
+                labels.scatter_(0, neg_idx, 0)
             gt_labels.append(labels)
             matched_gt_boxes.append(torch.zeros_like(anchors) if len(gt) == 0 else gt[matched_idxs])
-        return torch.stack(gt_labels), torch.stack(matched_gt_boxes)
+        gt_labels = torch.stack(gt_labels)
+        if batched:
+            gt_labels = self._subsample_batched(gt_labels)
+        return gt_labels, torch.stack(matched_gt_boxes)
+
+    batched_sampling = True     # class switch for A/B runs and tests (False: subsample_labels image by image)
+
+    def _subsample_batched(self, labels):
+        """`subsample_labels` + the fill / scatter of the loop above for all images at once and without a device->host read
+        (per image the loop reads the device twice and sorts ~270 000 keys twice for its two `randperm`s): ONE random permutation
+        of the B*R keys, then per row the num_pos smallest keys among the positives and the num_neg smallest among the negatives
+        (`topk`).  Any subset of a random permutation is in uniformly random order, so this draws the same distribution; with
+        `torch.randperm` patched to arange (the parity tests) it is the reference's choice exactly: the first positives /
+        negatives in anchor order."""
+        B, R = labels.shape
+        dev = labels.device
+        bs = self.batch_size_per_image
+        cap_pos = int(bs * self.positive_fraction)
+        key = torch.randperm(B * R, device=dev).view(B, R)
+        big = B * R
+        pos, neg = labels == 1, labels == 0
+        kp, kn = min(cap_pos, R), min(bs, R)
+        tp = torch.topk(torch.where(pos, key, torch.full_like(key, big)), kp, dim=1, largest=False)[1]
+        tn = torch.topk(torch.where(neg, key, torch.full_like(key, big)), kn, dim=1, largest=False)[1]
+        npos = pos.sum(1).clamp(max=cap_pos)
+        nneg = torch.minimum(neg.sum(1), bs - npos)
+        out = torch.full((B, R + 1), -1, dtype=labels.dtype, device=dev)       # column R swallows the unused slots
+        jp = torch.arange(kp, device=dev)[None, :]
+        jn = torch.arange(kn, device=dev)[None, :]
+        out.scatter_(1, torch.where(jp < npos[:, None], tp, torch.full_like(tp, R)), 1)
+        out.scatter_(1, torch.where(jn < nneg[:, None], tn, torch.full_like(tn, R)), 0)
+        out[:, R] = -1
+        return out[:, :R].contiguous()
 
     def losses(self, anchors, flat_logits, gt_labels, flat_deltas, gt_boxes):
         """reference rpn.py:328-400 (smooth_l1 branch).  flat_logits [N,R], flat_deltas [N,R,4]."""

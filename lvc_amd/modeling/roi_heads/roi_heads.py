@@ -66,11 +66,82 @@ class ROIHeads(nn.Module):
 
     relabel_ignored_gt = True
 
+    batched_sampling = True     # class switch for A/B runs and tests (False: the per-image loop in every case)
+
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets, inference=False, log=None):
         """reference lvc roi_heads.py:173-278: append GT, match (IoU kernel), gt_ignores toggle, subsample.
         `log` (default: not inference) controls only the EventStorage scalars: CascadeROIHeads inherits detectron2's
         label_and_sample_proposals, whose evaluation call still subsamples and merely skips the logging."""
+        if (self.batched_sampling and not inference and self.proposal_append_gt and len(proposals) > 0
+                and all(len(t) > 0 and not (self.relabel_ignored_gt and t.has("gt_ignores")) for t in targets)
+                and all(p.proposal_boxes.tensor.is_cuda for p in proposals)):
+            return self._label_and_sample_batched(proposals, targets, (not inference) if log is None else log)
+        return self._label_and_sample_loop(proposals, targets, inference, log)
+
+    def _label_and_sample_batched(self, proposals, targets, log):
+        """The training case of the loop below for the whole batch with ONE device->host read (the per-image loop reads the device
+        ~5 times per image: `nonzero`, the fg / bg counts): labels of all images in one padded [B, W] table, the fg / bg subsets
+        drawn by ranking ONE random permutation of B*W keys within each row (any subset of a random permutation is in uniformly
+        random order, so this is `positive[randperm(n)[:num_pos]]` in distribution; with `torch.randperm` patched to arange
+        -- the parity tests -- it is the reference's selection exactly: the first num_pos positives, the first num_neg
+        negatives, fg before bg).  Needs: training, PROPOSAL_APPEND_GT, every image with at least one gt box and (for lvc's own
+        ROIHeads, which relabel proposals on ignored gt boxes) no gt_ignores field."""
+        import math
+
+        B, dev = len(proposals), proposals[0].proposal_boxes.tensor.device
+        K_, bs = self.num_classes, self.batch_size_per_image
+        gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+        ns = [len(p) + len(t) for p, t in zip(proposals, targets)]
+        W = max(max(ns), bs)
+        boxes = torch.zeros(B, W, 4, device=dev)
+        logits = torch.zeros(B, W, device=dev)
+        labels = torch.full((B, W), -1, dtype=torch.int64, device=dev)     # -1: ignored / padding
+        midx = torch.zeros(B, W, dtype=torch.int64, device=dev)
+        for i, (prop, tgt) in enumerate(zip(proposals, targets)):
+            gt, n, npr = tgt.gt_boxes.tensor, ns[i], len(prop)
+            boxes[i, :npr] = prop.proposal_boxes.tensor
+            boxes[i, npr:n] = gt
+            logits[i, :npr] = prop.objectness_logits
+            logits[i, npr:n] = gt_logit
+            m, l = self.proposal_matcher.match(gt, boxes[i, :n])
+            gc = tgt.gt_classes.to(torch.int64)[m]
+            labels[i, :n] = torch.where(l == 0, torch.full_like(gc, K_), torch.where(l == -1, torch.full_like(gc, -1), gc))
+            midx[i, :n] = m
+        key = torch.randperm(B * W, device=dev).view(B, W)
+        fg = (labels >= 0) & (labels != K_)
+        bg = labels == K_
+        big = B * W
+        sf = torch.argsort(torch.where(fg, key, torch.full_like(key, big)), dim=1)
+        sb = torch.argsort(torch.where(bg, key, torch.full_like(key, big)), dim=1)
+        npos = fg.sum(1).clamp(max=int(bs * self.positive_sample_fraction))
+        nneg = torch.minimum(bg.sum(1), bs - npos)
+        j = torch.arange(bs, device=dev)[None, :]
+        sampled = torch.where(j < npos[:, None], sf[:, :bs], torch.gather(sb, 1, (j - npos[:, None]).clamp(0, W - 1)))
+        s_boxes = torch.gather(boxes, 1, sampled[:, :, None].expand(B, bs, 4))
+        s_logits = torch.gather(logits, 1, sampled)
+        s_cls = torch.gather(labels, 1, sampled)
+        s_m = torch.gather(midx, 1, sampled)
+        counts = torch.stack([npos, nneg], 1).tolist()      # the one device->host read
+        out = []
+        for i, (prop, tgt) in enumerate(zip(proposals, targets)):
+            c = counts[i][0] + counts[i][1]
+            inst = Instances(prop.image_size)
+            inst.proposal_boxes = Boxes(s_boxes[i, :c])
+            inst.objectness_logits = s_logits[i, :c]
+            inst.gt_classes = s_cls[i, :c]
+            st = s_m[i, :c]
+            for name, val in tgt.get_fields().items():
+                if name.startswith("gt_") and not inst.has(name):
+                    inst.set(name, val[st])
+            out.append(inst)
+        if log:
+            storage = get_event_storage()
+            storage.put_scalar("roi_head/num_fg_samples", sum(c[0] for c in counts) / B)
+            storage.put_scalar("roi_head/num_bg_samples", sum(c[1] for c in counts) / B)
+        return out
+
+    def _label_and_sample_loop(self, proposals, targets, inference=False, log=None):
         out, num_fg, num_bg = [], [], []
         for prop, tgt in zip(proposals, targets):
             gt = tgt.gt_boxes.tensor
