@@ -420,3 +420,95 @@ def test_proposal_network_training_equals_rpn_part_of_the_detector(monkeypatch):
     with torch.no_grad():
         out = net([{"image": _batch(g)[0]["image"], "height": 240, "width": 320}])
     assert "proposals" in out[0] and len(out[0]["proposals"]) > 0
+
+
+def _random_proposals_and_targets(g, B=4, num_classes=20):
+    from lvc_amd.structures import Boxes, Instances
+
+    D = "cuda:0"
+    props, tgts = [], []
+    for i in range(B):
+        h, w = 300 + 20 * i, 400
+        ng = 2 + i
+        xy = torch.rand(ng, 2, generator=g) * torch.tensor([w * 0.5, h * 0.5])
+        wh = 30 + torch.rand(ng, 2, generator=g) * torch.tensor([w * 0.4, h * 0.4])
+        gt = torch.cat([xy, xy + wh], 1)
+        n = 900 + 37 * i
+        near = gt[torch.randint(0, ng, (n // 3,), generator=g)] + 8 * torch.randn(n // 3, 4, generator=g)   # high-IoU proposals
+        xy2 = torch.rand(n - n // 3, 2, generator=g) * torch.tensor([w * 0.7, h * 0.7])
+        far = torch.cat([xy2, xy2 + 10 + torch.rand(n - n // 3, 2, generator=g) * 120], 1)
+        boxes = torch.cat([near, far])[torch.randperm(n, generator=g)]
+        p = Instances((h, w))
+        p.proposal_boxes = Boxes(boxes.to(D))
+        p.objectness_logits = torch.randn(n, generator=g).to(D)
+        t = Instances((h, w))
+        t.gt_boxes = Boxes(gt.to(D))
+        t.gt_classes = torch.randint(0, num_classes, (ng,), generator=g).to(D)
+        props.append(p)
+        tgts.append(t)
+    return props, tgts
+
+
+def test_batched_proposal_sampling_equals_the_per_image_loop(monkeypatch):
+    """`ROIHeads._label_and_sample_batched` (one device read per batch) against the per-image loop (the reference's steps one by
+    one): identical Instances when `torch.randperm` is the identity (the parity tests' convention); with the real RNG the
+    sample keeps the reference's invariants (512 per image, at most 128 foreground, no proposal twice, labels untouched)."""
+    from lvc_amd.utils.events import EventStorage
+
+    model = _train_model()
+    heads = model.roi_heads
+    g = torch.Generator().manual_seed(12)
+    props, tgts = _random_proposals_and_targets(g)
+    with EventStorage(0), monkeypatch.context() as mp:
+        mp.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+        a = heads._label_and_sample_batched(props, tgts, True)
+        b = heads._label_and_sample_loop(props, tgts, False, None)
+    for x, y in zip(a, b):
+        assert len(x) == len(y) == heads.batch_size_per_image
+        for f in ("objectness_logits", "gt_classes"):
+            assert torch.equal(x.get(f), y.get(f)), f
+        assert torch.equal(x.proposal_boxes.tensor, y.proposal_boxes.tensor) and torch.equal(x.gt_boxes.tensor, y.gt_boxes.tensor)
+    with EventStorage(0):
+        torch.manual_seed(3)
+        c = heads._label_and_sample_batched(props, tgts, True)
+        d = heads._label_and_sample_batched(props, tgts, True)
+    assert not all(torch.equal(x.proposal_boxes.tensor, y.proposal_boxes.tensor) for x, y in zip(c, d)), "two draws, same sample"
+    K_ = heads.num_classes
+    for x, ref in zip(c, b):
+        fg = x.gt_classes != K_
+        assert len(x) == 512 and int(fg.sum()) <= 128 and int(fg.sum()) == int((ref.gt_classes != K_).sum())
+        assert bool((x.gt_classes[: int(fg.sum())] != K_).all()), "foreground first"
+        assert torch.unique(x.proposal_boxes.tensor, dim=0).shape[0] == 512
+
+
+def test_batched_anchor_sampling_equals_the_per_image_loop(monkeypatch):
+    """`RPN._subsample_batched` against `subsample_labels` image by image: identical labels with the identity permutation; with
+    the real RNG 256 labelled anchors per image, at most 128 positive, all drawn from the matching labels."""
+    from lvc_amd.modeling.sampling import subsample_labels
+
+    model = _train_model()
+    rpn = model.proposal_generator
+    g = torch.Generator().manual_seed(8)
+    B, R = 3, 50000
+    raw = torch.full((B, R), -1, dtype=torch.int8)
+    raw[torch.rand(B, R, generator=g) < 0.7] = 0
+    raw[torch.rand(B, R, generator=g) < 0.004] = 1
+    raw[2] = torch.where(torch.rand(R, generator=g) < 0.0005, torch.ones(R, dtype=torch.int8), raw[2].clamp(max=0))   # few positives
+    raw = raw.to("cuda:0")
+    with monkeypatch.context() as mp:
+        mp.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+        got = rpn._subsample_batched(raw.clone())
+        want = []
+        for i in range(B):
+            lab = raw[i].clone()
+            p, n = subsample_labels(lab, rpn.batch_size_per_image, rpn.positive_fraction, 0)
+            lab.fill_(-1)
+            lab.scatter_(0, p, 1)
+            lab.scatter_(0, n, 0)
+            want.append(lab)
+    assert torch.equal(got, torch.stack(want))
+    torch.manual_seed(1)
+    r = rpn._subsample_batched(raw.clone())
+    assert ((r >= 0).sum(1) == rpn.batch_size_per_image).all() and ((r == 1).sum(1) <= 128).all()
+    assert bool(((r == 1) <= (raw == 1)).all()) and bool(((r == 0) <= (raw == 0)).all())
+    assert int((r[2] == 1).sum()) == int((raw[2] == 1).sum())     # fewer positives than the cap: all of them are kept
