@@ -550,7 +550,7 @@ def infer_main(c, args):
         print(json.dumps(line))
 
 
-def _live_conv_pmc(timeout_s=150):
+def _live_conv_pmc(timeout_s=90):
     """HBM-side traffic and matrix-pipe occupancy of the dominant kernel's largest launch (3x3 256 -> 256 on the batch's p2 map:
     fpn_output2 / rpn_head.conv), measured on THIS box: three rocprofv3 passes (--pmc FETCH_SIZE | --pmc WRITE_SIZE | the SQ
     counters; each with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of scripts/probe_one.py in a subprocess.
