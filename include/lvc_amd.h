@@ -88,6 +88,14 @@ int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_split, const
 int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                            const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* The RPN head in one launch (detectron2/modeling/proposal_generator/rpn.py:108-127): conv 3x3 s1 p1 + affine + ReLU, then a
+ * 1x1 predictor layer (objectness_logits | anchor_deltas fused into one [pK, K] matrix) applied to each output tile while it
+ * is still in LDS -- the K-channel hidden map never reaches HBM.  pred_w_split: fp16 planes [2][32][K] of the predictor
+ * weights zero-padded to 32 rows (lvc_split_weights), pred_bias [pK]; pout [N*H*W, ldp] fp32 is zeroed by the call and
+ * receives one atomic add per element and 128-channel half (two addends: order-independent).  K % 128 == 0, pK <= 32. */
+int lvc_conv3x3_relu_pred_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                     int N, int H, int W, int C, int K, int Kg, const unsigned short* pred_w_split,
+                                     const float* pred_bias, float* pout, int pK, int ldp, void* workspace, void* stream);
 
 /* Two-way fp16 split form of the POINTWISE shapes of lvc_conv2d_nhwc_bf16x3 (csrc/conv_f16x2.hip): R = S = 1, pad 0
  * and (C <= 512 or N*Ho*Wo >= 2048); anything else returns LVC_ERR_INVALID.  w_split as lvc_conv3x3_nhwc_f16x2. */

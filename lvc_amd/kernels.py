@@ -282,6 +282,11 @@ FUSE_PROJECTION = _os.environ.get("LVC_FUSE_PROJECTION", "1") != "0"
 _H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "64"))   # 64-channel streams too since the LDS-DMA kernel (0.32 -> 0.27 ms on res2 conv3)
 # pointwise fp16x2 layers on the LDS-DMA kernel (csrc/conv_pw_dma.hip); 0 = the register-staged conv_pw256_f16x2_kernel
 PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
+# experiment (LVC_RPN_FUSED_PRED=1): the RPN head's 3x3 conv + ReLU + 1x1 predictors as one launch where the 3x3 runs on the fp16x2
+# halo kernel (no hidden map in HBM).  Parity-tested; measured SLOWER (p2: 1.81 - 1.93 vs 1.75 - 1.79 ms, bench 537 vs 544 img/s):
+# the 3x3 kernel is bound by the matrix pipe, its output stores were already hidden, and the predictor epilogue (LDS round trip,
+# 24 MFMAs, 512 atomics per wave and tile) costs more than the 0.14 ms predictor launch it replaces
+RPN_FUSED_PRED = _os.environ.get("LVC_RPN_FUSED_PRED", "0") == "1"
 _HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -359,6 +364,40 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e1.record()
         c_real = 3 if pc.mode == 1 else C
         timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1, engine))
+    return out
+
+
+def split_planes_f16x2(w):
+    """[2, *w.shape] fp16 planes (w1 = fp16(w), w2 = fp16((w - w1) * 2048)) of an fp32 tensor (lvc_split_weights)."""
+    _req_cuda(w)
+    w = w.detach().float().contiguous()
+    out = torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.float16)
+    check(_lib.lib().lvc_split_weights(ptr(w), c_longlong(w.numel()), c_int(2), ptr(out), ptr(_conv_error_view(w.device)), _stream(w)),
+          "lvc_split_weights")
+    return out
+
+
+def can_fuse_conv3x3_pred(x, pc):
+    """The shapes `conv3x3_relu_pred` takes: the 3x3 layers conv2d_nhwc would put on the two-way fp16 halo kernel, K % 128 == 0."""
+    N, H, W, C = x.shape
+    return (CONV_ENGINE == "bf16x3" and CONV_SPLIT == "f16x2" and CONV_HALO and RPN_FUSED_PRED and pc.mode == 0 and pc.R == 3 and pc.S == 3
+            and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0 and pc.K % 128 == 0
+            and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES)
+
+
+def conv3x3_relu_pred(x, pc, pred_planes, pred_bias, pK):
+    """relu(conv3x3(x) * scale + shift) followed by the 1x1 predictor (planes from `split_planes_f16x2` of the zero-padded
+    [32, K] weight matrix), hidden map kept on chip (lvc_conv3x3_relu_pred_nhwc_f16x2).  Returns [N,H,W,pK_padded_to_4]."""
+    _req_cuda(x, pred_planes, pred_bias)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    N, H, W, C = x.shape
+    assert C == pc.C and pred_planes.shape == (2, 32, pc.K) and pred_planes.is_contiguous()
+    ldp = (pK + 3) // 4 * 4
+    out = torch.empty(N, H, W, ldp, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().lvc_conv3x3_relu_pred_nhwc_f16x2(ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), c_int(N), c_int(H), c_int(W),
+                                                     c_int(C), c_int(pc.K), c_int(pc.Kg), ptr(pred_planes), ptr(pred_bias), ptr(out),
+                                                     c_int(pK), c_int(ldp), ptr(conv_workspace(x.device)), _stream(x))
+    check(rc, "lvc_conv3x3_relu_pred_nhwc_f16x2")
     return out
 
 

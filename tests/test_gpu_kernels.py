@@ -591,3 +591,39 @@ def test_preprocess_batch_equals_per_image():
         for i, im in enumerate(imgs):
             K.preprocess_into(im, b[i], mean, std)
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 200, 336), (8, 100, 168), (1, 67, 93)])
+def test_rpn_head_fused_predictors_equal_the_two_launch_form(shape, monkeypatch):
+    """lvc_conv3x3_relu_pred_nhwc_f16x2 (conv 3x3 + ReLU + objectness | deltas on the tile in LDS, no hidden map in HBM)
+    against the same head as conv launch + predictor launch: equal to fp32 summation-order noise (the fused form adds the two
+    128-channel halves with one atomic each), on tile-edge shapes too.  An experiment switch (measured slower, kernels.py)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.proposal_generator.rpn import StandardRPNHead
+
+    N, H, W = shape
+    torch.manual_seed(0)
+    head = StandardRPNHead(in_channels=256, num_anchors=3).to("cuda:0")
+    with torch.no_grad():
+        head.conv.weight.normal_(0, 0.02)
+        head.conv.bias.normal_(0, 0.1)
+        head.objectness_logits.weight.normal_(0, 0.05)
+        head.anchor_deltas.weight.normal_(0, 0.05)
+        head.objectness_logits.bias.normal_(0, 0.5)
+        head.anchor_deltas.bias.normal_(0, 0.5)
+    x = torch.randn(N, H, W, 256, device="cuda:0").abs()
+    calls = []
+    orig = K.conv3x3_relu_pred
+    monkeypatch.setattr(K, "conv3x3_relu_pred", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    monkeypatch.setattr(K, "_HALO_H2_MIN_TILES", 0)
+    monkeypatch.setattr(K, "RPN_FUSED_PRED", True)
+    with torch.no_grad():
+        fused = head.forward_nhwc([x])[0]
+        assert len(calls) == 1
+        monkeypatch.setattr(K, "RPN_FUSED_PRED", False)
+        plain = head.forward_nhwc([x])[0]
+        assert len(calls) == 1
+    assert fused.shape == plain.shape
+    scale = float(plain[..., :15].abs().max())
+    assert float((fused[..., :15] - plain[..., :15]).abs().max()) <= 2e-6 * scale
+    K.check_conv_error_word(x.device)
