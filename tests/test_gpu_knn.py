@@ -335,3 +335,30 @@ def test_per_row_margins_bound_the_pre_filter_error(Dm):
     err = (K.gemm_f16(qh, sh).double() - qn.double() @ sn.double().t()).abs().max(dim=1)[0]
     assert (2.0 * err <= margins.double()).all()
     assert margins.max().item() < VERIFY_MARGIN and margins.median().item() < 0.7 * VERIFY_MARGIN
+
+
+def test_knn_sweep_edge_sizes():
+    """No queries, one query, the minimum of ten shots, an odd number of shots, duplicate shots (exact ties -> lower index) and a
+    zero query row (its normalised row is 0: every similarity ties at 0 -> the first ten shots)."""
+    from lvc_amd.label_verification import knn_sweep
+    from oracle import knn as oknn
+
+    g = torch.Generator().manual_seed(2)
+    Dm = 64
+    for S, Q in [(10, 0), (10, 1), (11, 5), (333, 1), (64, 70)]:
+        classes = torch.randint(0, 5, (S,), generator=g)
+        shots = torch.randn(S, Dm, generator=g) + 0.2
+        if S >= 64:
+            shots[7] = shots[3]                                    # an exact duplicate
+        q = torch.randn(Q, Dm, generator=g) + 0.2
+        det = torch.randint(0, 5, (Q,), generator=g)
+        if Q >= 5:
+            q[2] = shots.mean(0)                                   # centred row = 0
+            q[3] = shots[3]                                        # ties with the duplicate pair at the top
+        top, keep = knn_sweep(classes.to(D), shots.to(D), q.to(D), det.to(D), 10, True)
+        assert top.shape == (Q, 10) and keep.shape == (Q,)
+        if Q:
+            ref_top = oknn.dense(classes, shots, q, True)
+            ref_keep = oknn.get_nn_class_confirmatory(ref_top, det, 10)
+            rows = [i for i in range(Q) if not (Q >= 5 and i == 2)]     # the zero row: similarities are rounding noise around 0
+            assert torch.equal(top.cpu()[rows], ref_top[rows]) and torch.equal(keep.cpu()[rows], ref_keep[rows])
