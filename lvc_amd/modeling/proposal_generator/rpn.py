@@ -114,6 +114,26 @@ class StandardRPNHead(nn.Module):
         return [to_nchw_view(t[..., :A]) for t in fused], [to_nchw_view(t[..., A:A + A * Bd]) for t in fused]
 
 
+class _MatchedGT:
+    """The matched gt box of every anchor, kept as (gt boxes, matched index) per image and gathered for chosen anchors only."""
+
+    def __init__(self, per_image):
+        gts = [g for g, _ in per_image]
+        dev = per_image[0][1].device
+        self.table = torch.cat(gts + [torch.zeros(1, 4, device=dev, dtype=gts[0].dtype)], 0)     # last row: images without gt
+        n = [len(g) for g in gts]
+        zero_row = sum(n)
+        base, o = [], 0
+        for k in n:
+            base.append(o if k else zero_row)      # an image without gt has matched index 0 everywhere -> the zero row
+            o += k
+        self.base = torch.tensor(base, dtype=torch.int64, device=dev)
+        self.midx = torch.stack([m for _, m in per_image])
+
+    def gather(self, img, idx):
+        return self.table[self.midx[img, idx] + self.base[img]]
+
+
 class _FusedPredictorFn(torch.autograd.Function):
     """objectness_logits | anchor_deltas as ONE 1x1 conv over the hidden map (forward: `fused_predictor`); backward
     splits the fused weight / bias gradient back onto the two reference parameters (rpn.py:92-106)."""
@@ -194,10 +214,11 @@ class RPN(nn.Module):
 
     # ------------------------------------------------------------------ training
     @torch.no_grad()
-    def label_and_sample_anchors(self, anchors, gt_instances):
+    def label_and_sample_anchors(self, anchors, gt_instances, lazy=False):
         """reference rpn.py:269-325.  anchors: [R,4] tensor of all anchors; returns (labels [N,R] int8 in {-1,0,1},
-        matched gt boxes [N,R,4])."""
-        gt_labels, matched_gt_boxes = [], []
+        matched gt boxes [N,R,4]).  lazy (the training forward): the second value is a `_MatchedGT` that gathers the gt boxes of
+        the SAMPLED anchors only (`losses` needs 256 per image, not the [N,R,4] table: 34 MB per step at 268 569 anchors)."""
+        gt_labels, matched_gt_boxes, matched = [], [], []
         batched = self.batched_sampling and anchors.is_cuda and len(gt_instances) > 0
         for inst in gt_instances:
             gt = inst.gt_boxes.tensor
@@ -213,11 +234,14 @@ class RPN(nn.Module):
                 labels.scatter_(0, pos_idx, 1)
                 labels.scatter_(0, neg_idx, 0)
             gt_labels.append(labels)
-            matched_gt_boxes.append(torch.zeros_like(anchors) if len(gt) == 0 else gt[matched_idxs])
+            if lazy:
+                matched.append((gt, matched_idxs))
+            else:
+                matched_gt_boxes.append(torch.zeros_like(anchors) if len(gt) == 0 else gt[matched_idxs])
         gt_labels = torch.stack(gt_labels)
         if batched:
             gt_labels = self._subsample_batched(gt_labels)
-        return gt_labels, torch.stack(matched_gt_boxes)
+        return gt_labels, (_MatchedGT(matched) if lazy else torch.stack(matched_gt_boxes))
 
     batched_sampling = True     # class switch for A/B runs and tests (False: subsample_labels image by image)
 
@@ -258,11 +282,12 @@ class RPN(nn.Module):
         storage.put_scalar("rpn/num_neg_anchors", float((gt_labels == 0).sum()) / num_images)
         img, idx = (gt_labels >= 0).nonzero(as_tuple=True)
         norm = float(self.batch_size_per_image * num_images)
+        gtb = gt_boxes.gather(img, idx) if isinstance(gt_boxes, _MatchedGT) else gt_boxes[img, idx]
         if torch.is_grad_enabled() and flat_logits.requires_grad:
-            out = _RpnLossFn.apply(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gt_boxes[img, idx],
+            out = _RpnLossFn.apply(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gtb,
                                    gt_labels[img, idx], self.smooth_l1_beta, norm)
         else:
-            out = K.rpn_losses(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gt_boxes[img, idx],
+            out = K.rpn_losses(flat_logits[img, idx], flat_deltas[img, idx], anchors[idx], gtb,
                                gt_labels[img, idx], self.smooth_l1_beta, norm)
         return {"loss_rpn_cls": out[0] * self.loss_weight.get("loss_rpn_cls", 1.0),
                 "loss_rpn_loc": out[1] * self.loss_weight.get("loss_rpn_loc", 1.0)}
@@ -284,7 +309,7 @@ class RPN(nn.Module):
             flat_logits = torch.cat([f[..., :A].reshape(N, -1) for f in fused], 1)
             flat_deltas = torch.cat([f[..., A:5 * A].reshape(N, -1, 4) for f in fused], 1)
             anchors = torch.cat(self.anchor_generator._grid_anchors([f.shape[1:3] for f in flist]), 0)
-            gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances)
+            gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances, lazy=True)
             losses = self.losses(anchors, flat_logits, gt_labels, flat_deltas, gt_boxes)
             with torch.no_grad():
                 boxes, logits, count = self.predict_proposals_batched(feats, sizes, fused=fused)
