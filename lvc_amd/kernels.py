@@ -287,7 +287,7 @@ PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
 # the 3x3 kernel is bound by the matrix pipe, its output stores were already hidden, and the predictor epilogue (LDS round trip,
 # 24 MFMAs, 512 atomics per wave and tile) costs more than the 0.14 ms predictor launch it replaces
 RPN_FUSED_PRED = _os.environ.get("LVC_RPN_FUSED_PRED", "0") == "1"
-_HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
+_HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None):
