@@ -35,6 +35,7 @@ struct RoiAlignArgs {
   float* out;
   long long so_k, so_c, so_h, so_w;  // output strides (elements)
   int* status;                   // device status word (bit 0: negative RoI size with aligned=true)
+  int xcd_rows;                  // LDS-staged forward: the output rows of a RoI on one XCD (LVC_ROI_XCD_ROWS, default 1)
 };
 
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(RoiAlignArgs p) {
@@ -197,8 +198,20 @@ __global__ __launch_bounds__(64) void roi_align_fwd_nhwc4_kernel(RoiAlignArgs p)
 __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArgs p) {
   __shared__ __attribute__((aligned(16))) float win[ROI_LDS_MAX_PIX * 256];
   const int tid = threadIdx.x;
-  const int k = blockIdx.x / p.ph;
-  const int ph = blockIdx.x - k * p.ph;
+  // workgroup -> (RoI, output row).  The hardware deals consecutive workgroups to the 8 XCDs in turn; the rows of one RoI read
+  // overlapping feature rows and the same columns, so they are kept on ONE XCD (one fetch of the window into that L2 instead of
+  // one per XCD): groups of p.ph consecutive slots of an XCD form a RoI, RoIs are dealt to the XCDs round robin
+  int k, ph;
+  if (p.xcd_rows) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = slot / p.ph;
+    ph = slot - g * p.ph;
+    k = g * 8 + xcd;
+    if (k >= p.K) return;
+  } else {
+    k = blockIdx.x / p.ph;
+    ph = blockIdx.x - k * p.ph;
+  }
   const int cbase = blockIdx.y * 256;
   const int cq = tid & 63, bin = tid >> 6;   // bin = pw (8 slots, p.pw <= 8 used)
   const float* r = p.rois + (long long)k * 5;
@@ -289,7 +302,9 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArg
 static int launch(RoiAlignArgs& a, void* stream) {
   if (a.K == 0) return LVC_OK;
   if (a.nhwc && (a.C & 255) == 0 && a.pw <= 8 && a.num_valid == nullptr && a.so_c == 1 && !getenv("LVC_ROI_DIRECT")) {
-    dim3 gridl(a.K * a.ph, a.C / 256), blockl(512);
+    static const int xcd_rows = [] { const char* e = getenv("LVC_ROI_XCD_ROWS"); return e ? atoi(e) : 1; }();
+    a.xcd_rows = xcd_rows;
+    dim3 gridl(xcd_rows ? lvc_cdiv(a.K, 8) * 8 * a.ph : a.K * a.ph, a.C / 256), blockl(512);
     hipLaunchKernelGGL(roi_align_fwd_nhwc_lds_kernel, gridl, blockl, 0, (hipStream_t)stream, a);
     LVC_CHECK_LAUNCH();
     return LVC_OK;
