@@ -444,11 +444,11 @@ def infer_main(c, args):
 
         pipe = PipelinedInference(model, args.pipeline_depth)
         for _ in range(2 * args.pipeline_depth):
-            pipe.submit(batch)
+            pipe.submit(batch, collectable=False)
         _barrier(c)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            pipe.submit(batch)
+            pipe.submit(batch, collectable=False)
         _barrier(c)
         pdt = time.perf_counter() - t1
         pipe.synchronize()

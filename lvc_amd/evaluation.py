@@ -20,43 +20,72 @@ from . import kernels as K
 from .modeling.roi_heads.roi_heads import CandidateOverflow, instances_from_batched, widen_limits
 
 
+def _limits(model):
+    """The widenable limits a pass is launched under (`roi_heads.widen_limits`): (candidate-list capacity, operand split)."""
+    heads = getattr(model, "roi_heads", None)
+    return (getattr(heads, "det_max_candidates", None), K.CONV_SPLIT)
+
+
 class PipelinedInference:
     def __init__(self, model, depth=2):
         assert depth >= 1
         self.model = model
         self.streams = [torch.cuda.Stream(device=model.device) for _ in range(depth)]
+        self._busy = [False] * depth   # one uncollected ticket per stream: the conv error word lives in the stream's workspace
         self._n = 0
 
-    def submit(self, batched_inputs, do_postprocess=True):
-        """Launch one batch; returns a ticket for `collect`.  Nothing is synchronised here."""
-        s = self.streams[self._n % len(self.streams)]
+    def submit(self, batched_inputs, do_postprocess=True, collectable=True):
+        """Launch one batch; returns a ticket for `collect`.  Nothing is synchronised here.  A stream carries one
+        uncollected batch at a time (its status / error words are per stream), so at most `depth` tickets are open.
+        collectable=False: a throughput-only launch (timing loops) whose results are never read; no ticket."""
+        k = self._n % len(self.streams)
+        if not collectable:
+            s = self.streams[k]
+            self._n += 1
+            s.wait_stream(torch.cuda.current_stream(self.model.device))
+            with torch.cuda.stream(s), torch.no_grad():
+                self.model.inference_batched(batched_inputs, do_postprocess)
+            return None
+        if self._busy[k]:
+            raise RuntimeError("PipelinedInference: collect() the oldest ticket before submitting batch %d "
+                               "(depth %d)" % (self._n, len(self.streams)))
+        s = self.streams[k]
         self._n += 1
+        self._busy[k] = True
         s.wait_stream(torch.cuda.current_stream(self.model.device))   # inputs produced on the caller's stream
+        limits = _limits(self.model)
         with torch.cuda.stream(s), torch.no_grad():
             out = self.model.inference_batched(batched_inputs, do_postprocess)
         sizes = []
         for inp in batched_inputs:
             ref = inp["image"].shape[-2:] if "image" in inp else inp["raw"].shape[:2]
             sizes.append((inp.get("height", int(ref[0])), inp.get("width", int(ref[1]))))
-        return (out, s, sizes, batched_inputs, do_postprocess)
+        return (out, s, sizes, batched_inputs, do_postprocess, k, limits)
 
     def collect(self, ticket):
         """Wait for that batch only and build its `Instances` (the reference's per-image output dicts)."""
-        (ob, osc, ocl, cnt, status), s, sizes, batched_inputs, do_postprocess = ticket
+        (ob, osc, ocl, cnt, status), s, sizes, batched_inputs, do_postprocess, k, limits = ticket
+        cur = torch.cuda.current_stream(self.model.device)
+        rerun = False
         with torch.cuda.stream(s):
             try:
                 insts = instances_from_batched(ob, osc, ocl, cnt, sizes, status)   # one D2H read on that stream
             except (CandidateOverflow, K.Fp16RangeError) as e:
-                # a limit the reference does not have was hit by this batch: widen it and run the batch again, here
-                if not widen_limits(self.model, e):
+                # a limit the reference does not have was hit by this batch.  Widen it (a no-op when an earlier ticket
+                # already did) and run the batch again if it was LAUNCHED under narrower limits than the current ones --
+                # batches submitted before the widening overflow one after the other and each needs its own re-run.
+                widen_limits(self.model, e)
+                if _limits(self.model) == limits:
+                    self._busy[k] = False
                     raise
-                with torch.no_grad():
-                    return self.model.inference(batched_inputs, do_postprocess=do_postprocess)
-        # the results were allocated and written on the side stream: order the caller's stream behind it and tell the
-        # caching allocator that the caller's stream uses them too
-        cur = torch.cuda.current_stream(self.model.device)
+                rerun = True
+        self._busy[k] = False
+        # the results were allocated and written on the side stream: order the caller's stream behind it
         cur.wait_stream(s)
-        for t in (ob, osc, ocl, cnt):
+        if rerun:
+            with torch.no_grad():   # on the caller's stream: the outputs then belong to it like any other result
+                return self.model.inference(batched_inputs, do_postprocess=do_postprocess)
+        for t in (ob, osc, ocl, cnt):   # tell the caching allocator that the caller's stream uses them too
             t.record_stream(cur)
         return [{"instances": r} for r in insts]
 
@@ -72,10 +101,10 @@ def inference_on_dataset(model, data_loader, depth=2):
     pipe = PipelinedInference(model, depth)
     pending = collections.deque()
     for inputs in data_loader:
-        pending.append((inputs, pipe.submit(inputs)))
-        if len(pending) > depth:
+        if len(pending) == depth:      # the stream the next batch goes to still carries the oldest one
             i, t = pending.popleft()
             yield i, pipe.collect(t)
+        pending.append((inputs, pipe.submit(inputs)))
     while pending:
         i, t = pending.popleft()
         yield i, pipe.collect(t)

@@ -197,6 +197,15 @@ class Fp16RangeError(LvcNativeError):
 
 
 _RANGE_FALLBACK_LOGGED = False
+_LOGGED_ONCE = set()
+
+
+def _log_once(key, msg, *args):
+    if key not in _LOGGED_ONCE:
+        _LOGGED_ONCE.add(key)
+        import logging
+
+        logging.getLogger("lvc_amd").warning(msg, *args)
 
 
 def use_range_free_split(reason=""):
@@ -339,7 +348,13 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
         elif engine == "f16x2_pw":
-            fn = "lvc_conv2d_nhwc_f16x2_dma" if PW_DMA and out.numel() < (1 << 29) and (residual is None or residual.numel() < (1 << 29)) else "lvc_conv2d_nhwc_f16x2"
+            # the LDS-DMA kernel addresses outputs / residuals through 32-bit buffer descriptors (< 2^29 elements) and moves
+            # residual rows in 32-channel chunks; anything else stays on the register-staged kernel (logged once)
+            dma_ok = out.numel() < (1 << 29) and (residual is None or (residual.numel() < (1 << 29) and pc.K % 32 == 0))
+            if PW_DMA and not dma_ok:
+                _log_once("pw_dma_fallback", "pointwise layer %dx%d->%d (%d output elements) is outside the LDS-DMA kernel's "
+                          "range; it runs on the register-staged fp16x2 kernel", N * H * W, C, pc.K, out.numel())
+            fn = "lvc_conv2d_nhwc_f16x2_dma" if PW_DMA and dma_ok else "lvc_conv2d_nhwc_f16x2"
             st = getattr(_lib.lib(), fn)(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),

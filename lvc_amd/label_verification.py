@@ -43,7 +43,7 @@ def get_descriptors(model, data_loader, pixel_mean, pixel_std):
     with torch.no_grad():
         for data in data_loader:
             crops = preprocess_crops(data, pixel_mean, pixel_std).to(model.device)
-            feats = model(crops) if len(crops) else torch.zeros(0, model.embed_dim)
+            feats = _descriptor_pass(model, crops) if len(crops) else torch.zeros(0, model.embed_dim)
             item = data[0]
             item.pop("image", None)
             item["instances"].remove("crops")
@@ -51,6 +51,21 @@ def get_descriptors(model, data_loader, pixel_mean, pixel_std):
             item["instances"] = item["instances"].to("cpu")
             out.append(item)
     return out
+
+
+def _descriptor_pass(model, crops):
+    """One batch of crops through the descriptor network.  Its Linear layers run on the fp16x2 split kernels, so the pass
+    ends by reading the conv range word (as the detector passes do): an activation beyond fp16's range repeats the batch on
+    the range-free bf16x3 kernels instead of returning invalid descriptors (and instead of leaving the bit for the next
+    detector pass to trip over)."""
+    from .modeling.roi_heads.roi_heads import run_with_fallbacks
+
+    def once():
+        feats = model(crops)
+        K.check_conv_error_word(crops.device)
+        return feats
+
+    return run_with_fallbacks(model, once)
 
 
 def assemble_tensors(shot_features):

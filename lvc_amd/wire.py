@@ -185,17 +185,33 @@ def save_pseudo_label_dataset(meta_dataset, annotations, images, dt_path, K_min,
 
 
 def create_coco_dataset_from_dets(gt_dataset, category_dataset, results_rows, train_imgs, dt_path, K_min, K_max, top=False,
-                                  full=False, ar=0.0, category_ids=None, full_dataset=False):
+                                  full=False, ar=0.0, category_ids=None, full_dataset=False, all_cats=False):
     """The reference tool's main() (:240-263) on loaded json: `gt_dataset` supplies the image table, `category_dataset`
-    the categories and every other top-level key of the output (with `full_dataset` the detections file itself supplies
-    them), `results_rows` the detector's rows (or, with `full_dataset`, complete annotation rows)."""
-    index = DetectionIndex(gt_dataset["images"], results_rows, category_dataset.get("categories"), full_dataset)
-    cats = category_ids if category_ids is not None else novel_category_ids(category_dataset["categories"])
+    the categories and every other top-level key of the output, `results_rows` the detector's rows.  With `full_dataset`
+    (`--full-dataset`: the detections file is itself a COCO document, `COCO_PK.loadRes` :48-50) `results_rows` is that
+    document: its `annotations` are complete rows indexed over ITS image table, and save_coco (:196-200) copies ITS
+    top-level keys; the returned images still come from `gt_dataset` (`coco_gt.loadImgs`, :259).  `all_cats`
+    (`--all-cats`): every category id in ascending order instead of the novel ones (:256) and the `_allcats` file suffix."""
+    if full_dataset:
+        if not isinstance(results_rows, dict):
+            raise TypeError("full_dataset: pass the loaded detections document (a COCO dict with annotations / images)")
+        dt_doc = results_rows
+        index = DetectionIndex(dt_doc["images"], dt_doc["annotations"], category_dataset.get("categories"), True)
+    else:
+        dt_doc = None
+        index = DetectionIndex(gt_dataset["images"], results_rows, category_dataset.get("categories"), False)
+    if category_ids is not None:
+        cats = category_ids
+    elif all_cats:
+        cats = sorted(c["id"] for c in category_dataset["categories"])
+    else:
+        cats = novel_category_ids(category_dataset["categories"])
     anns = select_pseudo_labels(index, cats, train_imgs, K_min, K_max, top, full, ar)
     img_ids = list(set(r["image_id"] for r in anns))
-    images = [index.by_id[i] for i in img_ids]
-    meta = category_dataset
-    return save_pseudo_label_dataset(meta, anns, images, dt_path, K_min, K_max, top, full, ar), anns
+    gt_by_id = {im["id"]: im for im in gt_dataset["images"]}
+    images = [gt_by_id[i] for i in img_ids]
+    meta = dt_doc if full_dataset else category_dataset
+    return save_pseudo_label_dataset(meta, anns, images, dt_path, K_min, K_max, top, full, ar, all_cats), anns
 
 
 VOC_NOVEL_NAMES = ("airplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "dining table", "dog",

@@ -18,9 +18,9 @@ for _ in range(20):
     with torch.no_grad(): out = model.inference_batched(batch)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 pipe = PipelinedInference(model, 2)
-for _ in range(4): pipe.submit(batch)
+for _ in range(4): pipe.submit(batch, collectable=False)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(20): pipe.submit(batch)
+for _ in range(20): pipe.submit(batch, collectable=False)
 torch.cuda.synchronize(); dp = time.perf_counter() - t0
 pipe.synchronize()
 print("R101-FPN: %.1f img/s (%.2f ms per batch of 8); two batches in flight: %.1f img/s; detections %s" % (160 / dt, dt / 20 * 1e3, 160 / dp, out[3].tolist()))

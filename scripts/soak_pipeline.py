@@ -15,8 +15,8 @@ for depth in (2, 3):
     pipe = PipelinedInference(model, depth)
     t0 = time.perf_counter()
     last = None
-    for i in range(600):
-        last = pipe.submit(batch)
-    out = pipe.collect(last)
+    for i in range(599):
+        pipe.submit(batch, collectable=False)
+    out = pipe.collect(pipe.submit(batch))
     pipe.synchronize()
     print("depth %d: 600 batches, %.1f img/s, last batch detections %s" % (depth, 4800 / (time.perf_counter() - t0), [len(o["instances"]) for o in out]), flush=True)

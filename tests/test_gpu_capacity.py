@@ -127,3 +127,54 @@ def test_activation_beyond_fp16_range_falls_back_to_bf16x3(monkeypatch, caplog):
         print(k, "relative error on the bf16x3 fallback", err)
         assert err <= 2e-4, k
     assert len(out[0]["instances"]) >= 0
+
+
+def test_pipelined_two_consecutive_overflows(caplog, monkeypatch):
+    """Batches in flight (`PipelinedInference`, depth 2 and 3): every batch submitted under the narrow limits overflows
+    on its own when it is collected -- the SECOND one after the limit is already widened -- and each is re-run; an
+    fp16-range batch on one stream is neither blamed on, nor hidden by, the batch on the other stream."""
+    from lvc_amd import kernels as K
+    from lvc_amd.evaluation import inference_on_dataset
+    from lvc_amd.utils import synthetic as syn
+    from test_gpu_e2e import _model
+
+    dev = torch.device("cuda:0")
+    loader = [[{"image": syn.synthetic_image(30 + 2 * b + i, 200, 320).to(dev), "height": 200, "width": 320}
+               for i in range(2)] for b in range(4)]
+    for depth in (2, 3):
+        model = _model()
+        model.roi_heads.test_score_thresh = 0.0
+        with torch.no_grad():
+            ref = [model(batch) for batch in loader]          # sequential: first call widens, rest run wide
+        assert model.roi_heads.det_max_candidates is None
+        model.roi_heads.det_max_candidates = 16384            # narrow again: `depth` batches launch under it
+        got = list(inference_on_dataset(model, loader, depth=depth))
+        assert model.roi_heads.det_max_candidates is None and len(got) == len(loader)
+        for (_, outs), r in zip(got, ref):
+            for o, q in zip(outs, r):
+                a, b = o["instances"], q["instances"]
+                assert len(a) == len(b) == 100
+                assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor) and torch.equal(a.scores, b.scores)
+    # range overflow: batches 1 and 2 (consecutive, different streams) carry an out-of-range image
+    monkeypatch.setattr(K, "CONV_SPLIT", "f16x2")
+    monkeypatch.setattr(K, "_RANGE_FALLBACK_LOGGED", False)
+    model = _model()
+    hot = []
+    for b in range(4):
+        batch = []
+        for i in range(2):
+            img = syn.synthetic_image(50 + 2 * b + i, 160, 192)
+            if b in (1, 2) and i == 0:
+                img[:, 40:60, 50:70] = 1.0e5
+            batch.append({"image": img.to(dev)})
+        hot.append(batch)
+    got = list(inference_on_dataset(model, hot, depth=2))
+    assert K.CONV_SPLIT == "bf16x3"
+    with torch.no_grad():
+        ref = [model(batch) for batch in hot]                 # all on the range-free kernels now
+    for b, ((_, outs), r) in enumerate(zip(got, ref)):
+        for o, q in zip(outs, r):
+            a, q = o["instances"], q["instances"]
+            assert len(a) == len(q)
+            if b >= 1:   # batch 0 legitimately ran on the fp16x2 kernels; from the first re-run on everything is bf16x3
+                assert torch.equal(a.pred_boxes.tensor, q.pred_boxes.tensor) and torch.equal(a.scores, q.scores)
