@@ -88,6 +88,17 @@ int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_split, const
 int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                            const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* Single-accumulator, software-pipelined form of lvc_conv3x3_nhwc_f16x2 (csrc/conv3x3_halo_s1.hip; the forward 3x3 layers of
+ * detectron2/modeling/backbone/resnet.py:195-211, fpn.py:101-113 and proposal_generator/rpn.py:108-127).  Same arguments and
+ * results except the weights: w_split = the [2][Kpad][Kg] fp16 planes of lvc_split_weights_rowscaled (row k times 2^e_k, the
+ * residual plane unscaled), and `scale` (never NULL) = (the layer's per-channel scale or 1) x row_factor[k] of that call.
+ * Activations are multiplied by 2^4 before their split: |a| > 4094 (or NaN) sets bit 1 of the workspace error word. */
+int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                           const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
+                           int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* wp [rows][Kg] fp32 (lvc_pack_conv_weights) -> planes_out [2][rows][Kg] fp16: w1 = fp16(wp 2^e), w2 = fp16(wp 2^e - w1) with
+ * e = 13 - floor(log2(max |wp[row][:]|)) per row (0 for an all-zero row); row_factor[row] = 2^-(e + 4). */
+int lvc_split_weights_rowscaled(const float* wp, int rows, int Kg, void* planes_out, float* row_factor, void* stream);
 /* The RPN head in one launch (detectron2/modeling/proposal_generator/rpn.py:108-127): conv 3x3 s1 p1 + affine + ReLU, then a
  * 1x1 predictor layer (objectness_logits | anchor_deltas fused into one [pK, K] matrix) applied to each output tile while it
  * is still in LDS -- the K-channel hidden map never reaches HBM.  pred_w_split: fp16 planes [2][32][K] of the predictor

@@ -33,13 +33,14 @@ class PackedConv:
     scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
     """
 
-    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h")
+    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h", "_w2s")
 
     def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
         self.w, self.scale, self.shift = w, scale, shift
         self.K, self.C, self.R, self.S, self.stride, self.pad, self.Kg, self.mode = K, C, R, S, stride, pad, Kg, mode
         self._w3 = None
         self._w2h = None
+        self._w2s = None
 
     def _split(self, planes):
         n = self.w.numel()
@@ -63,6 +64,22 @@ class PackedConv:
         if self._w2h is None:
             self._w2h = self._split(2)
         return self._w2h
+
+
+    def split2s(self):
+        """([2, Kpad, Kg] fp16 planes of the ROW-SCALED weights, scale' [K] fp32) for the single-accumulator form of the two-way
+        fp16 split (csrc/conv3x3_halo_s1.hip): row k is multiplied by 2^e_k (largest entry into [2^13, 2^14)) and split
+        without a plane scale, w 2^e = w1 + w2; scale' = (the layer's per-channel scale or 1) * 2^-(e_k + 4) undoes that and
+        the kernel's 2^4 activation scale in the epilogue.  Powers of two: the scaling itself is exact."""
+        if self._w2s is None:
+            rows, Kg = self.w.shape
+            planes = torch.empty((2, rows, Kg), device=self.w.device, dtype=torch.float16)
+            fac = torch.empty(rows, device=self.w.device, dtype=torch.float32)
+            check(_lib.lib().lvc_split_weights_rowscaled(ptr(self.w), c_int(rows), c_int(Kg), ptr(planes), ptr(fac), _stream(self.w)),
+                  "lvc_split_weights_rowscaled")
+            fac = fac[: self.K]
+            self._w2s = (planes, (fac * self.scale if self.scale is not None else fac).contiguous())
+        return self._w2s
 
 
 def conv_affine(bias=None, bn=None, eps=1e-5):
@@ -296,6 +313,9 @@ PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
 # the 3x3 kernel is bound by the matrix pipe, its output stores were already hidden, and the predictor epilogue (LDS round trip,
 # 24 MFMAs, 512 atomics per wave and tile) costs more than the 0.14 ms predictor launch it replaces
 RPN_FUSED_PRED = _os.environ.get("LVC_RPN_FUSED_PRED", "0") == "1"
+# 3x3 fp16x2 layers of the FORWARD pass on the single-accumulator, software-pipelined kernel (csrc/conv3x3_halo_s1.hip); 0 = the
+# round-1 main + cross accumulator kernel (conv3x3_halo_h2.hip), which data gradients (explicit `split`) always use
+HALO_S1 = _os.environ.get("LVC_HALO_S1", "1") != "0"
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -335,7 +355,14 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if engine == "f16x2_halo":
+        if engine == "f16x2_halo" and HALO_S1 and split is None:
+            planes, scale2 = pc.split2s()
+            st = _lib.lib().lvc_conv3x3_nhwc_f16s1(
+                ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(residual), ptr(out),
+                c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
+                c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv3x3_nhwc_f16s1")
+        elif engine == "f16x2_halo":
             st = _lib.lib().lvc_conv3x3_nhwc_f16x2(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
