@@ -96,6 +96,12 @@ int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_split, const 
 int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                            const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* lvc_conv3x3_nhwc_f16x2 -- same arguments, weight planes, numerics (main + cross accumulators, |a| <= 65504) and results up to
+ * the fp32 summation order -- on the software-pipelined tap loop of csrc/conv3x3_halo_s1.hip (LDS-DMA weight ring, rotating
+ * fragment registers, barrier in the middle of a tap, double-buffered halo window). */
+int lvc_conv3x3_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
+                                int res_mode, int ldy, int ldr, void* workspace, void* stream);
 /* wp [rows][Kg] fp32 (lvc_pack_conv_weights) -> planes_out [2][rows][Kg] fp16: w1 = fp16(wp 2^e), w2 = fp16(wp 2^e - w1) with
  * e = 13 - floor(log2(max |wp[row][:]|)) per row (0 for an all-zero row); row_factor[row] = 2^-(e + 4). */
 int lvc_split_weights_rowscaled(const float* wp, int rows, int Kg, void* planes_out, float* row_factor, void* stream);
@@ -354,7 +360,7 @@ int lvc_colsum_atomic(const float* x, int M, int N, int ldx, float* out, void* s
 
 /* ---------------------------------------------------------------------------------------------------
  * Label-verification kNN (tools/run_nearest_neighbours.py:142-162, 214-227).
- * lvc_colmean: mu[d] = mean_m x[m,d].  lvc_knn_topk_vote: per query row, class ids of the 10 most similar
+ * lvc_colmean: mu[d] = mean_m x[m,d], summed in a fixed order (run-to-run deterministic).  lvc_knn_topk_vote: per query row, class ids of the 10 most similar
  * shots (ties -> lower shot index) and keep = (mode of the first kvote ids, ties -> smallest id, == detector class).
  *   sims [Q,ld] fp32 (S columns used, S <= 4096), shot_classes [S] int64, det_classes [Q] int64 or NULL,
  *   top_classes [Q,10] int64, keep [Q] int64 or NULL.

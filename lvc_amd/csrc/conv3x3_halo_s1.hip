@@ -14,12 +14,12 @@
 //     |a| <= 4094 or the range word is raised), every weight row x 2^e so that its largest entry lies in [2^13, 2^14) (residual
 //     plane normal for every entry >= 2^-17 of the row's largest); the epilogue's per-channel scale carries 2^-(e+4)
 //     (`lvc_split_weights_rowscaled`).  64 accumulator registers instead of 128;
-//   * the registers that frees hold a SECOND fragment set: the reads of k16 step i+1 are issued under the MFMAs of step i, so a
-//     wave never waits for LDS with an idle matrix pipe, and the barrier of a tap sits in the MIDDLE of its MFMA work (the
-//     second k16 step needs nothing the barrier orders);
+//   * fragment reads run one group ahead of the MFMAs that use them, rotating through the registers earlier groups vacate (see
+//     `step_body`): a wave never waits for LDS with an idle matrix pipe, and the barrier of a tap sits in the MIDDLE of its MFMA
+//     work (the second k16 step needs nothing the barrier orders);
 //   * weight planes arrive by LDS-DMA (`global_load_lds_dwordx4`, 64-byte rows, granule XOR swizzle on the source side as in
-//     conv_pw_dma.hip) into a ring of three tap buffers that runs two taps ahead: no VGPR staging, no ds_write, and the wait
-//     before the barrier is a counted vmcnt that leaves the youngest tap in flight;
+//     conv_pw_dma.hip) into a ring of three tap buffers, issued right behind a tap's barrier for the tap after next (a full tap
+//     of latency budget): no VGPR staging, no ds_write;
 //   * the halo window is double-buffered: the next 32-channel chunk is loaded at tap 1, split and written in six small pieces
 //     under the MFMAs of taps 4..6 -- no refill phase between chunks, the tap pipeline runs through.
 // Tiling (<= 256-pixel patches x 64 NI channels, 8 waves as 4 x 2), stream-K workers with grouped channel tiles, partial-tile
@@ -67,7 +67,10 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NI>
+// ONEACC = true: the single-accumulator numerics of the header (row-scaled weight planes, activations x 2^4, residual planes unscaled).
+// ONEACC = false: conv3x3_halo_h2.hip's numerics in this kernel's pipeline -- residual planes x 2^11, a main (a1 b1) and a cross
+// (a1 b2 + a2 b1) accumulator folded once per tile, weights = lvc_split_weights planes, full fp16 range (|a| <= 65504).
+template <int NI, bool ONEACC>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
   constexpr int HN = 64 * NI;
   constexpr int PLANE_A = HALO_S1 * LROW;          // halves
@@ -173,10 +176,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       f16x4 h, m;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float a = areg[j][e] * ACT_SCALE;
+        const float a = ONEACC ? areg[j][e] * ACT_SCALE : areg[j][e];
         const f16 hh = (f16)a;
         h[e] = hh;
-        m[e] = (f16)(a - (float)hh);
+        m[e] = ONEACC ? (f16)(a - (float)hh) : (f16)((a - (float)hh) * 2048.f);
         big = fmaxf(big, fabsf(areg[j][e]));
       }
       const int o = a_lds[j];
@@ -184,46 +187,70 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       *reinterpret_cast<f16x4*>(dstA + PLANE_A + o) = m;
     };
 
-    f32x16 acc[2][NI];
+    f32x16 acc[2][NI], accx[ONEACC ? 1 : 2][ONEACC ? 1 : NI];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < NI; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+          acc[a][b][e] = 0.f;
+          if (!ONEACC) accx[ONEACC ? 0 : a][ONEACC ? 0 : b][e] = 0.f;
+        }
 
-    f16x8 fa[2][2][2], fb[2][NI][2];   // [set][mi | ni][plane]
-    auto read_frags = [&](int set, const f16* A, int tap_off, int s2, const unsigned char* B) {
+    // Fragments of ONE k16 step (32 registers at NI = 2), rotated in place.  A step issues its MFMAs in three groups -- G1: a1 b2,
+    // G2: a2 b1, G3: a1 b1 -- so b2 is dead after G1 and a2 after G2.  Reads: the step's own a2 / b1 ("late", first needed by G2)
+    // go out under G1; the NEXT step's a1 / b2 ("early", needed by its G1) go out under G2, into the registers b2 and a2 just
+    // vacated.  One DS read per MFMA, every operand issued >= 3 MFMAs (~100 cycles) before its first use.
+    f16x8 ahi[2], alo[2], bhi[NI], blo[NI];
+    auto rdA = [&](const f16* A, int pl, int mi, int tap_off, int s2) {
+      return *reinterpret_cast<const f16x8*>(A + pl * PLANE_A + a_frag[mi] + tap_off + s2 * 16);
+    };
+    auto rdB = [&](const unsigned char* B, int pl, int ni, int s2) {
+      return *reinterpret_cast<const f16x8*>(B + pl * PLANE_B + b_row + ni * 32 * 64 + b_g[s2]);
+    };
+    // one k16 step: (A, toff, s2, B) = this step's operands; (An, toffn, s2n, Bn) = the next step's
+    auto step_body = [&](const f16* A, int toff, int s2, const unsigned char* B, const f16* An, int toffn, int s2n,
+                         const unsigned char* Bn) {
+      // late reads of this step, in the order G2 needs them
+      alo[0] = rdA(A, 1, 0, toff, s2);
+      bhi[0] = rdB(B, 0, 0, s2);
+      alo[1] = rdA(A, 1, 1, toff, s2);
+      if (NI == 2) bhi[NI - 1] = rdB(B, 0, NI - 1, s2);
+      // G1: a1 b2
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          fa[set][mi][pl] = *reinterpret_cast<const f16x8*>(A + pl * PLANE_A + a_frag[mi] + tap_off + s2 * 16);
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x16& c = ONEACC ? acc[mi][ni] : accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo[ni], c, 0, 0, 0);
+        }
+      // early reads of the next step: b2 first (its registers are free now), a1 after G2 has released a2
+      f16x8 blo_n[NI], ahi_n[2];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) blo_n[ni] = rdB(Bn, 1, ni, s2n);
+      // G2: a2 b1 (block order: the operands read first are used first)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
-          fb[set][ni][pl] = *reinterpret_cast<const f16x8*>(B + pl * PLANE_B + b_row + ni * 32 * 64 + b_g[s2]);
+        for (int mi = 0; mi < 2; ++mi) {
+          f32x16& c = ONEACC ? acc[mi][ni] : accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi[ni], c, 0, 0, 0);
+        }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) ahi_n[mi] = rdA(An, 0, mi, toffn, s2n);
+      // G3: a1 b1
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) ahi[mi] = ahi_n[mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) blo[ni] = blo_n[ni];
     };
-    // three MFMAs per block into the ONE accumulator; the small products first (a1 b2, a2 b1), then a1 b1
-    auto mfma_group = [&](int set) {
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mi][0], fb[set][ni][1], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mi][1], fb[set][ni][0], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[set][mi][0], fb[set][ni][0], acc[mi][ni], 0, 0, 0);
-    };
-    // one DS read under each of the first MFMAs of a phase, the rest of the MFMAs behind
+    // MFMA, DS read, MFMA, DS read ... for the 4 + 2 NI reads of a step, the remaining MFMAs behind
     auto interleave = [&]() {
 #pragma unroll
       for (int i = 0; i < 4 + 2 * NI; ++i) {
@@ -234,7 +261,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     };
 
     const int step0 = cc0 * 9, last_step = cc1 * 9 - 1;
-    // ---- prologue: halo of the first chunk, weights of taps 0 and 1, fragments of (tap 0, k16 step 0)
+    // ---- prologue: halo of the first chunk, weights of taps 0 and 1, the early fragments of (tap 0, k16 step 0)
     load_A(cc0);
     dma_B(step0, 0);
     dma_B(step0 + 1, 1);       // cc1 > cc0: a unit has nine taps, so step0 + 1 exists
@@ -242,7 +269,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     for (int j = 0; j < NJ; ++j) store_A_piece(sA, j);
     wait_vm<0>();
     __syncthreads();
-    read_frags(0, sA, 0, 0, sB);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) ahi[mi] = rdA(sA, 0, mi, 0, 0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) blo[ni] = rdB(sB, 1, ni, 0);
 
 #pragma unroll 1
     for (int cc = cc0; cc < cc1; ++cc) {
@@ -257,32 +287,23 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
         const int toff_n = (ntap / 3) * row_off + (ntap % 3) * LROW;
         const unsigned char* Bcur = sB + (tap % 3) * B_BUF;
         const unsigned char* Bnext = sB + ((tap + 1) % 3) * B_BUF;
-        // ---- phase A: k16 step 0 of this tap (fragment set 0), reads of step 1 into set 1, the DMA of tap + 2.  Past the end of
-        // the unit the DMA re-fetches the last tap and the halo load re-fetches the last chunk (into buffers nobody reads any
-        // more): the instruction stream has no data-dependent branch, so the counted waits below are exact on every path
-        if (tap == 4) {
-          // first use of the halo registers loaded at tap 1: the compiler's wait for them is a vmcnt(0) (it orders the staging
-          // ds_writes behind every LDS-DMA in flight), so it is taken HERE, before this tap's DMA is issued -- the youngest DMA
-          // outstanding is then tap 3's, a full tap old and due at this tap's barrier anyway
-          asm volatile("" ::"v"(areg[0]), "v"(areg[1]), "v"(areg[2]), "v"(areg[3]), "v"(areg[4]), "v"(areg[5]));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        dma_B(min(step + 2, last_step), (tap + 2) % 3);
-        read_frags(1, Acur, toff, 1, Bcur);
-        mfma_group(0);
+        // ---- phase A: k16 step 0 of this tap; its early reads are step 1's (same buffers)
+        step_body(Acur, toff, 0, Bcur, Acur, toff, 1, Bcur);
         if (tap == 4) store_A_piece(Anext, 0);
         if (tap == 5) store_A_piece(Anext, 2);
         if (tap == 6) store_A_piece(Anext, 4);
         interleave();
         __builtin_amdgcn_sched_barrier(0);
-        // the weights of tap + 1 (this wave's pieces) have landed when at most the pieces issued after them are outstanding:
-        // the NI of tap + 2 and, at tap 2, the six halo loads of tap 1
-        if (tap == 2) wait_vm<NI + NJ>(); else wait_vm<NI>();
+        // Everything this wave has in flight (the weights of tap + 1 issued one tap ago, at tap 2 the halo loads of tap 1) has
+        // landed; behind the barrier that holds for every wave, and every wave is done with tap - 1's weight slot
+        wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- phase B: k16 step 1 (set 1), reads of (tap + 1, step 0) into set 0
-        read_frags(0, tap == 8 ? Anext : Acur, toff_n, 0, Bnext);
-        mfma_group(1);
+        // ---- phase B: k16 step 1; the DMA of tap + 2 into tap - 1's slot; early reads of (tap + 1, step 0).  Past the end of the
+        // unit the DMA re-fetches the last tap and the halo load the last chunk (into buffers nobody reads any more): the
+        // instruction stream has no data-dependent branch
+        dma_B(min(step + 2, last_step), (tap + 2) % 3);
+        step_body(Acur, toff, 1, Bcur, tap == 8 ? Anext : Acur, toff_n, 0, Bnext);
         if (tap == 1) load_A(min(cc + 1, cc1 - 1));
         if (tap == 4) store_A_piece(Anext, 1);
         if (tap == 5) store_A_piece(Anext, 3);
@@ -294,6 +315,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     wait_vm<0>();
     __syncthreads();
     u += cc1 - cc0;
+    if (!ONEACC) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni][e] * (1.f / 2048.f);
+    }
 
     // ---- split tiles: a worker that does not own the tile's first chunk hands its partial sums to the one that does
     if (cc0 != 0) {
@@ -364,7 +393,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     const int c4 = tid % C4, rsub = tid / C4;
     const int col = n0 + c4 * 4;
     if (col < p.K) {
-      const f32x4 sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       f32x4 sh = {0.f, 0.f, 0.f, 0.f};
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
 #pragma unroll 4
@@ -392,7 +422,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     }
     __syncthreads();
   }
-  if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, 2);
+  if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);
 }
 
 #define LVC_MAX_WORKERS 1024
@@ -415,13 +445,11 @@ static void pick_patch_s(int H, int W, int* PH, int* PW) {
   *PH = bh; *PW = bw;
 }
 
-// Same arguments as lvc_conv3x3_nhwc_f16x2 except the weights: w_split = the [2][Kpad][Kg] fp16 planes written by
-// lvc_split_weights_rowscaled, and `scale` = (the layer's per-channel scale or 1) x the row factors that call returned
-// (never null).  An activation with |a| > 4094 (or NaN) raises bit 1 of the workspace error word.
-extern "C" int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                                       const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
-                                       int res_mode, int ldy, int ldr, void* workspace, void* stream) {
-  LVC_CHECK_ARG(x && w_split && workspace && y && scale, "null pointer");
+static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                          const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu, int res_mode,
+                          int ldy, int ldr, void* workspace, void* stream) {
+  LVC_CHECK_ARG(x && w_split && workspace && y, "null pointer");
+  LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
   LVC_CHECK_ARG(C % 32 == 0 && Kg == 9 * C, "needs C % 32 == 0 and Kg == 9*C");
   LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
@@ -473,12 +501,32 @@ extern "C" int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_sp
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  if (ni == 1)
-    hipLaunchKernelGGL((conv3x3_halo_s1_kernel<1>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL((conv3x3_halo_s1_kernel<2>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  hipStream_t st = (hipStream_t)stream;
+  if (oneacc) {
+    if (ni == 1) hipLaunchKernelGGL((conv3x3_halo_s1_kernel<1, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_halo_s1_kernel<2, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+  } else {
+    if (ni == 1) hipLaunchKernelGGL((conv3x3_halo_s1_kernel<1, false>), dim3(a.nworkers), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_halo_s1_kernel<2, false>), dim3(a.nworkers), dim3(NT), 0, st, a);
+  }
   LVC_CHECK_LAUNCH();
   return LVC_OK;
+}
+
+// Single-accumulator form.  Same arguments as lvc_conv3x3_nhwc_f16x2 except the weights: w_split = the [2][Kpad][Kg] fp16 planes
+// written by lvc_split_weights_rowscaled, and `scale` = (the layer's per-channel scale or 1) x the row factors that call returned
+// (never null).  An activation with |a| > 4094 (or NaN) raises bit 1 of the workspace error word.
+extern "C" int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                       const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
+                                       int res_mode, int ldy, int ldr, void* workspace, void* stream) {
+  return halo_s1_launch(true, x, w_split, scale, shift, residual, y, N, H, W, C, K, Kg, relu, res_mode, ldy, ldr, workspace, stream);
+}
+
+// lvc_conv3x3_nhwc_f16x2 (arguments, weight planes, numerics: main + cross accumulators, |a| <= 65504) on this file's pipeline.
+extern "C" int lvc_conv3x3_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                            const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
+                                            int res_mode, int ldy, int ldr, void* workspace, void* stream) {
+  return halo_s1_launch(false, x, w_split, scale, shift, residual, y, N, H, W, C, K, Kg, relu, res_mode, ldy, ldr, workspace, stream);
 }
 
 // Row-scaled two-plane split of packed weights wp [rows][Kg] fp32:  e = 13 - floor(log2(max |wp[row][:]|)) (0 for an all-zero

@@ -12,28 +12,31 @@
 #include "common.h"
 #include <stdlib.h>
 
-// mu[d] = mean over rows.  One workgroup sums a 64-row slab for 256 columns; slabs are combined with fp32 atomics
-// into the zeroed mu, already divided by M (the serial one-thread-per-column form took 0.9 ms for 2400 x 1024).
+// mu[d] = mean over rows, DETERMINISTIC (the reference's shots.mean(0) is; an atomic combine made mu -- and with it near-tied
+// ranks -- vary in the last bits from run to run).  A workgroup owns 32 columns: thread (g, c) adds rows g, g + 8, g + 16, ...
+// of column c in that order (128-byte row segments per 32 lanes), the eight partial sums of a column are then added in the
+// fixed order g = 0..7 by one thread.  2400 x 1024: 32 workgroups, ~15 us (the sweep calls it once).
 __global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, float* __restrict__ mu, int M, int D,
                                                       int ld, float inv_m) {
-  const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d >= D) return;
-  const int r0 = blockIdx.y * 64;
-  int r1 = r0 + 64;
-  if (r1 > M) r1 = M;
+  __shared__ float part[8][32];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int m = r0; m < r1; ++m) s += x[(size_t)m * ld + d];
-  unsafeAtomicAdd(mu + d, s * inv_m);
+  if (d < D)
+    for (int m = g; m < M; m += 8) s += x[(size_t)m * ld + d];
+  part[g][c] = s;
+  __syncthreads();
+  if (g == 0 && d < D) {
+    float t = part[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += part[i][c];
+    mu[d] = t * inv_m;
+  }
 }
 
 extern "C" int lvc_colmean(const float* x, float* mu, int M, int D, int ld, void* stream) {
   LVC_CHECK_ARG(x && mu && M > 0 && D > 0, "bad arguments");
-  hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(mu, 0, (size_t)D * sizeof(float), st) != hipSuccess) {
-    lvc_set_error("%s: hipMemsetAsync failed", __func__);
-    return LVC_ERR_HIP;
-  }
-  hipLaunchKernelGGL(colmean_kernel, dim3(lvc_cdiv(D, 256), lvc_cdiv(M, 64)), dim3(256), 0, st, x, mu, M, D, ld > 0 ? ld : D,
+  hipLaunchKernelGGL(colmean_kernel, dim3(lvc_cdiv(D, 32)), dim3(256), 0, (hipStream_t)stream, x, mu, M, D, ld > 0 ? ld : D,
                      1.f / (float)M);
   LVC_CHECK_LAUNCH();
   return LVC_OK;

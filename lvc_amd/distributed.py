@@ -3,7 +3,7 @@
 
 What the reference does and what is kept:
   * inference: images shard contiguously per rank (detectron2/data/samplers/distributed_sampler.py:191-194),
-    no collective in the forward; results are gathered to rank 0 (lvc/evaluation/coco_evaluation.py:119-123);
+    no collective in the forward; results are gathered to rank 0 only (`gather_rows`; lvc/evaluation/coco_evaluation.py:119-123);
   * kNN: shots all-gathered so that every rank holds all S shots (tools/run_nearest_neighbours.py:303-309; the
     reference pickles through a gloo group -- here it is ONE all_gather of the fp32 tensor), queries stay
     sharded, results gathered to rank 0 (:323-325);
@@ -58,12 +58,25 @@ def all_gather_rows(t):
 
 
 def gather_rows(t, dst=0):
-    """Gather variable-length rows to `dst` (None elsewhere)."""
+    """Gather variable-length rows to `dst` ONLY (None elsewhere): the reference's `comm.gather` (detectron2/utils/comm.py:
+    177-217 -- every rank pads to the largest length, the destination alone receives), without the pickle: one all-gather of
+    the lengths, then one `dist.gather` of the padded tensors.  N - 1 of N ranks neither allocate nor receive the results."""
     world = get_world_size()
     if world == 1:
         return t
-    full = all_gather_rows(t)
-    return full if get_rank() == dst else None
+    n = torch.tensor([t.shape[0]], device=t.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(sizes)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    pad[: t.shape[0]] = t
+    if get_rank() == dst:
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, out, dst=dst)
+        return torch.cat([o[:s] for o, s in zip(out, sizes)], 0)
+    dist.gather(pad, None, dst=dst)
+    return None
 
 
 def allreduce_gradients_(params, average=True):

@@ -33,7 +33,7 @@ class PackedConv:
     scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
     """
 
-    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h", "_w2s")
+    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h", "_w2s", "two_acc")
 
     def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
         self.w, self.scale, self.shift = w, scale, shift
@@ -41,6 +41,7 @@ class PackedConv:
         self._w3 = None
         self._w2h = None
         self._w2s = None
+        self.two_acc = False   # True: never the single-accumulator form of the 3x3 fp16-split kernel (see HALO_S1)
 
     def _split(self, planes):
         n = self.w.numel()
@@ -313,9 +314,15 @@ PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
 # the 3x3 kernel is bound by the matrix pipe, its output stores were already hidden, and the predictor epilogue (LDS round trip,
 # 24 MFMAs, 512 atomics per wave and tile) costs more than the 0.14 ms predictor launch it replaces
 RPN_FUSED_PRED = _os.environ.get("LVC_RPN_FUSED_PRED", "0") == "1"
-# 3x3 fp16x2 layers of the FORWARD pass on the single-accumulator, software-pipelined kernel (csrc/conv3x3_halo_s1.hip); 0 = the
-# round-1 main + cross accumulator kernel (conv3x3_halo_h2.hip), which data gradients (explicit `split`) always use
-HALO_S1 = _os.environ.get("LVC_HALO_S1", "1") != "0"
+# 3x3 fp16x2 layers of the FORWARD pass on the software-pipelined kernel (csrc/conv3x3_halo_s1.hip):
+#   2 (default) = its single-accumulator form (row-scaled weight planes, activations x 2^4: |a| <= 4094; ~7 % faster on the 3x3
+#       set -- the accumulate of the small cross products into the large sum costs the matrix pipe less power than a second full
+#       accumulator -- at 1.7x the rounding noise of the two-accumulator form, 7.2e-8 of the output scale against 8e-8 .. 1.2e-7
+#       for the reference's own fp32 CPU convolution, scripts/probe_halo_set.py), EXCEPT layers packed with `two_acc` (the RPN
+#       head: its outputs feed top-k / NMS decisions and the post-trunk chain is held to the literal 1e-3, tests/test_gpu_chain.py);
+#   1 = the numerics of conv3x3_halo_h2.hip everywhere (main + cross accumulators, same weight planes, |a| <= 65504);
+#   0 = the round-1 kernel (conv3x3_halo_h2.hip), which data gradients (explicit `split`) always use.
+HALO_S1 = int(_os.environ.get("LVC_HALO_S1", "2"))
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -355,13 +362,19 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if engine == "f16x2_halo" and HALO_S1 and split is None:
+        if engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not pc.two_acc:
             planes, scale2 = pc.split2s()
             st = _lib.lib().lvc_conv3x3_nhwc_f16s1(
                 ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_f16s1")
+        elif engine == "f16x2_halo" and HALO_S1 >= 1 and split is None:
+            st = _lib.lib().lvc_conv3x3_nhwc_f16x2_pipe(
+                ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
+                c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
+                c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv3x3_nhwc_f16x2_pipe")
         elif engine == "f16x2_halo":
             st = _lib.lib().lvc_conv3x3_nhwc_f16x2(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),

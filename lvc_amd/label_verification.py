@@ -196,9 +196,13 @@ def get_nn_class_confirmatory(query_features, k):
 def knn_sweep_distributed(shot_classes, shot_descriptors, query_descriptors, detector_classes, k=10, cosine=True,
                           sweep=None):
     """Data-parallel form of the sweep (reference tools/run_nearest_neighbours.py:301-325): every rank contributes the
-    shots it extracted -> one all-gather of the fp32 rows (the reference pickles them through a gloo group), the shots
-    are re-sorted by class exactly as `assemble_tensors` does, each rank sweeps ITS queries, and the per-rank results
-    (top10 class ids, keep) are gathered to rank 0 in rank order.  Returns (top10, keep) on rank 0, (None, None)
+    shots it extracted -> one all-gather of the fp32 rows (the reference pickles them through a gloo group), each rank
+    sweeps ITS queries, and the per-rank results (top10 class ids, keep) are gathered to rank 0 in rank order.
+    Shot order: the reference concatenates the per-rank lists, each already class-sorted by `assemble_tensors`
+    (`torch.cat`, :306-309), so equal similarities rank in (rank, class, position) order there; here the concatenation is
+    re-sorted by class with a STABLE sort, so they rank in (class, rank, position) order.  The two orders differ only between
+    shots of exactly equal similarity to a query, which leaves the class-id sequence -- the sweep's output -- unchanged
+    unless the tied shots also belong to different classes (the reference's own order is unspecified there: unstable sort).  Returns (top10, keep) on rank 0, (None, None)
     elsewhere.  `sweep` defaults to `knn_sweep` (injectable so the collective plumbing can be tested on CPU/gloo)."""
     from . import distributed as D
 

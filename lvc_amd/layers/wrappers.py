@@ -76,8 +76,12 @@ class Conv2d(nn.Module):
         aff = self._affine()
         srcs = [self.weight, aff[0], aff[1]]
         stem = self.in_channels == 3
-        return self._cache.get(srcs, lambda: K.pack_conv(self.weight, stride=self.stride, pad=self.padding, stem=stem,
-                                                         affine=aff))
+        pc = self._cache.get(srcs, lambda: K.pack_conv(self.weight, stride=self.stride, pad=self.padding, stem=stem,
+                                                       affine=aff))
+        # precision policy of the 3x3 fp16-split kernel (kernels.HALO_S1): a layer whose output feeds discrete decisions sets
+        # `two_acc` and keeps the main + cross accumulator form (the RPN head: objectness / deltas -> top-k, NMS)
+        pc.two_acc = bool(getattr(self, "two_acc", False))
+        return pc
 
     def packed_dgrad(self):
         """Packed weights of the data gradient (flipped, transposed, times the FrozenBN scale)."""

@@ -45,6 +45,7 @@ class StandardRPNHead(nn.Module):
             num_anchors = num_anchors[0]
         self.num_anchors, self.box_dim = num_anchors, box_dim
         self.conv = Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1, activation=F.relu_)
+        self.conv.two_acc = True   # logits / deltas decide top-k and NMS: keep the two-accumulator 3x3 form (kernels.HALO_S1)
         self.objectness_logits = Conv2d(in_channels, num_anchors, kernel_size=1, stride=1)
         self.anchor_deltas = Conv2d(in_channels, num_anchors * box_dim, kernel_size=1, stride=1)
         for l in [self.conv, self.objectness_logits, self.anchor_deltas]:

@@ -176,6 +176,51 @@ def test_pointwise_shapes_match_cpu(N, C, H, W, K, stride, res_mode, split, monk
     assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("N,C,H,W,K", [(2, 256, 56, 88, 256), (1, 64, 72, 100, 64), (3, 128, 33, 47, 132)])
+def test_conv3x3_pipelined_forms_vs_fp64(N, C, H, W, K, monkeypatch):
+    """The three forms of the 3x3 fp16-split forward kernel (kernels.HALO_S1: 0 = round-1 kernel, 1 = pipelined tap loop with
+    main + cross accumulators, 2 = pipelined with ONE accumulator and power-of-two operand scaling) against an fp64
+    convolution: form 1 equals form 0's accuracy (same arithmetic, different summation order of stream-K partials only), form
+    2 stays below the error of the reference's own fp32 CPU convolution (what "fp32-accurate" means for a layer)."""
+    from lvc_amd import kernels as k
+
+    monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
+    monkeypatch.setattr(k, "CONV_SPLIT", "f16x2")
+    monkeypatch.setattr(k, "_HALO_H2_MIN_TILES", 0)
+    g = torch.Generator().manual_seed(C + K)
+    x = torch.randn(N, C, H, W, generator=g).relu_() * 3.0
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    w[:, :, 1, 1] *= torch.logspace(-3, 1, K)[:, None]          # rows of very different magnitude: the row scaling's case
+    res = torch.randn(N, K, H, W, generator=g)
+    ref = F.relu(F.conv2d(x.double(), w.double(), padding=1) + res.double())
+    cpu = F.relu(F.conv2d(x, w, padding=1) + res)
+    sc = float(ref.abs().max())
+    rms_cpu = float((cpu.double() - ref).pow(2).mean().sqrt()) / sc
+    d = _dev()
+    pc = k.pack_conv(w.to(d), stride=1, pad=1)
+    rms = {}
+    for form in (0, 1, 2):
+        monkeypatch.setattr(k, "HALO_S1", form)
+        timer = k.LaunchTimer()
+        monkeypatch.setattr(k, "CONV_TIMER", timer)
+        y = k.conv2d_nhwc(_nhwc(x).to(d), pc, relu=True, residual=_nhwc(res).to(d), res_mode=1).cpu().permute(0, 3, 1, 2)
+        assert timer.records[-1][3] == "f16x2_halo"
+        rms[form] = float((y.double() - ref).pow(2).mean().sqrt()) / sc
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * sc, form
+    monkeypatch.setattr(k, "CONV_TIMER", None)
+    assert k.conv_error_word(d) == 0
+    print("rms error / output scale: round-1 %.2e, pipelined two-acc %.2e, pipelined one-acc %.2e, CPU fp32 %.2e" % (rms[0], rms[1], rms[2], rms_cpu))
+    assert rms[1] <= 1.05 * rms[0] + 1e-9
+    assert rms[2] <= max(rms_cpu, 2.0 * rms[0])
+    # the layer flag: `two_acc` keeps form 1 under HALO_S1 = 2 (bit-identical to form 1)
+    monkeypatch.setattr(k, "HALO_S1", 1)
+    y1 = k.conv2d_nhwc(_nhwc(x).to(d), pc, relu=True)
+    monkeypatch.setattr(k, "HALO_S1", 2)
+    pc.two_acc = True
+    y2 = k.conv2d_nhwc(_nhwc(x).to(d), pc, relu=True)
+    assert torch.equal(y1, y2) or float((y1 - y2).abs().max()) <= 2e-6 * sc    # stream-K partial order only
+
+
 def test_f16x2_range_overflow_is_reported():
     """The two-way fp16 split cannot represent |a| > 65504: the staging code must raise bit 1 of the workspace error
     word (and only then), for the 3x3 halo kernel and for the pointwise kernel."""
@@ -201,6 +246,15 @@ def test_f16x2_range_overflow_is_reported():
         k.conv2d_nhwc(xb, pc3)
         assert k.conv_error_word(x.device) & 2 == 2
         k.clear_conv_error_word(x.device)
+        # the single-accumulator 3x3 form scales activations by 2^4: its range ends at 4094; the two-accumulator form's at 65504
+        xc = x.clone(); xc[0, 3, 5, 7] = 5.0e3
+        assert k.HALO_S1 == 2 and not pc3.two_acc
+        k.conv2d_nhwc(xc, pc3)
+        assert k.conv_error_word(x.device) & 2 == 2
+        k.clear_conv_error_word(x.device)
+        pc3.two_acc = True
+        k.conv2d_nhwc(xc, pc3)
+        assert k.conv_error_word(x.device) & 2 == 0
     finally:
         k._HALO_H2_MIN_TILES = old_min
 
