@@ -19,6 +19,9 @@ Rank 0 prints ONE JSON line carrying
   cpu_baseline        the CPU oracle timed on this host (rank 0, N = 1 only), 5 warm-up + 20 timed images
   rccl / per_rank     (N > 1 or under a launcher) the RCCL world and every rank's own rate
   dp_legs             (N > 1) short RCCL legs: cfg-3 fine-tune steps with the gradient all-reduce, sharded kNN sweep
+  train               (N = 1) cfg-3 fine-tune step (bs 8), cfg-5 R101 box-corrector step (bs 2) with ms forward / backward /
+                      optimizer, and R101-FPN inference img/s
+  timed_batch_parity  the timed batch's detections against the CPU oracle's (the run exits non-zero below 0.9 matched)
 `--workload train` / `--workload knn` time those two data-parallel legs as the main metric instead.
 """
 import argparse
@@ -137,13 +140,14 @@ def _max_and_all(c, dt):
 
 
 # ----------------------------------------------------------------------------------------------- kNN (cfg 4)
-def _knn_inputs(c, rows, seed, classes=None, centers=None, spread=0.0):
-    """Synthetic descriptors.  `classes` given: class-structured rows centers[class] + spread * noise + 0.3 (what a descriptor
-    network produces for objects of 80 classes: the premise of a kNN vote); None: unstructured N(0, 1) rows."""
+def _knn_inputs(c, rows, seed, classes=None, centers=None, spread=0.0, D=None):
+    """Synthetic descriptors.  classes None: N(0, 1) rows (SURVEY 8(d) cfg 4's inputs).  `classes` given: class-structured rows
+    centers[class] + spread * noise + 0.3 (what a descriptor network produces for objects of 80 classes: the premise of a
+    kNN vote)."""
     import torch
 
     g = torch.Generator(device=c.dev).manual_seed(seed)
-    x = torch.randn(rows, KNN_D, device=c.dev, generator=g)
+    x = torch.randn(rows, D or KNN_D, device=c.dev, generator=g)
     if classes is None:
         return x
     return centers[classes] + spread * x + 0.3
@@ -153,10 +157,11 @@ def knn_leg(c, steps, warmup, sample_check=2048):
     """BASELINE configs[3]: Q = 120 000 queries (sharded over the ranks: strong scaling), S = 2400 shots of 80 classes,
     D = 1024, cosine, k = 10.  Every rank contributes S / world shots to ONE RCCL all-gather, sweeps its own queries,
     results are gathered to rank 0 (reference tools/run_nearest_neighbours.py:301-325).
-    Inputs: class-structured descriptors (80 class directions, 30 shots each, queries of a random class, 30 % of the detector
-    labels wrong); the unstructured N(0,1) inputs of the earlier rounds are timed next to them (`unstructured`): the two-stage
-    sweep re-evaluates a neighbour in fp32 only where a shot of ANOTHER class is within the pre-filter's error margin, which
-    unstructured rows make the common case."""
+    Headline inputs: `randn(120000, 1024)` queries / `randn(2400, 1024)` shots, as SURVEY 8(d) defines cfg 4.  Timed next to
+    them: class-structured descriptors (80 class directions, 30 shots each, queries of a random class, 30 % of the detector
+    labels wrong) -- the two-stage sweep re-evaluates a neighbour in fp32 only where a shot of ANOTHER class is within the
+    pre-filter's error margin, which unstructured rows make the common case -- and D = 384 (the ViT-S/8 descriptor width of
+    tools/run_nearest_neighbours.py:292-293)."""
     import torch
 
     from lvc_amd import distributed as D
@@ -172,8 +177,8 @@ def knn_leg(c, steps, warmup, sample_check=2048):
     gq = torch.Generator(device=c.dev).manual_seed(200 + c.rank)
     qcls = torch.randint(0, 80, (len(rng),), device=c.dev, generator=gq)
     det = torch.where(torch.rand(len(rng), device=c.dev, generator=gq) < 0.7, qcls, torch.randint(0, 80, (len(rng),), device=c.dev, generator=gq))
-    inputs = {"structured": (_knn_inputs(c, len(srng), 7 + c.rank, cls, centers, 2.0), _knn_inputs(c, len(rng), 100 + c.rank, qcls, centers, 2.5)),
-              "unstructured": (_knn_inputs(c, len(srng), 7 + c.rank), _knn_inputs(c, len(rng), 100 + c.rank))}
+    inputs = {"randn": (_knn_inputs(c, len(srng), 7 + c.rank), _knn_inputs(c, len(rng), 100 + c.rank)),
+              "structured": (_knn_inputs(c, len(srng), 7 + c.rank, cls, centers, 2.0), _knn_inputs(c, len(rng), 100 + c.rank, qcls, centers, 2.5))}
 
     def timed(shots, q, n):
         def step():
@@ -191,66 +196,66 @@ def knn_leg(c, steps, warmup, sample_check=2048):
         dt, _ = _max_and_all(c, time.perf_counter() - t0)
         return dt / n, res
 
-    per, (top, keep) = timed(*inputs["structured"], steps)
-    if os.environ.get("LVC_BENCH_KNN_STRUCTURED_ONLY") == "1":     # profiler runs: one kind of input per trace
-        per_u, top_u = per, top
-        inputs["unstructured"] = inputs["structured"]
+    only = os.environ.get("LVC_BENCH_KNN_ONLY")      # profiler runs: one kind of input per trace ("randn" | "structured")
+    per, (top, keep) = timed(*inputs[only or "randn"], steps)
+    if only:
+        per_s, top_s, keep_s = per, top, keep
     else:
-        per_u, (top_u, _) = timed(*inputs["unstructured"], steps)
+        per_s, (top_s, keep_s) = timed(*inputs["structured"], steps)
     path = "two-stage (fp16 pre-filter GEMM + exact fp32 verification)" if LV.KNN_TWO_STAGE else "single-stage (fp32-accurate f16x2 GEMM + top-k)"
+    fl = 2.0 * KNN_Q * KNN_S * KNN_D
     out = {"workload": "kNN label verification: Q=%d (sharded %d/rank) x S=%d x D=%d, cosine, top-10 + vote" % (KNN_Q, len(rng), KNN_S, KNN_D),
-           "path": path, "inputs": "class-structured synthetic descriptors (80 classes x 30 shots, 30 % wrong detector labels)",
+           "path": path, "inputs": "randn(Q, D) queries / randn(S, D) shots (SURVEY 8(d) cfg 4)" if not only else only,
            "ms_per_sweep": round(per * 1e3, 3), "queries_per_s": round(KNN_Q / per),
-           "algorithmic_tflops": round(2.0 * KNN_Q * KNN_S * KNN_D / per / 1e12, 1),
+           "algorithmic_tflops": round(fl / per / 1e12, 1),
            "algorithmic_bytes": KNN_Q * KNN_D * 4 + KNN_S * KNN_D * 4 + KNN_Q * 10 * 8,
            "kept_fraction": round(float(keep.float().mean()), 4) if keep is not None else None}   # gathered to rank 0 only
     out["algorithmic_GBps"] = round(out["algorithmic_bytes"] / per / 1e9, 1)
     out["frac_of_hbm_peak"] = round(out["algorithmic_bytes"] / per / 1e9 / PEAK_HBM_GBPS, 4)
     # one fp16 MFMA per product in the pre-filter (dense fp16 peak); the single-stage path needs three (f16x2 peak)
     peak = PEAK_F16X2_TFLOPS * 3 if LV.KNN_TWO_STAGE else PEAK_F16X2_TFLOPS
-    out["frac_of_mfma_peak"] = round(2.0 * KNN_Q * KNN_S * KNN_D / per / 1e12 / peak, 4)
+    out["frac_of_mfma_peak"] = round(fl / per / 1e12 / peak, 4)
     out["mfma_peak_tflops"] = round(peak, 1)
-    out["unstructured"] = {"inputs": "N(0,1) rows (the earlier rounds' input)", "ms_per_sweep": round(per_u * 1e3, 3),
-                           "queries_per_s": round(KNN_Q / per_u)}
+    out["structured"] = {"inputs": "class-structured synthetic descriptors (80 classes x 30 shots, 30 % wrong detector labels)",
+                         "ms_per_sweep": round(per_s * 1e3, 3), "queries_per_s": round(KNN_Q / per_s),
+                         "kept_fraction": round(float(keep_s.float().mean()), 4) if keep_s is not None else None}
+    if not only and not c.use_dist:
+        # D = 384: the descriptor width of the ViT-S/8 the reference verifies with
+        sh3, q3 = _knn_inputs(c, KNN_S, 17, D=384), _knn_inputs(c, KNN_Q, 117, D=384)
+        for _ in range(2):
+            knn_sweep(cls, sh3, q3, det, 10, True)
+        _barrier(c)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            knn_sweep(cls, sh3, q3, det, 10, True)
+        _barrier(c)
+        p3 = (time.perf_counter() - t0) / steps
+        out["d384"] = {"workload": "Q=%d x S=%d x D=384 (ViT-S/8 descriptors), randn inputs" % (KNN_Q, KNN_S), "ms_per_sweep": round(p3 * 1e3, 3),
+                       "queries_per_s": round(KNN_Q / p3), "algorithmic_bytes": KNN_Q * 384 * 4 + KNN_S * 384 * 4 + KNN_Q * 80,
+                       "algorithmic_GBps": round((KNN_Q * 384 * 4 + KNN_S * 384 * 4 + KNN_Q * 80) / p3 / 1e9, 1)}
+        del sh3, q3
     if c.rank == 0 and not c.use_dist and sample_check:
         from oracle import knn as oknn
 
-        for name, t in (("structured", top), ("unstructured", top_u)):
+        for name, t in ((only or "randn", top), ("structured", top_s)):
             shots, q = inputs[name]
             ref = oknn.dense(cls.cpu(), shots.cpu(), q[:sample_check].cpu(), True)
             same = "%d / %d" % (int((t[:sample_check].cpu() == ref).all(dim=1).sum()), sample_check)
-            if name == "structured":
+            if name != "structured" or only == "structured":
                 out["top10_rows_identical_to_oracle"] = same
             else:
-                out["unstructured"]["top10_rows_identical_to_oracle"] = same
+                out["structured"]["top10_rows_identical_to_oracle"] = same
     return out
 
 
 # ----------------------------------------------------------------------------------------------- training (cfg 3)
-def train_leg(c, steps, warmup, batch_per_gpu=8):
-    """BASELINE configs[2]: COCO 30-shot novel fine-tune (only the box predictor trains: 4 tensors, 0.41 MB of
-    gradients), R50-FPN, 8 images of 800x1333 per GPU, gradients averaged with ONE flattened all-reduce over RCCL
-    (lvc/engine/defaults.py:326-331), SGD step."""
+def _train_batch(c, batch_per_gpu, num_classes, with_proposals=False):
     import torch
 
-    from lvc_amd import distributed as D
-    from lvc_amd.config import set_global_cfg
-    from lvc_amd.config.presets import base_rcnn_fpn
-    from lvc_amd.modeling import build_model
     from lvc_amd.structures import Boxes, Instances
     from lvc_amd.utils import synthetic as syn
-    from lvc_amd.utils.events import EventStorage
 
-    cfg = base_rcnn_fpn(num_classes=20, device="cuda:%d" % c.local_rank)
-    cfg.MODEL.BACKBONE.FREEZE = True
-    cfg.MODEL.PROPOSAL_GENERATOR.FREEZE = True
-    cfg.MODEL.ROI_HEADS.FREEZE_FEAT = True
-    set_global_cfg(cfg)
-    model = build_model(cfg)
-    syn.conditioned_r50_fpn_(model)
-    model.train()
     g = torch.Generator().manual_seed(1 + c.rank)
-    torch.manual_seed(20 + c.rank)          # per-rank sampling seed = SEED + rank (lvc/engine/defaults.py:198)
     batch = []
     for i in range(batch_per_gpu):
         h, w, n = 800, 1333, 8
@@ -258,22 +263,81 @@ def train_leg(c, steps, warmup, batch_per_gpu=8):
         y1 = torch.rand(n, generator=g) * (h - 300)
         bw = 40 + torch.rand(n, generator=g) * 250
         bh = 40 + torch.rand(n, generator=g) * 250
+        boxes = torch.stack([x1, y1, x1 + bw, y1 + bh], 1)
         inst = Instances((h, w))
-        inst.gt_boxes = Boxes(torch.stack([x1, y1, x1 + bw, y1 + bh], 1))
-        inst.gt_classes = torch.randint(0, 20, (n,), generator=g)
-        batch.append({"image": syn.synthetic_image(1 + (c.rank * batch_per_gpu + i) % 16).to(c.dev), "instances": inst,
-                      "height": h, "width": w})
+        inst.gt_boxes = Boxes(boxes)
+        inst.gt_classes = torch.randint(0, num_classes, (n,), generator=g)
+        d = {"image": syn.synthetic_image(1 + (c.rank * batch_per_gpu + i) % 16).to(c.dev), "instances": inst, "height": h, "width": w}
+        if with_proposals:     # the box corrector trains on jittered ground-truth boxes handed over as proposals (LOAD_PROPOSALS)
+            props = Instances((h, w))
+            props.proposal_boxes = Boxes(boxes.repeat(8, 1) + torch.randn(8 * n, 4, generator=g) * 10)
+            props.objectness_logits = torch.zeros(8 * n)
+            d["proposals"] = props
+        batch.append(d)
+    return batch
+
+
+def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
+    """which = "cfg3": BASELINE configs[2], COCO 30-shot novel fine-tune (only the box predictor trains: 4 tensors, 0.41 MB of
+    gradients), R50-FPN, 8 images of 800x1333 per GPU, gradients averaged with ONE flattened all-reduce over RCCL
+    (lvc/engine/defaults.py:326-331), SGD step (detectron2/engine/train_loop.py:211-250).
+    which = "cfg5": BASELINE configs[4], the box corrector (tools/train_net_reg.py: CascadeROIHeads + BoxOnlyLayersCascade on RBG
+    proposals, cascade_ubbr_R_101_FPN_base.yaml: FREEZE_AT 2, 133 trainable tensors), R101-FPN, 2 images of 800x1333 per GPU
+    (IMS_PER_BATCH 16 over 8 GPUs), gradients through `GradientBuckets` (64 MB buckets launched under the backward).
+    `phases`: after the timed steps, three more with a synchronize between forward / backward / optimizer (attribution only)."""
+    import torch
+
+    from lvc_amd import distributed as D
+    from lvc_amd.config import set_global_cfg
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    if which == "cfg3":
+        cfg = base_rcnn_fpn(num_classes=20, device="cuda:%d" % c.local_rank)
+        cfg.MODEL.BACKBONE.FREEZE = True
+        cfg.MODEL.PROPOSAL_GENERATOR.FREEZE = True
+        cfg.MODEL.ROI_HEADS.FREEZE_FEAT = True
+        depth, ncls = 50, 20
+    else:
+        cfg = base_rcnn_fpn(depth=101, num_classes=60, device="cuda:%d" % c.local_rank)
+        M = cfg.MODEL
+        M.ROI_HEADS.NAME = "CascadeROIHeads"; M.ROI_HEADS.OUTPUT_LAYER = "BoxOnlyLayersCascade"
+        M.ROI_HEADS.PROPOSAL_APPEND_GT = False; M.ROI_HEADS.POSITIVE_FRACTION = 1.0
+        M.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 64; M.ROI_HEADS.IOU_THRESHOLDS = [0.3]
+        M.ROI_BOX_HEAD.NUM_FC = 3; M.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = True
+        M.ROI_BOX_CASCADE_HEAD.IOUS = (0.3, 0.5, 0.7); M.PROPOSAL_GENERATOR.NAME = "RBG"; M.LOAD_PROPOSALS = True
+        depth, ncls = 101, 60
+    set_global_cfg(cfg)
+    model = build_model(cfg)
+    syn.conditioned_r50_fpn_(model, depth=depth)
+    model.train()
+    torch.manual_seed(20 + c.rank)          # per-rank sampling seed = SEED + rank (lvc/engine/defaults.py:198)
+    batch = _train_batch(c, batch_per_gpu, ncls, with_proposals=which != "cfg3")
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    opt = torch.optim.SGD(params, lr=1e-3 if which == "cfg3" else 1e-4, momentum=0.9, weight_decay=1e-4)
+    buckets = D.GradientBuckets(params) if which != "cfg3" else None
     nbytes = 0
 
-    def step():
+    def step(sync=None):
         nonlocal nbytes
+        t = [time.perf_counter()]
         losses = model(batch)
-        opt.zero_grad(set_to_none=True)
+        if sync:
+            torch.cuda.synchronize(); t.append(time.perf_counter())
+        opt.zero_grad(set_to_none=buckets is None)
         sum(losses.values()).backward()
-        nbytes = D.allreduce_gradients_(params)
+        if buckets is not None:
+            nbytes = buckets.finish()
+        else:
+            nbytes = D.allreduce_gradients_(params)
+        if sync:
+            torch.cuda.synchronize(); t.append(time.perf_counter())
         opt.step()
+        if sync:
+            torch.cuda.synchronize(); t.append(time.perf_counter())
+            sync.append([b - a for a, b in zip(t, t[1:])])
         return losses
 
     with EventStorage(0):
@@ -285,6 +349,10 @@ def train_leg(c, steps, warmup, batch_per_gpu=8):
             losses = step()
         _barrier(c)
         dt, every = _max_and_all(c, time.perf_counter() - t0)
+        ph = []
+        if phases:
+            for _ in range(3):
+                step(sync=ph)
     chk = torch.cat([p.detach().reshape(-1) for p in params]).double().sum()
     same = None
     if c.use_dist:      # after averaged gradients + identical SGD steps every rank must hold the same parameters
@@ -294,11 +362,48 @@ def train_leg(c, steps, warmup, batch_per_gpu=8):
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         same = bool(float(hi - lo) == 0.0)
-    return {"workload": "cfg 3 novel fine-tune step (fwd + bwd of the box predictor + RCCL gradient all-reduce + SGD), "
-                        "R50-FPN, %d x 800x1333 per GPU" % batch_per_gpu,
-            "value": round(c.world * batch_per_gpu * steps / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
-            "global_batch": batch_per_gpu * c.world, "gradient_bytes_allreduced": nbytes,
-            "parameters_identical_across_ranks": same, "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}}
+    name = ("cfg 3 novel fine-tune step (fwd + bwd of the box predictor + RCCL gradient all-reduce + SGD), R50-FPN" if which == "cfg3" else
+            "cfg 5 box-corrector step (tools/train_net_reg.py: fwd + bwd through res3..res5 / FPN / cascade heads + bucketed RCCL gradient exchange + SGD), R101-FPN")
+    out = {"workload": "%s, %d x 800x1333 per GPU" % (name, batch_per_gpu), "trainable_tensors": len(params),
+           "value": round(c.world * batch_per_gpu * steps / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
+           "global_batch": batch_per_gpu * c.world, "gradient_bytes_allreduced": nbytes,
+           "parameters_identical_across_ranks": same, "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}}
+    if ph:
+        out["ms_forward_backward_optimizer"] = [round(1e3 * sum(p[i] for p in ph) / len(ph), 2) for i in range(3)]
+        out["phase_note"] = "3 extra steps with a synchronize after each phase (attribution; the timed steps have none)"
+    if buckets is not None:
+        buckets.remove()
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def r101_leg(c, steps=10, warmup=3):
+    """R101-FPN inference at the headline's batch (the depth BASELINE configs[4] names), same timing rules."""
+    import torch
+
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+
+    model = build_model(base_rcnn_fpn(depth=101, device="cuda:%d" % c.local_rank)).eval()
+    syn.conditioned_r50_fpn_(model, depth=101)
+    batch = [{"image": syn.synthetic_image(1 + (c.rank * BATCH_PER_GPU + i) % 16).to(c.dev), "height": 800, "width": 1333} for i in range(BATCH_PER_GPU)]
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = model.inference_batched(batch)
+        _barrier(c)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model.inference_batched(batch)
+        _barrier(c)
+        dt, _ = _max_and_all(c, time.perf_counter() - t0)
+    n_det = out[3].tolist()
+    del model
+    torch.cuda.empty_cache()
+    return {"workload": "R101-FPN GeneralizedRCNN inference, bs=%d synthetic 3x800x1333 per GPU" % BATCH_PER_GPU,
+            "value": round(c.world * BATCH_PER_GPU * steps / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
+            "detections_per_image": n_det}
 
 
 # ----------------------------------------------------------------------------------------------- HBM-side kernels
@@ -523,9 +628,17 @@ def infer_main(c, args):
                         bk.update(_knn_kernels_alone(c))
             else:
                 extras["dp_legs"] = {"knn": knn_leg(c, 3, 1)}
-                extras["dp_legs"]["train_cfg3"] = train_leg(c, 3, 1)
+                extras["dp_legs"]["train_cfg3"] = train_leg(c, 3, 1, phases=False)
         except Exception as e:
             extras["dp_legs_error"] = repr(e)
+        # BASELINE configs[2] / [4] are training workloads and configs[4] names R101: their one-GPU rates, every run
+        if c.world == 1:
+            for key, fn in (("train_cfg3", lambda: train_leg(c, 5, 2, 8, "cfg3")), ("train_cfg5_r101", lambda: train_leg(c, 5, 2, 2, "cfg5")),
+                            ("r101_inference", lambda: r101_leg(c))):
+                try:
+                    extras.setdefault("train", {})[key] = fn()
+                except Exception as e:
+                    extras.setdefault("train", {})[key] = {"error": repr(e)}
 
     cpu_baseline = parity = None
     if c.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:

@@ -2,7 +2,7 @@
 # kNN sweep kernels: kernel trace + stats, then FETCH_SIZE / WRITE_SIZE / busy counters in separate --pmc passes (kernel trace only)
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/knn_pmc
-export LVC_BENCH_KNN_STRUCTURED_ONLY=1
+export LVC_BENCH_KNN_ONLY=${LVC_BENCH_KNN_ONLY:-randn}
 CMD="python $GRAFT_REPO_ROOT/bench.py --workload knn --steps 5 --warmup 2 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > /dev/null 2>&1
 i=0
