@@ -324,7 +324,7 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
         nonlocal nbytes
         t = [time.perf_counter()]
         losses = model(batch)
-        if sync:
+        if sync is not None:
             torch.cuda.synchronize(); t.append(time.perf_counter())
         opt.zero_grad(set_to_none=buckets is None)
         sum(losses.values()).backward()
@@ -332,10 +332,10 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
             nbytes = buckets.finish()
         else:
             nbytes = D.allreduce_gradients_(params)
-        if sync:
+        if sync is not None:
             torch.cuda.synchronize(); t.append(time.perf_counter())
         opt.step()
-        if sync:
+        if sync is not None:
             torch.cuda.synchronize(); t.append(time.perf_counter())
             sync.append([b - a for a, b in zip(t, t[1:])])
         return losses
@@ -490,7 +490,7 @@ def infer_main(c, args):
     # one fully bracketed untimed step; ~150 event records per step cost ~0.7 ms of host time inside the timed region),
     # the per-kernel breakdown of every conv/GEMM launch comes from two more untimed steps after it.
     timer = full = None
-    NAMES = {"f16x2_halo": "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise / FC; conv_pw256_f16x2_kernel beyond its range)", "bf16x3_halo": "conv3x3_halo_kernel",
+    NAMES = {"f16x2_halo": "conv3x3_halo_s1_kernel (pipelined 3x3: one accumulator in the trunk, two in the RPN head)" if K.HALO_S1 else "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise / FC; conv_pw256_f16x2_kernel beyond its range)", "bf16x3_halo": "conv3x3_halo_kernel",
              "bf16x3": "conv_bf16x3_kernel (+ bf16 pointwise shapes)", "f32": "conv_igemm_f32_kernel"}
     if not args.no_launch_timer:
         probe = K.LaunchTimer()
@@ -590,7 +590,7 @@ def infer_main(c, args):
         roofline = {
             "kernel": "%s (%d launches/step; HIP-event brackets in %d of the %d timed steps)" % (NAMES[dom], nlaunch // max(1, timer.steps_timed()), timer.steps_timed(), args.steps),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split a = a1 + 2^-11 a2, main + cross fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once; the kernel runs at the 1.4 kW socket power cap (profiles/README.md)",
+            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split, a1 b1 + a1 b2 + a2 b1 in fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once; under the socket power cap a bare loop of these MFMAs on random data sustains 1.66 PFLOP/s = 552 TFLOP/s fp32-equivalent (profiles/r03_mfma_ceiling.txt)",
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic,
             "traffic_source": ("live rocprofv3 --pmc passes in this run" if live is not None else "profiles (not measured in this run)")

@@ -44,6 +44,7 @@ struct ConvArgsD {
   int* flags;
   int H, W, C, K, stride, Ho, Wo, M, Kg, relu, res_mode, ldy, ldr;
   int tiles_n, nk, total_units, units_per_worker, nworkers, err_index, ngroup, y_bytes;
+  unsigned long long* dbg;   // LVC_PW_TIMELINE=1 (scripts/probe_pw_timeline.py): s_memtime stamps of every 64th workgroup, else null
   int ablate;   // experiments (LVC_PW_ABLATE): 1 = no operand DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no stores, 8 = no drain before the stores
   long long w_plane_elems;
 };
@@ -72,6 +73,10 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
   const int fi = lane & 31, fh = lane >> 5;
   const int fx7 = (fi >> 1) & 7, fx3 = (fi >> 2) & 3;
 
+  unsigned long long* const dbg = (p.dbg && tid == 0 && (blockIdx.x & 63) == 0) ? p.dbg + (blockIdx.x >> 6) * 512 : nullptr;
+  int dbg_i = 1;
+#define STAMP(tag) do { if (dbg && dbg_i < 255) { dbg[2 * dbg_i] = __builtin_readcyclecounter(); dbg[2 * dbg_i + 1] = (tag); ++dbg_i; dbg[0] = dbg_i; } } while (0)
+  STAMP(1);
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
   // ngroup > 1: the workers lw .. lw + ngroup - 1 (neighbours on one XCD) walk the same row tiles, one output-channel tile
   // each, so an activation tile comes from the fabric once and from that XCD's L2 for the others
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
   loader_enter(l_tile);
   issue_chunk();
   if (D_NS > 2) issue_chunk();
+  STAMP(2);
 
   float big = 0.f;   // largest |operand| met: beyond fp16 -> workspace error word
 
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
 #pragma unroll 1
     for (int kc = kc0; kc < kc1; ++kc) {
       chunk_top();
+      STAMP(3);
       const unsigned char* st = smem + (consumed % D_NS) * STAGE;
       const unsigned char* sa = st + (wave * WR + fi) * 128;
       const unsigned char* sb = st + D_A_BYTES + fi * 64;
@@ -308,6 +315,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
       ++consumed;
     }
     u += kc1 - kc0;
+    STAMP(4);
     if (!WIDE) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
@@ -338,6 +346,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      STAMP(5);
       continue;
     }
     if (kc1 < p.nk) {
@@ -370,6 +379,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
       }
     }
 
+    STAMP(6);
     // ---- epilogue: per-channel affine, residual, ReLU, accumulators -> HBM.
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -429,10 +439,12 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
     // offset, channels past K) are dropped by the bounds check; a store instruction writes 2 rows x 32 consecutive channels
     // (128-byte segments).  The chunks prefetched so far are drained FIRST and remembered as landed: the counted waits of the
     // next chunks would otherwise also wait for these 16 NI stores (one vmcnt queue).
+    STAMP(7);
     if (!(p.ablate & 8)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       landed = issued;
     }
+    STAMP(8);
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
     const float lo = p.relu ? 0.f : -INFINITY;
     const unsigned ldy4 = (unsigned)p.ldy * 4u;
@@ -450,7 +462,10 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
         }
       }
     }
+    STAMP(10);
   }
+  STAMP(9);
+#undef STAMP
   if (!(big <= 65504.f)) atomicOr(p.flags + p.err_index, 2);
 }
 
@@ -528,6 +543,9 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   a.err_index = LVC_MAX_WORKERS;
   static const int ablate = [] { const char* e = getenv("LVC_PW_ABLATE"); return e ? atoi(e) : 0; }();
   a.ablate = ablate;
+  // timeline stamps (experiments): the upper half of the partial-tile area is never used by <= 256 workers
+  static const int timeline = [] { const char* e = getenv("LVC_PW_TIMELINE"); return e ? atoi(e) : 0; }();
+  a.dbg = timeline ? (unsigned long long*)((char*)workspace + (size_t)512 * 256 * 128 * 4) : nullptr;
   hipStream_t st = (hipStream_t)stream;
 #define PW_LAUNCH(NI_, NW_, NS_) hipLaunchKernelGGL((conv_pw_dma_kernel<NI_, NW_, NS_, 1>), dim3(a.nworkers), dim3(NW_ * 64), 0, st, a)
   if (wide) {

@@ -13,8 +13,8 @@ the fp64 argument carried to the OUTPUTS.
    scores of matched detections, error(GPU, fp64) against error(CPU fp32, fp64) and asserts the GPU is no further
    from the exact answer than the reference is (R50 small + 800x1333, R101 small).
 
-3. A floor on the fraction of reference detections the HIP path reproduces within the literal 1e-3, so that it cannot
-   silently regress.
+3. The fraction of reference detections the HIP path reproduces within the literal 1e-3 must reach the fraction the fp64
+   evaluation itself reproduces (minus 2 points): tied to the measured fp64 evidence, not to a hand-set floor.
 """
 import numpy as np
 import pytest
@@ -52,50 +52,89 @@ def _chain_gpu(model, feats_cpu, sizes, out_hw):
             cnt.cpu().tolist())
 
 
-@pytest.mark.parametrize("seeds,hw", [((1, 2), (800, 1333)), ((3, 4), (320, 480))])
+def _near_tie_pairs(sorted_scores, tie):
+    """Entries of a descending score list that sit within `tie` of a neighbour (each may legitimately trade places)."""
+    s = sorted_scores.double()
+    close = (s[:-1] - s[1:]).abs() <= tie
+    flag = torch.zeros(len(s), dtype=torch.bool)
+    flag[:-1] |= close
+    flag[1:] |= close
+    return int(flag.sum())
+
+
+# seeds 1..8 at 800x1333 = the batch bench.py times (`timed_batch_parity` re-checks it end to end in every bench run)
+@pytest.mark.parametrize("seeds,hw", [((1, 2, 3, 4, 5, 6, 7, 8), (800, 1333)), ((3, 4), (320, 480))])
 def test_post_trunk_chain_exact_decisions_and_1e3(seeds, hw):
+    """No hand-set allowances: every budget below is measured, in this test, on the ORACLE itself -- the same chain evaluated
+    in fp64 from the same features says how far a correct fp32 evaluation may sit from the exact answer, and therefore how
+    far two correct fp32 evaluations may sit from each other:
+      * TIE (scores that may come out in either order) = 4 x the largest |fp32 - fp64| of the oracle's own logits / scores
+        (two evaluations, each off by up to that much, in opposite directions, on both entries of a pair);
+      * rows allowed to trade places = the entries of the oracle's list that HAVE a neighbour within TIE;
+      * proposal boxes: |GPU - oracle fp32| <= 2 x the largest |oracle fp32 - oracle fp64| + 2 fp32 ulp at the image width
+        (both are within that distance of the exact box);
+      * final detections: the literal 1e-3 of north_star on scores and boxes."""
     from lvc_amd.utils import synthetic as syn
     from oracle import rcnn as orc
 
     model = _r50()
     sd = r50_state_dict()
+    sd64 = {k: v.double() for k, v in sd.items()}
     spec = orc.RCNNSpec()
     inputs = [{"image": syn.synthetic_image(s, *hw), "height": hw[0], "width": hw[1]} for s in seeds]
     with torch.no_grad():
         imgs, sizes = orc.preprocess([b["image"] for b in inputs], spec.pixel_mean, spec.pixel_std, 32)
         feats = orc.fpn(sd, orc.resnet(sd, imgs, 50))
         ref, mid = orc.generalized_rcnn_inference(sd, spec, inputs, return_intermediates=True, feats=feats)
+        ref64, mid64 = orc.generalized_rcnn_inference(sd64, spec, inputs, return_intermediates=True,
+                                                      feats={k: v.double() for k, v in feats.items()})
     pb, pl, pc, ob, osc, ocl, orow, cnt = _chain_gpu(model, feats, sizes, [hw] * len(inputs))
+    ulp = 2.0 * 2.0 ** -23 * 2048.0          # two fp32 ulp of a coordinate below 2048 px
     for i in range(len(inputs)):
         rb, rl = mid["proposals"][i]
+        rb64, rl64 = mid64["proposals"][i]
         assert pc[i] == len(rb), "image %d: %d proposals vs %d" % (i, pc[i], len(rb))
-        # Same proposals in the same order == identical top-k selection and identical NMS keep decisions.  Two entries
-        # may trade places only when the ORACLE's own logits for them are closer than TIE (the two fp32 evaluations
-        # of the RPN head differ by a few ulp of the logit, |dlogit| <= 1e-5: measured below).
-        perm, moved = _tie_aware_order(pb[i, : pc[i]], pl[i, : pc[i]], rb, rl, PROP_BOX_TOL, 1e-3, TIE)
+        # the oracle against itself in fp64: match its two proposal lists generously (no order requirement: near-ties differ)
+        n = min(len(rb), len(rb64))
+        d = (rb[:n, None, :].double() - rb64[None, :n, :]).abs().max(dim=2)[0]
+        j = d.argmin(dim=1)
+        near = d[torch.arange(n), j] <= 0.05
+        e_box = float(d[torch.arange(n), j][near].max())
+        e_log = float((rl[:n].double() - rl64[j])[near].abs().max())
+        tie = max(4.0 * e_log, 1e-6)
+        box_tol = 2.0 * e_box + ulp
+        budget = _near_tie_pairs(rl, tie)
+        # Same proposals in the same order == identical top-k selection and identical NMS keep decisions, up to near-ties
+        perm, moved = _tie_aware_order(pb[i, : pc[i]], pl[i, : pc[i]], rb, rl, box_tol, 1e-3, tie)
         dbox = (pb[i, : pc[i]] - rb[perm]).abs().max(dim=1)[0]
         dlog = (pl[i, : pc[i]] - rl[perm]).abs()
-        print("image %d: %d proposals, identical set; %d rows in a near-tie swap (|dlogit| < %.0e); worst |box| %.2e px, "
-              "worst |logit| %.2e" % (i, pc[i], moved, TIE, float(dbox.max()), float(dlog.max())))
-        assert moved <= 6
+        print("image %d: %d proposals, identical set; oracle fp32-vs-fp64: |logit| %.2e |box| %.2e px -> TIE %.1e, box bar %.2e px, "
+              "%d entries in near-ties; GPU: %d rows swapped, worst |box| %.2e px, worst |logit| %.2e"
+              % (i, pc[i], e_log, e_box, tie, box_tol, budget, moved, float(dbox.max()), float(dlog.max())))
+        assert moved <= budget
+        assert float(dlog.max()) <= 2.0 * e_log + 1e-6
         r = ref[i]
         n = cnt[i]
         assert n == len(r["scores"]), "image %d: %d detections vs %d" % (i, n, len(r["scores"]))
         # detections: (class, source proposal) identical, in the oracle's order up to score near-ties
+        r64 = ref64[i]
+        m = min(len(r["scores"]), len(r64["scores"]))
+        d64 = (r["pred_boxes"][:m, None, :].double() - r64["pred_boxes"][None, :m, :]).abs().max(dim=2)[0]
+        j64 = d64.argmin(dim=1)
+        ok64 = (d64[torch.arange(m), j64] <= 0.05) & (r["pred_classes"][:m] == r64["pred_classes"][j64])
+        e_score = float((r["scores"][:m].double() - r64["scores"][j64])[ok64].abs().max())
+        tie_s = max(4.0 * e_score, 1e-6)
+        dbudget = _near_tie_pairs(r["scores"], tie_s)
         src = perm[orow[i, :n]]                     # the GPU's source rows in the oracle's proposal numbering
         key_g = torch.stack([ocl[i, :n].double(), src.double()], 1)
         key_r = torch.stack([r["pred_classes"].double(), r["rows"].double()], 1)
-        dperm, dmoved = _tie_aware_order(key_g, osc[i, :n], key_r, r["scores"], 0.0, 1e-3, TIE)
+        dperm, dmoved = _tie_aware_order(key_g, osc[i, :n], key_r, r["scores"], 0.0, 1e-3, tie_s)
         ds = float((osc[i, :n] - r["scores"][dperm]).abs().max())
         db = float((ob[i, :n] - r["pred_boxes"][dperm]).abs().max())
-        print("image %d: %d detections, classes and source rows identical (%d in a near-tie swap); worst |score| %.2e, "
-              "worst |box| %.2e px" % (i, n, dmoved, ds, db))
-        assert dmoved <= 4
+        print("image %d: %d detections, classes and source rows identical; oracle fp32-vs-fp64 |score| %.2e -> TIE %.1e, %d entries "
+              "in near-ties; GPU: %d swapped, worst |score| %.2e, worst |box| %.2e px" % (i, n, e_score, tie_s, dbudget, dmoved, ds, db))
+        assert dmoved <= dbudget
         assert ds <= 1e-3 and db <= 1e-3
-
-
-TIE = 5e-5            # two scores closer than this in the oracle's own evaluation may come out in either order
-PROP_BOX_TOL = 2.5e-3  # proposals: RPN deltas agree to ~1e-6, times exp(dw) x 724-px anchors (fp32 ulp at 1333 px: 1.2e-4)
 
 
 def _tie_aware_order(vals, scores, ref_vals, ref_scores, val_tol, score_tol, tie):
@@ -167,6 +206,19 @@ def _fp64_compare(model, sd, spec, inputs, tag):
         assert np.percentile(e_gb, 90) <= 1.5 * np.percentile(e_cb, 90) + 1e-6
         assert np.median(e_gs) <= 1.25 * np.median(e_cs) + 1e-8
         assert np.percentile(e_gs, 90) <= 1.5 * np.percentile(e_cs, 90) + 1e-8
+        # The literal 1e-3 of north_star, end to end: the fraction of the reference's (fp32 CPU) detections the HIP path
+        # reproduces within 1e-3 must be no smaller than the fraction of them that the EXACT evaluation confirms within 1e-3
+        # (minus 2 points of matching noise) -- i.e. the HIP path agrees with the reference as well as the truth does.
+        tight_g, _, _ = match_fraction(g.pred_boxes.tensor, g.scores, g.pred_classes, r32[i]["pred_boxes"], r32[i]["scores"],
+                                       r32[i]["pred_classes"], box_tol=1e-3, score_tol=1e-3)
+        tight_c, _, _ = match_fraction(r64[i]["pred_boxes"].float(), r64[i]["scores"].float(), r64[i]["pred_classes"], r32[i]["pred_boxes"],
+                                       r32[i]["scores"], r32[i]["pred_classes"], box_tol=1e-3, score_tol=1e-3)
+        loose_g, wb, ws = match_fraction(g.pred_boxes.tensor, g.scores, g.pred_classes, r32[i]["pred_boxes"], r32[i]["scores"],
+                                         r32[i]["pred_classes"], box_tol=0.1, score_tol=2e-3)
+        print("   reference detections within 1e-3 of: the HIP path %.1f%%, the fp64 evaluation %.1f%%; within 0.1 px / 2e-3 of the "
+              "HIP path %.1f%% (worst %.2e px, %.2e)" % (100 * tight_g, 100 * tight_c, 100 * loose_g, wb, ws))
+        assert tight_g >= tight_c - 0.02
+        assert loose_g >= 0.9
 
 
 def test_final_outputs_vs_fp64_r50():
@@ -196,33 +248,3 @@ def test_final_outputs_vs_fp64_r101():
     _fp64_compare(model, sd, orc.RCNNSpec(depth=101), inputs, "R101 small")
 
 
-# Measured on MI355X (round 2): see DESIGN.md section 4 for the numbers these floors sit under.
-TIGHT_FLOOR = {"e2e_r50_fpn_small": 0.02, "e2e_r50_fpn_800x1333": 0.02}
-
-
-@pytest.mark.parametrize("name", sorted(TIGHT_FLOOR))
-def test_within_1e3_fraction_floor(name):
-    """Fraction of the reference-CPU detections reproduced within the LITERAL 1e-3 (box px and score, same class)."""
-    from helpers import gold
-    from lvc_amd.utils import synthetic as syn
-
-    model = _r50()
-    if name.endswith("small"):
-        inputs = [{"image": syn.synthetic_image(3, 240, 320), "height": 480, "width": 640},
-                  {"image": syn.synthetic_image(4, 200, 352), "height": 200, "width": 352}]
-    else:
-        inputs = [{"image": syn.synthetic_image(1), "height": 800, "width": 1333},
-                  {"image": syn.synthetic_image(2), "height": 800, "width": 1333}]
-    g = gold(name)
-    with torch.no_grad():
-        out = model(inputs)
-    fr = []
-    for i in range(len(inputs)):
-        inst = out[i]["instances"].to("cpu")
-        tight, _, _ = match_fraction(inst.pred_boxes.tensor, inst.scores, inst.pred_classes, g["det_boxes%d" % i],
-                                     g["det_scores%d" % i], g["det_classes%d" % i], box_tol=1e-3, score_tol=1e-3)
-        loose, wb, ws = match_fraction(inst.pred_boxes.tensor, inst.scores, inst.pred_classes, g["det_boxes%d" % i],
-                                       g["det_scores%d" % i], g["det_classes%d" % i], box_tol=0.1, score_tol=2e-3)
-        print("%s image %d: within 1e-3: %.1f%%; within 0.1 px / 2e-3: %.1f%% (worst %.2e px, %.2e)" % (name, i, 100 * tight, 100 * loose, wb, ws))
-        fr.append(tight)
-    assert min(fr) >= TIGHT_FLOOR[name], fr
