@@ -135,6 +135,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
     }
     l_nj = min(NI, (p.K - tn * GBN + 31) >> 5);   // 32-channel blocks of this tile that exist
   };
+  unsigned res_mask = 0;          // bit (i & 31): chunk i is a residual chunk (4 MI DMA pieces instead of NPER)
   int issued = 0, consumed = 0;   // chunks of this worker, both count from 0; ring slot = counter % D_NS
   int landed = 0;                 // chunks [0, landed) are known to have landed (a full drain happened after their issue)
   auto next_segment = [&]() {
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
           glds16(bsrc[j] + l_kc * 32, st + D_A_BYTES + pl * B_PLANE + rb * 16 * 64);
         }
       }
+      res_mask &= ~(1u << (issued & 31));
       ++l_kc; ++lu; ++issued;
       if (l_kc == p.nk || lu == u_end) {
         if (res_layer && l_seg0 == 0 && l_nj > 0) { l_phase = 1; l_j = 0; }
@@ -166,13 +168,10 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
         const int c0 = tile_n_of(l_tile) * GBN + l_j * 32;
 #pragma unroll
         for (int i = 0; i < 4 * MI; ++i) glds16(rsrc[i] + c0, st + (wave * WR + i * 8) * 128);
-#pragma unroll
-        for (int j = 0; j < NBW; ++j) {   // same instruction count as a K chunk (the counted waits rely on it); data unused
-          const int idx = (wave * NBW + j) % (4 * NI);
-          const int pl = idx / (2 * NI), rb = idx % (2 * NI);
-          glds16(bsrc[j], st + D_A_BYTES + pl * B_PLANE + rb * 16 * 64);
-        }
       }
+      // a residual chunk carries only the 4 MI activation-slot pieces (no weight planes): remembered per ring position so that
+      // the counted wait of the chunk BEFORE it leaves exactly these outstanding
+      res_mask |= 1u << (issued & 31);
       ++issued;
       if (++l_j == l_nj) next_segment();
     }
@@ -182,8 +181,10 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
   // the barrier every wave is done with chunk consumed - 1, whose slot takes chunk consumed + D_NS - 1
   auto chunk_top = [&]() {
     if (consumed >= landed) {
-      if (D_NS > 2 && issued - consumed >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (D_NS > 2 && issued - consumed >= 2) {
+        if ((res_mask >> ((consumed + 1) & 31)) & 1u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * MI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPER) : "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     issue_chunk();

@@ -343,6 +343,20 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         assert residual.is_contiguous() and residual.dtype == torch.float32
         if res_mode == 0:
             res_mode = 1
+    # The split-precision kernels address their operands through 32-bit buffer descriptors (< 2 GiB per tensor).  A batch whose
+    # input / output / residual reaches 2^29 elements (32 images on the p2 map) is run in image groups that stay below it --
+    # same kernels, same values (a tile never spans two images) -- instead of failing (logged once)
+    big = max(x.numel(), out.numel(), residual.numel() if residual is not None else 0)
+    if big >= (1 << 29) and N > 1 and out.is_contiguous() and out.shape[-1] == pc.K:
+        per_image = (big + N - 1) // N
+        nb = max(1, ((1 << 29) - 1) // per_image)
+        _log_once("conv_batch_split", "conv/GEMM layer with %d elements in one tensor (batch %d): run in groups of %d images to stay "
+                  "inside the kernels' 2 GiB buffer descriptors", big, N, nb)
+        for n0 in range(0, N, nb):
+            n1 = min(N, n0 + nb)
+            conv2d_nhwc(x[n0:n1], pc, relu=relu, residual=residual[n0:n1] if residual is not None else None, res_mode=res_mode,
+                        out=out[n0:n1], split=split)
+        return out
     ldr = residual.shape[-1] if residual is not None else 0
     engine = "f32"
     halo = CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0
@@ -392,8 +406,9 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
             # residual rows in 32-channel chunks; anything else stays on the register-staged kernel (logged once)
             dma_ok = out.numel() < (1 << 29) and (residual is None or (residual.numel() < (1 << 29) and pc.K % 32 == 0))
             if PW_DMA and not dma_ok:
-                _log_once("pw_dma_fallback", "pointwise layer %dx%d->%d (%d output elements) is outside the LDS-DMA kernel's "
-                          "range; it runs on the register-staged fp16x2 kernel", N * H * W, C, pc.K, out.numel())
+                _log_once("pw_dma_fallback", "pointwise layer %dx%d->%d (%d output elements, residual %s) is outside the LDS-DMA "
+                          "kernel's range; it runs on the register-staged fp16x2 kernel", N * H * W, C, pc.K, out.numel(),
+                          "yes" if residual is not None else "no")
             fn = "lvc_conv2d_nhwc_f16x2_dma" if PW_DMA and dma_ok else "lvc_conv2d_nhwc_f16x2"
             st = getattr(_lib.lib(), fn)(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),

@@ -180,27 +180,37 @@ def test_pipelined_two_consecutive_overflows(caplog, monkeypatch):
                 assert torch.equal(a.pred_boxes.tensor, q.pred_boxes.tensor) and torch.equal(a.scores, q.scores)
 
 
-def test_pointwise_beyond_2_29_elements_falls_back_and_logs(caplog, monkeypatch):
-    """A pointwise layer whose output reaches 2^29 elements (batch 32 on the p2 map) is outside the 32-bit buffer descriptors of
-    the LDS-DMA kernel: it must run on the register-staged fp16x2 kernel, say so once, and give the same values."""
+def test_layers_beyond_2_29_elements_run_in_image_groups(caplog, monkeypatch):
+    """A layer whose tensors reach 2^29 elements (batch 32 on the p2 map: 2.2 GB of fp32) is outside the 32-bit buffer
+    descriptors of the split-precision kernels: it must run in image groups that stay inside them -- same kernels, same
+    values -- and say so once (pointwise with residual, and the 3x3 kernel)."""
     from lvc_amd import kernels as K
 
     monkeypatch.setattr(K, "_LOGGED_ONCE", set())
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(3)
     x = torch.randn(32, 200, 336, 256, device=dev, generator=g)
+    res = torch.randn(32, 200, 336, 256, device=dev, generator=g)
     w = torch.randn(256, 256, 1, 1, device=dev, generator=g) * 0.06
     pc = K.pack_conv(w)
     with caplog.at_level(logging.WARNING, logger="lvc_amd"):
-        y = K.conv2d_nhwc(x, pc, relu=True)
-        K.conv2d_nhwc(x, pc, relu=True, out=y)
+        y = K.conv2d_nhwc(x, pc, relu=True, residual=res)
+        K.conv2d_nhwc(x, pc, relu=True, residual=res, out=y)
     assert y.numel() >= 1 << 29
-    msgs = [r.getMessage() for r in caplog.records if "LDS-DMA" in r.getMessage()]
+    msgs = [r.getMessage() for r in caplog.records if "groups of" in r.getMessage()]
     assert len(msgs) == 1, msgs                                   # logged once
-    ys = K.conv2d_nhwc(x[30:32].contiguous(), pc, relu=True)      # 2 images: the LDS-DMA kernel
+    ys = K.conv2d_nhwc(x[30:32].contiguous(), pc, relu=True, residual=res[30:32].contiguous())
     torch.cuda.synchronize()
     assert K.conv_error_word(dev) == 0
     sc = float(ys.abs().max())
-    assert float((y[30:32] - ys).abs().max()) <= 4e-6 * sc        # same arithmetic, different summation grouping
-    ref = torch.relu(x[31, 100, :8].double() @ w[:, :, 0, 0].double().t())
+    assert float((y[30:32] - ys).abs().max()) <= 4e-6 * sc        # the same kernel on the same images
+    ref = torch.relu(x[31, 100, :8].double() @ w[:, :, 0, 0].double().t() + res[31, 100, :8].double())
     assert float((y[31, 100, :8].double() - ref).abs().max()) <= 2e-5 * sc
+    del res, ys
+    w3 = torch.randn(256, 256, 3, 3, device=dev, generator=g) * 0.02
+    pc3 = K.pack_conv(w3, stride=1, pad=1)
+    K.conv2d_nhwc(x, pc3, relu=True, out=y)
+    ys = K.conv2d_nhwc(x[5:6].contiguous(), pc3, relu=True)
+    torch.cuda.synchronize()
+    assert K.conv_error_word(dev) == 0
+    assert float((y[5:6] - ys).abs().max()) <= 4e-6 * float(ys.abs().max())
