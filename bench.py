@@ -48,7 +48,7 @@ def _self_launch(args):
     import torch
 
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and os.environ.get("LVC_BENCH_ALLOW_SHARED_GPU") != "1":
         print(json.dumps({"error": "bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, have), "n_gpus": args.gpus}))
         sys.exit(3)
     with socket.socket() as s:
@@ -56,10 +56,34 @@ def _self_launch(args):
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def _pin_rank_to_cpus(local_rank, world):
+    """One slice of the host's CPUs per rank (contiguous: a slice stays on one socket / CCD group), and a thread pool sized
+    for it: eight ranks' Python launch loops and torch CPU pools otherwise migrate over -- and oversubscribe -- the same
+    cores.  Returns a description for the bench line, or None when the platform has no affinity call."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    per = max(1, len(cpus) // max(1, world))
+    mine = cpus[local_rank * per: (local_rank + 1) * per] or cpus
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    threads = max(1, min(8, len(mine)))
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    try:
+        import torch
+
+        torch.set_num_threads(threads)
+    except Exception:
+        pass
+    return {"cpus": "%d-%d" % (mine[0], mine[-1]), "count": len(mine), "threads": threads}
 
 
 def _cpu_model():
@@ -100,17 +124,26 @@ def _setup():
     c.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     c.world = int(os.environ.get("WORLD_SIZE", "1"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    ndev = torch.cuda.device_count()
+    # LVC_BENCH_ALLOW_SHARED_GPU=1 (tests on a one-GPU box): ranks share devices round-robin and talk through gloo -- RCCL refuses
+    # two ranks on one device.  Everything else (launcher, rank-sharded inputs, legs, JSON merge) is the N-GPU path.
+    shared = ndev < c.world and os.environ.get("LVC_BENCH_ALLOW_SHARED_GPU") == "1"
+    c.local_rank = c.local_rank % ndev if shared else c.local_rank
     torch.cuda.set_device(c.local_rank)
     c.dev = torch.device("cuda", c.local_rank)
     c.use_dist = c.world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
     c.rccl = None
     if c.use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=c.dev)  # "nccl" is RCCL on ROCm
+        pin = _pin_rank_to_cpus(int(os.environ.get("LOCAL_RANK", "0")), c.world) if c.world > 1 else None
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=c.dev)  # "nccl" is RCCL on ROCm
         one = torch.ones(1, device=c.dev)
         dist.all_reduce(one)
         c.rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                  "allreduce_of_ones": float(one.item())}
+                  "allreduce_of_ones": float(one.item()), "devices_shared": bool(shared), "cpu_affinity_rank0": pin}
         assert dist.get_world_size() == c.world and float(one.item()) == c.world
     return c
 
@@ -562,6 +595,30 @@ def infer_main(c, args):
                      "unit": "img/s", "ms_per_step": round(1e3 * pmax / args.steps, 3),
                      "note": "same K steps, batches in flight on 2 HIP streams; results bit-identical (tests/test_gpu_pipeline.py)"}
 
+    # The same K steps as ONE hipGraph launch each (lvc_amd.evaluation.GraphedInference): what the step costs when the host's
+    # launch loop is taken out of it (eight ranks share one host at N = 8).  Not `value`.
+    graphed = None
+    if not args.no_extras:
+        try:
+            from lvc_amd.evaluation import GraphedInference
+
+            gi = GraphedInference(model, batch)
+            for _ in range(3):
+                gi.replay()
+            _barrier(c)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                gi.replay()
+            _barrier(c)
+            gdt, _ = _max_and_all(c, time.perf_counter() - t1)
+            same = all(bool(torch.equal(a, b)) for a, b in zip(gi.out, out))
+            graphed = {"value": round(c.world * BATCH_PER_GPU * args.steps / gdt, 2), "unit": "img/s", "ms_per_step": round(1e3 * gdt / args.steps, 3),
+                       "outputs_bit_identical_to_eager": same,
+                       "note": "inference_batched captured in one hipGraph and replayed (host cost per step: one graph launch)"}
+            del gi
+        except Exception as e:
+            graphed = {"error": repr(e)}
+
     total_imgs = c.world * BATCH_PER_GPU * args.steps
     value = total_imgs / dt_max
 
@@ -658,7 +715,7 @@ def infer_main(c, args):
                        "detections_per_image": n_det},
             "rccl": c.rccl, "per_rank": {"img_per_s": [round(BATCH_PER_GPU * args.steps / t, 2) for t in dt_all],
                                          "seconds": [round(t, 4) for t in dt_all], "max_over_ranks_s": round(dt_max, 4)},
-            "roofline": roofline, "value_through_forward": through_forward, "pipelined": pipelined,
+            "roofline": roofline, "value_through_forward": through_forward, "pipelined": pipelined, "graphed": graphed,
             "cpu_baseline": cpu_baseline, "timed_batch_parity": parity,
         }
         line.update(extras)

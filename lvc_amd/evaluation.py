@@ -96,6 +96,59 @@ class PipelinedInference:
                 K.check_conv_error_word(self.model.device)
 
 
+class GraphedInference:
+    """`inference_batched` captured once in a hipGraph and replayed: the ~150 kernel launches of a batch become one graph launch,
+    so the host side of a step is a few microseconds whatever the Python around it costs -- what matters when eight ranks' launch
+    loops share one host.  The forward qualifies as written: fixed shapes, no host read, no allocation outside torch's caching
+    allocator (which gives the capture a private pool), per-batch constants cached on the device, the stream-K workspace owned
+    by the capture stream.
+
+        g = GraphedInference(model, batch)        # batch: list of {"image": CHW tensor, "height", "width"}, fixed sizes
+        boxes, scores, classes, count, status = g.replay(next_batch)      # device tensors, overwritten by the next replay
+        instances = g.instances()                 # one D2H read, as GeneralizedRCNN.inference does
+
+    Outputs are bit-identical to the eager call (tests/test_gpu_pipeline.py).  A capacity / range condition (roi_heads.
+    widen_limits) raised by `instances()` invalidates the graph: build a new one after the limits changed."""
+
+    def __init__(self, model, batched_inputs, do_postprocess=True):
+        assert all("image" in b for b in batched_inputs), "graphed inference takes preprocessed {'image': CHW} inputs"
+        self.model = model
+        dev = model.device
+        self.static = []
+        for b in batched_inputs:
+            c = dict(b)
+            c["image"] = b["image"].to(dev).clone().contiguous()
+            self.static.append(c)
+        self.sizes = []
+        for inp in self.static:
+            h, w = inp["image"].shape[-2:]
+            self.sizes.append((inp.get("height", int(h)), inp.get("width", int(w))))
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(2):       # packs weights, fills the constant cache, creates this stream's workspace
+                model.inference_batched(self.static, do_postprocess)
+            self.stream.synchronize()
+            K.check_conv_error_word(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = model.inference_batched(self.static, do_postprocess)
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+
+    def replay(self, batched_inputs=None):
+        if batched_inputs is not None:
+            assert len(batched_inputs) == len(self.static)
+            for dst, src in zip(self.static, batched_inputs):
+                assert src["image"].shape == dst["image"].shape and src["image"].dtype == dst["image"].dtype, "graph shapes are fixed"
+                dst["image"].copy_(src["image"], non_blocking=True)
+        self.graph.replay()
+        return self.out
+
+    def instances(self):
+        ob, osc, ocl, cnt, status = self.out
+        return [{"instances": r} for r in instances_from_batched(ob, osc, ocl, cnt, self.sizes, status)]
+
+
 def inference_on_dataset(model, data_loader, depth=2):
     """Yield (inputs, outputs) for every batch of `data_loader`, in order, keeping `depth` batches in flight."""
     pipe = PipelinedInference(model, depth)

@@ -46,8 +46,36 @@ def test_bench_knn_leg_under_the_launcher_initialises_rccl():
     """What the driver does for N > 1, at N = 1: torch.distributed.run + backend "nccl" (= RCCL)."""
     out = _torchrun(1, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--workload", "knn")
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-    assert line["rccl"] == {"backend": "nccl", "world_size": 1, "allreduce_of_ones": 1.0}
+    assert {k: line["rccl"][k] for k in ("backend", "world_size", "allreduce_of_ones", "devices_shared")} == {
+        "backend": "nccl", "world_size": 1, "allreduce_of_ones": 1.0, "devices_shared": False}
     assert line["n_gpus"] == 1 and line["unit"] == "queries/s" and line["value"] > 1e6
+
+
+def test_bench_gpus_2_end_to_end_on_this_box():
+    """`python bench.py --gpus 2` as the driver would run it on a 2-GPU node -- the self-launcher, one rank per GPU (two ranks
+    sharing the one GPU through gloo when the box has a single device: LVC_BENCH_ALLOW_SHARED_GPU=1), rank-sharded synthetic
+    images, per-rank CPU pinning, max-over-ranks timing, the two data-parallel legs (cfg-3 step with the gradient exchange and
+    equal parameters on every rank, sharded kNN sweep gathered to rank 0) and ONE merged JSON line from rank 0."""
+    import torch
+
+    env = _env()
+    env.pop("OMP_NUM_THREADS", None)
+    if torch.cuda.device_count() < 2:
+        env["LVC_BENCH_ALLOW_SHARED_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-live-pmc", "--pipeline-depth", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 alone prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["global_batch"] == 16
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["allreduce_of_ones"] == 2.0
+    assert line["rccl"]["backend"] == ("nccl" if torch.cuda.device_count() >= 2 else "gloo")
+    assert len(line["per_rank"]["img_per_s"]) == 2 and line["value"] > 0
+    assert line["config"]["detections_per_image"] == [100] * 8
+    legs = line["dp_legs"]
+    assert legs["train_cfg3"]["parameters_identical_across_ranks"] is True and legs["train_cfg3"]["global_batch"] == 16
+    assert legs["knn"]["top10_rows_identical_to_oracle"] if "top10_rows_identical_to_oracle" in legs["knn"] else legs["knn"]["queries_per_s"] > 0
 
 
 def _worker(mode):

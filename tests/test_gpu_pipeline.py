@@ -31,3 +31,29 @@ def test_pipelined_inference_equals_sequential():
                 assert a.image_size == b.image_size and len(a) == len(b) > 0
                 assert torch.equal(a.pred_boxes.tensor, b.pred_boxes.tensor)
                 assert torch.equal(a.scores, b.scores) and torch.equal(a.pred_classes, b.pred_classes)
+
+
+def test_graphed_inference_is_bit_identical_to_eager():
+    """`GraphedInference`: the whole forward as one hipGraph launch -- captured once, replayed on new images of the same
+    shapes; outputs equal the eager call's bit for bit, replay after replay."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.evaluation import GraphedInference
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+
+    model = build_model(base_rcnn_fpn()).eval()
+    syn.conditioned_r50_fpn_(model)
+    dev = torch.device("cuda:0")
+    batches = [[{"image": syn.synthetic_image(20 + 3 * b + i, 416, 608).to(dev), "height": 832, "width": 1216} for i in range(3)]
+               for b in range(3)]
+    with torch.no_grad():
+        eager = [[t.clone() for t in model.inference_batched(b)] for b in batches]
+    g = GraphedInference(model, batches[0])
+    for rnd in range(2):
+        for b, ref in zip(batches, eager):
+            out = g.replay(b)
+            torch.cuda.synchronize()
+            for a, r in zip(out, ref):
+                assert torch.equal(a, r)
+            inst = g.instances()
+            assert len(inst) == 3 and all(len(x["instances"]) == int(c) for x, c in zip(inst, ref[3].tolist()))
