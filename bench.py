@@ -411,6 +411,48 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
     return out
 
 
+def descriptor_leg(c, batch=64, steps=5, warmup=2):
+    """the descriptor network in front of the kNN sweep (tools/run_nearest_neighbours.py:102-128 get_descriptors,
+    :292-293 DINO ViT-S/8): crops/s on 224x224 crops at batch 64, random-init weights of that architecture.  Algorithmic work per
+    crop: 12 blocks x (qkv + proj + fc1 + fc2 over 785 tokens x 384 channels + two 785 x 785 x 64 products per head) + the patch
+    embedding."""
+    import torch
+
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.vit import seeded_state_dict_, vit_small
+
+    m = vit_small(8)
+    seeded_state_dict_(m, 0)
+    m = m.to(c.dev).eval()
+    g = torch.Generator(device=c.dev).manual_seed(3)
+    x = torch.rand(batch, 3, 224, 224, device=c.dev, generator=g) * 255.0
+    mean, std = [123.675, 116.28, 103.53], [58.395, 57.12, 57.375]
+    N, D, Hd = 785, 384, 6
+    gflop = (12 * (2 * N * D * (3 * D + D + 4 * D + 4 * D) + 4 * Hd * N * N * 64) + 2 * 784 * 192 * D) / 1e9
+    with torch.no_grad():
+        for _ in range(warmup):
+            y = m(x, mean, std)
+        _barrier(c)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = m(x, mean, std)
+        _barrier(c)
+        dt = (time.perf_counter() - t0) / steps
+        qkv = torch.randn(batch * N, 3 * D, device=c.dev, generator=g)
+        att = _event_ms(lambda: K.mha(qkv, batch, N, Hd, 64, 0.125), 5)
+    K.check_conv_error_word(c.dev)
+    out = {"workload": "ViT-S/8 descriptors, %d crops of 3x224x224 per batch (785 tokens, 12 blocks, 6 heads)" % batch,
+           "value": round(batch / dt, 1), "unit": "crops/s", "ms_per_batch": round(dt * 1e3, 3), "algorithmic_gflop_per_crop": round(gflop, 2),
+           "tflops": round(gflop * batch / dt / 1e3, 1), "frac_of_f16x2_peak": round(gflop * batch / dt / 1e3 / PEAK_F16X2_TFLOPS, 4),
+           "attention_kernel": {"kernel": "mha_mfma_kernel (+ mha_split_kernel): softmax(q k^T / 8) v for %d x %d heads of 785 x 64" % (batch, Hd),
+                                "ms_per_layer": round(att, 4), "tflops": round(4.0 * batch * Hd * N * N * 64 / att / 1e9, 1),
+                                "frac_of_f16x2_peak": round(4.0 * batch * Hd * N * N * 64 / att / 1e9 / PEAK_F16X2_TFLOPS, 4)},
+           "descriptor_norm_finite": bool(torch.isfinite(y).all())}
+    del m, x, qkv
+    torch.cuda.empty_cache()
+    return out
+
+
 def r101_leg(c, steps=10, warmup=3):
     """R101-FPN inference at the headline's batch (the depth BASELINE configs[4] names), same timing rules."""
     import torch
@@ -691,7 +733,7 @@ def infer_main(c, args):
         # BASELINE configs[2] / [4] are training workloads and configs[4] names R101: their one-GPU rates, every run
         if c.world == 1:
             for key, fn in (("train_cfg3", lambda: train_leg(c, 5, 2, 8, "cfg3")), ("train_cfg5_r101", lambda: train_leg(c, 5, 2, 2, "cfg5")),
-                            ("r101_inference", lambda: r101_leg(c))):
+                            ("r101_inference", lambda: r101_leg(c)), ("descriptors", lambda: descriptor_leg(c))):
                 try:
                     extras.setdefault("train", {})[key] = fn()
                 except Exception as e:

@@ -416,13 +416,22 @@ int lvc_knn_verify_lists(const void* lists, const int* counts, int Q, int S, con
  *   lvc_layernorm    : torch.nn.LayerNorm over rows of D <= 2048 elements (biased variance, eps inside the sqrt)
  *   lvc_gelu         : torch.nn.GELU() exact (erf) form, n % 4 == 0
  *   lvc_mha          : qkv [B*N, 3*H*64] (column = which*H*64 + h*64 + d) -> out [B*N, H*64] =
- *                      softmax(q k^T * scale) v per (image, head); head_dim must be 64 */
+ *                      softmax(q k^T * scale) v per (image, head); head_dim must be 64 (one thread per query, fp32 VALU)
+ *   lvc_mha_mfma     : the same result on the matrix cores (csrc/vit.hip: both products as fp32-accurate two-way fp16 splits, the
+ *                      probabilities stay in registers between them); workspace = lvc_mha_workspace_bytes(B, N, H) bytes,
+ *                      16-byte aligned (fp16 operand planes of q, k, v) */
 int lvc_vit_patchify(const float* img, float* out, int B, int C, int H, int W, int ps, void* stream);
+/* lvc_vit_patchify of (img - mean[c]) / std[c] (tools/run_nearest_neighbours.py:95-99 preprocess_crops fused into the gather);
+ * mean / std: HOST arrays of C <= 8 floats. */
+int lvc_vit_patchify_norm(const float* img, const float* mean, const float* std, float* out, int B, int C, int H, int W, int ps,
+                          void* stream);
 int lvc_vit_tokens(const float* emb, const float* cls, const float* pos, float* out, int B, int P, int D, void* stream);
 int lvc_layernorm(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int M, int D, float eps,
                   void* stream);
 int lvc_gelu(const float* x, float* y, long long n, void* stream);
 int lvc_mha(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, void* stream);
+long long lvc_mha_workspace_bytes(int B, int N, int H);
+int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, void* stream);
 
 #ifdef __cplusplus
 }

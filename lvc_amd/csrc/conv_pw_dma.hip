@@ -447,7 +447,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
     }
     STAMP(8);
     const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
-    const float lo = p.relu ? 0.f : -INFINITY;
+    const float lo = p.relu == 1 ? 0.f : -INFINITY;
     const unsigned ldy4 = (unsigned)p.ldy * 4u;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -458,7 +458,9 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
         const unsigned cbase = col < p.K ? rbase + (unsigned)col * 4u : 0x80000000u;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const float v = fmaxf(acc[mi][ni][e], lo);
+          float v = acc[mi][ni][e];
+          // relu == 2: torch.nn.GELU() (exact erf form), the same expression as lvc_gelu (vit.hip) -> the same bits
+          v = p.relu == 2 ? v * 0.5f * (1.f + erff(v * 0.70710678118654752440f)) : fmaxf(v, lo);
           if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
         }
       }

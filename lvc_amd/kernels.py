@@ -326,8 +326,10 @@ HALO_S1 = int(_os.environ.get("LVC_HALO_S1", "2"))
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
-def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None):
+def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None, act=None):
     """x: [N,H,W,C] fp32 contiguous (NHWC).  Returns [N,Ho,Wo,K].
+    act="gelu": torch.nn.GELU() (erf form) on the result -- in the epilogue of the LDS-DMA pointwise kernel where the layer
+    runs on it (bit-identical to a separate lvc_gelu pass), as a second launch otherwise.
     split: None = the configured split (LVC_CONV_SPLIT); "bf16x3" keeps the fp32 exponent range (gradients).
     res_mode 1: residual has the output's shape; 2: residual is [N,Ho/2,Wo/2,K] and is
     nearest-x2-upsampled on the fly (FPN top-down path, reference fpn.py:131-133)."""
@@ -355,7 +357,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         for n0 in range(0, N, nb):
             n1 = min(N, n0 + nb)
             conv2d_nhwc(x[n0:n1], pc, relu=relu, residual=residual[n0:n1] if residual is not None else None, res_mode=res_mode,
-                        out=out[n0:n1], split=split)
+                        out=out[n0:n1], split=split, act=act)
         return out
     ldr = residual.shape[-1] if residual is not None else 0
     engine = "f32"
@@ -410,10 +412,13 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                           "kernel's range; it runs on the register-staged fp16x2 kernel", N * H * W, C, pc.K, out.numel(),
                           "yes" if residual is not None else "no")
             fn = "lvc_conv2d_nhwc_f16x2_dma" if PW_DMA and dma_ok else "lvc_conv2d_nhwc_f16x2"
+            fused_act = act == "gelu" and fn.endswith("_dma") and not relu
+            if fused_act:
+                act = None
             st = getattr(_lib.lib(), fn)(
                 ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.R), c_int(pc.S),
-                c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
+                c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(2 if fused_act else 1 if relu else 0), c_int(res_mode),
                 c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv2d_nhwc_f16x2")
         else:
@@ -434,6 +439,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e1.record()
         c_real = 3 if pc.mode == 1 else C
         timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1, engine))
+    if act == "gelu":
+        check(_lib.lib().lvc_gelu(ptr(out), ptr(out), c_longlong(out.numel()), _stream(out)), "lvc_gelu")
+    elif act is not None:
+        raise ValueError("unknown activation {!r}".format(act))
     return out
 
 
@@ -1235,8 +1244,9 @@ def crop_resize_nearest(image, windows, out_size=224):
 
 
 # --------------------------------------------------------------------------- descriptor network (ViT) pieces
-def vit_patchify(img, patch_size, kpad=None):
-    """img [B,C,H,W] fp32 -> [B*P, kpad] rows (column c*ps*ps + r*ps + s; zero columns up to kpad, a multiple of 32)."""
+def vit_patchify(img, patch_size, kpad=None, mean=None, std=None):
+    """img [B,C,H,W] fp32 -> [B*P, kpad] rows (column c*ps*ps + r*ps + s; zero columns up to kpad, a multiple of 32).
+    mean / std (sequences of C floats): the rows of (img - mean[c]) / std[c] -- get_descriptors' crop normalisation fused in."""
     _req_cuda(img)
     B, C, H, W = img.shape
     kc = C * patch_size * patch_size
@@ -1244,10 +1254,16 @@ def vit_patchify(img, patch_size, kpad=None):
     P = (H // patch_size) * (W // patch_size)
     if kpad == kc:
         out = torch.empty(B * P, kc, device=img.device, dtype=torch.float32)
+        if mean is not None:
+            m = (c_float * C)(*[float(v) for v in mean])
+            s_ = (c_float * C)(*[float(v) for v in std])
+            check(_lib.lib().lvc_vit_patchify_norm(ptr(img), m, s_, ptr(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(patch_size),
+                                                   _stream(img)), "lvc_vit_patchify_norm")
+            return out
         check(_lib.lib().lvc_vit_patchify(ptr(img), ptr(out), c_int(B), c_int(C), c_int(H), c_int(W), c_int(patch_size), _stream(img)),
               "lvc_vit_patchify")
         return out
-    tmp = vit_patchify(img, patch_size)
+    tmp = vit_patchify(img, patch_size, mean=mean, std=std)
     out = torch.zeros(B * P, kpad, device=img.device, dtype=torch.float32)
     out[:, :kc] = tmp
     return out
@@ -1281,11 +1297,22 @@ def gelu(x):
     return y
 
 
-def mha(qkv, B, N, num_heads, head_dim, scale):
-    """qkv [B*N, 3*H*head_dim] -> [B*N, H*head_dim] (softmax(q k^T scale) v per image and head)."""
+MHA_MFMA = _os.environ.get("LVC_MHA_MFMA", "1") != "0"   # 0: the one-thread-per-query fp32 VALU kernel of round 2 (lvc_mha)
+
+
+def mha(qkv, B, N, num_heads, head_dim, scale, mfma=None):
+    """qkv [B*N, 3*H*head_dim] -> [B*N, H*head_dim] (softmax(q k^T scale) v per image and head).  Default: the matrix-core
+    kernel (lvc_mha_mfma: fp32-accurate two-way fp16 split, probabilities kept in registers between the two products);
+    mfma=False (or LVC_MHA_MFMA=0): the scalar fp32 kernel."""
     _req_cuda(qkv)
     qkv = qkv.contiguous()
     out = torch.empty(B * N, num_heads * head_dim, device=qkv.device, dtype=torch.float32)
+    if (MHA_MFMA if mfma is None else mfma) and head_dim == 64:
+        lib = _lib.lib()
+        lib.lvc_mha_workspace_bytes.restype = c_longlong
+        ws = torch.empty(max(16, lib.lvc_mha_workspace_bytes(c_int(B), c_int(N), c_int(num_heads))), dtype=torch.uint8, device=qkv.device)
+        check(lib.lvc_mha_mfma(ptr(qkv), ptr(out), ptr(ws), c_int(B), c_int(N), c_int(num_heads), c_float(scale), _stream(qkv)), "lvc_mha_mfma")
+        return out
     check(_lib.lib().lvc_mha(ptr(qkv), ptr(out), c_int(B), c_int(N), c_int(num_heads), c_int(head_dim), c_float(scale), _stream(qkv)),
           "lvc_mha")
     return out

@@ -42,8 +42,9 @@ def get_descriptors(model, data_loader, pixel_mean, pixel_std):
     out = []
     with torch.no_grad():
         for data in data_loader:
-            crops = preprocess_crops(data, pixel_mean, pixel_std).to(model.device)
-            feats = _descriptor_pass(model, crops) if len(crops) else torch.zeros(0, model.embed_dim)
+            # raw crops go to the device; (x - mean) / std happens inside the network's patch gather (lvc_vit_patchify_norm)
+            crops = torch.cat([x["instances"].crops for x in data]).to(model.device)
+            feats = _descriptor_pass(model, crops, pixel_mean, pixel_std) if len(crops) else torch.zeros(0, model.embed_dim)
             item = data[0]
             item.pop("image", None)
             item["instances"].remove("crops")
@@ -53,7 +54,7 @@ def get_descriptors(model, data_loader, pixel_mean, pixel_std):
     return out
 
 
-def _descriptor_pass(model, crops):
+def _descriptor_pass(model, crops, pixel_mean=None, pixel_std=None):
     """One batch of crops through the descriptor network.  Its Linear layers run on the fp16x2 split kernels, so the pass
     ends by reading the conv range word (as the detector passes do): an activation beyond fp16's range repeats the batch on
     the range-free bf16x3 kernels instead of returning invalid descriptors (and instead of leaving the bit for the next
@@ -61,7 +62,7 @@ def _descriptor_pass(model, crops):
     from .modeling.roi_heads.roi_heads import run_with_fallbacks
 
     def once():
-        feats = model(crops)
+        feats = model(crops, pixel_mean, pixel_std) if pixel_mean is not None else model(crops)
         K.check_conv_error_word(crops.device)
         return feats
 

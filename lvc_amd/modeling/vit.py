@@ -40,13 +40,14 @@ class _Linear(nn.Module):
         nn.init.trunc_normal_(self.weight, std=0.02)
         self._packed = _Cache()
 
-    def forward(self, x, residual=None):
-        """x [M, din] device rows -> [M, dout]; `residual` [M, dout] is added in the GEMM epilogue."""
+    def forward(self, x, residual=None, act=None):
+        """x [M, din] device rows -> [M, dout]; `residual` [M, dout] is added in the GEMM epilogue; act="gelu": the exact
+        GELU in the same epilogue."""
         pc = self._packed.get([self.weight] + ([self.bias] if self.bias is not None else []),
                               lambda: K.pack_linear(self.weight, self.bias))
         M = x.shape[0]
         y = K.conv2d_nhwc(x.view(M, 1, 1, x.shape[1]), pc,
-                          residual=residual.view(M, 1, 1, residual.shape[1]) if residual is not None else None)
+                          residual=residual.view(M, 1, 1, residual.shape[1]) if residual is not None else None, act=act)
         return y.view(M, -1)
 
 
@@ -90,7 +91,7 @@ class _Block(nn.Module):
         qkv = a.qkv(self.norm1(t))
         y = K.mha(qkv, B, N, a.num_heads, t.shape[1] // a.num_heads, a.scale)
         t = a.proj(y, residual=t)
-        y = K.gelu(self.mlp.fc1(self.norm2(t)))
+        y = self.mlp.fc1(self.norm2(t), act="gelu")      # GELU in fc1's epilogue: the [M, 4 dim] hidden map makes one trip less
         return self.mlp.fc2(y, residual=t)
 
 
@@ -120,8 +121,10 @@ class VisionTransformer(nn.Module):
     def device(self):
         return self.cls_token.device
 
-    def forward(self, x):
-        """x [B, 3, 224, 224] normalised crops on the device -> [B, embed_dim] class-token descriptors."""
+    def forward(self, x, pixel_mean=None, pixel_std=None):
+        """x [B, 3, 224, 224] crops on the device -> [B, embed_dim] class-token descriptors.  x is normalised already
+        (reference `preprocess_crops`), or raw with pixel_mean / pixel_std given: the normalisation then happens inside the
+        patch gather (one pass less over the crops, the same fp32 arithmetic)."""
         if not x.is_cuda:
             raise RuntimeError("lvc_amd VisionTransformer needs device tensors; there is no CPU path")
         B, C, H, W = x.shape
@@ -132,7 +135,7 @@ class VisionTransformer(nn.Module):
         kc = C * pe.patch_size * pe.patch_size
         kpad = (kc + 31) // 32 * 32
         pc = pe._packed.get([pe.proj.weight, pe.proj.bias], lambda: self._pack_patch(pe, kc, kpad))
-        patches = K.vit_patchify(x.float().contiguous(), pe.patch_size, kpad)
+        patches = K.vit_patchify(x.float().contiguous(), pe.patch_size, kpad, mean=pixel_mean, std=pixel_std)
         M = patches.shape[0]
         emb = K.conv2d_nhwc(patches.view(M, 1, 1, kpad), pc).view(M, self.embed_dim)
         N = pe.num_patches + 1

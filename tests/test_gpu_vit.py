@@ -30,21 +30,24 @@ def test_layernorm_gelu_patchify_tokens():
     assert torch.equal(t, ref)
 
 
-@pytest.mark.parametrize("B,N", [(2, 785), (1, 197), (3, 64)])
-def test_attention_matches_torch(B, N):
+@pytest.mark.parametrize("mfma", [True, False])
+@pytest.mark.parametrize("B,N", [(2, 785), (1, 197), (3, 64), (2, 1), (1, 130)])
+def test_attention_matches_torch(B, N, mfma):
+    """Both attention kernels (matrix-core: lvc_mha_mfma, the default; scalar fp32: lvc_mha) against fp64, at the error level of
+    torch's own fp32 CPU evaluation; token counts that are not multiples of the 64-key tile / the 128-query block."""
     from lvc_amd import kernels as K
 
     g = torch.Generator().manual_seed(N)
     H, Dh = 6, 64
     qkv = torch.randn(B * N, 3 * H * Dh, generator=g) * 1.5
-    out = K.mha(qkv.cuda(), B, N, H, Dh, Dh ** -0.5).cpu()
+    out = K.mha(qkv.cuda(), B, N, H, Dh, Dh ** -0.5, mfma=mfma).cpu()
     t = qkv.double().view(B, N, 3, H, Dh).permute(2, 0, 3, 1, 4)
     ref = (((t[0] @ t[1].transpose(-2, -1)) * Dh ** -0.5).softmax(-1) @ t[2]).transpose(1, 2).reshape(B * N, H * Dh)
     t32 = qkv.view(B, N, 3, H, Dh).permute(2, 0, 3, 1, 4)
     cpu32 = (((t32[0] @ t32[1].transpose(-2, -1)) * Dh ** -0.5).softmax(-1) @ t32[2]).transpose(1, 2).reshape(B * N, H * Dh)
     err = float((out.double() - ref).abs().max())
     err32 = float((cpu32.double() - ref).abs().max())
-    print("attention B=%d N=%d: max abs error vs fp64 %.2e (torch CPU fp32: %.2e)" % (B, N, err, err32))
+    print("attention (%s) B=%d N=%d: max abs error vs fp64 %.2e (torch CPU fp32: %.2e)" % ("mfma" if mfma else "valu", B, N, err, err32))
     assert err <= 2 * err32 + 1e-6
 
 
