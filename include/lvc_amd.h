@@ -102,6 +102,18 @@ int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_split, const 
 int lvc_conv3x3_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                                 const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                                 int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* Pointwise (R = S = 1, pad 0) layers with a long contraction on the pipelined loop of the 3x3 kernel (csrc/conv_pw_s1.hip; the conv1
+ * / FC layers of detectron2/modeling/backbone/resnet.py:195-211, roi_heads/box_head.py:80-93 and the ViT linears): y = act(conv(x,
+ * w) * scale + shift (+ residual)), x [N,H,W,C] fp32 NHWC with C % 32 == 0, stride >= 1, relu: 0 none / 1 ReLU / 2 exact GELU,
+ * res_mode / ldy / ldr / workspace as lvc_conv2d_nhwc_f16x2.  _f16x2_pipe: the numerics and weight planes of
+ * lvc_conv2d_nhwc_f16x2 (|a| <= 65504).  _f16s1: the single-accumulator form, w_split / scale as for lvc_conv3x3_nhwc_f16s1
+ * (|a| <= 4094). */
+int lvc_conv1x1_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
+                                int res_mode, int ldy, int ldr, void* workspace, void* stream);
+int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                           const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
+                           int res_mode, int ldy, int ldr, void* workspace, void* stream);
 /* wp [rows][Kg] fp32 (lvc_pack_conv_weights) -> planes_out [2][rows][Kg] fp16: w1 = fp16(wp 2^e), w2 = fp16(wp 2^e - w1) with
  * e = 13 - floor(log2(max |wp[row][:]|)) per row (0 for an all-zero row); row_factor[row] = 2^-(e + 4). */
 int lvc_split_weights_rowscaled(const float* wp, int rows, int Kg, void* planes_out, float* row_factor, void* stream);

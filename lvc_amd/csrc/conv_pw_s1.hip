@@ -1,0 +1,481 @@
+// conv_pw_s1.hip -- pointwise (1x1 / FC) layers with a long contraction on the software-pipelined loop of conv3x3_halo_s1.hip
+// (round 3): the two-way fp16 operand split, a 256-row x 64 NI-channel tile per workgroup, 8 waves as 4 x 2 (wave tile 64 x 32 NI),
+// per 32-channel chunk two k16 steps with the workgroup barrier BETWEEN them, fragments rotating through the registers earlier MFMA
+// groups vacate, weight planes by LDS-DMA into a ring of three chunk buffers.
+//
+// Why next to conv_pw_dma.hip.  That kernel streams RAW fp32 activation rows into LDS and splits them at fragment time; a wave
+// owns 32 rows x all 128 channels (so that an element is split once), reads ten fragments per twelve MFMAs, and every wave issues
+// six DMA instructions, waits, reads and converts at the top of every chunk: its timeline (scripts/probe_pw_timeline.py) shows
+// 2.2 - 3.6 us per chunk against 0.7 - 1.0 us of matrix work -- fine for the memory-bound layers (they run at 5 TB/s of HBM traffic),
+// far from the matrix pipe on the layers with a long contraction (box-head fc1: 12544 -> 1024, res4 / res5 conv1, the ViT
+// linears).  Here the activation chunk goes HBM -> registers (issued three chunks ahead) -> split ONCE per tile -> two fp16
+// planes in a double-buffered LDS image, after which the tap loop of the 3x3 kernel applies unchanged with one tap per chunk.
+//
+// Numerics: ONEACC = false -- a main (a1 b1) and a cross (a1 b2 + a2 b1, x 2^-11) accumulator, the planes of lvc_split_weights,
+// |a| <= 65504: the same arithmetic as conv_pw_dma.hip / conv_f16x2.hip.  ONEACC = true -- one accumulator, row-scaled weight
+// planes and activations x 2^4 as in conv3x3_halo_s1.hip (|a| <= 4094).
+// The asynchronous loads are written as inline asm and waited for with counted vmcnt waits that are TIED to the destination
+// registers (the compiler's own bookkeeping would wait for everything in flight, LDS-DMA included, at the first use).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+#define PM 256            // rows per tile
+#define AROW 64           // bytes per activation row and plane in LDS (32 halves, unpadded: the 16-byte granules are XOR-swizzled
+                          // by (row >> 2) & 3 exactly like the weight rows, conflict-free for the ds_read_b128 lane groups)
+#define NJ 4              // float4 slots per thread and chunk (256 rows x 8 slots / 512 threads)
+#define NT 512
+#define SPIN_LIMIT (1 << 24)
+#define ACT_SCALE 16.f
+#define ACT_MAX 4094.f
+
+struct PwArgsS {
+  const float* x;
+  const unsigned short* w;   // [2][Kpad][Kg] fp16 planes
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  float* partials;
+  int* flags;
+  int H, W, C, K, stride, Ho, Wo, M, relu, res_mode, ldy, ldr;
+  int tiles_n, nk, total_units, units_per_worker, nworkers, err_index, ngroup;
+  int x_bytes;
+  long long w_plane_elems;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+// buffer_load_dwordx4 the compiler does not track: out-of-range offsets return zeros; completion through wait_tied
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load_untracked(u32x4 rsrc, unsigned voff, unsigned soff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return v;
+}
+// at most N vector-memory operations outstanding; the four registers become usable only behind it
+template <int N> __device__ __forceinline__ void wait_tied(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int NI, bool ONEACC>
+__global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
+  constexpr int HN = 64 * NI;
+  constexpr int PLANE_A = PM * AROW;               // bytes
+  constexpr int A_BUF = 2 * PLANE_A;               // bytes per activation buffer (two planes)
+  constexpr int A_BYTES = 3 * A_BUF;               // THREE buffers (98,304 B): chunk i+1 is written during phase A of chunk i, while
+                                                   // slower waves may still read chunk i-1 in their phase B of chunk i-1
+  constexpr int PLANE_B = HN * 64;                 // bytes
+  constexpr int B_BUF = 2 * PLANE_B;
+  constexpr int RING_BYTES = A_BYTES + 3 * B_BUF;
+  constexpr int CS_STRIDE = HN + 4;
+  constexpr int CS_BYTES = PM * CS_STRIDE * 4;
+  constexpr int SMEM_BYTES = RING_BYTES > CS_BYTES ? RING_BYTES : CS_BYTES;
+  constexpr int RBLK = HN / 16;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[SMEM_BYTES];
+  unsigned char* sA = smem_raw;
+  unsigned char* sB = smem_raw + A_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 31, fh = lane >> 5;
+  const int q = tid & 7;
+  const int arid = tid >> 3;
+  const int hrow = (arid & 1) * 4 + ((arid >> 1) & 3) + (arid >> 3) * 8;    // tile rows hrow + 64 j (conflict-free 80-byte-pitch stores)
+
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  const int wq = p.ngroup > 1 ? lw / p.ngroup : lw;
+  const int wsel = p.ngroup > 1 ? lw - wq * p.ngroup : 0;
+  int u = wq * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.total_units);
+
+  // buffer descriptor of x by hand (the asm load takes four SGPRs): base, stride 0, num_records = bytes, raw dword format
+  const unsigned long long xbase = (unsigned long long)p.x;
+  const u32x4 xres = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)xbase), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(xbase >> 32) & 0xffffu),
+                      (unsigned)p.x_bytes, 0x00020000u};
+  const int fx3 = (fi >> 2) & 3;
+  const int a_row[2] = {(wm * 64 + fi) * AROW, (wm * 64 + 32 + fi) * AROW};
+  const int b_row = (wn * 32 * NI + fi) * 64;
+  const int b_g[2] = {((0 + fh) ^ fx3) * 16, ((2 + fh) ^ fx3) * 16};
+  int a_lds[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = hrow + 64 * j;
+    a_lds[j] = row * AROW + (((q >> 1) ^ ((row >> 2) & 3)) << 4) + (q & 1) * 8;     // bytes
+  }
+  float big = 0.f;
+
+  while (u < u_end) {
+    const int tile = u / p.nk;
+    const int cc0 = u - tile * p.nk;
+    const int cc1 = min(p.nk, cc0 + (u_end - u));
+    const int tile_n = p.ngroup > 1 ? wsel : tile % p.tiles_n;
+    const int tile_m = p.ngroup > 1 ? tile : tile / p.tiles_n;
+    const int m0 = tile_m * PM;
+    const int n0 = tile_n * HN;
+
+    unsigned a_off[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int m = m0 + hrow + 64 * j;
+      const int n = m / (p.Ho * p.Wo);
+      const int rem = m - n * (p.Ho * p.Wo);
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      a_off[j] = m < p.M ? (unsigned)(((n * p.H + ho * p.stride) * p.W + wo * p.stride) * p.C + q * 4) * 4u : 0x80000000u;
+    }
+    const unsigned short* bsrc[NI];
+    int bdst[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int idx = wave * NI + j;
+      const int pl = idx / RBLK, rb = idx - pl * RBLK;
+      const int row = rb * 16 + (lane >> 2);
+      const int G = (lane & 3) ^ ((row >> 2) & 3);
+      bsrc[j] = p.w + (size_t)pl * p.w_plane_elems + (size_t)(n0 + row) * p.C + G * 8;
+      bdst[j] = pl * PLANE_B + rb * 16 * 64;
+    }
+    auto dma_B = [&](int cc, int buf) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j) glds16(bsrc[j] + cc * 32, sB + buf * B_BUF + bdst[j]);
+    };
+    // three activation register sets: chunk cc lives in set cc % 3 from its load (issued at chunk cc - 3 + ...) to its split
+    f32x4 ar[3][NJ];
+    auto load_A = [&](int set, int cc) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) ar[set][j] = load_untracked(xres, a_off[j], (unsigned)cc * 128u);
+    };
+    auto store_A = [&](int set, unsigned char* dstA) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        f16x4 h, m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = ONEACC ? ar[set][j][e] * ACT_SCALE : ar[set][j][e];
+          const f16 hh = (f16)a;
+          h[e] = hh;
+          m[e] = ONEACC ? (f16)(a - (float)hh) : (f16)((a - (float)hh) * 2048.f);
+          big = fmaxf(big, fabsf(ar[set][j][e]));
+        }
+        *reinterpret_cast<f16x4*>(dstA + a_lds[j]) = h;
+        *reinterpret_cast<f16x4*>(dstA + PLANE_A + a_lds[j]) = m;
+      }
+    };
+
+    f32x16 acc[2][NI], accx[ONEACC ? 1 : 2][ONEACC ? 1 : NI];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NI; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          acc[a][b][e] = 0.f;
+          if (!ONEACC) accx[ONEACC ? 0 : a][ONEACC ? 0 : b][e] = 0.f;
+        }
+
+    f16x8 ahi[2], alo[2], bhi[NI], blo[NI];
+    auto rdA = [&](const unsigned char* A, int pl, int mi, int s2) {
+      return *reinterpret_cast<const f16x8*>(A + pl * PLANE_A + a_row[mi] + b_g[s2]);
+    };
+    auto rdB = [&](const unsigned char* B, int pl, int ni, int s2) {
+      return *reinterpret_cast<const f16x8*>(B + pl * PLANE_B + b_row + ni * 32 * 64 + b_g[s2]);
+    };
+    // one k16 step (see conv3x3_halo_s1.hip `step_body`): late reads of this step under G1, early reads of the next under G2
+    auto step_body = [&](const unsigned char* A, int s2, const unsigned char* B, const unsigned char* An, int s2n, const unsigned char* Bn) {
+      alo[0] = rdA(A, 1, 0, s2);
+      bhi[0] = rdB(B, 0, 0, s2);
+      alo[1] = rdA(A, 1, 1, s2);
+      if (NI == 2) bhi[NI - 1] = rdB(B, 0, NI - 1, s2);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          f32x16& c = ONEACC ? acc[mi][ni] : accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo[ni], c, 0, 0, 0);
+        }
+      f16x8 blo_n[NI], ahi_n[2];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) blo_n[ni] = rdB(Bn, 1, ni, s2n);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          f32x16& c = ONEACC ? acc[mi][ni] : accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi[ni], c, 0, 0, 0);
+        }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) ahi_n[mi] = rdA(An, 0, mi, s2n);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) ahi[mi] = ahi_n[mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) blo[ni] = blo_n[ni];
+    };
+
+    // ---- prologue.  VMEM order: A(c0), A(c0+1), A(c0+2), B(c0), B(c0+1); chunks past the unit's end re-fetch its last chunk
+    const int last = cc1 - 1;
+    load_A(0, cc0);
+    load_A(1, min(cc0 + 1, last));
+    load_A(2, min(cc0 + 2, last));
+    dma_B(cc0, 0);
+    dma_B(min(cc0 + 1, last), 1);
+    wait_tied<2 * NJ + 2 * NI>(ar[0][0], ar[0][1], ar[0][2], ar[0][3]);
+    store_A(0, sA);
+    wait_vm<0>();
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) ahi[mi] = rdA(sA, 0, mi, 0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) blo[ni] = rdB(sB, 1, ni, 0);
+    // At the top of chunk i (i = cc - cc0) the VMEM queue holds, oldest first:  A(i+1), A(i+2) | B(i+1) issued at i-1  [i = 0: the
+    // prologue's order, everything landed but nothing that matters is missing].  Steady state per chunk, program order:
+    //   phase A: split + store A(i+1) -> needs A(i+1): everything issued after it may stay outstanding
+    //   barrier: needs B(i+1)
+    //   phase B: issue B(i+2), A(i+3)
+    // so before the store at most  [A(i+2)] + [B(i+1)] = NJ + NI  newer operations exist (issue order: ..., B(i+1), A(i+2) at chunk
+    // i-1) and before the barrier at most A(i+2) = NJ.
+    auto chunk = [&](int i, int k) {      // k = i % 3, compile-time: activation buffer, weight slot and register set of chunk i
+      const int cc = cc0 + i;
+      const int kn = (k + 1) % 3;
+      const unsigned char* Acur = sA + k * A_BUF;
+      unsigned char* Anext = sA + kn * A_BUF;
+      const unsigned char* Bcur = sB + k * B_BUF;
+      const unsigned char* Bnext = sB + kn * B_BUF;
+      // ---- phase A: chunk i+1 (set / buffer kn: last read in phase B of chunk i-2, before the previous barrier) is split and stored
+      wait_tied<NJ + NI>(ar[kn][0], ar[kn][1], ar[kn][2], ar[kn][3]);
+      step_body(Acur, 0, Bcur, Acur, 1, Bcur);
+      store_A(kn, Anext);
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vm<NJ>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase B: weights of chunk i+2 into chunk i-1's slot, activations of chunk i+3 into chunk i's registers
+      dma_B(min(cc + 2, last), (k + 2) % 3);
+      load_A(k, min(cc + 3, last));
+      step_body(Acur, 1, Bcur, Anext, 0, Bnext);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    const int nchunks = cc1 - cc0;
+#pragma unroll 1
+    for (int i = 0; i < nchunks; i += 3) {
+      chunk(i, 0);
+      if (i + 1 < nchunks) chunk(i + 1, 1);
+      if (i + 2 < nchunks) chunk(i + 2, 2);
+    }
+    wait_vm<0>();
+    __syncthreads();
+    u += nchunks;
+    if (!ONEACC) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni][e] * (1.f / 2048.f);
+    }
+
+    // ---- split tiles (the protocol of the other stream-K kernels)
+    if (cc0 != 0) {
+      float* dst = p.partials + (size_t)lw * (NT * 32 * NI);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
+            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4) = v;
+          }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      continue;
+    }
+    if (cc1 < p.nk) {
+      const int last_unit = tile * p.nk + p.nk - 1;
+      const int wstep = p.ngroup > 1 ? p.ngroup : 1;
+      const int last_worker = (last_unit / p.units_per_worker) * wstep + wsel;
+      for (int pw = lw + wstep; pw <= last_worker; pw += wstep) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > SPIN_LIMIT) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const float* src = p.partials + (size_t)pw * (NT * 32 * NI);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4);
+              acc[mi][ni][e4 * 4 + 0] += v[0]; acc[mi][ni][e4 * 4 + 1] += v[1];
+              acc[mi][ni][e4 * 4 + 2] += v[2]; acc[mi][ni][e4 * 4 + 3] += v[3];
+            }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
+    // ---- epilogue through LDS: affine, residual (same shape, or the nearest-x2 upsample of the half-size map), ReLU / GELU
+    float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+          const int col = wn * 32 * NI + ni * 32 + fi;
+          Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
+        }
+    __syncthreads();
+    constexpr int C4 = HN / 4;
+    constexpr int RPI = NT / C4;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    if (col < p.K) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+#pragma unroll 4
+      for (int it = 0; it < PM / RPI; ++it) {
+        const int r = it * RPI + rsub;
+        const int m = m0 + r;
+        if (m < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+          v = v * sc + sh;
+          if (p.res_mode == 1) {
+            v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + col);
+          } else if (p.res_mode == 2) {
+            const int n = m / (p.Ho * p.Wo);
+            const int rem = m - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+          }
+          if (p.relu == 1) {
+            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+          } else if (p.relu == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.f + erff(v[e] * 0.70710678118654752440f));
+          }
+          *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + col) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);
+}
+
+#define LVC_MAX_WORKERS 1024
+static int g_cus_pw_s = 0;
+
+static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                        const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu, int res_mode,
+                        int ldy, int ldr, void* workspace, void* stream) {
+  LVC_CHECK_ARG(x && w_split && y && workspace, "null pointer");
+  LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && stride >= 1, "non-positive dimension");
+  LVC_CHECK_ARG(C % 32 == 0, "needs C % 32 == 0");
+  LVC_CHECK_ARG(relu >= 0 && relu <= 2, "relu: 0 none, 1 ReLU, 2 GELU");
+  LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
+  const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+  if (res_mode == 2) LVC_CHECK_ARG(Ho % 2 == 0 && Wo % 2 == 0, "upsample-add needs even output size");
+  PwArgsS a;
+  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.H = H; a.W = W; a.C = C; a.K = K; a.stride = stride; a.Ho = Ho; a.Wo = Wo;
+  const long long Mll = (long long)N * Ho * Wo;
+  LVC_CHECK_ARG(Mll < (1ll << 31), "too many output pixels");
+  a.M = (int)Mll; a.relu = relu; a.res_mode = res_mode;
+  a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
+  LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
+  LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)workspace & 15) == 0 &&
+                    ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 && ((uintptr_t)residual & 15) == 0,
+                "pointers must be 16-byte aligned");
+  const long long xb = (long long)N * H * W * C * 4;
+  LVC_CHECK_ARG(xb < (1ll << 31), "input tensor must be smaller than 2 GiB");
+  a.x_bytes = (int)xb;
+  const int ni = K <= 64 ? 1 : 2;
+  const int HN = 64 * ni;
+  a.tiles_n = lvc_cdiv(K, HN);
+  a.nk = C / 32;
+  const int tiles_m = lvc_cdiv(a.M, PM);
+  long long units = (long long)tiles_m * a.tiles_n * a.nk;
+  LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
+  a.total_units = (int)units;
+  a.w_plane_elems = (long long)(lvc_cdiv(K, 128) * 128) * C;
+  if (g_cus_pw_s == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    g_cus_pw_s = cus;
+  }
+  int cap = g_cus_pw_s;
+  if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
+  a.ngroup = 1;
+  if ((a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && cap % a.tiles_n == 0 && units / a.tiles_n >= (long long)(cap / a.tiles_n) * 4) {
+    a.ngroup = a.tiles_n;       // the workers of one row tile's channel tiles are neighbours on one XCD: the rows come from L2
+    units /= a.tiles_n;
+    cap /= a.tiles_n;
+    a.total_units = (int)units;
+  }
+  const int min_units = 4;     // a worker's pipeline restarts per tile segment: keep segments >= 4 chunks
+  int workers = (int)((units + min_units - 1) / min_units);
+  if (workers > cap) workers = cap;
+  a.units_per_worker = (int)((units + workers - 1) / workers);
+  a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker) * a.ngroup;
+  a.partials = (float*)workspace;
+  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
+  a.err_index = LVC_MAX_WORKERS;
+  hipStream_t st = (hipStream_t)stream;
+  if (oneacc) {
+    if (ni == 1) hipLaunchKernelGGL((conv_pw_s1_kernel<1, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_pw_s1_kernel<2, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+  } else {
+    if (ni == 1) hipLaunchKernelGGL((conv_pw_s1_kernel<1, false>), dim3(a.nworkers), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((conv_pw_s1_kernel<2, false>), dim3(a.nworkers), dim3(NT), 0, st, a);
+  }
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// Pointwise (R = S = 1, pad 0) layer y = act(conv(x, w) * scale + shift (+ residual)), x [N,H,W,C] fp32 NHWC (C % 32 == 0), two-way
+// fp16 split with the numerics and weight planes of lvc_conv2d_nhwc_f16x2 (lvc_split_weights; |a| <= 65504).  relu: 0 none,
+// 1 ReLU, 2 exact GELU.  Meant for layers with a long contraction (C >= 256); any C % 32 == 0 is accepted.
+extern "C" int lvc_conv1x1_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                            const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
+                                            int res_mode, int ldy, int ldr, void* workspace, void* stream) {
+  return pw_s1_launch(false, x, w_split, scale, shift, residual, y, N, H, W, C, K, stride, relu, res_mode, ldy, ldr, workspace, stream);
+}
+
+// The single-accumulator form: w_split / scale from lvc_split_weights_rowscaled as for lvc_conv3x3_nhwc_f16s1 (|a| <= 4094).
+extern "C" int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                       const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
+                                       int res_mode, int ldy, int ldr, void* workspace, void* stream) {
+  return pw_s1_launch(true, x, w_split, scale, shift, residual, y, N, H, W, C, K, stride, relu, res_mode, ldy, ldr, workspace, stream);
+}

@@ -171,10 +171,14 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False,
     return PackedConv(wp, scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
 
 
-def pack_linear(weight, bias=None, split=None):
+def pack_linear(weight, bias=None, split=None, two_acc=True):
     """weight [K_out, K_in] -> a 1x1 'conv' over M x 1 x 1 x K_in rows.  split: the operand split the GEMM will be
-    asked for (None = LVC_CONV_SPLIT), so that the matching planes are produced by the packing launch."""
-    return pack_conv(weight[:, :, None, None], bias=bias, split=split)
+    asked for (None = LVC_CONV_SPLIT), so that the matching planes are produced by the packing launch.
+    two_acc (default True): fully-connected layers feed scores, box deltas and kNN rankings -- they keep the main + cross
+    accumulator form of the fp16 split (kernels.PW_S1); the descriptor network's linears pass False."""
+    pc = pack_conv(weight[:, :, None, None], bias=bias, split=split)
+    pc.two_acc = bool(two_acc)
+    return pc
 
 
 _CONV_WS = {}
@@ -323,6 +327,10 @@ RPN_FUSED_PRED = _os.environ.get("LVC_RPN_FUSED_PRED", "0") == "1"
 #   1 = the numerics of conv3x3_halo_h2.hip everywhere (main + cross accumulators, same weight planes, |a| <= 65504);
 #   0 = the round-1 kernel (conv3x3_halo_h2.hip), which data gradients (explicit `split`) always use.
 HALO_S1 = int(_os.environ.get("LVC_HALO_S1", "2"))
+# pointwise fp16x2 layers with at least LVC_PW_S1_MIN_C input channels on the pipelined kernel (csrc/conv_pw_s1.hip): 2 = its
+# single-accumulator form except `two_acc` layers, 1 = two accumulators everywhere, 0 = off (the LDS-DMA kernel for all of them)
+PW_S1 = int(_os.environ.get("LVC_PW_S1", "2"))
+_PW_S1_MIN_C = int(_os.environ.get("LVC_PW_S1_MIN_C", "256"))
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -403,6 +411,28 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
+        elif (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and residual is None
+              and out.numel() < (1 << 29)):
+            # pointwise layers WITHOUT a residual and with >= 256 input channels on the pipelined kernel (csrc/conv_pw_s1.hip:
+            # fc1 0.75 -> 0.59 ms, res4 / res5 conv1 -10..15 %; layers with a residual are faster on the LDS-DMA kernel, whose ring
+            # prefetches the residual rows: scripts/probe_pw_set.py); precision policy as for the 3x3 layers
+            one = PW_S1 == 2 and not pc.two_acc
+            fused_act = act == "gelu" and not relu
+            if fused_act:
+                act = None
+            code = c_int(2 if fused_act else 1 if relu else 0)
+            if one:
+                planes, scale2 = pc.split2s()
+                st = _lib.lib().lvc_conv1x1_nhwc_f16s1(
+                    ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(residual), ptr(out), c_int(N), c_int(H), c_int(W), c_int(C),
+                    c_int(pc.K), c_int(pc.stride), code, c_int(res_mode), c_int(out.shape[-1]), c_int(ldr),
+                    ptr(conv_workspace(x.device)), _stream(x))
+            else:
+                st = _lib.lib().lvc_conv1x1_nhwc_f16x2_pipe(
+                    ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), ptr(residual), ptr(out), c_int(N), c_int(H), c_int(W), c_int(C),
+                    c_int(pc.K), c_int(pc.stride), code, c_int(res_mode), c_int(out.shape[-1]), c_int(ldr),
+                    ptr(conv_workspace(x.device)), _stream(x))
+            check(st, "lvc_conv1x1_nhwc_f16s1" if one else "lvc_conv1x1_nhwc_f16x2_pipe")
         elif engine == "f16x2_pw":
             # the LDS-DMA kernel addresses outputs / residuals through 32-bit buffer descriptors (< 2^29 elements) and moves
             # residual rows in 32-channel chunks; anything else stays on the register-staged kernel (logged once)

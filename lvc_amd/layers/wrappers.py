@@ -196,7 +196,7 @@ class Linear(nn.Module):
         self._cache = _PackedCache()
 
     def packed(self):
-        return self._cache.get([self.weight, self.bias], lambda: K.pack_linear(self.weight, self.bias))
+        return self._cache.get([self.weight, self.bias], lambda: K.pack_linear(self.weight, self.bias))   # two_acc: kernels.pack_linear
 
     def forward(self, x, relu=False):
         require_device(x, "Linear")

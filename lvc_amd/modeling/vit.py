@@ -44,7 +44,7 @@ class _Linear(nn.Module):
         """x [M, din] device rows -> [M, dout]; `residual` [M, dout] is added in the GEMM epilogue; act="gelu": the exact
         GELU in the same epilogue."""
         pc = self._packed.get([self.weight] + ([self.bias] if self.bias is not None else []),
-                              lambda: K.pack_linear(self.weight, self.bias))
+                              lambda: K.pack_linear(self.weight, self.bias, two_acc=False))
         M = x.shape[0]
         y = K.conv2d_nhwc(x.view(M, 1, 1, x.shape[1]), pc,
                           residual=residual.view(M, 1, 1, residual.shape[1]) if residual is not None else None, act=act)
@@ -150,7 +150,7 @@ class VisionTransformer(nn.Module):
         w = pe.proj.weight.detach().reshape(pe.proj.weight.shape[0], kc)
         if kpad != kc:
             w = torch.nn.functional.pad(w, (0, kpad - kc))
-        return K.pack_linear(w.contiguous(), pe.proj.bias)
+        return K.pack_linear(w.contiguous(), pe.proj.bias, two_acc=False)
 
 
 def vit_small(patch_size=8, **kw):

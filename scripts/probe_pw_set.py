@@ -12,7 +12,11 @@ LAYERS = [("res2 c1 256>64", 8, 200, 336, 256, 64, 0), ("res2 c3 64>256+r", 8, 2
           ("res5 c1 2048>512", 8, 25, 42, 2048, 512, 0), ("res5 c3 512>2048+r", 8, 25, 42, 512, 2048, 1),
           ("fpn lat2 256>256+up", 8, 200, 336, 256, 256, 2), ("fpn lat3 512>256+up", 8, 100, 168, 512, 256, 2),
           ("fc1 12544>1024", 8000, 1, 1, 12544, 1024, 0), ("fc2 1024>1024", 8000, 1, 1, 1024, 1024, 0)]
-tot = 0.0
+LAYERS += [("res4 c1s2 1024>512?", 8, 50, 84, 512, 256, 0), ("vit qkv 384>1152", 50240, 1, 1, 384, 1152, 0), ("vit fc1 384>1536", 50240, 1, 1, 384, 1536, 0),
+           ("vit fc2 1536>384", 50240, 1, 1, 1536, 384, 0)]
+MODES = [int(v) for v in os.environ.get("PW_S1_MODES", "0,1,2").split(",")]
+tot = {m: 0.0 for m in MODES}
+k._PW_S1_MIN_C = int(os.environ.get("LVC_PW_S1_MIN_C", "64"))
 for name, N, H, W, C, K, rm in LAYERS:
     xs = [torch.randn(N, H, W, C, device=d) for _ in range(3)]
     w = torch.randn(K, C, 1, 1, device=d) * (2.0 / C) ** 0.5
@@ -21,14 +25,21 @@ for name, N, H, W, C, K, rm in LAYERS:
     if rm == 1: res = [torch.randn(N, H, W, K, device=d) for _ in range(3)]
     if rm == 2: res = [torch.randn(N, H // 2, W // 2, K, device=d) for _ in range(3)]
     y = torch.empty(N, H, W, K, device=d)
-    f = lambda i: k.conv2d_nhwc(xs[i % 3], pc, relu=True, residual=res[i % 3] if res else None, res_mode=rm, out=y)
-    for i in range(6): f(i)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(30): f(i)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 30
-    tot += ms
-    print("%-22s %.4f ms  %6.1f TF/s" % (name, ms, 2.0 * N * H * W * C * K / ms / 1e9))
-print("sum %.4f ms  (LVC_PW_PF=%s)" % (tot, os.environ.get("LVC_PW_PF", "0")))
+    line = "%-22s" % name
+    ref = None
+    for mode in MODES:
+        k.PW_S1 = mode
+        f = lambda i: k.conv2d_nhwc(xs[i % 3], pc, relu=True, residual=res[i % 3] if res else None, res_mode=rm, out=y)
+        for i in range(6): f(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(30): f(i)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 30
+        tot[mode] += ms
+        out = f(0).clone()
+        if ref is None: ref = out
+        line += " | mode %d: %.4f ms %6.1f TF/s (max diff vs mode %d: %.1e)" % (mode, ms, 2.0 * N * H * W * C * K / ms / 1e9, MODES[0], float((out - ref).abs().max()) / float(ref.abs().max()))
+    print(line, flush=True)
+print("sum " + ", ".join("mode %d: %.4f ms" % (m, tot[m]) for m in MODES) + "   (mode 0 = LDS-DMA kernel, 1 = pipelined two-acc, 2 = pipelined one-acc); conv error word %d" % k.conv_error_word(d))

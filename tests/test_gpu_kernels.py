@@ -681,3 +681,41 @@ def test_rpn_head_fused_predictors_equal_the_two_launch_form(shape, monkeypatch)
     scale = float(plain[..., :15].abs().max())
     assert float((fused[..., :15] - plain[..., :15]).abs().max()) <= 2e-6 * scale
     K.check_conv_error_word(x.device)
+
+
+@pytest.mark.parametrize("N,H,W,C,K,stride,act", [(2, 50, 84, 1024, 256, 1, "relu"), (1, 25, 42, 2048, 512, 1, None), (2, 57, 83, 512, 1024, 2, "relu"),
+                                                  (300, 1, 1, 12544, 1024, 1, "relu"), (5000, 1, 1, 384, 1152, 1, "gelu"), (3, 40, 52, 256, 64, 1, "relu"),
+                                                  (1, 31, 33, 288, 132, 1, None)])
+def test_pointwise_pipelined_forms_vs_fp64(N, H, W, C, K, stride, act, monkeypatch):
+    """csrc/conv_pw_s1.hip (residual-free pointwise layers with >= 256 input channels; kernels.PW_S1: 1 = two accumulators,
+    2 = one) against fp64: form 1 is BIT-IDENTICAL to the LDS-DMA kernel (the same arithmetic in the same order), form 2 stays
+    at the error level of an fp32 CPU evaluation; strides, ragged row / channel tails, the fused ReLU / GELU epilogues."""
+    from lvc_amd import kernels as k
+
+    monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
+    monkeypatch.setattr(k, "CONV_SPLIT", "f16x2")
+    g = torch.Generator().manual_seed(C + K + H)
+    x = torch.randn(N, H, W, C, generator=g)
+    w = torch.randn(K, C, 1, 1, generator=g) * (2.0 / C) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    xs = x[:, ::stride, ::stride]
+    z = xs.double() @ w[:, :, 0, 0].double().t() + b.double()
+    z32 = xs @ w[:, :, 0, 0].t() + b
+    fn = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, None: lambda t: t}[act]
+    ref, cpu = fn(z), fn(z32)
+    sc = float(ref.abs().max())
+    rms_cpu = float((cpu.double() - ref).pow(2).mean().sqrt()) / sc
+    d = _dev()
+    pc = k.pack_conv(w.to(d), bias=b.to(d), stride=stride)
+    out = {}
+    for form in (0, 1, 2):
+        monkeypatch.setattr(k, "PW_S1", form)
+        y = k.conv2d_nhwc(x.to(d), pc, relu=act == "relu", act="gelu" if act == "gelu" else None).cpu()
+        out[form] = y
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * sc, form
+    assert k.conv_error_word(d) == 0
+    rms = {f: float((out[f].double() - ref).pow(2).mean().sqrt()) / sc for f in out}
+    print("pointwise %s C=%d K=%d: rms error / scale  LDS-DMA %.2e, pipelined two-acc %.2e, one-acc %.2e, CPU fp32 %.2e" % ((N, H, W), C, K, rms[0], rms[1], rms[2], rms_cpu))
+    if N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) >= 2048 and C >= 64:     # both on a two-way fp16 kernel: same bits
+        assert torch.equal(out[0], out[1]) or float((out[0] - out[1]).abs().max()) <= 2e-6 * sc
+    assert rms[2] <= max(1.5 * rms_cpu, 2.0 * rms[0])
