@@ -117,14 +117,6 @@ int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_split, const 
 /* wp [rows][Kg] fp32 (lvc_pack_conv_weights) -> planes_out [2][rows][Kg] fp16: w1 = fp16(wp 2^e), w2 = fp16(wp 2^e - w1) with
  * e = 13 - floor(log2(max |wp[row][:]|)) per row (0 for an all-zero row); row_factor[row] = 2^-(e + 4). */
 int lvc_split_weights_rowscaled(const float* wp, int rows, int Kg, void* planes_out, float* row_factor, void* stream);
-/* The RPN head in one launch (detectron2/modeling/proposal_generator/rpn.py:108-127): conv 3x3 s1 p1 + affine + ReLU, then a
- * 1x1 predictor layer (objectness_logits | anchor_deltas fused into one [pK, K] matrix) applied to each output tile while it
- * is still in LDS -- the K-channel hidden map never reaches HBM.  pred_w_split: fp16 planes [2][32][K] of the predictor
- * weights zero-padded to 32 rows (lvc_split_weights), pred_bias [pK]; pout [N*H*W, ldp] fp32 is zeroed by the call and
- * receives one atomic add per element and 128-channel half (two addends: order-independent).  K % 128 == 0, pK <= 32. */
-int lvc_conv3x3_relu_pred_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                                     int N, int H, int W, int C, int K, int Kg, const unsigned short* pred_w_split,
-                                     const float* pred_bias, float* pout, int pK, int ldp, void* workspace, void* stream);
 
 /* Two-way fp16 split form of the POINTWISE shapes of lvc_conv2d_nhwc_bf16x3 (csrc/conv_f16x2.hip): R = S = 1, pad 0
  * and (C <= 512 or N*Ho*Wo >= 2048); anything else returns LVC_ERR_INVALID.  w_split as lvc_conv3x3_nhwc_f16x2. */
@@ -388,11 +380,6 @@ int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* 
  *   (contiguous, bit-identical to lvc_rownorm).
  * lvc_gemm_f16: y [M,ldy] fp32 = a [M,C] . b [N,ldb]^T on fp16 operands (csrc/gemm_h.hip; C % 32 == 0, ldb = elements
  *   between rows of b, 0 = C; y below 2 GiB) -- for unit-norm rows |y - exact| < 2^-10.
- * lvc_gemm_f16_emit: the same products without the matrix: every (m, n) with value >= lb[m] - margin is appended as the
- *   pair (fp32 value, int32 n) to lists[m][0..256) at a slot reserved by an atomic add on counts[m] (zero on entry; list
- *   order arbitrary; counts[m] > 256 = overflow, excess entries dropped).  lists: M * 256 * 8 bytes.
- * lvc_knn_lower_bound: lb[m] <= the 10th largest of row m of sub [Q,ld] (10 <= n <= 256 columns: similarities to a
- *   subset of the shots), hence <= the 10th largest over all shots.
  * lvc_knn_verify_topk_vote: per query row, the shots whose approximate similarity is within `margin` (>= 2 x that bound)
  *   of the 10th largest approximate value provably contain the exact ten best; those of them that have a shot of another
  *   class within margin are re-evaluated in fp32 from q [Q,ldq] (raw descriptors; (q - mu) / den[row] is redone exactly as
@@ -405,17 +392,10 @@ int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh,
                   float eps, int mode, void* stream);
 int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
                  void* stream);
-int lvc_gemm_f16_emit(const unsigned short* a, const unsigned short* b, int ldb, int M, int N, int C, const float* lb,
-                      float margin, void* lists, int* counts, void* stream);
-int lvc_knn_lower_bound(const float* sub, int ld, int Q, int n, float* lb, void* stream);
 int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
                              const float* den, const float* sn, int D, float margin, const float* margins,
                              const long long* shot_classes, const long long* det_classes, int kvote, long long* top_classes,
                              long long* keep, void* stream);
-/* lvc_knn_verify_topk_vote on the candidate lists of lvc_gemm_f16_emit instead of the dense matrix. */
-int lvc_knn_verify_lists(const void* lists, const int* counts, int Q, int S, const float* q, int ldq, const float* mu,
-                         const float* den, const float* sn, int D, float margin, const long long* shot_classes,
-                         const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Descriptor network of the label-verification step: DINO ViT-S/8 as loaded by

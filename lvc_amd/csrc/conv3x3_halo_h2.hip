@@ -49,13 +49,6 @@ struct HaloArgsH {
   int ngroup;   // > 1: workers lw, lw+1, .., lw+ngroup-1 (neighbours on one XCD) walk the SAME pixel tiles, one output-channel
                 // tile each, so a halo patch is fetched from the fabric once and served to the others by that XCD's L2
   int x_bytes, w_plane_bytes;
-  // PRED form (the RPN head: conv 3x3 + ReLU, then the 1x1 predictors on the tile while it still sits in LDS; the hidden map is
-  // never written): predictor weights as two fp16 planes [2][32][K] (rows >= pK zero), bias [pK], output [pixels][ldp] fp32,
-  // zero on entry (the two channel tiles of a pixel tile add their halves with one atomic each)
-  const unsigned short* pw;
-  const float* pbias;
-  float* pout;
-  int pK, ldp;
 };
 
 __device__ __forceinline__ void split2h(float a, f16& h, f16& m) {
@@ -65,7 +58,7 @@ __device__ __forceinline__ void split2h(float a, f16& h, f16& m) {
 
 // NI = 32-column MFMA blocks per wave: NI = 2 -> 128 output channels per tile (wave tile 64 x 64), NI = 1 -> 64 output
 // channels per tile (wave tile 64 x 32; the 64-channel res2 layers, which would waste half of a 128-wide tile).
-template <int NI, bool PRED = false>
+template <int NI>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_h2_kernel(HaloArgsH p) {
   constexpr int HN = 64 * NI;
   constexpr int PLANE_B = HN * LROW;
@@ -368,54 +361,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_h2_kernel(HaloArgsH p) {
             v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
             v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
           }
-          if constexpr (PRED) *reinterpret_cast<f32x4*>(Cs + r * CS_STRIDE + c4 * 4) = v;     // stays in LDS for the predictors
-          else *reinterpret_cast<f32x4*>(p.y + row * p.ldy + col) = v;
+          *reinterpret_cast<f32x4*>(p.y + row * p.ldy + col) = v;
         }
       }
     }
     __syncthreads();
-    if constexpr (PRED) {
-      // ---- the 1x1 predictors on this tile's HN channels: out[pixel][o] += sum_c hidden[pixel][n0 + c] * pw[o][n0 + c], the
-      // same two-way fp16 split (three MFMAs per k16 step).  Wave w takes tile rows 32 w .. 32 w + 31; the activation
-      // fragment comes from the LDS tile (fp32, split in registers), the weight fragment straight from L2 (16 KB per tile).
-      f32x16 pa, px;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { pa[e] = 0.f; px[e] = 0.f; }
-      const float* crow = Cs + (wave * 32 + fi) * CS_STRIDE + fh * 8;
-      const unsigned short* wrow = p.pw + (size_t)fi * p.K + n0 + fh * 8;
-      const size_t wplane = (size_t)32 * p.K;
-#pragma unroll
-      for (int ks = 0; ks < HN / 16; ++ks) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(crow + ks * 16);
-        const f32x4 a1 = *reinterpret_cast<const f32x4*>(crow + ks * 16 + 4);
-        f16x8 ha, la;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f16 h0, m0, h1, m1;
-          split2h(a0[e], h0, m0);
-          split2h(a1[e], h1, m1);
-          ha[e] = h0; la[e] = m0; ha[4 + e] = h1; la[4 + e] = m1;
-          if (!(fmaxf(fabsf(a0[e]), fabsf(a1[e])) <= 65504.f)) range_err = 1;
-        }
-        const f16x8 hb = *reinterpret_cast<const f16x8*>(wrow + ks * 16);
-        const f16x8 lb = *reinterpret_cast<const f16x8*>(wrow + wplane + ks * 16);
-        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, lb, px, 0, 0, 0);
-        pa = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, pa, 0, 0, 0);
-        px = __builtin_amdgcn_mfma_f32_32x32x16_f16(la, hb, px, 0, 0, 0);
-      }
-      if (fi < p.pK) {
-        const float b = (tile_n == 0 && p.pbias) ? p.pbias[fi] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int r = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const int py = r / p.PW, pxx = r - py * p.PW;
-          const int yy = y0 + py, xx = x0 + pxx;
-          if (r < p.MP && yy < p.H && xx < p.W)
-            atomicAdd(p.pout + ((size_t)(img * p.H + yy) * p.W + xx) * p.ldp + fi, pa[e] + px[e] * (1.f / 2048.f) + b);
-        }
-      }
-      __syncthreads();
-    }
   }
   if (range_err) atomicOr(p.flags + p.err_index, 2);
 }
@@ -442,44 +392,11 @@ static void pick_patch_h(int H, int W, int* PH, int* PW) {
 
 // Same arguments as lvc_conv3x3_nhwc_bf16x3 except the weight planes: w_split = [2][Kpad][Kg] fp16 (w1 = fp16(w),
 // w2 = fp16((w - w1) * 2048)), same k order.  No small-map fallback here: the caller routes those to the generic kernel.
-static int halo_h2_launch(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                          const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu, int res_mode,
-                          int ldy, int ldr, void* workspace, void* stream, const unsigned short* pw, const float* pbias,
-                          float* pout, int pK, int ldp);
-
 extern "C" int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale,
                                        const float* shift, const float* residual, float* y, int N, int H, int W, int C,
                                        int K, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
                                        void* stream) {
-  LVC_CHECK_ARG(y != nullptr, "null pointer");
-  return halo_h2_launch(x, w_split, scale, shift, residual, y, N, H, W, C, K, Kg, relu, res_mode, ldy, ldr, workspace, stream, nullptr,
-                        nullptr, nullptr, 0, 0);
-}
-
-// conv 3x3 (stride 1, pad 1) + affine + ReLU followed by a 1x1 predictor layer, without the hidden map in HBM (the RPN head of
-// detectron2/modeling/proposal_generator/rpn.py:108-127: `conv`, then `objectness_logits` | `anchor_deltas` as one 1x1 layer).
-// pred_w_split: [2][32][K] fp16 planes of the [pK, K] predictor weights (rows pK..31 zero; lvc_split_weights of the zero-padded
-// fp32 matrix), pred_bias [pK], pout [N*H*W, ldp] fp32 -- ZEROED by this call, then accumulated with atomic adds (two
-// addends per element: the result does not depend on their order).  K must be a multiple of 128, pK <= 32.
-extern "C" int lvc_conv3x3_relu_pred_nhwc_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                                                int N, int H, int W, int C, int K, int Kg, const unsigned short* pred_w_split,
-                                                const float* pred_bias, float* pout, int pK, int ldp, void* workspace, void* stream) {
-  LVC_CHECK_ARG(pred_w_split && pout && pK > 0 && pK <= 32 && ldp >= pK, "bad predictor arguments");
-  LVC_CHECK_ARG(K % 128 == 0, "the fused predictor form needs K % 128 == 0");
-  LVC_CHECK_ARG(((uintptr_t)pred_w_split & 15) == 0, "predictor planes must be 16-byte aligned");
-  if (hipMemsetAsync(pout, 0, (size_t)N * H * W * ldp * sizeof(float), (hipStream_t)stream) != hipSuccess) {
-    lvc_set_error("%s: hipMemsetAsync failed", __func__);
-    return LVC_ERR_HIP;
-  }
-  return halo_h2_launch(x, w_split, scale, shift, nullptr, nullptr, N, H, W, C, K, Kg, 1, 0, 0, 0, workspace, stream, pred_w_split,
-                        pred_bias, pout, pK, ldp);
-}
-
-static int halo_h2_launch(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                          const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu, int res_mode,
-                          int ldy, int ldr, void* workspace, void* stream, const unsigned short* pw, const float* pbias,
-                          float* pout, int pK, int ldp) {
-  LVC_CHECK_ARG(x && w_split && workspace, "null pointer");
+  LVC_CHECK_ARG(x && w_split && workspace && y, "null pointer");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
   LVC_CHECK_ARG(C % 32 == 0 && Kg == 9 * C, "needs C % 32 == 0 and Kg == 9*C");
   LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
@@ -491,7 +408,6 @@ static int halo_h2_launch(const float* x, const unsigned short* w_split, const f
   LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
-  a.pw = pw; a.pbias = pbias; a.pout = pout; a.pK = pK; a.ldp = ldp;
   pick_patch_h(H, W, &a.PH, &a.PW);
   if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
     int ph = 0, pw = 0;
@@ -533,13 +449,10 @@ static int halo_h2_launch(const float* x, const unsigned short* w_split, const f
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  if (pw) {
-    LVC_CHECK_ARG(ni == 2, "the fused predictor form needs more than 64 output channels");
-    hipLaunchKernelGGL((conv3x3_halo_h2_kernel<2, true>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
-  } else if (ni == 1)
-    hipLaunchKernelGGL((conv3x3_halo_h2_kernel<1, false>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+  if (ni == 1)
+    hipLaunchKernelGGL((conv3x3_halo_h2_kernel<1>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   else
-    hipLaunchKernelGGL((conv3x3_halo_h2_kernel<2, false>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((conv3x3_halo_h2_kernel<2>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -28,8 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// Two shapes of the same kernel: <NI, 8, 3> one workgroup of 8 waves per CU on 256-row tiles with a three-stage ring (the
-// default), and <NI, 4, 2>: two workgroups of 4 waves per CU on 128-row tiles, two stages each (an experiment switch).
+// <NI, 8, 3, 1>: one workgroup of 8 waves per CU on 256-row tiles with a three-stage ring (other shapes were measured and lost:
+// profiles/README.md round 2).
 #define SPIN_LIMIT (1 << 24)
 #define LVC_MAX_WORKERS 1024
 
@@ -206,24 +206,21 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
     const int m0 = tile_m * D_BM + wave * WR;   // first row of this wave
     const int n0 = tile_n * GBN;
 
-    // main (a1 b1) and cross (a1 b2 + a2 b1, weight 2^-11) accumulators.  The wide shape (MI == 2) has no room for 256
-    // cross registers next to 256 main ones: there the cross terms of ONE chunk go to a scratch accumulator per block and are
-    // folded into the main one right away (one fma per element and chunk)
-    constexpr bool WIDE = MI == 2;
-    f32x16 acc[MI][NI], accx[WIDE ? 1 : MI][WIDE ? 1 : NI];
+    // main (a1 b1) and cross (a1 b2 + a2 b1, weight 2^-11) accumulators
+    f32x16 acc[MI][NI], accx[MI][NI];
 #pragma unroll
     for (int a = 0; a < MI; ++a)
 #pragma unroll
       for (int b = 0; b < NI; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    if (!WIDE) {
+    {
 #pragma unroll
       for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int b = 0; b < NI; ++b)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) accx[WIDE ? 0 : a][WIDE ? 0 : b][e] = 0.f;
+          for (int e = 0; e < 16; ++e) accx[a][b][e] = 0.f;
     }
 
 #pragma unroll 1
@@ -234,51 +231,6 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
       const unsigned char* sa = st + (wave * WR + fi) * 128;
       const unsigned char* sb = st + D_A_BYTES + fi * 64;
       if (!(p.ablate & 2)) {
-        if constexpr (WIDE) {
-          // both k16 steps of the chunk at once: 8 activation fragments (split in registers), then per 32-channel block the
-          // four weight fragments, 2 main MFMAs per row block and a 4-MFMA cross chain into a scratch accumulator
-          f16x8 ha[MI][2], la[MI][2];
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const int G0 = s * 4 + fh * 2;
-              const f32x4 a0 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + ((G0 ^ fx7) * 16));
-              const f32x4 a1 = *reinterpret_cast<const f32x4*>(sa + mi * 32 * 128 + (((G0 + 1) ^ fx7) * 16));
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const f16 h0 = (f16)a0[e], h1 = (f16)a1[e];
-                ha[mi][s][e] = h0; ha[mi][s][4 + e] = h1;
-                la[mi][s][e] = (f16)((a0[e] - (float)h0) * 2048.f);
-                la[mi][s][4 + e] = (f16)((a1[e] - (float)h1) * 2048.f);
-                big = fmaxf(big, fmaxf(fabsf(a0[e]), fabsf(a1[e])));
-              }
-            }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) {
-            f16x8 hb[2], lb[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-              const int bo = ((s * 2 + fh) ^ fx3) * 16;
-              hb[s] = *reinterpret_cast<const f16x8*>(sb + ni * 32 * 64 + bo);
-              lb[s] = *reinterpret_cast<const f16x8*>(sb + B_PLANE + ni * 32 * 64 + bo);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-              f32x16 t;
-#pragma unroll
-              for (int e = 0; e < 16; ++e) t[e] = 0.f;
-              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][0], lb[0], t, 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][0], hb[0], acc[mi][ni], 0, 0, 0);
-              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi][0], hb[0], t, 0, 0, 0);
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][1], hb[1], acc[mi][ni], 0, 0, 0);
-              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi][1], lb[1], t, 0, 0, 0);
-              t = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi][1], hb[1], t, 0, 0, 0);
-#pragma unroll
-              for (int e = 0; e < 16; ++e) acc[mi][ni][e] += t[e] * (1.f / 2048.f);
-            }
-          }
-        } else {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int G0 = s * 4 + fh * 2;
@@ -304,26 +256,25 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
           const f16x8 hb = *reinterpret_cast<const f16x8*>(sb + ni * 32 * 64 + bo);
           const f16x8 lb = *reinterpret_cast<const f16x8*>(sb + B_PLANE + ni * 32 * 64 + bo);
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) accx[WIDE ? 0 : mi][WIDE ? 0 : ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi], lb, accx[WIDE ? 0 : mi][WIDE ? 0 : ni], 0, 0, 0);
+          for (int mi = 0; mi < MI; ++mi) accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi], lb, accx[mi][ni], 0, 0, 0);
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha[mi], hb, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) accx[WIDE ? 0 : mi][WIDE ? 0 : ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi], hb, accx[WIDE ? 0 : mi][WIDE ? 0 : ni], 0, 0, 0);
+          for (int mi = 0; mi < MI; ++mi) accx[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(la[mi], hb, accx[mi][ni], 0, 0, 0);
         }
       }
-        }
       }
       ++consumed;
     }
     u += kc1 - kc0;
     STAMP(4);
-    if (!WIDE) {
+    {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += accx[WIDE ? 0 : mi][WIDE ? 0 : ni][e] * (1.f / 2048.f);
+          for (int e = 0; e < 16; ++e) acc[mi][ni][e] += accx[mi][ni][e] * (1.f / 2048.f);
     }
 
     // ---- split tiles (same protocol as conv_f16x2.hip / conv_igemm.hip): a worker that starts inside a tile hands its
@@ -504,15 +455,7 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   a.nk = Kg / 32;
   const int gbn = K <= 32 ? 32 : K <= 64 ? 64 : 128;
   a.tiles_n = lvc_cdiv(K, gbn);
-  // shape: 8 waves x 256-row tiles, one workgroup per CU; LVC_PW_DMA_SHAPE=4 selects 4 waves x 128-row tiles, two workgroups
-  // per CU (measured 0 - 12 % slower on every layer of the R50-FPN set, profiles/README.md round 2: the weight planes are
-  // delivered twice as often per row and the exposed latencies per CU stay the same)
-  static const int shape_env = [] { const char* e = getenv("LVC_PW_DMA_SHAPE"); return e ? atoi(e) : 0; }();
-  // LVC_PW_DMA_SHAPE=64: 4 waves with 64-row x 128-channel wave tiles, one wave per SIMD (512 registers each): a weight
-  // fragment feeds two row blocks, so LDS reads per MFMA drop from 1.08 KB to 0.75 KB
-  const bool wide = shape_env == 64 && K > 64;
-  const int nw = wide || shape_env == 4 ? 4 : 8;
-  const int bm = wide ? 256 : nw * 32;
+  const int nw = 8, bm = 256;     // 8 waves x 32 rows, one workgroup per CU
   const int tiles_m = lvc_cdiv(a.M, bm);
   long long units = (long long)tiles_m * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
@@ -524,7 +467,7 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
       cus = 256;
     g_cus_d = cus;
   }
-  int cap = g_cus_d * (nw == 4 && !wide ? 2 : 1);   // resident workgroups per CU
+  int cap = g_cus_d;   // one resident workgroup per CU
   if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
   const int min_units = 4;
   int workers = (int)((units + min_units - 1) / min_units);
@@ -551,13 +494,8 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   a.dbg = timeline ? (unsigned long long*)((char*)workspace + (size_t)512 * 256 * 128 * 4) : nullptr;
   hipStream_t st = (hipStream_t)stream;
 #define PW_LAUNCH(NI_, NW_, NS_) hipLaunchKernelGGL((conv_pw_dma_kernel<NI_, NW_, NS_, 1>), dim3(a.nworkers), dim3(NW_ * 64), 0, st, a)
-  if (wide) {
-    hipLaunchKernelGGL((conv_pw_dma_kernel<4, 4, 3, 2>), dim3(a.nworkers), dim3(256), 0, st, a);
-  } else if (nw == 8) {
-    if (gbn == 32) PW_LAUNCH(1, 8, 3); else if (gbn == 64) PW_LAUNCH(2, 8, 3); else PW_LAUNCH(4, 8, 3);
-  } else {
-    if (gbn == 32) PW_LAUNCH(1, 4, 2); else if (gbn == 64) PW_LAUNCH(2, 4, 2); else PW_LAUNCH(4, 4, 2);
-  }
+  (void)nw;
+  if (gbn == 32) PW_LAUNCH(1, 8, 3); else if (gbn == 64) PW_LAUNCH(2, 8, 3); else PW_LAUNCH(4, 8, 3);
 #undef PW_LAUNCH
   LVC_CHECK_LAUNCH();
   return LVC_OK;

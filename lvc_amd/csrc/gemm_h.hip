@@ -25,7 +25,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define GH_NS 4
 #define GH_A_BYTES (256 * 64)
 #define GH_STAGE (2 * GH_A_BYTES)
-#define GH_LIST_CAP 256
 
 struct GemmHArgs {
   const unsigned short* a;
@@ -33,11 +32,6 @@ struct GemmHArgs {
   float* y;
   int M, N, C, ldb, ldy, nk, tiles_m, tiles_n, nworkers, ngroup;
   unsigned y_bytes;
-  // emitting form: instead of y, every (row, column) with value >= lb[row] - margin is appended to the row's list
-  const float* lb;
-  float margin;
-  float2* lists;     // [M][GH_LIST_CAP] (value, column index bits)
-  int* counts;       // [M], zero on entry; a count above GH_LIST_CAP means the row's list overflowed
   int ablate;   // experiments (LVC_GH_ABLATE): 1 = no operand DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no stores
 };
 
@@ -48,10 +42,8 @@ __device__ __forceinline__ void gh_glds16(const void* g, void* l) {
   __builtin_amdgcn_global_load_lds((gh_glb_ptr_t)g, (gh_lds_ptr_t)l, 16, 0, 0);
 }
 
-template <bool EMIT>
 __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[GH_NS * GH_STAGE];
-  __shared__ float s_thr[8][64];   // emitting form: lb[row] - margin of each wave's 64 rows
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,80 +167,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     landed = issued;
     const int m0 = tile_m * 256 + wm * 64, n0 = tile_n * 256 + wn * 128;
-    if constexpr (!EMIT) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        const unsigned rbase = (unsigned)(m0 + mi * 32 + 4 * fh) * ldy4;
+    for (int mi = 0; mi < 2; ++mi) {
+      const unsigned rbase = (unsigned)(m0 + mi * 32 + 4 * fh) * ldy4;
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int col = n0 + ni * 32 + fi;
-          const unsigned cbase = col < p.N ? rbase + (unsigned)col * 4u : 0x80000000u;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const float v = acc[mi][ni][e];   // a scalar copy: __builtin_bit_cast on the vector element itself reads element 0
-            if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
-          }
-        }
-      }
-    } else {
-      // ---- emitting epilogue.  A wave holds 64 rows x 128 columns: accumulator element (mi, e) of lane (fi, fh) is row
-      // m0 + mi*32 + 8*(e>>2) + 4*fh + (e&3), column n0 + ni*32 + fi.  Pass 1 counts the passing columns per row (four ballots
-      // per row pair; the low / high half of a ballot is the fh = 0 / 1 row) and parks the counts in lane k = mi*16 + e (fh = 0)
-      // and 32 + k (fh = 1); one atomic add per row reserves the slots; pass 2 redoes the ballots and writes (value, column).
-      // thresholds of the wave's 64 rows through LDS (beside the ring): lane L fetches row m0 + L once
-      s_thr[wave][lane] = m0 + lane < p.M ? p.lb[m0 + lane] - p.margin : INFINITY;
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-      const float* thr_w = s_thr[wave] + 4 * fh;
-      bool colok[4];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) colok[ni] = n0 + ni * 32 + fi < p.N;
-      int mycnt = 0;
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = n0 + ni * 32 + fi;
+        const unsigned cbase = col < p.N ? rbase + (unsigned)col * 4u : 0x80000000u;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          int clo = 0, chi = 0;
-          const float t = thr_w[mi * 32 + 8 * (e >> 2) + (e & 3)];
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            const float v = acc[mi][ni][e];
-            const unsigned long long m = __ballot(colok[ni] && v >= t);
-            clo += __popc((unsigned)m);
-            chi += __popc((unsigned)(m >> 32));
-          }
-          const int k = mi * 16 + e;
-          mycnt = lane == k ? clo : lane == 32 + k ? chi : mycnt;
+          const float v = acc[mi][ni][e];   // a scalar copy: __builtin_bit_cast on the vector element itself reads element 0
+          if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
         }
-      int base = 0;
-      {
-        const int k = lane & 31;
-        const int r = m0 + (k >> 4) * 32 + 8 * ((k & 15) >> 2) + 4 * fh + (k & 3);
-        if (mycnt > 0 && r < p.M) base = atomicAdd(p.counts + r, mycnt);
       }
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int k = mi * 16 + e;
-          const int blo = __builtin_amdgcn_readlane(base, k), bhi = __builtin_amdgcn_readlane(base, 32 + k);
-          int off = fh ? bhi : blo;
-          const int r = m0 + mi * 32 + 8 * (e >> 2) + 4 * fh + (e & 3);
-          float2* lr = p.lists + (size_t)r * GH_LIST_CAP;
-          const float t = thr_w[mi * 32 + 8 * (e >> 2) + (e & 3)];
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) {
-            const float v = acc[mi][ni][e];
-            const bool pass = colok[ni] && v >= t;
-            const unsigned long long m = __ballot(pass);
-            const unsigned half = fh ? (unsigned)(m >> 32) : (unsigned)m;
-            const int slot = off + __popc(half & ((1u << fi) - 1u));
-            if (pass && slot < GH_LIST_CAP) {
-              const int col = n0 + ni * 32 + fi;
-              lr[slot] = float2{v, __builtin_bit_cast(float, col)};
-            }
-            off += __popc(half);
-          }
-        }
     }
   };
   Half H0, H1;
@@ -289,25 +220,20 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 static int g_cus_h = 0;
 
 static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
-                           const float* lb, float margin, void* lists, int* counts, void* stream) {
+                           void* stream) {
   LVC_CHECK_ARG(M >= 0 && N > 0 && C > 0, "bad shape");
   if (M == 0) return LVC_OK;
-  const bool emit = lists != nullptr;
-  LVC_CHECK_ARG(a && b && (emit ? (lb && counts) : y != nullptr), "null pointer");
+  LVC_CHECK_ARG(a && b && y, "null pointer");
   LVC_CHECK_ARG(C % 32 == 0, "needs C % 32 == 0");
   GemmHArgs g;
   g.a = a; g.b = b; g.y = y; g.M = M; g.N = N; g.C = C;
   g.ldb = ldb > 0 ? ldb : C;
   LVC_CHECK_ARG(g.ldb >= C && g.ldb % 8 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0, "operands must be 16-byte aligned (ldb % 8 == 0)");
   g.ldy = ldy > 0 ? ldy : N;
-  g.y_bytes = 0;
-  if (!emit) {
-    LVC_CHECK_ARG(g.ldy >= N, "ldy < N");
-    const long long yb = (long long)M * g.ldy * 4;
-    LVC_CHECK_ARG(yb < (1ll << 31), "output must be smaller than 2 GiB");
-    g.y_bytes = (unsigned)yb;
-  }
-  g.lb = lb; g.margin = margin; g.lists = (float2*)lists; g.counts = counts;
+  LVC_CHECK_ARG(g.ldy >= N, "ldy < N");
+  const long long yb = (long long)M * g.ldy * 4;
+  LVC_CHECK_ARG(yb < (1ll << 31), "output must be smaller than 2 GiB");
+  g.y_bytes = (unsigned)yb;
   g.nk = C / 32;
   static const int ablate = [] { const char* e = getenv("LVC_GH_ABLATE"); return e ? atoi(e) : 0; }();
   g.ablate = ablate;
@@ -326,8 +252,7 @@ static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int
   }
   g.nworkers = g_cus_h / 8 * 8;
   if (g.nworkers < 8) g.nworkers = 8;
-  if (emit) hipLaunchKernelGGL(gemm_f16_dma_kernel<true>, dim3(g.nworkers), dim3(512), 0, (hipStream_t)stream, g);
-  else hipLaunchKernelGGL(gemm_f16_dma_kernel<false>, dim3(g.nworkers), dim3(512), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(gemm_f16_dma_kernel, dim3(g.nworkers), dim3(512), 0, (hipStream_t)stream, g);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
@@ -337,14 +262,5 @@ static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int
 // order, 16-wide MFMA steps inside).
 extern "C" int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
                             void* stream) {
-  return gemm_f16_launch(a, b, ldb, y, M, N, C, ldy, nullptr, 0.f, nullptr, nullptr, stream);
-}
-
-// The same products, never written as a matrix: every (m, n) with value >= lb[m] - margin is appended as the pair
-// (fp32 value, int32 n) to lists[m][0 .. 256) at a slot reserved with an atomic add on counts[m] (zero on entry; the order of a
-// list is arbitrary; counts[m] > 256 = overflow, the entries past 256 are dropped).  lists: M * 256 * 8 bytes.
-extern "C" int lvc_gemm_f16_emit(const unsigned short* a, const unsigned short* b, int ldb, int M, int N, int C, const float* lb,
-                                 float margin, void* lists, int* counts, void* stream) {
-  LVC_CHECK_ARG(lists != nullptr, "null pointer");
-  return gemm_f16_launch(a, b, ldb, nullptr, M, N, C, 0, lb, margin, lists, counts, stream);
+  return gemm_f16_launch(a, b, ldb, y, M, N, C, ldy, stream);
 }

@@ -205,7 +205,6 @@ extern "C" int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const 
 // The query row is normalised on the fly from the raw descriptors exactly as lvc_rownorm does it ((q - mu) / den, den from
 // lvc_rownorm_h), and only for rows that have a flagged candidate.
 #define KV_MAX_CAND 192
-#define KV_LIST_CAP 256      // entries per row of the candidate lists the emitting GEMM writes (gemm_h.hip)
 
 template <int KTOP>
 struct KvLds {
@@ -446,109 +445,6 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
   kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep, stop_after);
 }
 
-// Form B: per row a LIST of (approximate similarity, shot index) pairs, every entry >= lb[row] - margin where lb[row] <= A10
-// (lvc_gemm_f16_emit, gemm_h.hip: the similarity matrix is never written).  The list holds every candidate of step 1 (they are
-// >= A10 - margin >= lb - margin) in arbitrary order; count[row] > KV_LIST_CAP means the list overflowed: every shot is evaluated.
-template <int KTOP>
-__global__ __launch_bounds__(256) void knn_verify_list_kernel(const float2* __restrict__ lists, const int* __restrict__ counts,
-                                                              int Q, int S, const float* __restrict__ q, int ldq,
-                                                              const float* __restrict__ mu, const float* __restrict__ den,
-                                                              const float* __restrict__ sn, int D, float margin,
-                                                              const long long* __restrict__ shot_classes,
-                                                              const long long* __restrict__ det_classes, int kvote,
-                                                              long long* __restrict__ top_classes, long long* __restrict__ keep) {
-  __shared__ float s_lv[4][KV_LIST_CAP];
-  __shared__ int s_li[4][KV_LIST_CAP];
-  __shared__ KvLds<KTOP> s_L[4];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= Q) return;
-  KvLds<KTOP>& L = s_L[w];
-  const int n = counts[row];
-  int ncand = KV_MAX_CAND + 1;      // overflow (or a list too short to hold ten shots: cannot happen with a valid lb) -> all shots
-  if (n <= KV_LIST_CAP && n >= KTOP) {
-    const float2* lr = lists + (size_t)row * KV_LIST_CAP;
-    float mv[KV_LIST_CAP / 64];
-    int mi[KV_LIST_CAP / 64];
-#pragma unroll
-    for (int j = 0; j < KV_LIST_CAP / 64; ++j) {
-      const int c = j * 64 + lane;
-      float2 e = {-INFINITY, 0.f};
-      if (c < n) e = lr[c];
-      mv[j] = e.x != e.x ? INFINITY : e.x;
-      mi[j] = __builtin_bit_cast(int, e.y);
-      s_lv[w][c] = mv[j];
-      s_li[w][c] = mi[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    // A10 = the entry of rank KTOP - 1 by (value descending, shot index ascending: the order of the matrix scan)
-#pragma unroll
-    for (int j = 0; j < KV_LIST_CAP / 64; ++j) {
-      if (j * 64 < n) {
-        const int c = j * 64 + lane;
-        int r = 0;
-        for (int l = 0; l < n; ++l) {
-          const float o = s_lv[w][l];
-          r += (o > mv[j] || (o == mv[j] && s_li[w][l] < mi[j])) ? 1 : 0;
-        }
-        if (c < n && r == KTOP - 1) L.T = mv[j];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    const float Tv = L.T - margin;
-    ncand = 0;
-#pragma unroll
-    for (int j = 0; j < KV_LIST_CAP / 64; ++j) {
-      const bool is_c = j * 64 + lane < n && mv[j] >= Tv;
-      const unsigned long long m = __ballot(is_c);
-      if (m) {
-        const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-        if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = mi[j]; L.ap[pos] = mv[j]; }
-        ncand += __popcll(m);
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  }
-  kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep, 0);
-}
-
-// lb[row] = a lower bound of the 10th largest value of row `row` of sub [Q, ld] (n <= 256 used columns: the approximate
-// similarities to a SUBSET of the shots): the lane maximum of rank 9 -- ten distinct entries are >= it.  -inf when fewer than ten
-// lanes hold a value.
-__global__ __launch_bounds__(256) void knn_lower_bound_kernel(const float* __restrict__ sub, int ld, int Q, int n, float* __restrict__ lb) {
-  __shared__ float s_lmax[4][64];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + w;
-  if (row >= Q) return;
-  const float* ar = sub + (size_t)row * ld;
-  float lmax = -INFINITY;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = j * 64 + lane;
-    float x = i < n ? ar[i] : -INFINITY;
-    if (x != x) x = -INFINITY;
-    lmax = fmaxf(lmax, x);
-  }
-  s_lmax[w][lane] = lmax;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  int rank = 0;
-#pragma unroll 8
-  for (int l = 0; l < 64; ++l) {
-    const float o = s_lmax[w][l];
-    rank += (o > lmax || (o == lmax && l < lane)) ? 1 : 0;
-  }
-  if (rank == 9) lb[row] = lmax;
-}
-
-extern "C" int lvc_knn_lower_bound(const float* sub, int ld, int Q, int n, float* lb, void* stream) {
-  LVC_CHECK_ARG(Q >= 0 && n >= 10 && n <= 256, "need 10..256 columns");
-  if (Q == 0) return LVC_OK;
-  LVC_CHECK_ARG(sub && lb, "null pointer");
-  hipLaunchKernelGGL(knn_lower_bound_kernel, dim3(lvc_cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, sub, ld > 0 ? ld : n, Q, n, lb);
-  LVC_CHECK_LAUNCH();
-  return LVC_OK;
-}
-
 #define KV_CHECKS()                                                                                                              \
   LVC_CHECK_ARG(Q >= 0 && S >= 10, "need at least 10 shots");                                                                    \
   if (Q == 0) return LVC_OK;                                                                                                     \
@@ -585,19 +481,6 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   else if (per <= 48) KV_LAUNCH(48);
   else KV_LAUNCH(64);
 #undef KV_LAUNCH
-  LVC_CHECK_LAUNCH();
-  return LVC_OK;
-}
-
-// The same on candidate lists: lists [Q][256] pairs (fp32 approximate similarity, int32 shot index) and counts [Q] as
-// lvc_gemm_f16_emit wrote them (every shot with approx >= lb[row] - margin, lb[row] <= the row's 10th largest approximate value).
-extern "C" int lvc_knn_verify_lists(const void* lists, const int* counts, int Q, int S, const float* q, int ldq, const float* mu,
-                                    const float* den, const float* sn, int D, float margin, const long long* shot_classes,
-                                    const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream) {
-  KV_CHECKS();
-  LVC_CHECK_ARG(lists && counts, "null pointer");
-  hipLaunchKernelGGL((knn_verify_list_kernel<10>), dim3(lvc_cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, (const float2*)lists, counts, Q,
-                     S, q, ldqq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

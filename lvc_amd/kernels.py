@@ -313,11 +313,6 @@ FUSE_PROJECTION = _os.environ.get("LVC_FUSE_PROJECTION", "1") != "0"
 _H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "64"))   # 64-channel streams too since the LDS-DMA kernel (0.32 -> 0.27 ms on res2 conv3)
 # pointwise fp16x2 layers on the LDS-DMA kernel (csrc/conv_pw_dma.hip); 0 = the register-staged conv_pw256_f16x2_kernel
 PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
-# experiment (LVC_RPN_FUSED_PRED=1): the RPN head's 3x3 conv + ReLU + 1x1 predictors as one launch where the 3x3 runs on the fp16x2
-# halo kernel (no hidden map in HBM).  Parity-tested; measured SLOWER (p2: 1.81 - 1.93 vs 1.75 - 1.79 ms, bench 537 vs 544 img/s):
-# the 3x3 kernel is bound by the matrix pipe, its output stores were already hidden, and the predictor epilogue (LDS round trip,
-# 24 MFMAs, 512 atomics per wave and tile) costs more than the 0.14 ms predictor launch it replaces
-RPN_FUSED_PRED = _os.environ.get("LVC_RPN_FUSED_PRED", "0") == "1"
 # 3x3 fp16x2 layers of the FORWARD pass on the software-pipelined kernel (csrc/conv3x3_halo_s1.hip):
 #   2 (default) = its single-accumulator form (row-scaled weight planes, activations x 2^4: |a| <= 4094; ~7 % faster on the 3x3
 #       set -- the accumulate of the small cross products into the large sum costs the matrix pipe less power than a second full
@@ -483,30 +478,6 @@ def split_planes_f16x2(w):
     out = torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.float16)
     check(_lib.lib().lvc_split_weights(ptr(w), c_longlong(w.numel()), c_int(2), ptr(out), ptr(_conv_error_view(w.device)), _stream(w)),
           "lvc_split_weights")
-    return out
-
-
-def can_fuse_conv3x3_pred(x, pc):
-    """The shapes `conv3x3_relu_pred` takes: the 3x3 layers conv2d_nhwc would put on the two-way fp16 halo kernel, K % 128 == 0."""
-    N, H, W, C = x.shape
-    return (CONV_ENGINE == "bf16x3" and CONV_SPLIT == "f16x2" and CONV_HALO and RPN_FUSED_PRED and pc.mode == 0 and pc.R == 3 and pc.S == 3
-            and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0 and pc.K % 128 == 0
-            and N * ((H * W + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES)
-
-
-def conv3x3_relu_pred(x, pc, pred_planes, pred_bias, pK):
-    """relu(conv3x3(x) * scale + shift) followed by the 1x1 predictor (planes from `split_planes_f16x2` of the zero-padded
-    [32, K] weight matrix), hidden map kept on chip (lvc_conv3x3_relu_pred_nhwc_f16x2).  Returns [N,H,W,pK_padded_to_4]."""
-    _req_cuda(x, pred_planes, pred_bias)
-    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
-    N, H, W, C = x.shape
-    assert C == pc.C and pred_planes.shape == (2, 32, pc.K) and pred_planes.is_contiguous()
-    ldp = (pK + 3) // 4 * 4
-    out = torch.empty(N, H, W, ldp, device=x.device, dtype=torch.float32)
-    rc = _lib.lib().lvc_conv3x3_relu_pred_nhwc_f16x2(ptr(x), ptr(pc.split2h()), ptr(pc.scale), ptr(pc.shift), c_int(N), c_int(H), c_int(W),
-                                                     c_int(C), c_int(pc.K), c_int(pc.Kg), ptr(pred_planes), ptr(pred_bias), ptr(out),
-                                                     c_int(pK), c_int(ldp), ptr(conv_workspace(x.device)), _stream(x))
-    check(rc, "lvc_conv3x3_relu_pred_nhwc_f16x2")
     return out
 
 
@@ -961,49 +932,6 @@ def gemm_f16(a, b, n=None, ldb=None):
 
 
 KNN_LIST_CAP = 256
-
-
-def gemm_f16_emit(a, b, lb, margin):
-    """The products of `gemm_f16(a, b)` as per-row candidate lists: (lists [M,256,2] fp32 view of (value, int32 column bits),
-    counts [M] int32) holding every column with value >= lb[row] - margin (lvc_gemm_f16_emit)."""
-    _req_cuda(a, b, lb)
-    M, C = a.shape
-    assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float16 and b.dtype == torch.float16 and b.shape[1] == C
-    assert lb.dtype == torch.float32 and lb.is_contiguous() and lb.numel() == M
-    lists = torch.empty(M, KNN_LIST_CAP, 2, device=a.device, dtype=torch.float32)
-    counts = torch.zeros(M, device=a.device, dtype=torch.int32)
-    rc = _lib.lib().lvc_gemm_f16_emit(ptr(a), ptr(b), c_int(C), c_int(M), c_int(b.shape[0]), c_int(C), ptr(lb), c_float(margin),
-                                      ptr(lists), ptr(counts), _stream(a))
-    check(rc, "lvc_gemm_f16_emit")
-    return lists, counts
-
-
-def knn_lower_bound(sub):
-    """lb [Q]: a lower bound of the 10th largest entry of each row of sub [Q, 10..256] (lvc_knn_lower_bound)."""
-    _req_cuda(sub)
-    assert sub.dtype == torch.float32 and sub.stride(1) == 1
-    lb = torch.full((sub.shape[0],), float("-inf"), device=sub.device, dtype=torch.float32)
-    rc = _lib.lib().lvc_knn_lower_bound(ptr(sub), c_int(sub.stride(0)), c_int(sub.shape[0]), c_int(sub.shape[1]), ptr(lb), _stream(sub))
-    check(rc, "lvc_knn_lower_bound")
-    return lb
-
-
-def knn_verify_lists(lists, counts, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None):
-    """`knn_verify_topk_vote` on the candidate lists of `gemm_f16_emit`."""
-    _req_cuda(lists, counts, q, sn, shot_classes, det_classes, mu, den)
-    Q, S = counts.shape[0], sn.shape[0]
-    assert lists.is_contiguous() and counts.dtype == torch.int32 and q.stride(1) == 1 and sn.is_contiguous()
-    assert q.dtype == torch.float32 and sn.dtype == torch.float32 and q.shape[1] == sn.shape[1] and shot_classes.dtype == torch.int64
-    top = torch.empty(Q, 10, dtype=torch.int64, device=q.device)
-    keep = torch.empty(Q, dtype=torch.int64, device=q.device) if det_classes is not None else None
-    if det_classes is not None:
-        det_classes = det_classes.contiguous()
-        assert det_classes.dtype == torch.int64
-    rc = _lib.lib().lvc_knn_verify_lists(ptr(lists), ptr(counts), c_int(Q), c_int(S), ptr(q), c_int(q.stride(0)), ptr(mu), ptr(den),
-                                         ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(shot_classes), ptr(det_classes), c_int(k),
-                                         ptr(top), ptr(keep), _stream(q))
-    check(rc, "lvc_knn_verify_lists")
-    return top, keep
 
 
 def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu=None, den=None, margins=None):

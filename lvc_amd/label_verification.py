@@ -16,9 +16,6 @@ from . import kernels as K
 KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
 # LVC_KNN_ROW_MARGINS=0: the worst-case margin 2^-9 for every row instead of the per-row bound from the measured rounding residuals
 KNN_ROW_MARGINS = os.environ.get("LVC_KNN_ROW_MARGINS", "1") != "0"
-# LVC_KNN_EMIT=1 (experiment, measured slower: profiles/README.md round 2): the pre-filter GEMM appends per-row candidate lists
-# from its epilogue instead of writing the [Q, S] matrix
-KNN_EMIT = os.environ.get("LVC_KNN_EMIT", "0") == "1"
 # unit-norm rows: |fp16 dot - exact| <= 2^-11 (|q| rounding) + 2^-11 (|s| rounding) + 2^-22 + fp32 accumulation
 # < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
 VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16
@@ -116,7 +113,7 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
         pc.shift = (-0.5 * (shots * shots).sum(1)).contiguous()
     tops, keeps = [], []
     # the two-stage path keeps only transient fp16 / fp32 copies per chunk: take as many rows as the GEMM's 2 GiB output allows
-    chunk = (TWO_STAGE_CHUNK if KNN_EMIT else min(TWO_STAGE_CHUNK, (2 ** 31 - 1) // (4 * S))) if two_stage else QUERY_CHUNK
+    chunk = min(TWO_STAGE_CHUNK, (2 ** 31 - 1) // (4 * S)) if two_stage else QUERY_CHUNK
     if large:
         chunk = max(256, min(QUERY_CHUNK, (2 ** 31 - 1) // (4 * S)))
     for s0 in range(0, max(Q, 1), chunk):
@@ -129,16 +126,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
             _, qh, den, qres = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False, want_resid=True)
             margins = pre_filter_margins(qres, sh_max, sres_max, D)
-            if KNN_EMIT:
-                # a lower bound of each row's 10th best similarity from a strided subset of <= 256 shots, then the full product
-                # with an epilogue that keeps only what can still matter (csrc/gemm_h.hip): no Q x S matrix in HBM
-                nsub = min(256, S)
-                lb = K.knn_lower_bound(K.gemm_f16(qh, sh, n=nsub, ldb=(S // nsub) * D))
-                lists, counts = K.gemm_f16_emit(qh, sh, lb, VERIFY_MARGIN)
-                t, kp = K.knn_verify_lists(lists, counts, qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den)
-            else:
-                t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den,
-                                               margins=margins if KNN_ROW_MARGINS else None)
+            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den,
+                                           margins=margins if KNN_ROW_MARGINS else None)
         else:
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)

@@ -53,7 +53,6 @@ class StandardRPNHead(nn.Module):
             nn.init.constant_(l.bias, 0)
         self._fused = _PackedCache()
         self._fused_dgrad = _PackedCache()
-        self._fused_planes = _PackedCache()
 
     def fused_predictor(self):
         o, d = self.objectness_logits, self.anchor_deltas
@@ -68,34 +67,13 @@ class StandardRPNHead(nn.Module):
 
         return self._fused.get([o.weight, o.bias, d.weight, d.bias], build)
 
-    def fused_predictor_planes(self):
-        """(fp16 planes [2,32,C] of the fused predictor matrix zero-padded to 32 rows, bias [A + A*box_dim]) for
-        `K.conv3x3_relu_pred`."""
-        o, d = self.objectness_logits, self.anchor_deltas
-
-        def build():
-            w = torch.cat([o.weight, d.weight], 0).detach().float().flatten(1)
-            assert w.shape[0] <= 32
-            wp = w.new_zeros(32, w.shape[1])
-            wp[: w.shape[0]] = w
-            return K.split_planes_f16x2(wp), torch.cat([o.bias, d.bias], 0).detach().float().contiguous()
-
-        return self._fused_planes.get([o.weight, o.bias, d.weight, d.bias], build)
-
     def forward_nhwc(self, feats):
         """feats: list of [B,H,W,C] -> list of fused [B,H,W,A+A*box_dim] tensors."""
         pc = self.fused_predictor()
         o, d = self.objectness_logits, self.anchor_deltas
         train = torch.is_grad_enabled() and any(p.requires_grad for p in (o.weight, o.bias, d.weight, d.bias))
         out = []
-        nout = o.weight.shape[0] + d.weight.shape[0]
         for x in feats:
-            if (not torch.is_grad_enabled() and x.is_cuda and nout <= 32 and self.conv.norm is None
-                    and K.can_fuse_conv3x3_pred(x, self.conv.packed())):
-                # the large levels: conv + ReLU + both predictors in one launch, the hidden map stays in LDS
-                planes, bias = self.fused_predictor_planes()
-                out.append(K.conv3x3_relu_pred(x.contiguous(), self.conv.packed(), planes, bias, nout))
-                continue
             h = self.conv.forward_nhwc(x)
             if train or (torch.is_grad_enabled() and h.requires_grad):
                 out.append(_FusedPredictorFn.apply(h, o.weight, o.bias, d.weight, d.bias, self))

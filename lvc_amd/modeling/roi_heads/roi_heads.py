@@ -229,10 +229,12 @@ class StandardROIHeads(ROIHeads):
 
     def forward(self, images, features, proposals, targets=None):
         """Reference signature (roi_heads.py:554-572): -> (list[Instances], losses)."""
-        if self.rbg:
-            raise NotImplementedError("RBG (box-corrector) evaluation is not implemented in lvc_amd round 1")
         if self.training:
             return self._forward_train(features, proposals, targets)
+        if self.rbg:
+            # reference roi_heads.py:561-562: with an RBG proposal generator the evaluation pass labels and subsamples the given
+            # proposals against the ground truth first (inference=True: no EventStorage scalars), then runs the usual box branch
+            proposals = self.label_and_sample_proposals(proposals, targets, inference=True)
         feats = {f: to_nhwc(features[f]) for f in self.in_features}
         dev = feats[self.in_features[0]].device
         require_device(feats[self.in_features[0]], "StandardROIHeads")

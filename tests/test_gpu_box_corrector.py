@@ -437,3 +437,41 @@ def test_box_corrector_evaluation_matches_reference(monkeypatch):
     err = float((out["output_ious"].cpu() - g["output_ious"]).abs().max())
     print("max |IoU_out - ref|", err)
     assert err <= 1e-3
+
+
+def test_standard_roi_heads_with_rbg_proposals_evaluates(monkeypatch):
+    """reference roi_heads.py:561-562: StandardROIHeads built under PROPOSAL_GENERATOR.NAME = "RBG" labels and subsamples the
+    given proposals against the ground truth before its usual box branch.  Equal to doing the two steps by hand."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.utils import synthetic as syn
+
+    cfg = base_rcnn_fpn(num_classes=20)
+    cfg.MODEL.PROPOSAL_GENERATOR.NAME = "RBG"
+    cfg.MODEL.LOAD_PROPOSALS = True
+    cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 32
+    model = build_model(cfg).eval()
+    syn.conditioned_r50_fpn_(model)
+    heads = model.roi_heads
+    assert heads.rbg
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    img = syn.synthetic_image(5, 256, 320).to(dev)
+    gt = torch.tensor([[30.0, 40.0, 150.0, 200.0], [100.0, 60.0, 300.0, 220.0]])
+    tgt = Instances((256, 320))
+    tgt.gt_boxes = Boxes(gt.to(dev))
+    tgt.gt_classes = torch.tensor([3, 7], device=dev)
+    props = Instances((256, 320))
+    props.proposal_boxes = Boxes((gt.repeat(12, 1) + torch.randn(24, 4, generator=g) * 6).to(dev))
+    props.objectness_logits = torch.zeros(24, device=dev)
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    with torch.no_grad():
+        images = model.preprocess_image([{"image": img}])
+        feats = model.backbone(images.tensor)
+        out, _ = heads(images, feats, [props], [tgt])
+        sampled = heads.label_and_sample_proposals([props], [tgt], inference=True)
+        heads.rbg = False
+        ref, _ = heads(images, feats, sampled, None)
+    assert len(out) == 1 and len(out[0]) == len(ref[0])
+    assert torch.equal(out[0].pred_boxes.tensor, ref[0].pred_boxes.tensor) and torch.equal(out[0].scores, ref[0].scores)

@@ -647,42 +647,6 @@ def test_preprocess_batch_equals_per_image():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("shape", [(2, 200, 336), (8, 100, 168), (1, 67, 93)])
-def test_rpn_head_fused_predictors_equal_the_two_launch_form(shape, monkeypatch):
-    """lvc_conv3x3_relu_pred_nhwc_f16x2 (conv 3x3 + ReLU + objectness | deltas on the tile in LDS, no hidden map in HBM)
-    against the same head as conv launch + predictor launch: equal to fp32 summation-order noise (the fused form adds the two
-    128-channel halves with one atomic each), on tile-edge shapes too.  An experiment switch (measured slower, kernels.py)."""
-    from lvc_amd import kernels as K
-    from lvc_amd.modeling.proposal_generator.rpn import StandardRPNHead
-
-    N, H, W = shape
-    torch.manual_seed(0)
-    head = StandardRPNHead(in_channels=256, num_anchors=3).to("cuda:0")
-    with torch.no_grad():
-        head.conv.weight.normal_(0, 0.02)
-        head.conv.bias.normal_(0, 0.1)
-        head.objectness_logits.weight.normal_(0, 0.05)
-        head.anchor_deltas.weight.normal_(0, 0.05)
-        head.objectness_logits.bias.normal_(0, 0.5)
-        head.anchor_deltas.bias.normal_(0, 0.5)
-    x = torch.randn(N, H, W, 256, device="cuda:0").abs()
-    calls = []
-    orig = K.conv3x3_relu_pred
-    monkeypatch.setattr(K, "conv3x3_relu_pred", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
-    monkeypatch.setattr(K, "_HALO_H2_MIN_TILES", 0)
-    monkeypatch.setattr(K, "RPN_FUSED_PRED", True)
-    with torch.no_grad():
-        fused = head.forward_nhwc([x])[0]
-        assert len(calls) == 1
-        monkeypatch.setattr(K, "RPN_FUSED_PRED", False)
-        plain = head.forward_nhwc([x])[0]
-        assert len(calls) == 1
-    assert fused.shape == plain.shape
-    scale = float(plain[..., :15].abs().max())
-    assert float((fused[..., :15] - plain[..., :15]).abs().max()) <= 2e-6 * scale
-    K.check_conv_error_word(x.device)
-
-
 @pytest.mark.parametrize("N,H,W,C,K,stride,act", [(2, 50, 84, 1024, 256, 1, "relu"), (1, 25, 42, 2048, 512, 1, None), (2, 57, 83, 512, 1024, 2, "relu"),
                                                   (300, 1, 1, 12544, 1024, 1, "relu"), (5000, 1, 1, 384, 1152, 1, "gelu"), (3, 40, 52, 256, 64, 1, "relu"),
                                                   (1, 31, 33, 288, 132, 1, None)])
