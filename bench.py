@@ -565,7 +565,8 @@ def infer_main(c, args):
     # one fully bracketed untimed step; ~150 event records per step cost ~0.7 ms of host time inside the timed region),
     # the per-kernel breakdown of every conv/GEMM launch comes from two more untimed steps after it.
     timer = full = None
-    NAMES = {"f16x2_halo": "conv3x3_halo_s1_kernel (pipelined 3x3: one accumulator in the trunk, two in the RPN head)" if K.HALO_S1 else "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise / FC; conv_pw256_f16x2_kernel beyond its range)", "bf16x3_halo": "conv3x3_halo_kernel",
+    NAMES = {"f16x2_halo": "conv3x3_halo_s1_kernel (pipelined 3x3: one accumulator in the trunk, two in the RPN head)" if K.HALO_S1 else "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise: the layers with a residual / fewer than 256 input channels)",
+             "f16x2_pws1": "conv_pw_s1_kernel (pipelined pointwise / FC: residual-free layers with >= 256 input channels)", "bf16x3_halo": "conv3x3_halo_kernel",
              "bf16x3": "conv_bf16x3_kernel (+ bf16 pointwise shapes)", "f32": "conv_igemm_f32_kernel"}
     if not args.no_launch_timer:
         probe = K.LaunchTimer()
@@ -693,7 +694,7 @@ def infer_main(c, args):
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic,
             "traffic_source": ("live rocprofv3 --pmc passes in this run" if live is not None else "profiles (not measured in this run)")
-                              + ": fabric bytes FETCH_SIZE x2 + WRITE_SIZE of ONE p2 3x3 launch (the dominant kernel's largest, 2 of its 22 launches per step) vs 1.10 GB algorithmic",
+                              + ": fabric bytes FETCH_SIZE x2 + WRITE_SIZE of ONE p2 3x3 launch (the 3x3 kernel's largest, 2 of its 22 launches per step) vs 1.10 GB algorithmic",
             "mfma_utilisation_pmc": pmc,
             "kernel_ms_per_step": round(ms / max(1, timer.steps_timed()), 3), "launch_avg_ms": round(ms / nlaunch, 4)}
         other = {}
@@ -806,7 +807,7 @@ def _live_conv_pmc(timeout_s=90):
         cyc = agg.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         alg = 8 * 200 * 336 * 256 * 4 * 2 + 256 * 2304 * 4      # the p2 activation tensor read once and written once + the weights
         out = {"source": "live: rocprofv3 --pmc passes of scripts/probe_one.py 8 256 200 336 256 3 1 1 on this box, inside this bench run",
-               "launch": "conv3x3_halo_h2_kernel, 3x3 256 -> 256 on [8,200,336,256] (the largest launch of the dominant kernel, 2 per step)",
+               "launch": "the 3x3 fp16-split kernel (conv3x3_halo_s1_kernel unless LVC_HALO_S1=0), 3x3 256 -> 256 on [8,200,336,256]: the largest 3x3 launch, 2 per step",
                "hbm_bytes_per_launch": int(2 * agg["FETCH_SIZE"] * 1024 + agg["WRITE_SIZE"] * 1024),
                "correction": "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM), WRITE_SIZE as is",
                "algorithmic_bytes_per_launch": alg,

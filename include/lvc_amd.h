@@ -370,6 +370,15 @@ int lvc_colsum_atomic(const float* x, int M, int N, int ldx, float* out, void* s
  *   top_classes [Q,10] int64, keep [Q] int64 or NULL.
  */
 int lvc_colmean(const float* x, float* mu, int M, int D, int ld, void* stream);
+/* Shot sets of any size (tools/run_nearest_neighbours.py:146-160 ranks any S): lvc_knn_topk_candidates writes, for ONE block of
+ * S <= 4096 columns of sims [Q,ld], the ten best (similarity, idx_base + column) pairs per row (cand_val / cand_idx [Q,10];
+ * value descending, ties -> lower index, padded with (-inf, INT_MAX)); lvc_knn_merge_vote ranks nlists <= 64 such lists
+ * ([nlists][Q][10]) against each other, gathers the classes and votes: outputs as lvc_knn_topk_vote.
+ * lvc_max_f32: out[0] = max of x[0..n). */
+int lvc_knn_topk_candidates(const float* sims, int ld, int Q, int S, int idx_base, float* cand_val, int* cand_idx, void* stream);
+int lvc_knn_merge_vote(const float* cand_val, const int* cand_idx, int nlists, int Q, const long long* shot_classes,
+                       const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream);
+int lvc_max_f32(const float* x, long long n, float* out, void* stream);
 int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* shot_classes,
                       const long long* det_classes, int kvote, long long* top_classes, long long* keep,
                       void* stream);

@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void knn_topk_vote_kernel(const float* __restr
                                                             const long long* __restrict__ shot_classes,
                                                             const long long* __restrict__ det_classes, int kvote,
                                                             long long* __restrict__ top_classes,
-                                                            long long* __restrict__ keep) {
+                                                            long long* __restrict__ keep, float* __restrict__ cand_val,
+                                                            int* __restrict__ cand_idx, int idx_base) {
+  // cand_val / cand_idx != NULL (shot sets beyond one launch: lvc_knn_topk_candidates): the KTOP best (value, idx_base + index)
+  // pairs of this column block are written instead of classes; lvc_knn_merge_vote ranks the blocks' lists against each other
   __shared__ float s_lmax[4][64];
   __shared__ float s_cval[4][KNN_MAX_CAND];
   __shared__ int s_cidx[4][KNN_MAX_CAND];
@@ -114,9 +117,14 @@ __global__ __launch_bounds__(256) void knn_topk_vote_kernel(const float* __restr
         r += (o > mv || (o == mv && oi < mi)) ? 1 : 0;
       }
       if (c < total && r < KTOP) {
-        const long long cl = shot_classes[mi];
-        s_cls[w][r] = cl;
-        top_classes[(size_t)row * KTOP + r] = cl;
+        if (cand_val) {
+          cand_val[(size_t)row * KTOP + r] = mv;
+          cand_idx[(size_t)row * KTOP + r] = idx_base + mi;
+        } else {
+          const long long cl = shot_classes[mi];
+          s_cls[w][r] = cl;
+          top_classes[(size_t)row * KTOP + r] = cl;
+        }
       }
     }
   } else {
@@ -136,14 +144,19 @@ __global__ __launch_bounds__(256) void knn_topk_vote_kernel(const float* __restr
       for (int j = 0; j < PER; ++j)
         if (j * 64 + lane == bi) v[j] = -INFINITY;   // owner lane retires the winner
       if (lane == 0) {
-        const long long cl = (bi < S) ? shot_classes[bi] : -1;
-        s_cls[w][r] = cl;
-        top_classes[(size_t)row * KTOP + r] = cl;
+        if (cand_val) {
+          cand_val[(size_t)row * KTOP + r] = bi < S ? best : -INFINITY;
+          cand_idx[(size_t)row * KTOP + r] = bi < S ? idx_base + bi : 0x7fffffff;
+        } else {
+          const long long cl = (bi < S) ? shot_classes[bi] : -1;
+          s_cls[w][r] = cl;
+          top_classes[(size_t)row * KTOP + r] = cl;
+        }
       }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  if (lane == 0 && keep) {
+  if (lane == 0 && keep && !cand_val) {
     // torch.mode over the first kvote votes: most frequent value, ties -> smallest value
     long long mode = -1; int mcount = 0;
     for (int a = 0; a < kvote; ++a) {
@@ -155,22 +168,15 @@ __global__ __launch_bounds__(256) void knn_topk_vote_kernel(const float* __restr
   }
 }
 
-// sims [Q, ld] fp32 (S used columns); shot_classes [S] int64; det_classes [Q] int64 or NULL;
-// top_classes [Q,10] int64 (class ids of the 10 most similar shots, most similar first); keep [Q] int64 or NULL.
-extern "C" int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* shot_classes,
-                                 const long long* det_classes, int kvote, long long* top_classes, long long* keep,
-                                 void* stream) {
-  LVC_CHECK_ARG(Q >= 0 && S >= 10, "need at least 10 shots");
-  if (Q == 0) return LVC_OK;
-  LVC_CHECK_ARG(sims && shot_classes && top_classes, "null pointer");
-  LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
-  LVC_CHECK_ARG(kvote >= 1 && kvote <= 10, "k must be in 1..10 (the reference stores top-10)");
+static int knn_topk_launch(const float* sims, int ld, int Q, int S, const long long* shot_classes, const long long* det_classes,
+                           int kvote, long long* top_classes, long long* keep, float* cand_val, int* cand_idx, int idx_base,
+                           void* stream) {
   const int per = lvc_cdiv(S, 64);
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
 #define KNN_LAUNCH(P) hipLaunchKernelGGL((knn_topk_vote_kernel<10, P>), grid, block, 0, st, sims, ldd, Q, S, shot_classes, \
-                                         det_classes, kvote, top_classes, keep)
+                                         det_classes, kvote, top_classes, keep, cand_val, cand_idx, idx_base)
   if (per <= 8) KNN_LAUNCH(8);
   else if (per <= 16) KNN_LAUNCH(16);
   else if (per <= 24) KNN_LAUNCH(24);
@@ -183,6 +189,113 @@ extern "C" int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const 
   return LVC_OK;
 }
 
+// sims [Q, ld] fp32 (S used columns); shot_classes [S] int64; det_classes [Q] int64 or NULL;
+// top_classes [Q,10] int64 (class ids of the 10 most similar shots, most similar first); keep [Q] int64 or NULL.
+extern "C" int lvc_knn_topk_vote(const float* sims, int ld, int Q, int S, const long long* shot_classes,
+                                 const long long* det_classes, int kvote, long long* top_classes, long long* keep,
+                                 void* stream) {
+  LVC_CHECK_ARG(Q >= 0 && S >= 10, "need at least 10 shots");
+  if (Q == 0) return LVC_OK;
+  LVC_CHECK_ARG(sims && shot_classes && top_classes, "null pointer");
+  LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
+  LVC_CHECK_ARG(kvote >= 1 && kvote <= 10, "k must be in 1..10 (the reference stores top-10)");
+  return knn_topk_launch(sims, ld, Q, S, shot_classes, det_classes, kvote, top_classes, keep, nullptr, nullptr, 0, stream);
+}
+
+// Shot sets of any size (LVIS: 1230 classes x 10 shots): the caller cuts the columns into blocks of <= 4096 shots, this call
+// writes the ten best (similarity, idx_base + column) pairs of ONE block per row (value descending, ties -> lower index; rows of
+// a block with fewer than ten columns are padded with (-inf, INT_MAX)), and lvc_knn_merge_vote ranks the blocks' lists:
+// the exact top ten of the whole row are among the per-block top tens.
+extern "C" int lvc_knn_topk_candidates(const float* sims, int ld, int Q, int S, int idx_base, float* cand_val, int* cand_idx,
+                                       void* stream) {
+  LVC_CHECK_ARG(Q >= 0 && S >= 1, "bad sizes");
+  if (Q == 0) return LVC_OK;
+  LVC_CHECK_ARG(sims && cand_val && cand_idx, "null pointer");
+  LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
+  return knn_topk_launch(sims, ld, Q, S, nullptr, nullptr, 10, nullptr, nullptr, cand_val, cand_idx, idx_base, stream);
+}
+
+// cand_val / cand_idx [nlists][Q][10]: per row the 10 x nlists candidates are ranked (value descending, ties -> lower shot index),
+// the ten best give top_classes [Q,10] and the vote / keep exactly as lvc_knn_topk_vote does.  One wave per row.
+#define KM_MAX 640
+__global__ __launch_bounds__(256) void knn_merge_vote_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                             int nlists, int Q, const long long* __restrict__ shot_classes,
+                                                             const long long* __restrict__ det_classes, int kvote,
+                                                             long long* __restrict__ top_classes, long long* __restrict__ keep) {
+  __shared__ float s_v[4][KM_MAX];
+  __shared__ int s_i[4][KM_MAX];
+  __shared__ long long s_cls[4][10];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= Q) return;
+  const int total = nlists * 10;
+  for (int c = lane; c < total; c += 64) {
+    const int l = c / 10, r = c - l * 10;
+    s_v[w][c] = cand_val[((size_t)l * Q + row) * 10 + r];
+    s_i[w][c] = cand_idx[((size_t)l * Q + row) * 10 + r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    const int c = c0 + lane;
+    const float mv = c < total ? s_v[w][c] : -INFINITY;
+    const int mi = c < total ? s_i[w][c] : 0x7fffffff;
+    int r = 0;
+    for (int l = 0; l < total; ++l) {
+      const float o = s_v[w][l];
+      const int oi = s_i[w][l];
+      r += (o > mv || (o == mv && oi < mi)) ? 1 : 0;
+    }
+    if (c < total && r < 10 && mi != 0x7fffffff) {
+      const long long cl = shot_classes[mi];
+      s_cls[w][r] = cl;
+      top_classes[(size_t)row * 10 + r] = cl;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (lane == 0 && keep) {
+    long long mode = -1; int mcount = 0;
+    for (int a = 0; a < kvote; ++a) {
+      int c = 0;
+      for (int b = 0; b < kvote; ++b) c += (s_cls[w][b] == s_cls[w][a]);
+      if (c > mcount || (c == mcount && s_cls[w][a] < mode)) { mcount = c; mode = s_cls[w][a]; }
+    }
+    keep[row] = (det_classes && det_classes[row] == mode) ? 1 : 0;
+  }
+}
+
+extern "C" int lvc_knn_merge_vote(const float* cand_val, const int* cand_idx, int nlists, int Q, const long long* shot_classes,
+                                  const long long* det_classes, int kvote, long long* top_classes, long long* keep, void* stream) {
+  LVC_CHECK_ARG(Q >= 0 && nlists >= 1 && nlists * 10 <= KM_MAX, "between 1 and 64 candidate lists");
+  if (Q == 0) return LVC_OK;
+  LVC_CHECK_ARG(cand_val && cand_idx && shot_classes && top_classes, "null pointer");
+  LVC_CHECK_ARG(kvote >= 1 && kvote <= 10, "k must be in 1..10 (the reference stores top-10)");
+  hipLaunchKernelGGL(knn_merge_vote_kernel, dim3(lvc_cdiv(Q, 4)), dim3(256), 0, (hipStream_t)stream, cand_val, cand_idx, nlists, Q,
+                     shot_classes, det_classes, kvote, top_classes, keep);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// out[0] = max over x[0 .. n) (-inf for n = 0; NaN entries are ignored).  One workgroup: for the handful of per-shot statistics
+// the sweep's margins need.
+__global__ __launch_bounds__(256) void max_f32_kernel(const float* __restrict__ x, long long n, float* __restrict__ out) {
+  __shared__ float red[256];
+  float m = -INFINITY;
+  for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, x[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+extern "C" int lvc_max_f32(const float* x, long long n, float* out, void* stream) {
+  LVC_CHECK_ARG(x && out && n >= 0, "bad arguments");
+  hipLaunchKernelGGL(max_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Two-stage exact top-10: the [Q, S] matrix handed in is an APPROXIMATION of the similarities (lvc_gemm_f16, gemm_h.hip: every

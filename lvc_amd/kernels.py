@@ -374,6 +374,9 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         h2_pw = (not halo and (split or CONV_SPLIT) == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= _H2_PW_MIN_C
                  and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3 (f16x2 there: 0.312 vs 0.335 ms alone, no gain end to end)
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
+        if (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and residual is None
+                and out.numel() < (1 << 29)):
+            engine = "f16x2_pws1"     # residual-free, >= 256 input channels: the pipelined pointwise kernel (csrc/conv_pw_s1.hip)
     timer = CONV_TIMER
     if timer is not None and (not timer.active or (timer.only is not None and engine not in timer.only)):
         timer = None
@@ -406,8 +409,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
-        elif (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and residual is None
-              and out.numel() < (1 << 29)):
+        elif engine == "f16x2_pws1":
             # pointwise layers WITHOUT a residual and with >= 256 input channels on the pipelined kernel (csrc/conv_pw_s1.hip:
             # fc1 0.75 -> 0.59 ms, res4 / res5 conv1 -10..15 %; layers with a residual are faster on the LDS-DMA kernel, whose ring
             # prefetches the residual rows: scripts/probe_pw_set.py); precision policy as for the 3x3 layers
@@ -898,6 +900,44 @@ def knn_topk_vote(sims, num_shots, shot_classes, det_classes, k):
                                       ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(sims))
     check(rc, "lvc_knn_topk_vote")
     return top, keep
+
+
+def knn_topk_vote_blocks(sims, num_shots, shot_classes, det_classes, k, block=4096):
+    """`knn_topk_vote` for any number of shots (LVIS-sized sets): the columns are cut into equal blocks of <= 4096 shots, each
+    block's ten best (similarity, shot index) pairs per row are found (lvc_knn_topk_candidates), and one merge launch ranks
+    the lists, gathers the classes and votes (lvc_knn_merge_vote).  The exact top ten of a row are among the per-block top
+    tens, and both steps use the reference's tie rule (lower shot index first): the same answer as one launch over the row."""
+    _req_cuda(sims, shot_classes, det_classes)
+    Q = sims.shape[0]
+    assert sims.stride(1) == 1 and shot_classes.dtype == torch.int64 and shot_classes.is_contiguous()
+    nblk = (num_shots + block - 1) // block
+    assert 1 <= nblk <= 64, "at most 64 x 4096 shots"
+    per = (num_shots + nblk - 1) // nblk
+    cv = torch.empty(nblk, Q, 10, dtype=torch.float32, device=sims.device)
+    ci = torch.empty(nblk, Q, 10, dtype=torch.int32, device=sims.device)
+    lib = _lib.lib()
+    for b in range(nblk):
+        s0, s1 = b * per, min(num_shots, (b + 1) * per)
+        check(lib.lvc_knn_topk_candidates(ptr(sims[:, s0:]), c_int(sims.stride(0)), c_int(Q), c_int(s1 - s0), c_int(s0), ptr(cv[b]),
+                                          ptr(ci[b]), _stream(sims)), "lvc_knn_topk_candidates")
+    top = torch.empty(Q, 10, dtype=torch.int64, device=sims.device)
+    keep = torch.empty(Q, dtype=torch.int64, device=sims.device) if det_classes is not None else None
+    if det_classes is not None:
+        det_classes = det_classes.contiguous()
+        assert det_classes.dtype == torch.int64
+    check(lib.lvc_knn_merge_vote(ptr(cv), ptr(ci), c_int(nblk), c_int(Q), ptr(shot_classes), ptr(det_classes), c_int(k), ptr(top),
+                                 ptr(keep), _stream(sims)), "lvc_knn_merge_vote")
+    return top, keep
+
+
+def max_f32(x):
+    """[1] fp32 device tensor: the maximum of x (lvc_max_f32)."""
+    _req_cuda(x)
+    x = x.contiguous()
+    assert x.dtype == torch.float32
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(_lib.lib().lvc_max_f32(ptr(x), c_longlong(x.numel()), ptr(out), _stream(x)), "lvc_max_f32")
+    return out
 
 
 def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True, want_resid=False):

@@ -85,16 +85,20 @@ def pre_filter_margins(qres, sh_max, sres_max, D):
 
 
 def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classes=None, k=10, cosine=True):
-    """shot_descriptors [S,D], shot_classes [S] int64, query_descriptors [Q,D] (device, fp32, D % 32 == 0).
+    """shot_descriptors [S,D], shot_classes [S] int64, query_descriptors [Q,D] (device, fp32; any S >= 10, any D).
     Returns (top10_shots [Q,10] int64 class ids, keep [Q] int64 or None)."""
     shots = shot_descriptors.contiguous().float()
     q = query_descriptors.contiguous().float()
     S, D = shots.shape
     Q = q.shape[0]
     if D % 32 != 0:
-        raise RuntimeError("descriptor dimension must be a multiple of 32 (got {})".format(D))
+        # the GEMM kernels contract in chunks of 32: zero columns change neither dot products, norms nor the column mean
+        pad = 32 - D % 32
+        shots = torch.nn.functional.pad(shots, (0, pad))
+        q = torch.nn.functional.pad(q, (0, pad))
+        D += pad
     shot_classes = shot_classes.to(torch.int64).contiguous()
-    large = S > MAX_SHOTS_PER_LAUNCH     # beyond the top-k kernels' row length (LVIS-sized shot sets): ranked by a stable torch sort
+    large = S > MAX_SHOTS_PER_LAUNCH     # beyond the top-k kernels' row length (LVIS-sized shot sets): ranked in blocks + one merge launch
     two_stage = KNN_TWO_STAGE and cosine and D <= 2048 and S >= 10 and not large
     if cosine:
         mu = K.colmean(shots)
@@ -102,8 +106,9 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             sn, sh, _, sres = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1, want_resid=True)
             # pieces of the per-row error bound of the fp16 pre-filter (pre_filter_margins): the largest fp16-row norm and the
             # largest rounding-residual norm over the shots
-            sh_max = sh.float().norm(dim=1).max()
-            sres_max = sres.max()
+            # |s_h| <= |s| + |s - s_h| = 1 + residual (the rows are unit vectors to 1e-7): no separate norm pass
+            sres_max = K.max_f32(sres)
+            sh_max = 1.0 + 1e-6 + sres_max
         else:
             sn = K.rownorm(shots, mu=mu, eps=1e-8, mode=1)
             pc = K.pack_linear(sn)
@@ -132,14 +137,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
             sims = K.linear(qn, pc)
             if large:
-                # the same similarities (HIP GEMM), ranked with the reference's tie rule by a stable descending sort
-                t = shot_classes[torch.sort(sims, dim=1, descending=True, stable=True)[1][:, :10]]
-                kp = None
-                if dc is not None:     # mode of the first k ids, the SMALLEST id among equally frequent ones (CPU torch.mode's rule)
-                    tk = t[:, :k]
-                    cnt = (tk[:, :, None] == tk[:, None, :]).sum(2)
-                    mode = torch.where(cnt == cnt.max(1, keepdim=True)[0], tk, torch.full_like(tk, 2 ** 62)).min(1)[0]
-                    kp = (mode == dc).to(torch.int64)
+                # shot sets beyond one launch's row length: per-block top tens + one merge / vote launch, all on the device
+                t, kp = K.knn_topk_vote_blocks(sims, S, shot_classes, dc, k, block=MAX_SHOTS_PER_LAUNCH)
             else:
                 t, kp = K.knn_topk_vote(sims, S, shot_classes, dc, k)
         tops.append(t)

@@ -237,8 +237,9 @@ def test_fp16_gemm_error_bound_and_exactness():
 
 @pytest.mark.parametrize("cosine", [True, False])
 def test_knn_sweep_more_shots_than_a_kernel_row(cosine):
-    """S > 4096 (an LVIS-sized shot set; the reference has no cap): the sweep ranks the HIP GEMM's similarities with a stable
-    sort instead of the 4096-wide top-k kernels; same answers as the oracle."""
+    """S > 4096 (an LVIS-sized shot set; the reference has no cap): per-block top tens (lvc_knn_topk_candidates) + one merge /
+    vote launch (lvc_knn_merge_vote) instead of the 4096-wide top-k kernels; same answers as the oracle -- and as a stable
+    descending sort of the very same similarity matrix, exactly (the reference's tie rule at every step)."""
     from lvc_amd.label_verification import knn_sweep
     from oracle import knn as oknn
 
@@ -254,6 +255,37 @@ def test_knn_sweep_more_shots_than_a_kernel_row(cosine):
     ref_keep = oknn.get_nn_class_confirmatory(ref_top, qcls, 10)
     assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 3e-3
     assert (keep.cpu() != ref_keep).float().mean() <= 3e-3
+    # the block / merge kernels against a stable sort of ONE similarity matrix, with planted exact ties across blocks
+    from lvc_amd import kernels as K
+
+    sims = torch.randn(Q, 12300, generator=g)
+    sims[:, 9000] = sims[:, 17]           # ties between blocks: the lower shot index must win
+    sims[:50, 4100:4110] = 9.0            # ten equal maxima inside one block
+    sims[50:60, ::1230] = 8.0             # ten equal values spread over the blocks
+    cls = torch.randint(0, 1230, (12300,), generator=g)
+    t2, k2 = K.knn_topk_vote_blocks(sims.to(D), 12300, cls.to(D), qcls.to(D), 10)
+    order = torch.sort(sims, dim=1, descending=True, stable=True)[1][:, :10]
+    assert torch.equal(t2.cpu(), cls[order])
+    mode = torch.mode(cls[order], dim=1)[0]
+    assert torch.equal(k2.cpu(), (mode == qcls).long())
+
+
+def test_knn_sweep_pads_descriptor_width():
+    """D % 32 != 0 (any descriptor network): zero columns are appended -- same ranking as the oracle on the unpadded rows."""
+    from lvc_amd.label_verification import knn_sweep
+    from oracle import knn as oknn
+
+    g = torch.Generator().manual_seed(11)
+    S, Dm, Q = 600, 100, 900
+    classes = torch.sort(torch.randint(0, 40, (S,), generator=g))[0]
+    centers = torch.randn(40, Dm, generator=g)
+    shots = centers[classes] + 1.5 * torch.randn(S, Dm, generator=g) + 0.3
+    qcls = torch.randint(0, 40, (Q,), generator=g)
+    q = centers[qcls] + 2.0 * torch.randn(Q, Dm, generator=g) + 0.3
+    for cosine in (True, False):
+        top, keep = knn_sweep(classes.to(D), shots.to(D), q.to(D), qcls.to(D), 10, cosine)
+        ref_top = oknn.dense(classes, shots, q, cosine)
+        assert (top.cpu() != ref_top).any(dim=1).float().mean() <= 3e-3
 
 
 @pytest.mark.parametrize("Dm", [64, 384, 1024])
