@@ -45,7 +45,6 @@ struct ConvArgsD {
   int H, W, C, K, stride, Ho, Wo, M, Kg, relu, res_mode, ldy, ldr;
   int tiles_n, nk, total_units, units_per_worker, nworkers, err_index, ngroup, y_bytes;
   unsigned long long* dbg;   // LVC_PW_TIMELINE=1 (scripts/probe_pw_timeline.py): s_memtime stamps of every 64th workgroup, else null
-  int ablate;   // experiments (LVC_PW_ABLATE): 1 = no operand DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no stores, 8 = no drain before the stores
   long long w_plane_elems;
 };
 
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
   auto issue_chunk = [&]() {
     if (l_done) return;
     unsigned char* st = smem + (issued % D_NS) * STAGE;
-    const bool dma = !(p.ablate & 1) || issued < D_NS - 1;
+    const bool dma = true;
     if (l_phase == 0) {
       if (dma) {
 #pragma unroll
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
       const unsigned char* st = smem + (consumed % D_NS) * STAGE;
       const unsigned char* sa = st + (wave * WR + fi) * 128;
       const unsigned char* sb = st + D_A_BYTES + fi * 64;
-      if (!(p.ablate & 2)) {
+      {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int G0 = s * 4 + fh * 2;
@@ -392,7 +391,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
     // (128-byte segments).  The chunks prefetched so far are drained FIRST and remembered as landed: the counted waits of the
     // next chunks would otherwise also wait for these 16 NI stores (one vmcnt queue).
     STAMP(7);
-    if (!(p.ablate & 8)) {
+    {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       landed = issued;
     }
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
           float v = acc[mi][ni][e];
           // relu == 2: torch.nn.GELU() (exact erf form), the same expression as lvc_gelu (vit.hip) -> the same bits
           v = p.relu == 2 ? v * 0.5f * (1.f + erff(v * 0.70710678118654752440f)) : fmaxf(v, lo);
-          if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
         }
       }
     }
@@ -487,8 +486,6 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  static const int ablate = [] { const char* e = getenv("LVC_PW_ABLATE"); return e ? atoi(e) : 0; }();
-  a.ablate = ablate;
   // timeline stamps (experiments): the upper half of the partial-tile area is never used by <= 256 workers
   static const int timeline = [] { const char* e = getenv("LVC_PW_TIMELINE"); return e ? atoi(e) : 0; }();
   a.dbg = timeline ? (unsigned long long*)((char*)workspace + (size_t)512 * 256 * 128 * 4) : nullptr;

@@ -32,7 +32,6 @@ struct GemmHArgs {
   float* y;
   int M, N, C, ldb, ldy, nk, tiles_m, tiles_n, nworkers, ngroup;
   unsigned y_bytes;
-  int ablate;   // experiments (LVC_GH_ABLATE): 1 = no operand DMA after the prologue, 2 = no fragment reads / MFMAs, 4 = no stores
 };
 
 typedef __attribute__((address_space(3))) void* gh_lds_ptr_t;
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   auto issue_chunk = [&]() {
     if (l_done) return;
     unsigned char* st = smem + (issued % GH_NS) * GH_STAGE;
-    if (!(p.ablate & 1) || issued < GH_NS) {
+    {
 #pragma unroll
       for (int j = 0; j < 2; ++j) gh_glds16(asrc[j] + l_kc * 32, st + (wave * 32 + j * 16) * 64);
 #pragma unroll
@@ -122,9 +121,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   // data would alternate "all waves on the LDS port" with "all waves on the matrix pipe"; one step ahead, the reads of the next
   // step travel under the eight MFMAs of this one.  Written as asm so that the scheduler cannot move the reads; a wait carries
   // the fragments (and the accumulator the preceding MFMAs end on) as operands, which pins the MFMAs on either side of it.
-  // (Measured on the 120k x 2400 x 1024 sweep: the same 0.85 ms as the compiler-scheduled read-then-multiply loop; with DMA
-  // and stores ablated the loop runs at 1.06 PFLOP/s either way -- what the matrix pipe delivers at the ~1.5 GHz it is
-  // power-capped to; operand DMA and the output stores then add 0.13 ms each: LVC_GH_ABLATE, profiles/README.md round 2.)
+  // (Measured on the 120k x 2400 x 1024 sweep, round 2: the same 0.85 ms as the compiler-scheduled read-then-multiply loop; with
+  // DMA and stores ablated the loop ran at 1.06 PFLOP/s, operand DMA and the output stores add 0.13 ms each.  Round 3 reading:
+  // the kernel is bound by operand ingest -- 1 MB per 256 x 256 x 1024 tile at the ~20 - 25 GB/s a CU takes in -- not by the
+  // matrix pipe, which sustains 1.54 PFLOP/s at this fragment-read ratio: profiles/r03_mfma_ceiling.txt)
   struct Half { f16x8 a[2]; f16x8 b[4]; };
   const unsigned a_off = (unsigned)((wm * 64 + fi) * 64), b_off = (unsigned)(GH_A_BYTES + (wn * 128 + fi) * 64);
   const unsigned bo0 = (unsigned)((fh ^ fx3) * 16), bo1 = (unsigned)(((2 + fh) ^ fx3) * 16);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const float v = acc[mi][ni][e];   // a scalar copy: __builtin_bit_cast on the vector element itself reads element 0
-          if (!(p.ablate & 4)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, cbase + (unsigned)((e & 3) + 8 * (e >> 2)) * ldy4, 0, 0);
         }
       }
     }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   };
   wait_landed(0);
   __builtin_amdgcn_s_barrier();
-  if (!(p.ablate & 2)) read_half(H0, 0, bo0);
+  read_half(H0, 0, bo0);
   // step g: H0 holds (or is about to receive) the first k16 step of chunk g.  Before the barrier every wave has finished its
   // LDS reads of chunk g - 1 (so that slot can take chunk g - 1 + GH_NS) and its own DMA pieces of chunk g + 1 have landed.
 #pragma unroll 1
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
     if (more) wait_landed(g + 1);
     __builtin_amdgcn_s_barrier();
     if (g > 0) issue_chunk();
-    if (!(p.ablate & 2)) {
+    {
       wait_half(H0, acc[1][3]);
       read_half(H1, g, bo1);
       mfmas(H0);
@@ -235,8 +235,6 @@ static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int
   LVC_CHECK_ARG(yb < (1ll << 31), "output must be smaller than 2 GiB");
   g.y_bytes = (unsigned)yb;
   g.nk = C / 32;
-  static const int ablate = [] { const char* e = getenv("LVC_GH_ABLATE"); return e ? atoi(e) : 0; }();
-  g.ablate = ablate;
   g.tiles_m = lvc_cdiv(M, 256);
   g.tiles_n = lvc_cdiv(N, 256);
   static const int ngroup_env = [] { const char* e = getenv("LVC_GH_NGROUP"); return e ? atoi(e) : 0; }();

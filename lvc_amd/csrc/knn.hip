@@ -337,8 +337,7 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
                                           const float* __restrict__ q, const int ldq, const float* __restrict__ mu,
                                           const float* __restrict__ den, const float* __restrict__ sn, const int D, const float margin,
                                           const long long* __restrict__ shot_classes, const long long* __restrict__ det_classes,
-                                          const int kvote, long long* __restrict__ top_classes, long long* __restrict__ keep,
-                                          const int stop_after) {
+                                          const int kvote, long long* __restrict__ top_classes, long long* __restrict__ keep) {
   // exact similarities of the n shots listed through pos_of(k) -> position in (L.idx, L.val), four shot rows in flight.  Lane l
   // owns elements sl*256 + l*4 .. +3 of every 256-element slice sl (where below D); the query slice is fetched and normalised
   // per slice (an L1 hit after the first group) instead of being held in registers: the rare exact path must not set the
@@ -428,9 +427,7 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
       nflag += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (stop_after == 5) { if (nflag == 12345) top_classes[row] = 1; return; }
     if (nflag) exact_dots(nflag, [&](int k) { return (int)L.alist[k]; });
-    if (stop_after == 6) { if (L.val[0] == 99.f) top_classes[row] = 1; return; }
     nbest = keep_best(ncand);
   } else {
     // every shot exactly, in blocks of KV_MAX_CAND - KTOP next to the running best
@@ -477,8 +474,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
                                                                    int D, float margin_all, const float* __restrict__ margins,
                                                                    const long long* __restrict__ shot_classes,
                                                                    const long long* __restrict__ det_classes, int kvote,
-                                                                   long long* __restrict__ top_classes, long long* __restrict__ keep,
-                                                                   int stop_after) {
+                                                                   long long* __restrict__ top_classes, long long* __restrict__ keep) {
   __shared__ float s_lmax[4][64];
   __shared__ KvLds<KTOP> s_L[4];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -496,8 +492,6 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     if (v[j] != v[j]) v[j] = INFINITY;
     lmax = fmaxf(lmax, v[j]);
   }
-  // (stop_after: timing experiments, LVC_KV_STOP; results are then meaningless)
-  if (stop_after == 1) { if (lmax == 123.f) top_classes[row] = 1; return; }
   // ---- A10: exact 10th largest approximate value.  First a lower bound T (the lane maximum of rank KTOP-1), then the rank of
   // every value >= T among those values
   s_lmax[w][lane] = lmax;
@@ -523,7 +517,6 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  if (stop_after == 2) { if (total == 12345) top_classes[row] = 1; return; }
   float A10 = T;      // more than KV_MAX_CAND values >= T (near-constant row): T itself is a valid lower bound of A10
   if (total <= KV_MAX_CAND) {
     for (int c0 = 0; c0 < total; c0 += 64) {
@@ -540,7 +533,6 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     A10 = L.T;
   }
   const float Tv = A10 - margin;
-  if (stop_after == 3) { if (Tv == 123.f) top_classes[row] = 1; return; }
   // ---- candidates: approx >= A10 - margin
   int ncand = 0;
 #pragma unroll
@@ -554,8 +546,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  if (stop_after == 4) { if (ncand == 12345) top_classes[row] = 1; return; }
-  kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep, stop_after);
+  kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep);
 }
 
 #define KV_CHECKS()                                                                                                              \
@@ -583,9 +574,8 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
-  static const int stop_after = [] { const char* e = getenv("LVC_KV_STOP"); return e ? atoi(e) : 0; }();
 #define KV_LAUNCH(P) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, sn, D, \
-                                        margin, margins, shot_classes, det_classes, kvote, top_classes, keep, stop_after)
+                                        margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
   if (per <= 8) KV_LAUNCH(8);
   else if (per <= 16) KV_LAUNCH(16);
   else if (per <= 24) KV_LAUNCH(24);
