@@ -13,30 +13,39 @@
 #include <stdlib.h>
 
 // mu[d] = mean over rows, DETERMINISTIC (the reference's shots.mean(0) is; an atomic combine made mu -- and with it near-tied
-// ranks -- vary in the last bits from run to run).  A workgroup owns 32 columns: thread (g, c) adds rows g, g + 8, g + 16, ...
-// of column c in that order (128-byte row segments per 32 lanes), the eight partial sums of a column are then added in the
-// fixed order g = 0..7 by one thread.  2400 x 1024: 32 workgroups, ~15 us (the sweep calls it once).
-__global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, float* __restrict__ mu, int M, int D,
-                                                      int ld, float inv_m) {
-  __shared__ float part[8][32];
+// ranks -- vary in the last bits from run to run).  A workgroup of 1024 threads owns 32 columns: thread (g, c) adds rows g, g + 32,
+// g + 64, ... of column c in that order (128-byte row segments per 32 lanes; five loads in flight per thread), the 32 partial sums
+// of a column are then added in the fixed order g = 0..31 by one thread.  2400 x 1024: 32 workgroups, ~10 us.
+__global__ __launch_bounds__(1024) void colmean_kernel(const float* __restrict__ x, float* __restrict__ mu, int M, int D,
+                                                       int ld, float inv_m) {
+  __shared__ float part[32][33];
   const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int d = blockIdx.x * 32 + c;
   float s = 0.f;
-  if (d < D)
-    for (int m = g; m < M; m += 8) s += x[(size_t)m * ld + d];
+  if (d < D) {
+    int m = g;
+    for (; m + 128 < M; m += 160) {
+      float t[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) t[i] = x[(size_t)(m + 32 * i) * ld + d];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) s += t[i];
+    }
+    for (; m < M; m += 32) s += x[(size_t)m * ld + d];
+  }
   part[g][c] = s;
   __syncthreads();
   if (g == 0 && d < D) {
     float t = part[0][c];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) t += part[i][c];
+    for (int i = 1; i < 32; ++i) t += part[i][c];
     mu[d] = t * inv_m;
   }
 }
 
 extern "C" int lvc_colmean(const float* x, float* mu, int M, int D, int ld, void* stream) {
   LVC_CHECK_ARG(x && mu && M > 0 && D > 0, "bad arguments");
-  hipLaunchKernelGGL(colmean_kernel, dim3(lvc_cdiv(D, 32)), dim3(256), 0, (hipStream_t)stream, x, mu, M, D, ld > 0 ? ld : D,
+  hipLaunchKernelGGL(colmean_kernel, dim3(lvc_cdiv(D, 32)), dim3(1024), 0, (hipStream_t)stream, x, mu, M, D, ld > 0 ? ld : D,
                      1.f / (float)M);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
@@ -330,58 +339,94 @@ struct KvLds {
   float T;
 };
 
+// v + (the same value NSTEP lanes round the 16-lane row): one v_add_f32 with a DPP operand
+template <int CTRL>
+__device__ __forceinline__ float kv_add_ror(float v) {
+  return v + __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float kv_min_ror(float v) {
+  return fminf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xf, 0xf, false)));
+}
+// minimum over the 64 lanes (every lane gets it)
+__device__ __forceinline__ float kv_wave_min(float v) {
+  v = kv_min_ror<0x128>(v); v = kv_min_ror<0x124>(v); v = kv_min_ror<0x122>(v); v = kv_min_ror<0x121>(v);
+  const float r0 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+  const float r1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+  const float r2 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+  const float r3 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
 // Steps 2 and 3 of the comment above for one row (one wave): the candidates sit in L.ap / L.idx [0, ncand) when
 // ncand <= KV_MAX_CAND; a larger ncand means "evaluate every shot".  Writes top_classes[row] and keep[row].
-template <int KTOP>
+// NSL = 256-element slices of a descriptor row (D <= 256 NSL).
+template <int KTOP, int NSL>
 __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const int row, const int ncand, const int S,
                                           const float* __restrict__ q, const int ldq, const float* __restrict__ mu,
                                           const float* __restrict__ den, const float* __restrict__ sn, const int D, const float margin,
                                           const long long* __restrict__ shot_classes, const long long* __restrict__ det_classes,
                                           const int kvote, long long* __restrict__ top_classes, long long* __restrict__ keep) {
-  // exact similarities of the n shots listed through pos_of(k) -> position in (L.idx, L.val), four shot rows in flight.  Lane l
-  // owns elements sl*256 + l*4 .. +3 of every 256-element slice sl (where below D); the query slice is fetched and normalised
-  // per slice (an L1 hit after the first group) instead of being held in registers: the rare exact path must not set the
-  // register count -- and with it the occupancy -- of the scan that every row runs
-  const float* qr = q + (size_t)row * ldq;
-  const float dn = den ? den[row] : 1.f;
+  // Exact similarities of the n shots listed through pos_of(k) -> position in (L.idx, L.val), FOUR shot rows per round with all
+  // their loads in flight at once (one memory round trip per four shots).  Lane l owns elements sl*256 + l*4 .. +3 of every
+  // 256-element slice sl (where below D) and sums them in that order with fmas; the 64 partial sums of the four shots are added in
+  // a fixed tree: lanes l and l + 32 (v_permlane32_swap hands each half-wave two of the four shots), then the 16-lane rows two
+  // by two (v_permlane16_swap: row t now holds shot t), then inside the row.  The query row is normalised ((q - mu) / den, as
+  // lvc_rownorm does it) once per row, and only for rows that have a flagged candidate.
+  constexpr int CH = NSL < 4 ? NSL : 4;
+  float4 xq[NSL];
+  bool have_q = false;
+  auto load_q = [&]() {
+    const float* qr = q + (size_t)row * ldq;
+    const float dn = den ? den[row] : 1.f;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      const int d = sl * 256 + lane * 4;
+      float4 x = {0.f, 0.f, 0.f, 0.f};
+      if (d < D) {
+        x = *reinterpret_cast<const float4*>(qr + d);
+        if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + d); x.x -= m4.x; x.y -= m4.y; x.z -= m4.z; x.w -= m4.w; }
+        if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
+      }
+      xq[sl] = x;
+    }
+    have_q = true;
+  };
   auto exact_dots = [&](int n, auto pos_of) {
+    if (!have_q) load_q();
+    const int t_mine = lane >> 4;
     for (int k0 = 0; k0 < n; k0 += 4) {
       const float* sr[4];
-      int pos[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        pos[t] = pos_of(min(k0 + t, n - 1));
-        sr[t] = sn + (size_t)L.idx[pos[t]] * D;
-      }
+      for (int t = 0; t < 4; ++t) sr[t] = sn + (size_t)L.idx[pos_of(min(k0 + t, n - 1))] * D + lane * 4;
+      const int mypos = pos_of(min(k0 + t_mine, n - 1));
       float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-      for (int d0 = 0; d0 < D; d0 += 256) {
-        const int d = d0 + lane * 4;
-        const bool in = d < D;
-        float4 x = {0.f, 0.f, 0.f, 0.f};
-        float4 sv[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) sv[t] = in ? *reinterpret_cast<const float4*>(sr[t] + d) : float4{0.f, 0.f, 0.f, 0.f};
-        if (in) {
-          x = *reinterpret_cast<const float4*>(qr + d);
-          if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + d); x.x -= m4.x; x.y -= m4.y; x.z -= m4.z; x.w -= m4.w; }
-          if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
-        }
+      for (int c0 = 0; c0 < NSL; c0 += CH) {
+        float4 sv[4][CH];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          // explicit fmas: every row in flight must round the same way (identical shots tie exactly)
-          acc[t] = __builtin_fmaf(x.x, sv[t].x, acc[t]); acc[t] = __builtin_fmaf(x.y, sv[t].y, acc[t]);
-          acc[t] = __builtin_fmaf(x.z, sv[t].z, acc[t]); acc[t] = __builtin_fmaf(x.w, sv[t].w, acc[t]);
-        }
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+            sv[t][c] = (c0 + c) * 256 + lane * 4 < D ? *reinterpret_cast<const float4*>(sr[t] + (c0 + c) * 256) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            // explicit fmas: every row in flight must round the same way (identical shots tie exactly)
+            const float4 x = xq[c0 + c];
+            acc[t] = __builtin_fmaf(x.x, sv[t][c].x, acc[t]); acc[t] = __builtin_fmaf(x.y, sv[t][c].y, acc[t]);
+            acc[t] = __builtin_fmaf(x.z, sv[t][c].z, acc[t]); acc[t] = __builtin_fmaf(x.w, sv[t][c].w, acc[t]);
+          }
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] += __shfl_xor(acc[t], o);
-      if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) L.val[pos[t]] = acc[t];
-      }
+      const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[2]), false, false);
+      const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[1]), __float_as_uint(acc[3]), false, false);
+      const float s02 = __uint_as_float(p02[0]) + __uint_as_float(p02[1]);     // lanes 0..31: shot 0, lanes 32..63: shot 2
+      const float s13 = __uint_as_float(p13[0]) + __uint_as_float(p13[1]);     //              shot 1,               shot 3
+      const auto pr = __builtin_amdgcn_permlane16_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+      float u = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);               // 16-lane row t: shot t
+      u = kv_add_ror<0x128>(u); u = kv_add_ror<0x124>(u); u = kv_add_ror<0x122>(u); u = kv_add_ror<0x121>(u);
+      if ((lane & 15) == 0) L.val[mypos] = u;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   };
@@ -466,8 +511,13 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
   }
 }
 
-// Form A: the pre-filter similarities as a dense [Q, ld] matrix (lvc_gemm_f16).
-template <int KTOP, int PER>
+// Form A: the pre-filter similarities as a dense [Q, ld] matrix (lvc_gemm_f16).  One wave per row, the row's S values in PER
+// registers per lane:
+//   1. T = the KTOP-th largest of the 64 lane maxima (every lane counts the maxima above its own through 64 lane broadcasts; the
+//      smallest maximum with fewer than KTOP above it is T): a lower bound of A10, the row's KTOP-th largest value;
+//   2. ONE pass over the registers compacts the values >= T - margin into LDS (a superset of the candidates);
+//   3. A10 = the KTOP-th largest of those (every value >= T is among them); the entries below A10 - margin are dropped.
+template <int KTOP, int PER, int NSL>
 __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
                                                                    const float* __restrict__ q, int ldq, const float* __restrict__ mu,
                                                                    const float* __restrict__ den, const float* __restrict__ sn,
@@ -475,7 +525,6 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
                                                                    const long long* __restrict__ shot_classes,
                                                                    const long long* __restrict__ det_classes, int kvote,
                                                                    long long* __restrict__ top_classes, long long* __restrict__ keep) {
-  __shared__ float s_lmax[4][64];
   __shared__ KvLds<KTOP> s_L[4];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + w;
@@ -492,61 +541,51 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     if (v[j] != v[j]) v[j] = INFINITY;
     lmax = fmaxf(lmax, v[j]);
   }
-  // ---- A10: exact 10th largest approximate value.  First a lower bound T (the lane maximum of rank KTOP-1), then the rank of
-  // every value >= T among those values
-  s_lmax[w][lane] = lmax;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  int rank = 0;
-#pragma unroll 8
-  for (int l = 0; l < 64; ++l) {
-    const float o = s_lmax[w][l];
-    rank += (o > lmax || (o == lmax && l < lane)) ? 1 : 0;
-  }
-  if (rank == KTOP - 1) L.T = lmax;
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  const float T = L.T;
+  // ---- T: the lanes with fewer than KTOP lane maxima strictly above their own hold values >= the KTOP-th largest maximum
+  // (counted with multiplicity), which is itself one of them: T is their minimum
+  int above = 0;
+#pragma unroll
+  for (int l = 0; l < 64; ++l) above += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(lmax), l)) > lmax ? 1 : 0;
+  const float T = kv_wave_min(above < KTOP ? lmax : INFINITY);
+  const float Tv0 = T - margin;
   int total = 0;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const bool is_c = v[j] >= T;
+    const bool is_c = v[j] >= Tv0 && v[j] > -INFINITY;
     const unsigned long long m = __ballot(is_c);
     if (m) {
       const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-      if (is_c && pos < KV_MAX_CAND) L.val[pos] = v[j];
+      if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = j * 64 + lane; L.ap[pos] = v[j]; }
       total += __popcll(m);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  float A10 = T;      // more than KV_MAX_CAND values >= T (near-constant row): T itself is a valid lower bound of A10
+  int ncand = total;       // more than KV_MAX_CAND values >= T - margin (a near-constant row): every shot is evaluated exactly
   if (total <= KV_MAX_CAND) {
+    // A10 among the listed values, then only the entries >= A10 - margin stay (in order)
+    float a10 = INFINITY;
     for (int c0 = 0; c0 < total; c0 += 64) {
       const int c = c0 + lane;
-      const float mv = c < total ? L.val[c] : -INFINITY;
+      const float mv = c < total ? L.ap[c] : -INFINITY;
       int r = 0;
-      for (int l = 0; l < total; ++l) {
-        const float o = L.val[l];
-        r += (o > mv || (o == mv && l < c)) ? 1 : 0;
-      }
-      if (c < total && r == KTOP - 1) L.T = mv;
+      for (int l = 0; l < total; ++l) r += L.ap[l] > mv ? 1 : 0;
+      a10 = fminf(a10, r < KTOP && c < total ? mv : INFINITY);
     }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    A10 = L.T;
-  }
-  const float Tv = A10 - margin;
-  // ---- candidates: approx >= A10 - margin
-  int ncand = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const bool is_c = v[j] >= Tv && v[j] > -INFINITY;
-    const unsigned long long m = __ballot(is_c);
-    if (m) {
-      const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull));
-      if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = j * 64 + lane; L.ap[pos] = v[j]; }
+    const float Tv = kv_wave_min(a10) - margin;
+    ncand = 0;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int c = c0 + lane;
+      const float mv = c < total ? L.ap[c] : -INFINITY;
+      const int mi = c < total ? L.idx[c] : 0;
+      const bool live = mv >= Tv;
+      const unsigned long long m = __ballot(live);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      if (live) { const int pos = ncand + __popcll(m & ((1ull << lane) - 1ull)); L.ap[pos] = mv; L.idx[pos] = mi; }
       ncand += __popcll(m);
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  kv_finish<KTOP>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep);
+  kv_finish<KTOP, NSL>(L, lane, row, ncand, S, q, ldq, mu, den, sn, D, margin, shot_classes, det_classes, kvote, top_classes, keep);
 }
 
 #define KV_CHECKS()                                                                                                              \
@@ -574,8 +613,9 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
-#define KV_LAUNCH(P) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, sn, D, \
-                                        margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
+#define KV_LAUNCH_N(P, N) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, \
+                                             sn, D, margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
+#define KV_LAUNCH(P) do { if (D <= 512) KV_LAUNCH_N(P, 2); else if (D <= 1024) KV_LAUNCH_N(P, 4); else KV_LAUNCH_N(P, 8); } while (0)
   if (per <= 8) KV_LAUNCH(8);
   else if (per <= 16) KV_LAUNCH(16);
   else if (per <= 24) KV_LAUNCH(24);
@@ -583,6 +623,7 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   else if (per <= 40) KV_LAUNCH(40);
   else if (per <= 48) KV_LAUNCH(48);
   else KV_LAUNCH(64);
+#undef KV_LAUNCH_N
 #undef KV_LAUNCH
   LVC_CHECK_LAUNCH();
   return LVC_OK;
