@@ -135,46 +135,18 @@ extern "C" int lvc_maxpool2d_nhwc(const float* x, float* y, int N, int H, int W,
 // Row-wise L2 normalisation: y[m,:] = (x[m,:] - mu) / den,  den = |x-mu| + eps (mode 0, the form of
 // CosineSimOutputLayers, lvc/modeling/roi_heads/fast_rcnn.py:822-833) or max(|x-mu|, eps) (mode 1, the
 // form inside F.cosine_similarity used by tools/run_nearest_neighbours.py:150-153).  One wave per row.
-__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, const float* __restrict__ mu,
-                                                      float* __restrict__ y, int M, int D, int ldx, int ldy,
-                                                      float eps, int mode) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float* xr = x + (size_t)row * ldx;
+// VEC (D % 4 == 0 and 16-byte aligned rows): lane l owns elements 256 i + 4 l .. + 3 (one dwordx4 per 256-element slice) and adds
+// their squares in that order; otherwise lane l owns elements l, l + 64, ...  The 64 partial sums meet in a butterfly.
+// rownorm_h_kernel below sums in exactly the same orders.
+template <bool VEC>
+__device__ __forceinline__ float rownorm_sumsq(const float* __restrict__ xr, const float* __restrict__ mu, int D, int lane) {
   float ss = 0.f;
-  for (int d = lane; d < D; d += 64) {
-    float v = xr[d] - (mu ? mu[d] : 0.f);
-    ss += v * v;
-  }
-  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-  const float nrm = sqrtf(ss);
-  const float den = mode == 0 ? nrm + eps : (nrm > eps ? nrm : eps);
-  float* yr = y + (size_t)row * ldy;
-  for (int d = lane; d < D; d += 64) yr[d] = (xr[d] - (mu ? mu[d] : 0.f)) / den;
-}
-
-// lvc_rownorm for the two-stage kNN sweep: the normalised rows rounded to fp16 (round to nearest even; the operand of the
-// pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), the
-// 2-norm of each row's fp16 rounding residual resid [M] (what bounds the pre-filter's error for that row) and -- optionally --
-// the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
-template <int NPER>   // NPER * 64 >= D: the centred row stays in registers between the two passes (NPER = 0: it is read twice)
-__global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict__ x, const float* __restrict__ mu,
-                                                        float* __restrict__ y, _Float16* __restrict__ yh, float* __restrict__ dens,
-                                                        float* __restrict__ resid, int M, int D, int ldx, float eps, int mode) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float* xr = x + (size_t)row * ldx;
-  float ss = 0.f;
-  float c[NPER > 0 ? NPER : 1];
-  if constexpr (NPER > 0) {
-#pragma unroll
-    for (int i = 0; i < NPER; ++i) {
-      const int d = lane + 64 * i;
-      c[i] = d < D ? xr[d] - (mu ? mu[d] : 0.f) : 0.f;
+  if constexpr (VEC) {
+    for (int d = lane * 4; d < D; d += 256) {
+      float4 v = *reinterpret_cast<const float4*>(xr + d);
+      if (mu) { const float4 m = *reinterpret_cast<const float4*>(mu + d); v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
+      ss += v.x * v.x; ss += v.y * v.y; ss += v.z * v.z; ss += v.w * v.w;
     }
-#pragma unroll
-    for (int i = 0; i < NPER; ++i)
-      if (lane + 64 * i < D) ss += c[i] * c[i];     // the same order as the strided loop below
   } else {
     for (int d = lane; d < D; d += 64) {
       float v = xr[d] - (mu ? mu[d] : 0.f);
@@ -182,23 +154,83 @@ __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict_
     }
   }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  return ss;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                      float* __restrict__ y, int M, int D, int ldx, int ldy,
+                                                      float eps, int mode) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  const float nrm = sqrtf(rownorm_sumsq<VEC>(xr, mu, D, lane));
+  const float den = mode == 0 ? nrm + eps : (nrm > eps ? nrm : eps);
+  float* yr = y + (size_t)row * ldy;
+  if constexpr (VEC) {
+    for (int d = lane * 4; d < D; d += 256) {
+      float4 v = *reinterpret_cast<const float4*>(xr + d);
+      if (mu) { const float4 m = *reinterpret_cast<const float4*>(mu + d); v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
+      v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+      *reinterpret_cast<float4*>(yr + d) = v;
+    }
+  } else {
+    for (int d = lane; d < D; d += 64) yr[d] = (xr[d] - (mu ? mu[d] : 0.f)) / den;
+  }
+}
+
+// lvc_rownorm for the two-stage kNN sweep: the normalised rows rounded to fp16 (round to nearest even; the operand of the
+// pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), the
+// 2-norm of each row's fp16 rounding residual resid [M] (what bounds the pre-filter's error for that row) and -- optionally --
+// the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
+template <int NV, bool VEC>   // VEC: NV * 256 >= D, the centred row stays in registers between the two passes; else it is read twice
+__global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict__ x, const float* __restrict__ mu,
+                                                        float* __restrict__ y, _Float16* __restrict__ yh, float* __restrict__ dens,
+                                                        float* __restrict__ resid, int M, int D, int ldx, float eps, int mode) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float ss = 0.f;
+  float4 c[NV > 0 ? NV : 1];
+  if constexpr (VEC) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int d = i * 256 + lane * 4;
+      float4 v = {0.f, 0.f, 0.f, 0.f};
+      if (d < D) {
+        v = *reinterpret_cast<const float4*>(xr + d);
+        if (mu) { const float4 m = *reinterpret_cast<const float4*>(mu + d); v.x -= m.x; v.y -= m.y; v.z -= m.z; v.w -= m.w; }
+      }
+      c[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (i * 256 + lane * 4 < D) {     // the same order as rownorm_sumsq<true>
+        ss += c[i].x * c[i].x; ss += c[i].y * c[i].y; ss += c[i].z * c[i].z; ss += c[i].w * c[i].w;
+      }
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+  } else {
+    ss = rownorm_sumsq<false>(xr, mu, D, lane);
+  }
   const float nrm = sqrtf(ss);
   const float den = mode == 0 ? nrm + eps : (nrm > eps ? nrm : eps);
   if (dens && lane == 0) dens[row] = den;
   float* yr = y ? y + (size_t)row * D : nullptr;
   _Float16* hr = yh + (size_t)row * D;
   float rs = 0.f;     // sum of squares of the fp16 rounding residuals v - fp16(v) (each residual is exact in fp32)
-  if constexpr (NPER > 0) {
+  if constexpr (VEC) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < NPER; ++i) {
-      const int d = lane + 64 * i;
+    for (int i = 0; i < NV; ++i) {
+      const int d = i * 256 + lane * 4;
       if (d < D) {
-        const float v = c[i] / den;
-        const _Float16 h = (_Float16)v;
-        if (yr) yr[d] = v;
-        hr[d] = h;
-        const float r = v - (float)h;
-        rs += r * r;
+        float4 v = c[i];
+        v.x /= den; v.y /= den; v.z /= den; v.w /= den;
+        const h4_t h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        if (yr) *reinterpret_cast<float4*>(yr + d) = v;
+        *reinterpret_cast<h4_t*>(hr + d) = h;
+        const float r0 = v.x - (float)h[0], r1 = v.y - (float)h[1], r2 = v.z - (float)h[2], r3 = v.w - (float)h[3];
+        rs += r0 * r0; rs += r1 * r1; rs += r2 * r2; rs += r3 * r3;
       }
     }
   } else {
@@ -217,6 +249,11 @@ __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict_
   }
 }
 
+// rows that one dwordx4 per lane can walk: D a multiple of 4 and every pointer / row pitch 16-byte aligned
+static bool rownorm_vec_ok(const void* x, const void* mu, const void* y, int D, int ldx, int ldy) {
+  return D % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)mu) | ((uintptr_t)y)) & 15) == 0;
+}
+
 extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned short* yh, float* den, float* resid, int M, int D,
                              int ldx, float eps, int mode, void* stream) {
   LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
@@ -224,11 +261,13 @@ extern "C" int lvc_rownorm_h(const float* x, const float* mu, float* y, unsigned
   LVC_CHECK_ARG(x && yh, "null pointer");
   const dim3 grid(lvc_cdiv(M, 4)), block(256);
   const int ldxx = ldx > 0 ? ldx : D;
-#define RH_LAUNCH(N) hipLaunchKernelGGL(rownorm_h_kernel<N>, grid, block, 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, resid, M, D, ldxx, eps, mode)
-  if (D <= 512) RH_LAUNCH(8);
-  else if (D <= 1024) RH_LAUNCH(16);
-  else if (D <= 2048) RH_LAUNCH(32);
-  else RH_LAUNCH(0);
+#define RH_LAUNCH(N, V) hipLaunchKernelGGL((rownorm_h_kernel<N, V>), grid, block, 0, (hipStream_t)stream, x, mu, y, (_Float16*)yh, den, resid, M, D, ldxx, eps, mode)
+  // the fp16 rows are written 8 bytes per lane: D % 4 == 0 keeps every row of yh 8-byte aligned
+  const bool vec = rownorm_vec_ok(x, mu, y, D, ldxx, D) && (((uintptr_t)yh) & 7) == 0 && D <= 2048;
+  if (!vec) RH_LAUNCH(0, false);
+  else if (D <= 512) RH_LAUNCH(2, true);
+  else if (D <= 1024) RH_LAUNCH(4, true);
+  else RH_LAUNCH(8, true);
 #undef RH_LAUNCH
   LVC_CHECK_LAUNCH();
   return LVC_OK;
@@ -239,8 +278,11 @@ extern "C" int lvc_rownorm(const float* x, const float* mu, float* y, int M, int
   LVC_CHECK_ARG(M >= 0 && D > 0, "bad shape");
   if (M == 0) return LVC_OK;
   LVC_CHECK_ARG(x && y, "null pointer");
-  hipLaunchKernelGGL(rownorm_kernel, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, M, D,
-                     ldx > 0 ? ldx : D, ldy > 0 ? ldy : D, eps, mode);
+  const int ldxx = ldx > 0 ? ldx : D, ldyy = ldy > 0 ? ldy : D;
+  if (rownorm_vec_ok(x, mu, y, D, ldxx, ldyy))
+    hipLaunchKernelGGL(rownorm_kernel<true>, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, M, D, ldxx, ldyy, eps, mode);
+  else
+    hipLaunchKernelGGL(rownorm_kernel<false>, dim3(lvc_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, mu, y, M, D, ldxx, ldyy, eps, mode);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
