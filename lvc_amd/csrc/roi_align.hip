@@ -194,9 +194,16 @@ __global__ __launch_bounds__(64) void roi_align_fwd_nhwc4_kernel(RoiAlignArgs p)
 // feature pixel ~10 times (49 bins x g^2 samples x 4 taps over <= 9x9 pixels); after staging it is fetched from
 // L2/HBM once per output row (~3 rows each), which cuts the L2 read volume by ~3x.  Windows larger than
 // ROI_LDS_MAX_PIX pixels (very elongated boxes) take the direct-from-L2 loop: same arithmetic, same order.
-#define ROI_LDS_MAX_PIX 40
+#ifndef ROI_LDS_MAX_PIX
+#define ROI_LDS_MAX_PIX 24
+#endif
+#ifndef ROI_TAB
+#define ROI_TAB 32      // samples per pass of a wave's weight / offset table
+#endif
 __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArgs p) {
   __shared__ __attribute__((aligned(16))) float win[ROI_LDS_MAX_PIX * 256];
+  __shared__ float4 tab_w[8][ROI_TAB];     // per wave (bin): the four bilinear weights of up to 64 in-range samples ...
+  __shared__ int4 tab_o[8][ROI_TAB];       // ... and the element offsets of their four taps (into win when staged, else into the level's image)
   const int tid = threadIdx.x;
   // workgroup -> (RoI, output row).  The hardware deals consecutive workgroups to the 8 XCDs in turn; the rows of one RoI read
   // overlapping feature rows and the same columns, so they are kept on ONE XCD (one fetch of the window into that L2 instead of
@@ -259,49 +266,84 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArg
     }
     __syncthreads();
   }
-  if (bin >= p.pw || cbase + cq * 4 >= p.C) return;
+  if (bin >= p.pw) return;        // nothing below synchronises across waves
   const int pw = bin;
   float4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int iy = 0; iy < gh; ++iy) {
-    const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
-    for (int ix = 0; ix < gw; ++ix) {
+  // The sample positions, clamps and bilinear weights depend on (RoI, ph, pw, iy, ix) only -- the same for the 64 lanes of this
+  // wave.  64 samples at a time, lane = SAMPLE computes its four weights and tap offsets once (the reference's arithmetic), the
+  // in-range samples are compacted in order (iy outer, ix inner) into this wave's LDS table, and the channel loop below reads a
+  // sample as two broadcast ds_read_b128: ~25 instead of ~60 vector instructions per sample and wave, the sums term by term as
+  // the reference forms them.
+  const int nsamp = gh * gw;
+  float4* tw = tab_w[bin];
+  int4* to = tab_o[bin];
+  const bool c_ok = cbase + cq * 4 < p.C;
+  for (int s0 = 0; s0 < nsamp; s0 += ROI_TAB) {
+    const int smp = s0 + cq;
+    bool valid = smp < nsamp && cq < ROI_TAB;
+    float4 wv = {0.f, 0.f, 0.f, 0.f};
+    int4 ov = {0, 0, 0, 0};
+    if (valid) {
+      const int iy = smp / gw, ix = smp - iy * gw;
+      const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
       const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
       float x = xx, y = yy;
-      if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
-      if (y <= 0) y = 0;
-      if (x <= 0) x = 0;
-      int y_low = (int)y, x_low = (int)x, y_high, x_high;
-      if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
-      if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
-      const float ly = y - y_low, lx = x - x_low;
-      const float hy = 1.f - ly, hx = 1.f - lx;
-      const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-      float4 v1, v2, v3, v4;
-      if (staged) {
-        const float* wb = win + cq * 4;
-        v1 = *reinterpret_cast<const float4*>(wb + ((y_low - y0) * ncols + (x_low - x0)) * 256);
-        v2 = *reinterpret_cast<const float4*>(wb + ((y_low - y0) * ncols + (x_high - x0)) * 256);
-        v3 = *reinterpret_cast<const float4*>(wb + ((y_high - y0) * ncols + (x_low - x0)) * 256);
-        v4 = *reinterpret_cast<const float4*>(wb + ((y_high - y0) * ncols + (x_high - x0)) * 256);
-      } else {
-        v1 = *reinterpret_cast<const float4*>(in + (long long)(y_low * W + x_low) * C);
-        v2 = *reinterpret_cast<const float4*>(in + (long long)(y_low * W + x_high) * C);
-        v3 = *reinterpret_cast<const float4*>(in + (long long)(y_high * W + x_low) * C);
-        v4 = *reinterpret_cast<const float4*>(in + (long long)(y_high * W + x_high) * C);
+      if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) valid = false;
+      else {
+        if (y <= 0) y = 0;
+        if (x <= 0) x = 0;
+        int y_low = (int)y, x_low = (int)x, y_high, x_high;
+        if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+        const float ly = y - y_low, lx = x - x_low;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        wv = float4{hy * hx, hy * lx, ly * hx, ly * lx};
+        if (staged)
+          ov = int4{((y_low - y0) * ncols + (x_low - x0)) * 256, ((y_low - y0) * ncols + (x_high - x0)) * 256,
+                    ((y_high - y0) * ncols + (x_low - x0)) * 256, ((y_high - y0) * ncols + (x_high - x0)) * 256};
+        else
+          ov = int4{(y_low * W + x_low) * (int)C, (y_low * W + x_high) * (int)C, (y_high * W + x_low) * (int)C, (y_high * W + x_high) * (int)C};
       }
-      acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
-      acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
-      acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
-      acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
     }
+    const unsigned long long m = __ballot(valid);
+    const int n = __popcll(m);
+    if (valid) {
+      const int pos = __popcll(m & ((1ull << cq) - 1ull));
+      tw[pos] = wv;
+      to[pos] = ov;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (c_ok) {
+      // one sample per iteration: rounds of four samples with their sixteen taps in flight together measured slower (0.70 vs 0.66 ms on
+      // the bench batch's proposals): the kernel is bound by the taps' LDS / L1 throughput, not by their latency
+      auto run = [&](const float* base) {
+        for (int e = 0; e < n; ++e) {
+          const float4 w = tw[e];
+          const int4 o = to[e];
+          const float4 v1 = *reinterpret_cast<const float4*>(base + o.x), v2 = *reinterpret_cast<const float4*>(base + o.y);
+          const float4 v3 = *reinterpret_cast<const float4*>(base + o.z), v4 = *reinterpret_cast<const float4*>(base + o.w);
+          acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
+          acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
+          acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
+          acc.w += w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
+        }
+      };
+      if (staged) run(win + cq * 4);
+      else run(in);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
+  if (!c_ok) return;
   float4 o = {acc.x / count, acc.y / count, acc.z / count, acc.w / count};
   *reinterpret_cast<float4*>(p.out + (long long)k * p.so_k + ph * p.so_h + pw * p.so_w + cbase + cq * 4) = o;
 }
 
 static int launch(RoiAlignArgs& a, void* stream) {
   if (a.K == 0) return LVC_OK;
-  if (a.nhwc && (a.C & 255) == 0 && a.pw <= 8 && a.num_valid == nullptr && a.so_c == 1 && !getenv("LVC_ROI_DIRECT")) {
+  bool small = true;     // the staged kernel keeps tap offsets inside one image of a level as 32-bit element counts
+  for (int l = 0; l < LVC_MAX_LEVELS; ++l)
+    if (a.feat[l] && (long long)a.H[l] * a.W[l] * a.C >= (1ll << 31)) small = false;
+  if (a.nhwc && (a.C & 255) == 0 && a.pw <= 8 && a.num_valid == nullptr && a.so_c == 1 && small) {
     static const int xcd_rows = [] { const char* e = getenv("LVC_ROI_XCD_ROWS"); return e ? atoi(e) : 1; }();
     a.xcd_rows = xcd_rows;
     dim3 gridl(xcd_rows ? lvc_cdiv(a.K, 8) * 8 * a.ph : a.K * a.ph, a.C / 256), blockl(512);

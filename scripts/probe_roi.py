@@ -1,4 +1,4 @@
-"""ROIAlign of a real step (8 x 1000 proposals of the bench batch on p2..p5), event-timed; LVC_ROI_CS / LVC_ROI_DIRECT switch kernels."""
+"""ROIAlign of a real step (8 x 1000 proposals of the bench batch on p2..p5), event-timed."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -24,5 +24,4 @@ with torch.no_grad():
     for _ in range(20): out = pooler.pool_nhwc(flist, pboxes)
     e1.record(); torch.cuda.synchronize()
     wh = (pboxes[..., 2:] - pboxes[..., :2]).reshape(-1, 2)
-    print("CS=%s DIRECT=%s: %.4f ms  checksum %.6e   median proposal %.0f x %.0f px" % (os.environ.get("LVC_ROI_CS", "64"), os.environ.get("LVC_ROI_DIRECT", "-"),
-          e0.elapsed_time(e1) / 20, float(out.double().sum()), float(wh[:, 0].median()), float(wh[:, 1].median())))
+    print("%.4f ms  checksum %.6e   median proposal %.0f x %.0f px" % (e0.elapsed_time(e1) / 20, float(out.double().sum()), float(wh[:, 0].median()), float(wh[:, 1].median())))
