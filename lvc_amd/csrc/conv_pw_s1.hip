@@ -339,7 +339,38 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
       }
     }
 
-    // ---- epilogue through LDS: affine, residual (same shape, or the nearest-x2 upsample of the half-size map), ReLU / GELU
+    // ---- epilogue through LDS: affine, residual (same shape, or the nearest-x2 upsample of the half-size map), ReLU / GELU.
+    // The residual rows are requested one group of four output rows AHEAD (the first group before the accumulators go through
+    // LDS): not one exposed memory round trip per group.
+    constexpr int C4 = HN / 4;
+    constexpr int RPI = NT / C4;
+    constexpr int NIT = PM / RPI;
+    constexpr int NG = 4;
+    const int c4 = tid % C4, rsub = tid / C4;
+    const int col = n0 + c4 * 4;
+    const bool has_res = p.res_mode != 0 && col < p.K;
+    auto res_load = [&](int it) {
+      const int m = m0 + it * RPI + rsub;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < p.M) {
+        size_t ro = (size_t)m;
+        if (p.res_mode == 2) {
+          const int n = m / (p.Ho * p.Wo);
+          const int rem = m - n * (p.Ho * p.Wo);
+          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+        }
+        v = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+      }
+      return v;
+    };
+    f32x4 rv[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has_res) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) rv[i] = res_load(i);
+    }
     float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -348,43 +379,43 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const int col = wn * 32 * NI + ni * 32 + fi;
-          Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
+          const int colc = wn * 32 * NI + ni * 32 + fi;
+          Cs[row * CS_STRIDE + colc] = acc[mi][ni][e];
         }
     __syncthreads();
-    constexpr int C4 = HN / 4;
-    constexpr int RPI = NT / C4;
-    const int c4 = tid % C4, rsub = tid / C4;
-    const int col = n0 + c4 * 4;
     if (col < p.K) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-#pragma unroll 4
-      for (int it = 0; it < PM / RPI; ++it) {
-        const int r = it * RPI + rsub;
-        const int m = m0 + r;
-        if (m < p.M) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
-          v = v * sc + sh;
-          if (p.res_mode == 1) {
-            v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.ldr + col);
-          } else if (p.res_mode == 2) {
-            const int n = m / (p.Ho * p.Wo);
-            const int rem = m - n * (p.Ho * p.Wo);
-            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-            const size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
-            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
-          }
-          if (p.relu == 1) {
-            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-          } else if (p.relu == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
+#pragma unroll 1
+      for (int g = 0; g < NIT; g += NG) {
+        f32x4 rn[NG];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.f + erff(v[e] * 0.70710678118654752440f));
-          }
-          *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + col) = v;
+        for (int i = 0; i < NG; ++i) rn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (has_res && g + NG < NIT) {
+#pragma unroll
+          for (int i = 0; i < NG; ++i) rn[i] = res_load(g + NG + i);
         }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+          const int r = (g + i) * RPI + rsub;
+          const int m = m0 + r;
+          if (m < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+            v = v * sc + sh;
+            v += rv[i];
+            if (p.relu == 1) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            } else if (p.relu == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.f + erff(v[e] * 0.70710678118654752440f));
+            }
+            *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + col) = v;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NG; ++i) rv[i] = rn[i];
       }
     }
     __syncthreads();

@@ -326,6 +326,7 @@ HALO_S1 = int(_os.environ.get("LVC_HALO_S1", "2"))
 # single-accumulator form except `two_acc` layers, 1 = two accumulators everywhere, 0 = off (the LDS-DMA kernel for all of them)
 PW_S1 = int(_os.environ.get("LVC_PW_S1", "2"))
 _PW_S1_MIN_C = int(_os.environ.get("LVC_PW_S1_MIN_C", "256"))
+_PW_S1_RES = int(_os.environ.get("LVC_PW_S1_RES", "1"))     # 1: layers with a residual / upsample-add operand qualify too
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -374,7 +375,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         h2_pw = (not halo and (split or CONV_SPLIT) == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= _H2_PW_MIN_C
                  and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3 (f16x2 there: 0.312 vs 0.335 ms alone, no gain end to end)
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
-        if (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and residual is None
+        if (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and (residual is None or _PW_S1_RES)
                 and out.numel() < (1 << 29)):
             engine = "f16x2_pws1"     # residual-free, >= 256 input channels: the pipelined pointwise kernel (csrc/conv_pw_s1.hip)
     timer = CONV_TIMER
