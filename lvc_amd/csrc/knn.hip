@@ -517,7 +517,7 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
 //      smallest maximum with fewer than KTOP above it is T): a lower bound of A10, the row's KTOP-th largest value;
 //   2. ONE pass over the registers compacts the values >= T - margin into LDS (a superset of the candidates);
 //   3. A10 = the KTOP-th largest of those (every value >= T is among them); the entries below A10 - margin are dropped.
-template <int KTOP, int PER, int NSL>
+template <int KTOP, int PER, int NSL, bool VEC>
 __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
                                                                    const float* __restrict__ q, int ldq, const float* __restrict__ mu,
                                                                    const float* __restrict__ den, const float* __restrict__ sn,
@@ -534,10 +534,25 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
   const float* ar = approx + (size_t)row * ld;
   float v[PER];
   float lmax = -INFINITY;
+  // register j of lane l holds column col_of(j): one dwordx4 per lane and 256 columns when the rows are 16-byte aligned
+  auto col_of = [&](int j) { return VEC ? (j >> 2) * 256 + lane * 4 + (j & 3) : j * 64 + lane; };
+  if constexpr (VEC) {
+#pragma unroll
+    for (int jj = 0; jj < PER / 4; ++jj) {
+      const int i = jj * 256 + lane * 4;
+      float4 x = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      if (i < S) x = *reinterpret_cast<const float4*>(ar + i);
+      v[4 * jj + 0] = x.x; v[4 * jj + 1] = i + 1 < S ? x.y : -INFINITY; v[4 * jj + 2] = i + 2 < S ? x.z : -INFINITY; v[4 * jj + 3] = i + 3 < S ? x.w : -INFINITY;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = j * 64 + lane;
+      v[j] = i < S ? ar[i] : -INFINITY;
+    }
+  }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    const int i = j * 64 + lane;
-    v[j] = i < S ? ar[i] : -INFINITY;
     if (v[j] != v[j]) v[j] = INFINITY;
     lmax = fmaxf(lmax, v[j]);
   }
@@ -555,7 +570,7 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
     const unsigned long long m = __ballot(is_c);
     if (m) {
       const int pos = total + __popcll(m & ((1ull << lane) - 1ull));
-      if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = j * 64 + lane; L.ap[pos] = v[j]; }
+      if (is_c && pos < KV_MAX_CAND) { L.idx[pos] = col_of(j); L.ap[pos] = v[j]; }
       total += __popcll(m);
     }
   }
@@ -613,9 +628,11 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
-#define KV_LAUNCH_N(P, N) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, \
-                                             sn, D, margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
+#define KV_LAUNCH_V(P, N, V) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N, V>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, \
+                                                den, sn, D, margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
+#define KV_LAUNCH_N(P, N) do { if (vec) KV_LAUNCH_V(P, N, true); else KV_LAUNCH_V(P, N, false); } while (0)
 #define KV_LAUNCH(P) do { if (D <= 512) KV_LAUNCH_N(P, 2); else if (D <= 1024) KV_LAUNCH_N(P, 4); else KV_LAUNCH_N(P, 8); } while (0)
+  const bool vec = ldd % 4 == 0 && (((uintptr_t)approx) & 15) == 0;     // rows that dwordx4 loads can walk
   if (per <= 8) KV_LAUNCH(8);
   else if (per <= 16) KV_LAUNCH(16);
   else if (per <= 24) KV_LAUNCH(24);
@@ -624,6 +641,7 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   else if (per <= 48) KV_LAUNCH(48);
   else KV_LAUNCH(64);
 #undef KV_LAUNCH_N
+#undef KV_LAUNCH_V
 #undef KV_LAUNCH
   LVC_CHECK_LAUNCH();
   return LVC_OK;
