@@ -77,10 +77,15 @@ def assemble_tensors(shot_features):
 def pre_filter_margins(qres, sh_max, sres_max, D):
     """margin [Q] = 2 x the error bound of the fp16 pre-filter for each query row against ANY shot:
         |q.s - q_h.s_h| = |(q - q_h).s_h + q.(s - s_h)| <= |q - q_h| |s_h| + |q| |s - s_h|      (Cauchy-Schwarz, twice)
-    with the residual norms `rownorm_h` measured (qres per row, the shots' largest), |q| <= 1 + 1e-5, plus 2 D 2^-24 for the
-    fp32 accumulation of the pre-filter and of the exact re-evaluation (|sum of rounding errors| <= D u sum |q_i s_i| <= D u).
-    About half of the worst case 2^-9 (`VERIFY_MARGIN`) on real rows: fewer shots inside the window, fewer exact dot products."""
-    eps = qres * sh_max + sres_max * (1.0 + 1e-5) + 2.0 * D * 2.0 ** -24
+    with the residual norms `rownorm_h` measured (qres per row, the shots' largest) and |q| <= 1 + 1e-5, plus the fp32
+    accumulation of the two evaluations.  A sum of terms x_i is off by at most (roundings on a term's path) x (error per rounding)
+    x sum |x_i|, here sum |q_i s_i| <= |q| |s| <= 1: a pre-filter term passes one 16-wide MFMA step (at most 16 additions inside,
+    whatever their order) and the D / 16 - 1 accumulator updates behind it, each taken as 2^-23 (twice the round-to-nearest
+    unit, so that a truncating adder is covered); the exact re-evaluation of csrc/knn.hip sums 16 fmas per lane and a six-level
+    tree (22 roundings of 2^-24, taken as 32).  About half of the worst case 2^-9 (`VERIFY_MARGIN`) on real rows: fewer shots
+    inside the window, fewer exact dot products."""
+    acc = (2.0 * (D / 16.0 + 16.0) + 32.0) * 2.0 ** -24
+    eps = qres * sh_max + sres_max * (1.0 + 1e-5) + acc
     return (2.0 * (1.0 + 1e-4)) * eps
 
 
