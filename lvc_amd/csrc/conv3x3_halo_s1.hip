@@ -25,6 +25,7 @@
 // Tiling (<= 256-pixel patches x 64 NI channels, 8 waves as 4 x 2), stream-K workers with grouped channel tiles, partial-tile
 // hand-off and the epilogue through LDS are conv3x3_halo_h2.hip's.
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -53,6 +54,7 @@ struct HaloArgsS {
   int* flags;
   int N, H, W, C, K, relu, res_mode, ldy, ldr;
   int PH, PW, HW, HP, MP;
+  int inv_pw;                // ceil(2^16 / PW): (r * inv_pw) >> 16 == r / PW for the tile rows r < 256
   int tiles_x, tiles_y, tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
   int ngroup;
   int x_bytes;
@@ -70,6 +72,22 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 // ONEACC = true: the single-accumulator numerics of the header (row-scaled weight planes, activations x 2^4, residual planes unscaled).
 // ONEACC = false: conv3x3_halo_h2.hip's numerics in this kernel's pipeline -- residual planes x 2^11, a main (a1 b1) and a cross
 // (a1 b2 + a2 b1) accumulator folded once per tile, weights = lvc_split_weights planes, full fp16 range (|a| <= 65504).
+// Measured with the diagnostics build (-DHALO_TIMELINE, scripts/probe_halo_timeline.py, profiles/r03_halo_timeline.txt) on the p2
+// layer: a tap takes ~1950 cycles of which the SIMD's two waves need 1546 on the matrix pipe; the vmcnt wait in front of the barrier
+// is 80 - 90 cycles (the weight DMA has landed: its latency is not the bound), the barrier 110 - 750 by wave: the arbiter serves the
+// OLDER wave of a SIMD first (waves 0..3 run ahead, 1130 cycles per tap, and idle at the barrier while waves 4..7 finish alone).
+// Alternating s_setprio between the two (HALO_PRIO_MODE 1) evens the arrival out (1630 / 1775) but not the tap period (-0.4 % launch
+// time): left off.  Per tile, prologue 2.5 % and hand-off + epilogue 7 % of a workgroup's time run without MFMAs.
+#ifndef HALO_PRIO_MODE
+#define HALO_PRIO_MODE 0
+#endif
+#if HALO_PRIO_MODE == 1
+#define HALO_PRIO(first) do { if ((wave < 4) == (first)) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); } while (0)
+#elif HALO_PRIO_MODE == 2
+#define HALO_PRIO(first) do { if (first) { if (wave < 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(2); } } while (0)
+#else
+#define HALO_PRIO(first) do { } while (0)
+#endif
 template <int NI, bool ONEACC>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
   constexpr int HN = 64 * NI;
@@ -125,6 +143,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) a_lds[j] = min(hrow + 64 * j, p.HP - 1) * LROW + q * 4;
   float big = 0.f;   // largest |activation| staged: beyond the scaled fp16 range -> workspace error word
+#ifdef HALO_TIMELINE
+  // diagnostics build only (scripts/probe_halo_timeline.py): cycles of this wave between barriers, in the vmcnt wait, in the barrier
+  unsigned long long tl_run = 0, tl_vm = 0, tl_bar = 0, tl_last = 0, tl_pro = 0, tl_epi = 0, tl_hand = 0, tl_cs = 0, tl_t0 = __builtin_readcyclecounter();
+  unsigned tl_n = 0;
+#endif
   while (u < u_end) {
     const int tile = u / p.nk;
     const int cc0 = u - tile * p.nk;
@@ -261,6 +284,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     };
 
     const int step0 = cc0 * 9, last_step = cc1 * 9 - 1;
+#ifdef HALO_TIMELINE
+    const unsigned long long tl_p0 = __builtin_readcyclecounter();
+#endif
     // ---- prologue: halo of the first chunk, weights of taps 0 and 1, the early fragments of (tap 0, k16 step 0)
     load_A(cc0);
     dma_B(step0, 0);
@@ -274,6 +300,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) blo[ni] = rdB(sB, 1, ni, 0);
 
+#ifdef HALO_TIMELINE
+    tl_last = __builtin_readcyclecounter();
+    tl_pro += tl_last - tl_p0;
+#endif
 #pragma unroll 1
     for (int cc = cc0; cc < cc1; ++cc) {
       const int par = (cc - cc0) & 1;
@@ -288,6 +318,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
         const unsigned char* Bcur = sB + (tap % 3) * B_BUF;
         const unsigned char* Bnext = sB + ((tap + 1) % 3) * B_BUF;
         // ---- phase A: k16 step 0 of this tap; its early reads are step 1's (same buffers)
+        HALO_PRIO(true);
         step_body(Acur, toff, 0, Bcur, Acur, toff, 1, Bcur);
         if (tap == 4) store_A_piece(Anext, 0);
         if (tap == 5) store_A_piece(Anext, 2);
@@ -296,13 +327,23 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
         __builtin_amdgcn_sched_barrier(0);
         // Everything this wave has in flight (the weights of tap + 1 issued one tap ago, at tap 2 the halo loads of tap 1) has
         // landed; behind the barrier that holds for every wave, and every wave is done with tap - 1's weight slot
+#ifdef HALO_TIMELINE
+        const unsigned long long tl_1 = __builtin_readcyclecounter();
+        wait_vm<0>();
+        const unsigned long long tl_2 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        const unsigned long long tl_3 = __builtin_readcyclecounter();
+        tl_run += tl_1 - tl_last; tl_vm += tl_2 - tl_1; tl_bar += tl_3 - tl_2; tl_last = tl_3; ++tl_n;
+#else
         wait_vm<0>();
         __builtin_amdgcn_s_barrier();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // ---- phase B: k16 step 1; the DMA of tap + 2 into tap - 1's slot; early reads of (tap + 1, step 0).  Past the end of the
         // unit the DMA re-fetches the last tap and the halo load the last chunk (into buffers nobody reads any more): the
         // instruction stream has no data-dependent branch
         dma_B(min(step + 2, last_step), (tap + 2) % 3);
+        HALO_PRIO(false);
         step_body(Acur, toff, 1, Bcur, tap == 8 ? Anext : Acur, toff_n, 0, Bnext);
         if (tap == 1) load_A(min(cc + 1, cc1 - 1));
         if (tap == 4) store_A_piece(Anext, 1);
@@ -314,6 +355,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     }
     wait_vm<0>();
     __syncthreads();
+#ifdef HALO_TIMELINE
+    const unsigned long long tl_e0 = __builtin_readcyclecounter();
+    tl_run += tl_e0 - tl_last;
+#endif
     u += cc1 - cc0;
     if (!ONEACC) {
 #pragma unroll
@@ -375,6 +420,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       }
     }
 
+#ifdef HALO_TIMELINE
+    const unsigned long long tl_e1 = __builtin_readcyclecounter();
+    tl_hand += tl_e1 - tl_e0;
+#endif
     // ---- epilogue through LDS: tile row r is patch pixel (r / PW, r % PW)
     float* Cs = reinterpret_cast<float*>(smem_raw);
 #pragma unroll
@@ -388,6 +437,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
           Cs[row * CS_STRIDE + col] = acc[mi][ni][e];
         }
     __syncthreads();
+#ifdef HALO_TIMELINE
+    tl_cs += __builtin_readcyclecounter() - tl_e1;
+#endif
+    // Output rows: the whole loop is address arithmetic around one LDS read and one store per row, and it ran on the vector ALU for
+    // 5.6 % of the p2 layer's time (13.6 % on the 64-channel res2 layer; scripts/probe_halo_timeline.py): the pixel of tile row r comes
+    // from a multiply-shift (no integer division), the row's address from the tile origin plus a 32-bit pixel offset.
     constexpr int C4 = HN / 4;
     constexpr int RPI = NT / C4;
     const int c4 = tid % C4, rsub = tid / C4;
@@ -397,31 +452,59 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       f32x4 sh = {0.f, 0.f, 0.f, 0.f};
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+      const size_t origin = (size_t)(img * p.H + y0) * p.W + x0;          // pixel index of the patch's corner
+      float* const ybase = p.y + origin * p.ldy + col;
+      const int ylim = p.H - y0, xlim = p.W - x0;
+      const float* cs = Cs + rsub * CS_STRIDE + c4 * 4;
+      // one copy of the loop per (residual mode, ReLU): with the modes tested inside, every iteration ended in the compiler's
+      // vmcnt(0) lgkmcnt(0) -- the LDS read of a row and the acknowledgement of the previous row's store, one after the other,
+      // sixteen times per tile (the "output rows" share of scripts/probe_halo_timeline.py)
+      auto rows = [&](auto rm_tag, auto relu_tag) {
+        constexpr int RM = decltype(rm_tag)::value;
+        constexpr bool RELU = decltype(relu_tag)::value;
 #pragma unroll 4
-      for (int it = 0; it < HM / RPI; ++it) {
-        const int r = it * RPI + rsub;
-        const int py = r / p.PW, px = r - py * p.PW;
-        const int yy = y0 + py, xx = x0 + px;
-        if (r < p.MP && yy < p.H && xx < p.W) {
-          const size_t row = (size_t)(img * p.H + yy) * p.W + xx;
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
-          v = v * sc + sh;
-          if (p.res_mode == 1) {
-            v += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + col);
-          } else if (p.res_mode == 2) {
-            const size_t ro = ((size_t)(img * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1));
-            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        for (int it = 0; it < HM / RPI; ++it) {
+          const int r = it * RPI + rsub;
+          const int py = (r * p.inv_pw) >> 16, px = r - py * p.PW;
+          if (r < p.MP && py < ylim && px < xlim) {
+            const unsigned pix = (unsigned)(py * p.W + px);
+            f32x4 v = *reinterpret_cast<const f32x4*>(cs + it * RPI * CS_STRIDE);
+            v = v * sc + sh;
+            if (RM == 1) {
+              v += *reinterpret_cast<const f32x4*>(p.res + (origin + pix) * p.ldr + col);
+            } else if (RM == 2) {
+              const int yy = y0 + py, xx = x0 + px;
+              const size_t ro = ((size_t)(img * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1));
+              v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+            }
+            if (RELU) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            }
+#ifdef HALO_TL_NO_STORE     // diagnostics only: what the output-row loop costs without its stores
+            if (v[0] == 123456.f)
+#endif
+            *reinterpret_cast<f32x4*>(ybase + (size_t)pix * p.ldy) = v;
           }
-          if (p.relu) {
-            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-          }
-          *reinterpret_cast<f32x4*>(p.y + row * p.ldy + col) = v;
         }
-      }
+      };
+      using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+      if (p.res_mode == 0) { if (p.relu) rows(T0{}, std::true_type{}); else rows(T0{}, std::false_type{}); }
+      else if (p.res_mode == 1) { if (p.relu) rows(T1{}, std::true_type{}); else rows(T1{}, std::false_type{}); }
+      else { if (p.relu) rows(T2{}, std::true_type{}); else rows(T2{}, std::false_type{}); }
     }
     __syncthreads();
+#ifdef HALO_TIMELINE
+    tl_epi += __builtin_readcyclecounter() - tl_e0;
+#endif
   }
+#ifdef HALO_TIMELINE
+  if (lane == 0 && (blockIdx.x & 15) == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partials) + (size_t)512 * 256 * 128 * 4) + ((blockIdx.x >> 4) * 8 + wave) * 16;
+    d[0] = tl_run; d[1] = tl_vm; d[2] = tl_bar; d[3] = tl_n; d[4] = tl_pro; d[5] = tl_epi; d[6] = __builtin_readcyclecounter() - tl_t0; d[7] = 1;
+    d[8] = tl_hand; d[9] = tl_cs;
+  }
+#endif
   if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);
 }
 
@@ -467,6 +550,7 @@ static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_s
     if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_S1) { a.PH = ph; a.PW = pw; }
   }
   a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
+  a.inv_pw = (65536 + a.PW - 1) / a.PW;
   a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
   const int ni = K <= 64 ? 1 : 2;
   const int HN = 64 * ni;
