@@ -17,6 +17,7 @@
 // The asynchronous loads are written as inline asm and waited for with counted vmcnt waits that are TIED to the destination
 // registers (the compiler's own bookkeeping would wait for everything in flight, LDS-DMA included, at the first use).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -348,7 +349,8 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     constexpr int NG = 4;
     const int c4 = tid % C4, rsub = tid / C4;
     const int col = n0 + c4 * 4;
-    const bool has_res = p.res_mode != 0 && col < p.K;
+    const bool col_ok = col < p.K;
+    const bool has_res = p.res_mode != 0 && col_ok;
     auto res_load = [&](int it) {
       const int m = m0 + it * RPI + rsub;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -383,39 +385,58 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
           Cs[row * CS_STRIDE + colc] = acc[mi][ni][e];
         }
     __syncthreads();
-    if (col < p.K) {
+    if (col_ok) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+      const float* cs = Cs + rsub * CS_STRIDE + c4 * 4;
+      float* const yb = p.y + (size_t)(m0 + rsub) * p.ldy + col;
+      // one copy of the row loop per (residual?, activation): with the modes tested inside, every row ended in the compiler's
+      // vmcnt(0) lgkmcnt(0) -- its LDS read and the acknowledgement of the previous row's store, one after the other
+      auto rows = [&](auto res_tag, auto act_tag) {
+        constexpr bool RES = decltype(res_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll 1
-      for (int g = 0; g < NIT; g += NG) {
-        f32x4 rn[NG];
+        for (int g = 0; g < NIT; g += NG) {
+          f32x4 rn[NG];
+          if (RES) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) rn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (has_res && g + NG < NIT) {
+            for (int i = 0; i < NG; ++i) rn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g + NG < NIT) {
 #pragma unroll
-          for (int i = 0; i < NG; ++i) rn[i] = res_load(g + NG + i);
-        }
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-          const int r = (g + i) * RPI + rsub;
-          const int m = m0 + r;
-          if (m < p.M) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
-            v = v * sc + sh;
-            v += rv[i];
-            if (p.relu == 1) {
-              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-            } else if (p.relu == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = v[e] * 0.5f * (1.f + erff(v[e] * 0.70710678118654752440f));
+              for (int i = 0; i < NG; ++i) rn[i] = res_load(g + NG + i);
             }
-            *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.ldy + col) = v;
+          }
+          f32x4 v[NG];
+#pragma unroll
+          for (int i = 0; i < NG; ++i) v[i] = *reinterpret_cast<const f32x4*>(cs + (g + i) * RPI * CS_STRIDE);
+#pragma unroll
+          for (int i = 0; i < NG; ++i) {
+            const int m = m0 + (g + i) * RPI + rsub;
+            if (m < p.M) {
+              f32x4 o = v[i] * sc + sh;
+              if (RES) o += rv[i];
+              if (ACT == 1) {
+                o[0] = o[0] > 0.f ? o[0] : 0.f; o[1] = o[1] > 0.f ? o[1] : 0.f;
+                o[2] = o[2] > 0.f ? o[2] : 0.f; o[3] = o[3] > 0.f ? o[3] : 0.f;
+              } else if (ACT == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = o[e] * 0.5f * (1.f + erff(o[e] * 0.70710678118654752440f));
+              }
+              *reinterpret_cast<f32x4*>(yb + (size_t)((g + i) * RPI) * p.ldy) = o;
+            }
+          }
+          if (RES) {
+#pragma unroll
+            for (int i = 0; i < NG; ++i) rv[i] = rn[i];
           }
         }
-#pragma unroll
-        for (int i = 0; i < NG; ++i) rv[i] = rn[i];
+      };
+      using A0 = std::integral_constant<int, 0>; using A1 = std::integral_constant<int, 1>; using A2 = std::integral_constant<int, 2>;
+      if (has_res) {
+        if (p.relu == 1) rows(std::true_type{}, A1{}); else if (p.relu == 2) rows(std::true_type{}, A2{}); else rows(std::true_type{}, A0{});
+      } else {
+        if (p.relu == 1) rows(std::false_type{}, A1{}); else if (p.relu == 2) rows(std::false_type{}, A2{}); else rows(std::false_type{}, A0{});
       }
     }
     __syncthreads();

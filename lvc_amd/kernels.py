@@ -325,7 +325,8 @@ HALO_S1 = int(_os.environ.get("LVC_HALO_S1", "2"))
 # pointwise fp16x2 layers with at least LVC_PW_S1_MIN_C input channels on the pipelined kernel (csrc/conv_pw_s1.hip): 2 = its
 # single-accumulator form except `two_acc` layers, 1 = two accumulators everywhere, 0 = off (the LDS-DMA kernel for all of them)
 PW_S1 = int(_os.environ.get("LVC_PW_S1", "2"))
-_PW_S1_MIN_C = int(_os.environ.get("LVC_PW_S1_MIN_C", "256"))
+_PW_S1_MIN_C = int(_os.environ.get("LVC_PW_S1_MIN_C", "64"))
+_PW_S1_ONE_MIN_C = int(_os.environ.get("LVC_PW_S1_ONE_MIN_C", "256"))
 _PW_S1_RES = int(_os.environ.get("LVC_PW_S1_RES", "1"))     # 1: layers with a residual / upsample-add operand qualify too
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
@@ -377,7 +378,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
         if (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and (residual is None or _PW_S1_RES)
                 and out.numel() < (1 << 29)):
-            engine = "f16x2_pws1"     # residual-free, >= 256 input channels: the pipelined pointwise kernel (csrc/conv_pw_s1.hip)
+            engine = "f16x2_pws1"     # >= 64 input channels: the pipelined pointwise kernel (csrc/conv_pw_s1.hip)
     timer = CONV_TIMER
     if timer is not None and (not timer.active or (timer.only is not None and engine not in timer.only)):
         timer = None
@@ -411,10 +412,11 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                 c_int(res_mode), c_int(out.shape[-1]), c_int(ldr), ptr(conv_workspace(x.device)), _stream(x))
             check(st, "lvc_conv3x3_nhwc_bf16x3")
         elif engine == "f16x2_pws1":
-            # pointwise layers WITHOUT a residual and with >= 256 input channels on the pipelined kernel (csrc/conv_pw_s1.hip:
-            # fc1 0.75 -> 0.59 ms, res4 / res5 conv1 -10..15 %; layers with a residual are faster on the LDS-DMA kernel, whose ring
-            # prefetches the residual rows: scripts/probe_pw_set.py); precision policy as for the 3x3 layers
-            one = PW_S1 == 2 and not pc.two_acc
+            # pointwise layers with >= 64 input channels on the pipelined kernel (csrc/conv_pw_s1.hip: fc1 0.75 -> 0.59 ms, res4 / res5
+            # conv1 -10..15 %, the memory-bound res2 / res3 conv3 -2..9 % since its epilogue stopped serialising rows:
+            # scripts/probe_pw_set.py); precision policy as for the 3x3 layers, and the layers with < 256 input channels keep the
+            # two-accumulator form -- bit-identical to the LDS-DMA kernel they ran on before (they are memory-bound: the form costs nothing)
+            one = PW_S1 == 2 and not pc.two_acc and C >= _PW_S1_ONE_MIN_C
             fused_act = act == "gelu" and not relu
             if fused_act:
                 act = None
