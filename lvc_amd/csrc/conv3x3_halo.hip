@@ -329,28 +329,39 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_kernel(HaloArgs p) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+      // one copy of the row loop per (residual mode, ReLU): with the modes tested inside, every row ended in the compiler's
+      // vmcnt(0) lgkmcnt(0) -- its LDS read and the acknowledgement of the previous row's store one after the other (measured on
+      // conv3x3_halo_s1.hip, scripts/probe_halo_timeline.py)
+      auto rows = [&](auto rm_tag, auto relu_tag) {
+        constexpr int RM = decltype(rm_tag)::value;
+        constexpr bool RELU = decltype(relu_tag)::value;
 #pragma unroll 4
-      for (int it = 0; it < HM / RPI; ++it) {
-        const int r = it * RPI + rsub;
-        const int py = r / p.PW, px = r - py * p.PW;
-        const int yy = y0 + py, xx = x0 + px;
-        if (r < p.MP && yy < p.H && xx < p.W) {
-          const size_t row = (size_t)(img * p.H + yy) * p.W + xx;
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
-          v = v * sc + sh;
-          if (p.res_mode == 1) {
-            v += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + col);
-          } else if (p.res_mode == 2) {
-            const size_t ro = ((size_t)(img * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1));
-            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        for (int it = 0; it < HM / RPI; ++it) {
+          const int r = it * RPI + rsub;
+          const int py = r / p.PW, px = r - py * p.PW;
+          const int yy = y0 + py, xx = x0 + px;
+          if (r < p.MP && yy < p.H && xx < p.W) {
+            const size_t row = (size_t)(img * p.H + yy) * p.W + xx;
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+            v = v * sc + sh;
+            if (RM == 1) {
+              v += *reinterpret_cast<const f32x4*>(p.res + row * p.ldr + col);
+            } else if (RM == 2) {
+              const size_t ro = ((size_t)(img * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1));
+              v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+            }
+            if (RELU) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.y + row * p.ldy + col) = v;
           }
-          if (p.relu) {
-            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-          }
-          *reinterpret_cast<f32x4*>(p.y + row * p.ldy + col) = v;
         }
-      }
+      };
+      using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+      if (p.res_mode == 0) { if (p.relu) rows(T0{}, std::true_type{}); else rows(T0{}, std::false_type{}); }
+      else if (p.res_mode == 1) { if (p.relu) rows(T1{}, std::true_type{}); else rows(T1{}, std::false_type{}); }
+      else { if (p.relu) rows(T2{}, std::true_type{}); else rows(T2{}, std::false_type{}); }
     }
     __syncthreads();
   }

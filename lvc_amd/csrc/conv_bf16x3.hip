@@ -317,30 +317,39 @@ __global__ __launch_bounds__(NT, 2) void conv_bf16x3_kernel(ConvArgsB p) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
       if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
       if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+      // one copy of the row loop per (residual mode, ReLU): tested inside, the modes make every row end in a vmcnt(0) lgkmcnt(0)
+      auto rows = [&](auto rm_tag, auto relu_tag) {
+        constexpr int RM = decltype(rm_tag)::value;
+        constexpr bool RELU = decltype(relu_tag)::value;
 #pragma unroll 4
-      for (int it = 0; it < BM / RPI; ++it) {
-        const int r = it * RPI + rsub;
-        const int row = m0 + r;
-        if (row < p.M) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
-          v = v * sc + sh;
-          if (p.res_mode == 1) {
-            v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
-          } else if (p.res_mode == 2) {
-            int n = row / (p.Ho * p.Wo);
-            int rem = row - n * (p.Ho * p.Wo);
-            int ho = rem / p.Wo;
-            int wo = rem - ho * p.Wo;
-            size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
-            v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        for (int it = 0; it < BM / RPI; ++it) {
+          const int r = it * RPI + rsub;
+          const int row = m0 + r;
+          if (row < p.M) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS_STRIDE + c4 * 4);
+            v = v * sc + sh;
+            if (RM == 1) {
+              v += *reinterpret_cast<const f32x4*>(p.res + (size_t)row * p.ldr + col);
+            } else if (RM == 2) {
+              int n = row / (p.Ho * p.Wo);
+              int rem = row - n * (p.Ho * p.Wo);
+              int ho = rem / p.Wo;
+              int wo = rem - ho * p.Wo;
+              size_t ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+              v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+            }
+            if (RELU) {
+              v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
+              v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
           }
-          if (p.relu) {
-            v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
-            v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
-          }
-          *reinterpret_cast<f32x4*>(p.y + (size_t)row * p.ldy + col) = v;
         }
-      }
+      };
+      using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+      if (p.res_mode == 0) { if (p.relu) rows(T0{}, std::true_type{}); else rows(T0{}, std::false_type{}); }
+      else if (p.res_mode == 1) { if (p.relu) rows(T1{}, std::true_type{}); else rows(T1{}, std::false_type{}); }
+      else { if (p.relu) rows(T2{}, std::true_type{}); else rows(T2{}, std::false_type{}); }
     }
     __syncthreads();
   }
