@@ -116,8 +116,16 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     a_lds[j] = row * AROW + (((q >> 1) ^ ((row >> 2) & 3)) << 4) + (q & 1) * 8;     // bytes
   }
   float big = 0.f;
+#ifdef PW_TIMELINE
+  // diagnostics build only (scripts/probe_pw_s1_timeline.py): cycles of this wave in a tile's prologue, chunk loop, hand-off, epilogue
+  unsigned long long tl_pro = 0, tl_loop = 0, tl_hand = 0, tl_cs = 0, tl_rows = 0, tl_t0 = __builtin_readcyclecounter();
+  unsigned tl_tiles = 0, tl_chunks = 0;
+#endif
 
   while (u < u_end) {
+#ifdef PW_TIMELINE
+    const unsigned long long tl_a = __builtin_readcyclecounter();
+#endif
     const int tile = u / p.nk;
     const int cc0 = u - tile * p.nk;
     const int cc1 = min(p.nk, cc0 + (u_end - u));
@@ -249,6 +257,10 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     //   phase B: issue B(i+2), A(i+3)
     // so before the store at most  [A(i+2)] + [B(i+1)] = NJ + NI  newer operations exist (issue order: ..., B(i+1), A(i+2) at chunk
     // i-1) and before the barrier at most A(i+2) = NJ.
+#ifdef PW_TIMELINE
+    const unsigned long long tl_b = __builtin_readcyclecounter();
+    tl_pro += tl_b - tl_a;
+#endif
     auto chunk = [&](int i, int k) {      // k = i % 3, compile-time: activation buffer, weight slot and register set of chunk i
       const int cc = cc0 + i;
       const int kn = (k + 1) % 3;
@@ -279,6 +291,10 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     }
     wait_vm<0>();
     __syncthreads();
+#ifdef PW_TIMELINE
+    const unsigned long long tl_c = __builtin_readcyclecounter();
+    tl_loop += tl_c - tl_b; tl_chunks += nchunks; ++tl_tiles;
+#endif
     u += nchunks;
     if (!ONEACC) {
 #pragma unroll
@@ -343,18 +359,33 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     // ---- epilogue through LDS: affine, residual (same shape, or the nearest-x2 upsample of the half-size map), ReLU / GELU.
     // The residual rows are requested one group of four output rows AHEAD (the first group before the accumulators go through
     // LDS): not one exposed memory round trip per group.
-    constexpr int C4 = HN / 4;
-    constexpr int RPI = NT / C4;
-    constexpr int NIT = PM / RPI;
-    constexpr int NG = 4;
-    const int c4 = tid % C4, rsub = tid / C4;
-    const int col = n0 + c4 * 4;
-    const bool col_ok = col < p.K;
-    const bool has_res = p.res_mode != 0 && col_ok;
-    auto res_load = [&](int it) {
-      const int m = m0 + it * RPI + rsub;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M) {
+#ifdef PW_TIMELINE
+    const unsigned long long tl_d = __builtin_readcyclecounter();
+    tl_hand += tl_d - tl_c;
+#endif
+#ifdef PW_TIMELINE
+    unsigned long long tl_e = 0;
+#endif
+    if constexpr (ONEACC) {
+      constexpr int C4 = HN / 4;
+      constexpr int RPI = NT / C4;
+      constexpr int NIT = PM / RPI;
+      constexpr int NG = 4;
+      constexpr int NGR = NIT / NG;
+      const int c4 = tid % C4, rsub = tid / C4;
+      const int col = n0 + c4 * 4;
+      const bool col_ok = col < p.K;
+      const bool has_res = p.res_mode != 0 && col_ok;
+      // Residual rows: requested one group of four output rows AHEAD of their use into two register sets that alternate, the groups
+      // unrolled: the compiler's own counted wait then leaves the group just requested in flight.  (With one register set copied
+      // forward per group it waited for everything at the copy -- a memory round trip per group, a third to a half of the time of
+      // the layers with a residual: scripts/probe_pw_s1_timeline.py.)  Rows past the end re-read the last row.
+      int m0e = m0, cole = col;
+      asm volatile("" : "+s"(m0e), "+v"(cole));      // the residual addresses are formed HERE, not before the chunk loop (where they would
+                                                     // have to live through it in registers the loop does not have)
+      auto res_addr = [&](int it) {
+        int m = m0e + it * RPI + rsub;
+        m = m < p.M ? m : p.M - 1;
         size_t ro = (size_t)m;
         if (p.res_mode == 2) {
           const int n = m / (p.Ho * p.Wo);
@@ -362,85 +393,198 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
           const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
           ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
         }
-        v = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
-      }
-      return v;
-    };
-    f32x4 rv[NG];
+        return p.res + ro * p.ldr + cole;
+      };
+      f32x4 rr[2][NG];
+      auto res_issue = [&](int set, int g) {
 #pragma unroll
-    for (int i = 0; i < NG; ++i) rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (has_res) {
-#pragma unroll
-      for (int i = 0; i < NG; ++i) rv[i] = res_load(i);
-    }
-    float* Cs = reinterpret_cast<float*>(smem_raw);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-          const int colc = wn * 32 * NI + ni * 32 + fi;
-          Cs[row * CS_STRIDE + colc] = acc[mi][ni][e];
-        }
-    __syncthreads();
-    if (col_ok) {
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-      const float* cs = Cs + rsub * CS_STRIDE + c4 * 4;
-      float* const yb = p.y + (size_t)(m0 + rsub) * p.ldy + col;
-      // one copy of the row loop per (residual?, activation): with the modes tested inside, every row ended in the compiler's
-      // vmcnt(0) lgkmcnt(0) -- its LDS read and the acknowledgement of the previous row's store, one after the other
-      auto rows = [&](auto res_tag, auto act_tag) {
-        constexpr bool RES = decltype(res_tag)::value;
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll 1
-        for (int g = 0; g < NIT; g += NG) {
-          f32x4 rn[NG];
-          if (RES) {
-#pragma unroll
-            for (int i = 0; i < NG; ++i) rn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (g + NG < NIT) {
-#pragma unroll
-              for (int i = 0; i < NG; ++i) rn[i] = res_load(g + NG + i);
-            }
-          }
-          f32x4 v[NG];
-#pragma unroll
-          for (int i = 0; i < NG; ++i) v[i] = *reinterpret_cast<const f32x4*>(cs + (g + i) * RPI * CS_STRIDE);
-#pragma unroll
-          for (int i = 0; i < NG; ++i) {
-            const int m = m0 + (g + i) * RPI + rsub;
-            if (m < p.M) {
-              f32x4 o = v[i] * sc + sh;
-              if (RES) o += rv[i];
-              if (ACT == 1) {
-                o[0] = o[0] > 0.f ? o[0] : 0.f; o[1] = o[1] > 0.f ? o[1] : 0.f;
-                o[2] = o[2] > 0.f ? o[2] : 0.f; o[3] = o[3] > 0.f ? o[3] : 0.f;
-              } else if (ACT == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = o[e] * 0.5f * (1.f + erff(o[e] * 0.70710678118654752440f));
-              }
-              *reinterpret_cast<f32x4*>(yb + (size_t)((g + i) * RPI) * p.ldy) = o;
-            }
-          }
-          if (RES) {
-#pragma unroll
-            for (int i = 0; i < NG; ++i) rv[i] = rn[i];
-          }
+        for (int i = 0; i < NG; ++i) {
+          rr[set][i] = *reinterpret_cast<const f32x4*>(res_addr(g + i));
         }
       };
-      using A0 = std::integral_constant<int, 0>; using A1 = std::integral_constant<int, 1>; using A2 = std::integral_constant<int, 2>;
+      if (has_res) res_issue(0, 0);
+      float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            const int colc = wn * 32 * NI + ni * 32 + fi;
+            Cs[row * CS_STRIDE + colc] = acc[mi][ni][e];
+          }
+      __syncthreads();
+#ifdef PW_TIMELINE
+      tl_e = __builtin_readcyclecounter();
+      tl_cs += tl_e - tl_d;
+#endif
+      if (col_ok) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+        const float* cs = Cs + rsub * CS_STRIDE + c4 * 4;
+        float* const yb = p.y + (size_t)(m0 + rsub) * p.ldy + col;
+        // one copy of the row loop per (residual?, activation): with the modes tested inside, every row ended in the compiler's
+        // vmcnt(0) lgkmcnt(0) -- its LDS read and the acknowledgement of the previous row's store, one after the other
+        auto rows = [&](auto res_tag, auto act_tag) {
+          constexpr bool RES = decltype(res_tag)::value;
+          constexpr int ACT = decltype(act_tag)::value;
+          auto group = [&](int g, const f32x4* rcur) {
+            f32x4 v[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) v[i] = *reinterpret_cast<const f32x4*>(cs + (g + i) * RPI * CS_STRIDE);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+              const int m = m0 + (g + i) * RPI + rsub;
+              if (m < p.M) {
+                f32x4 o = v[i] * sc + sh;
+                if (RES) o += rcur[i];
+                if (ACT == 1) {
+                  o[0] = o[0] > 0.f ? o[0] : 0.f; o[1] = o[1] > 0.f ? o[1] : 0.f;
+                  o[2] = o[2] > 0.f ? o[2] : 0.f; o[3] = o[3] > 0.f ? o[3] : 0.f;
+                } else if (ACT == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) o[e] = o[e] * 0.5f * (1.f + erff(o[e] * 0.70710678118654752440f));
+                }
+                *reinterpret_cast<f32x4*>(yb + (size_t)((g + i) * RPI) * p.ldy) = o;
+              }
+            }
+          };
+          if constexpr (RES) {
+#pragma unroll
+            for (int gi = 0; gi < NGR; ++gi) {
+              if (gi + 1 < NGR) res_issue((gi + 1) & 1, (gi + 1) * NG);
+              group(gi * NG, rr[gi & 1]);
+            }
+          } else {
+#pragma unroll 1
+            for (int g = 0; g < NIT; g += NG) group(g, rr[0]);
+          }
+        };
+        using A0 = std::integral_constant<int, 0>; using A1 = std::integral_constant<int, 1>; using A2 = std::integral_constant<int, 2>;
+        if (has_res) {
+          if (p.relu == 1) rows(std::true_type{}, A1{}); else if (p.relu == 2) rows(std::true_type{}, A2{}); else rows(std::true_type{}, A0{});
+        } else {
+          if (p.relu == 1) rows(std::false_type{}, A1{}); else if (p.relu == 2) rows(std::false_type{}, A2{}); else rows(std::false_type{}, A0{});
+        }
+      }
+    } else {
+      // The two-accumulator form has no registers to spare: with the row groups unrolled (as above) the compiler spills 60 - 90
+      // registers and reloads them inside the loop (res2 conv3 0.257 -> 0.378 ms).  Rolled group loop, one residual register set
+      // copied forward per group, at the price of the compiler's full wait at the copy.
+      constexpr int C4 = HN / 4;
+      constexpr int RPI = NT / C4;
+      constexpr int NIT = PM / RPI;
+      constexpr int NG = 4;
+      const int c4 = tid % C4, rsub = tid / C4;
+      const int col = n0 + c4 * 4;
+      const bool col_ok = col < p.K;
+      const bool has_res = p.res_mode != 0 && col_ok;
+      auto res_load = [&](int it) {
+        const int m = m0 + it * RPI + rsub;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < p.M) {
+          size_t ro = (size_t)m;
+          if (p.res_mode == 2) {
+            const int n = m / (p.Ho * p.Wo);
+            const int rem = m - n * (p.Ho * p.Wo);
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+          }
+          v = *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
+        }
+        return v;
+      };
+      f32x4 rv[NG];
+#pragma unroll
+      for (int i = 0; i < NG; ++i) rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (has_res) {
-        if (p.relu == 1) rows(std::true_type{}, A1{}); else if (p.relu == 2) rows(std::true_type{}, A2{}); else rows(std::true_type{}, A0{});
-      } else {
-        if (p.relu == 1) rows(std::false_type{}, A1{}); else if (p.relu == 2) rows(std::false_type{}, A2{}); else rows(std::false_type{}, A0{});
+#pragma unroll
+        for (int i = 0; i < NG; ++i) rv[i] = res_load(i);
+      }
+      float* Cs = reinterpret_cast<float*>(smem_raw);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            const int colc = wn * 32 * NI + ni * 32 + fi;
+            Cs[row * CS_STRIDE + colc] = acc[mi][ni][e];
+          }
+      __syncthreads();
+#ifdef PW_TIMELINE
+      tl_e = __builtin_readcyclecounter();
+      tl_cs += tl_e - tl_d;
+#endif
+      if (col_ok) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
+        const float* cs = Cs + rsub * CS_STRIDE + c4 * 4;
+        float* const yb = p.y + (size_t)(m0 + rsub) * p.ldy + col;
+        // one copy of the row loop per (residual?, activation): with the modes tested inside, every row ended in the compiler's
+        // vmcnt(0) lgkmcnt(0) -- its LDS read and the acknowledgement of the previous row's store, one after the other
+        auto rows = [&](auto res_tag, auto act_tag) {
+          constexpr bool RES = decltype(res_tag)::value;
+          constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll 1
+          for (int g = 0; g < NIT; g += NG) {
+            f32x4 rn[NG];
+            if (RES) {
+#pragma unroll
+              for (int i = 0; i < NG; ++i) rn[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+              if (g + NG < NIT) {
+#pragma unroll
+                for (int i = 0; i < NG; ++i) rn[i] = res_load(g + NG + i);
+              }
+            }
+            f32x4 v[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) v[i] = *reinterpret_cast<const f32x4*>(cs + (g + i) * RPI * CS_STRIDE);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+              const int m = m0 + (g + i) * RPI + rsub;
+              if (m < p.M) {
+                f32x4 o = v[i] * sc + sh;
+                if (RES) o += rv[i];
+                if (ACT == 1) {
+                  o[0] = o[0] > 0.f ? o[0] : 0.f; o[1] = o[1] > 0.f ? o[1] : 0.f;
+                  o[2] = o[2] > 0.f ? o[2] : 0.f; o[3] = o[3] > 0.f ? o[3] : 0.f;
+                } else if (ACT == 2) {     // torch.nn.GELU(), the expression of lvc_gelu
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) o[e] = o[e] * 0.5f * (1.f + erff(o[e] * 0.70710678118654752440f));
+                }
+                *reinterpret_cast<f32x4*>(yb + (size_t)((g + i) * RPI) * p.ldy) = o;
+              }
+            }
+            if (RES) {
+#pragma unroll
+              for (int i = 0; i < NG; ++i) rv[i] = rn[i];
+            }
+          }
+        };
+        using A0 = std::integral_constant<int, 0>; using A1 = std::integral_constant<int, 1>; using A2 = std::integral_constant<int, 2>;
+        if (has_res) {
+          if (p.relu == 1) rows(std::true_type{}, A1{}); else if (p.relu == 2) rows(std::true_type{}, A2{}); else rows(std::true_type{}, A0{});
+        } else {
+          if (p.relu == 1) rows(std::false_type{}, A1{}); else if (p.relu == 2) rows(std::false_type{}, A2{}); else rows(std::false_type{}, A0{});
+        }
       }
     }
     __syncthreads();
+#ifdef PW_TIMELINE
+    tl_rows += __builtin_readcyclecounter() - tl_e;
+#endif
   }
+#ifdef PW_TIMELINE
+  if (lane == 0 && (blockIdx.x & 15) == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partials) + (size_t)512 * 256 * 128 * 4) + ((blockIdx.x >> 4) * 8 + wave) * 16;
+    d[0] = tl_pro; d[1] = tl_loop; d[2] = tl_hand; d[3] = tl_cs; d[4] = tl_rows; d[5] = tl_tiles; d[6] = tl_chunks; d[7] = __builtin_readcyclecounter() - tl_t0; d[8] = 1;
+  }
+#endif
   if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);
 }
 
