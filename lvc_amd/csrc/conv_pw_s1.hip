@@ -380,27 +380,35 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
       // unrolled: the compiler's own counted wait then leaves the group just requested in flight.  (With one register set copied
       // forward per group it waited for everything at the copy -- a memory round trip per group, a third to a half of the time of
       // the layers with a residual: scripts/probe_pw_s1_timeline.py.)  Rows past the end re-read the last row.
-      int m0e = m0, cole = col;
-      asm volatile("" : "+s"(m0e), "+v"(cole));      // the residual addresses are formed HERE, not before the chunk loop (where they would
-                                                     // have to live through it in registers the loop does not have)
-      auto res_addr = [&](int it) {
-        int m = m0e + it * RPI + rsub;
-        m = m < p.M ? m : p.M - 1;
-        size_t ro = (size_t)m;
-        if (p.res_mode == 2) {
-          const int n = m / (p.Ho * p.Wo);
-          const int rem = m - n * (p.Ho * p.Wo);
-          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-          ro = ((size_t)(n * (p.Ho >> 1) + (ho >> 1)) * (p.Wo >> 1) + (wo >> 1));
+      // Residual rows are requested in row order (it = 0, 1, ...): the row -> (image, y, x) decomposition the upsample-add needs is
+      // formed once and then STEPPED by RPI rows (a compare and a subtract instead of two integer divisions per row: those cost the
+      // FPN laterals ~9 k cycles per tile).  Rows past the end re-read the last valid row.
+      int r_m = m0 + rsub;
+      r_m = r_m < p.M ? r_m : p.M - 1;
+      int r_n = 0, r_ho = 0, r_wo = 0;
+      if (p.res_mode == 2) {
+        r_n = r_m / (p.Ho * p.Wo);
+        const int rem = r_m - r_n * (p.Ho * p.Wo);
+        r_ho = rem / p.Wo;
+        r_wo = rem - r_ho * p.Wo;
+      }
+      auto res_next = [&]() {
+        const size_t ro = p.res_mode == 2 ? ((size_t)(r_n * (p.Ho >> 1) + (r_ho >> 1)) * (p.Wo >> 1) + (r_wo >> 1)) : (size_t)r_m;
+        const float* a = p.res + ro * p.ldr + col;
+        if (r_m + RPI < p.M) {
+          r_m += RPI;
+          r_wo += RPI;
+          while (r_wo >= p.Wo) {
+            r_wo -= p.Wo;
+            if (++r_ho == p.Ho) { r_ho = 0; ++r_n; }
+          }
         }
-        return p.res + ro * p.ldr + cole;
+        return a;
       };
       f32x4 rr[2][NG];
       auto res_issue = [&](int set, int g) {
 #pragma unroll
-        for (int i = 0; i < NG; ++i) {
-          rr[set][i] = *reinterpret_cast<const f32x4*>(res_addr(g + i));
-        }
+        for (int i = 0; i < NG; ++i) rr[set][i] = *reinterpret_cast<const f32x4*>(res_next());
       };
       if (has_res) res_issue(0, 0);
       float* Cs = reinterpret_cast<float*>(smem_raw);
