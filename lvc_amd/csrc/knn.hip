@@ -379,15 +379,23 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
   auto load_q = [&]() {
     const float* qr = q + (size_t)row * ldq;
     const float dn = den ? den[row] : 1.f;
+    // every slice of the row (and of mu) is requested before the first is used: one memory round trip, not one per slice (the
+    // bounds test per slice made the compiler wait slice by slice); lanes past D read element 0 and are zeroed
+    float4 m4[NSL];
 #pragma unroll
     for (int sl = 0; sl < NSL; ++sl) {
       const int d = sl * 256 + lane * 4;
-      float4 x = {0.f, 0.f, 0.f, 0.f};
-      if (d < D) {
-        x = *reinterpret_cast<const float4*>(qr + d);
-        if (mu) { const float4 m4 = *reinterpret_cast<const float4*>(mu + d); x.x -= m4.x; x.y -= m4.y; x.z -= m4.z; x.w -= m4.w; }
-        if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
-      }
+      const int dd = d < D ? d : 0;
+      xq[sl] = *reinterpret_cast<const float4*>(qr + dd);
+      m4[sl] = mu ? *reinterpret_cast<const float4*>(mu + dd) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      const int d = sl * 256 + lane * 4;
+      float4 x = xq[sl];
+      if (mu) { x.x -= m4[sl].x; x.y -= m4[sl].y; x.z -= m4[sl].z; x.w -= m4[sl].w; }
+      if (den) { x.x /= dn; x.y /= dn; x.z /= dn; x.w /= dn; }
+      if (!(d < D)) x = float4{0.f, 0.f, 0.f, 0.f};
       xq[sl] = x;
     }
     have_q = true;
