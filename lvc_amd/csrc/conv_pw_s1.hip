@@ -119,6 +119,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
 #ifdef PW_TIMELINE
   // diagnostics build only (scripts/probe_pw_s1_timeline.py): cycles of this wave in a tile's prologue, chunk loop, hand-off, epilogue
   unsigned long long tl_pro = 0, tl_loop = 0, tl_hand = 0, tl_cs = 0, tl_rows = 0, tl_t0 = __builtin_readcyclecounter();
+  unsigned long long tl_wa = 0, tl_wv = 0, tl_wb = 0;   // inside the chunk loop: wait for the activation registers, vmcnt wait, barrier
   unsigned tl_tiles = 0, tl_chunks = 0;
 #endif
 
@@ -269,12 +270,26 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
       const unsigned char* Bcur = sB + k * B_BUF;
       const unsigned char* Bnext = sB + kn * B_BUF;
       // ---- phase A: chunk i+1 (set / buffer kn: last read in phase B of chunk i-2, before the previous barrier) is split and stored
+#ifdef PW_TIMELINE
+      const unsigned long long tl_1 = __builtin_readcyclecounter();
+#endif
       wait_tied<NJ + NI>(ar[kn][0], ar[kn][1], ar[kn][2], ar[kn][3]);
+#ifdef PW_TIMELINE
+      tl_wa += __builtin_readcyclecounter() - tl_1;
+#endif
       step_body(Acur, 0, Bcur, Acur, 1, Bcur);
       store_A(kn, Anext);
       __builtin_amdgcn_sched_barrier(0);
+#ifdef PW_TIMELINE
+      const unsigned long long tl_2 = __builtin_readcyclecounter();
+      wait_vm<NJ>();
+      const unsigned long long tl_3 = __builtin_readcyclecounter();
+      __builtin_amdgcn_s_barrier();
+      tl_wv += tl_3 - tl_2; tl_wb += __builtin_readcyclecounter() - tl_3;
+#else
       wait_vm<NJ>();
       __builtin_amdgcn_s_barrier();
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase B: weights of chunk i+2 into chunk i-1's slot, activations of chunk i+3 into chunk i's registers
       dma_B(min(cc + 2, last), (k + 2) % 3);
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
 #ifdef PW_TIMELINE
   if (lane == 0 && (blockIdx.x & 15) == 0) {
     unsigned long long* d = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(p.partials) + (size_t)512 * 256 * 128 * 4) + ((blockIdx.x >> 4) * 8 + wave) * 16;
-    d[0] = tl_pro; d[1] = tl_loop; d[2] = tl_hand; d[3] = tl_cs; d[4] = tl_rows; d[5] = tl_tiles; d[6] = tl_chunks; d[7] = __builtin_readcyclecounter() - tl_t0; d[8] = 1;
+    d[0] = tl_pro; d[1] = tl_loop; d[2] = tl_hand; d[3] = tl_cs; d[4] = tl_rows; d[5] = tl_tiles; d[6] = tl_chunks; d[7] = __builtin_readcyclecounter() - tl_t0; d[8] = 1; d[9] = tl_wa; d[10] = tl_wv; d[11] = tl_wb;
   }
 #endif
   if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);

@@ -36,7 +36,10 @@ for name, N, H, W, C, K, rm in LAYERS:
     if int(ok.sum()) == 0:
         print("%-22s %.1f us: not on the pipelined kernel" % (name, ms * 1e3)); continue
     r = t[ok, 0]
+    r7 = t[ok, 7]
     tot = r[:, 7].mean()
-    print("%-22s %7.1f us; wave 0 of %2d workgroups: %.1f tiles, %.1f chunks each; prologue %.1f %%, chunk loop %.1f %% (%.0f ticks / chunk), hand-off %.1f %%, accumulators through LDS %.1f %%, output rows %.1f %%; ticks/us %.0f" % (
+    print("%-22s %7.1f us; wave 0 of %2d workgroups: %.1f tiles, %.1f chunks each; prologue %.1f %%, chunk loop %.1f %% (%.0f ticks / chunk), hand-off %.1f %%, accumulators through LDS %.1f %%, output rows %.1f %%; per chunk, wave 0 / wave 7: wait for the activation registers %.0f / %.0f, vmcnt %.0f / %.0f, barrier %.0f / %.0f ticks; ticks/us %.0f" % (
         name, ms * 1e3, int(ok.sum()), r[:, 5].mean(), r[:, 6].mean(), 100 * r[:, 0].mean() / tot, 100 * r[:, 1].mean() / tot, (r[:, 1] / r[:, 6]).mean(),
-        100 * r[:, 2].mean() / tot, 100 * r[:, 3].mean() / tot, 100 * r[:, 4].mean() / tot, t[:, :, 7].max() / (ms * 1e3)))
+        100 * r[:, 2].mean() / tot, 100 * r[:, 3].mean() / tot, 100 * r[:, 4].mean() / tot,
+        (r[:, 9] / r[:, 6]).mean(), (r7[:, 9] / r7[:, 6]).mean(), (r[:, 10] / r[:, 6]).mean(), (r7[:, 10] / r7[:, 6]).mean(), (r[:, 11] / r[:, 6]).mean(), (r7[:, 11] / r7[:, 6]).mean(),
+        t[:, :, 7].max() / (ms * 1e3)))
