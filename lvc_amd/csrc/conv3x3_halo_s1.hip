@@ -481,9 +481,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
               v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
               v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
             }
-#ifdef HALO_TL_NO_STORE     // diagnostics only: what the output-row loop costs without its stores
-            if (v[0] == 123456.f)
-#endif
             *reinterpret_cast<f32x4*>(ybase + (size_t)pix * p.ldy) = v;
           }
         }
