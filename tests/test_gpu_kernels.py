@@ -146,11 +146,15 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, split, monkeypatch):
         (2, 512, 40, 52, 256, 1, 2),     # FPN lateral with top-down upsample-add
         (2, 256, 40, 52, 64, 1, 0),      # narrow output: 64-channel tile of the 256-row shape
         (2, 256, 40, 52, 16, 1, 0),      # RPN-predictor width: 32-channel tile
+        (8, 256, 24, 12, 128, 1, 2),     # upsample-add on a map narrower than a thread's row step (the stepped row decomposition wraps more than once)
+        (2, 256, 40, 52, 64, 1, 1),      # residual on the 64-channel tile of the pipelined kernel
+        (3, 128, 30, 44, 256, 1, 2),     # upsample-add below 256 input channels: the two-accumulator epilogue
     ],
 )
 @pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
 def test_pointwise_shapes_match_cpu(N, C, H, W, K, stride, res_mode, split, monkeypatch):
-    """1x1 layers through the pointwise shapes of the split-precision kernel (csrc/conv_bf16x3.hip) against F.conv2d."""
+    """1x1 layers through the pointwise shapes of the split-precision kernels (csrc/conv_bf16x3.hip; with split = f16x2 and >= 2048
+    output rows the pipelined kernel csrc/conv_pw_s1.hip, whose epilogue has one row loop per residual mode) against F.conv2d."""
     from lvc_amd import kernels as k
 
     monkeypatch.setattr(k, "CONV_SPLIT", split)
