@@ -565,8 +565,8 @@ def infer_main(c, args):
     # one fully bracketed untimed step; ~150 event records per step cost ~0.7 ms of host time inside the timed region),
     # the per-kernel breakdown of every conv/GEMM launch comes from two more untimed steps after it.
     timer = full = None
-    NAMES = {"f16x2_halo": "conv3x3_halo_s1_kernel (pipelined 3x3: one accumulator in the trunk, two in the RPN head)" if K.HALO_S1 else "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise: the layers with a residual / fewer than 256 input channels)",
-             "f16x2_pws1": "conv_pw_s1_kernel (pipelined pointwise / FC: residual-free layers with >= 256 input channels)", "bf16x3_halo": "conv3x3_halo_kernel",
+    NAMES = {"f16x2_halo": "conv3x3_halo_s1_kernel (pipelined 3x3: one accumulator in the trunk, two in the RPN head)" if K.HALO_S1 else "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise: the layers with fewer than 64 input or output channels)",
+             "f16x2_pws1": "conv_pw_s1_kernel (pipelined pointwise / FC: every layer with >= 64 input and output channels)", "bf16x3_halo": "conv3x3_halo_kernel",
              "bf16x3": "conv_bf16x3_kernel (+ bf16 pointwise shapes)", "f32": "conv_igemm_f32_kernel"}
     if not args.no_launch_timer:
         probe = K.LaunchTimer()
