@@ -636,7 +636,7 @@ def infer_main(c, args):
         pmax, _ = _max_and_all(c, pdt)
         pipelined = {"streams": args.pipeline_depth, "value": round(c.world * BATCH_PER_GPU * args.steps / pmax, 2),
                      "unit": "img/s", "ms_per_step": round(1e3 * pmax / args.steps, 3),
-                     "note": "same K steps, batches in flight on 2 HIP streams; results bit-identical (tests/test_gpu_pipeline.py)"}
+                     "note": "same K steps, batches in flight on 2 HIP streams -- what lvc_amd.evaluation.inference_on_dataset does by default (depth=2); results bit-identical (tests/test_gpu_pipeline.py); not `value` because overlapping launches stretch the per-launch times `roofline` is computed from"}
 
     # The same K steps as ONE hipGraph launch each (lvc_amd.evaluation.GraphedInference): what the step costs when the host's
     # launch loop is taken out of it (eight ranks share one host at N = 8).  Not `value`.
