@@ -93,7 +93,9 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
   const int fi = lane & 31, fh = lane >> 5;
   const int q = tid & 7;
   const int arid = tid >> 3;
-  const int hrow = (arid & 1) * 4 + ((arid >> 1) & 3) + (arid >> 3) * 8;    // tile rows hrow + 64 j (conflict-free 80-byte-pitch stores)
+  const int hrow = arid;    // tile rows hrow + 64 j: 32 lanes of a ds_write_b64 cover four consecutive 64-byte rows = the 64 banks once
+                            // (the 3x3 kernel's row order, made for its 80-byte pitch, put rows r and r + 4 -- the same banks -- into one pass:
+                            // SQ_LDS_BANK_CONFLICT was 25 % of the LDS-active cycles on fc1)
 
   const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
   const int wq = p.ngroup > 1 ? lw / p.ngroup : lw;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes over one pointwise layer: probe_pwdma_pmc.sh <tag> N H W C K stride res_mode
+# PMC passes over one pointwise layer (scripts/probe_pw_shape.py runs it; every rocprofv3 call under `timeout`): probe_pwdma_pmc.sh <tag> N H W C K stride res_mode
 cd /tmp; export TMPDIR=/tmp
 tag=$1; shift
 i=0
@@ -8,7 +8,7 @@ for ctr in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum" \
            "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o p$i -- python $GRAFT_REPO_ROOT/scripts/probe_pw_shape.py "$@" > /dev/null 2>&1
+  timeout 120 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag -o p$i -- python $GRAFT_REPO_ROOT/scripts/probe_pw_shape.py "$@" > /dev/null 2>&1
 done
 python - <<PY
 import csv, glob
