@@ -352,22 +352,33 @@ def test_roi_align_nchw_matches_oracle(scale, aligned, sr):
     assert (out - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
 
 
-def test_roi_align_fpn_nhwc_matches_oracle():
+@pytest.mark.parametrize("sr,aligned", [(0, True), (2, False), (0, False), (3, True)])
+def test_roi_align_fpn_nhwc_matches_oracle(sr, aligned):
+    """The engine's all-level NHWC kernel (per-wave sample tables, LDS-staged windows): adaptive grids with hundreds of samples per bin
+    (several table passes), fixed grids, both alignment conventions, and the degenerate RoIs of the NCHW test (zero area, the full
+    image, boxes touching / beyond the border) on every level."""
     from lvc_amd import kernels as k
     from oracle import ops as oops
 
-    g = torch.Generator().manual_seed(12)
+    g = torch.Generator().manual_seed(12 + sr)
     B, C = 2, 256
     scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
     feats = [torch.randn(B, C, int(800 * s), int(1344 * s), generator=g) for s in scales]
     rois = _rand_rois(g, 300, B, 1333, 800)
-    levels = torch.randint(0, 4, (300,), generator=g).int()
+    thin = _rand_rois(g, 60, B, 1333, 800, smin=2.0, smax=12.0)       # a few pixels wide ...
+    thin[:, 4] = (thin[:, 2] + 300 + 400 * torch.rand(60, generator=g)).clamp(max=800)     # ... and hundreds tall (the bench's proposals)
+    extra = torch.tensor([[0, 10, 10, 10, 10], [1, 0, 0, 1333, 800], [0, 1300, 780, 1333, 800], [1, 1332.5, 799.5, 1333, 800],
+                          [0, 0, 0, 0.5, 0.5], [1, 640, 0, 700, 800]], dtype=torch.float32)
+    rois = torch.cat([rois, thin, extra.repeat(4, 1)])
+    n = rois.shape[0]
+    levels = torch.randint(0, 4, (n,), generator=g).int()
+    levels[-24:] = torch.arange(4).repeat_interleave(6).int()         # every degenerate RoI once per level
     d = _dev()
-    out = k.roi_align_fpn_nhwc([_nhwc(f).to(d) for f in feats], scales, rois.to(d), levels.to(d), 7, 7, 0, True)
+    out = k.roi_align_fpn_nhwc([_nhwc(f).to(d) for f in feats], scales, rois.to(d), levels.to(d), 7, 7, sr, aligned)
     out = out.cpu().permute(0, 3, 1, 2)
     for l in range(4):
         sel = (levels == l).nonzero().view(-1)
-        ref = oops.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, 0, True)
+        ref = oops.roi_align_forward(feats[l], rois[sel], scales[l], 7, 7, sr, aligned)
         assert (out[sel] - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
 
 
