@@ -65,11 +65,17 @@ __device__ __forceinline__ void split2s(float a, f16& h, f16& m) {
   m = (f16)((a - (float)h) * 2048.f);
 }
 
-__global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
+__global__ __launch_bounds__(SP_NT, 4) void stem_pool_h2_kernel(StemArgsH p) {     // <= 128 registers: two workgroups (16 waves) per CU
   constexpr int IN_ELEMS = 2 * SP_PLANE_IN;        // 11,552 fp16 = 23,104 B
   constexpr int B_ELEMS = 2 * SP_PLANE_B;          // 5,120 fp16 = 10,240 B per buffer
-  constexpr int CS_OFF = (IN_ELEMS + 2 * B_ELEMS) * 2;
-  constexpr int SMEM_BYTES = CS_OFF + SP_M * SP_CS * 4;   // 43,584 + 66,640 = 110,224
+  // The conv tile of the epilogue (66,640 B) lies OVER the input window and the weight buffers (43,584 B): they are dead while it is
+  // pooled, and 66.6 KB per workgroup lets TWO workgroups share a CU -- one's barriers (a filter row has only 12 MFMAs per wave
+  // between them) and epilogue run under the other's MFMAs.  The next tile's window and first weight row wait in registers until
+  // the pooled rows are out.
+  constexpr int CS_OFF = 0;
+  constexpr int RING_BYTES = (IN_ELEMS + 2 * B_ELEMS) * 2;
+  constexpr int CS_BYTES = SP_M * SP_CS * 4;
+  constexpr int SMEM_BYTES = RING_BYTES > CS_BYTES ? RING_BYTES : CS_BYTES;   // 66,640
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[SMEM_BYTES];
   f16* sIn = reinterpret_cast<f16*>(smem_raw);
   f16* sB = sIn + IN_ELEMS;
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
 
   int range_err = 0;
   f32x4 wreg[SP_NLD];
-  u32x4 breg[1];
+  u32x4 breg[1], breg2;
   auto window_offsets = [&](int tile, unsigned* off) {
     const int tx = tile % p.tiles_x;
     const int t2 = tile / p.tiles_x;
@@ -158,6 +164,11 @@ __global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
                                             wres, b_off + (unsigned)(b_pl0 * p.w_plane_bytes), ld_r * 64, 0));
     ld_r = ld_r == 6 ? 0 : ld_r + 1;
   };
+  auto load_B2 = [&]() {     // the same request into the second register: the row behind the one still waiting in breg
+    breg2 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                          wres, b_off + (unsigned)(b_pl0 * p.w_plane_bytes), ld_r * 64, 0));
+    ld_r = ld_r == 6 ? 0 : ld_r + 1;
+  };
   auto store_B = [&](int buf) {
     f16* sb = sB + buf * B_ELEMS;
     *reinterpret_cast<u32x4*>(sb + b_pl0 * SP_PLANE_B + b_row * SP_LROW + b_q4 * 8) = breg[0];
@@ -203,11 +214,11 @@ __global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
     for (int r = 0; r < 7; ++r) {
       const f16* sb = sB + cur * B_ELEMS;
       read_frags(r * SP_IROW, sb, 0);
-      store_B(cur ^ 1);
+      if (r < 6) store_B(cur ^ 1);      // the next TILE's first row stays in breg: its buffer is under the conv tile until the pooling is done
       mfma_group();
       __builtin_amdgcn_sched_barrier(0);
       read_frags(r * SP_IROW, sb, 1);
-      load_B();
+      if (r < 6) load_B(); else load_B2();
       mfma_group();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -231,8 +242,6 @@ __global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
         }
       }
     const bool more = tile + p.nworkers < p.ntiles;
-    if (more) store_window();    // every wave passed the last tap's barrier: nobody reads the old window
-    if (tile + 2 * p.nworkers < p.ntiles) load_window(tile + 2 * p.nworkers);
     __syncthreads();
     const int cy0 = 2 * ty * SP_PH - 1, cx0 = 2 * tx * SP_PW - 1;   // conv coordinates of the patch origin
     for (int o = tid; o < SP_PH * SP_PW * 16; o += SP_NT) {
@@ -262,6 +271,11 @@ __global__ __launch_bounds__(SP_NT, 2) void stem_pool_h2_kernel(StemArgsH p) {
         if (p.y2) *reinterpret_cast<f32x4*>(p.y2 + ((size_t)(img * p.Hp + py) * p.Wp + px) * p.ldy2 + c4 * 4) = best;
       }
     }
+    __syncthreads();             // the conv tile has been read: its LDS is the window and the weight buffers again
+    if (more) store_window();
+    store_B(cur);                // filter row 0 of the next tile, then row 1 becomes the pending one
+    breg[0] = breg2;
+    if (tile + 2 * p.nworkers < p.ntiles) load_window(tile + 2 * p.nworkers);
     __syncthreads();
   }
   if (range_err && p.err) atomicOr(p.err, 2);
@@ -295,7 +309,7 @@ extern "C" int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned sho
       cus = 256;
     g_cus_stem_h = cus;
   }
-  a.nworkers = a.ntiles < g_cus_stem_h ? a.ntiles : g_cus_stem_h;   // one 129 KB workgroup per CU, tiles dealt round-robin
+  a.nworkers = a.ntiles < 2 * g_cus_stem_h ? a.ntiles : 2 * g_cus_stem_h;   // two 66.6 KB workgroups per CU, tiles dealt round-robin
   hipLaunchKernelGGL(stem_pool_h2_kernel, dim3(a.nworkers), dim3(SP_NT), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
