@@ -200,7 +200,7 @@ __global__ __launch_bounds__(64) void roi_align_fwd_nhwc4_kernel(RoiAlignArgs p)
 #ifndef ROI_TAB
 #define ROI_TAB 32      // samples per pass of a wave's weight / offset table
 #endif
-__global__ __launch_bounds__(512) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArgs p) {
+__global__ __launch_bounds__(512, 8) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArgs p) {
   __shared__ __attribute__((aligned(16))) float win[ROI_LDS_MAX_PIX * 256];
   __shared__ float4 tab_w[8][ROI_TAB];     // per wave (bin): the four bilinear weights of up to 64 in-range samples ...
   __shared__ int4 tab_o[8][ROI_TAB];       // ... and the element offsets of their four taps (into win when staged, else into the level's image)
