@@ -114,6 +114,19 @@ int lvc_conv1x1_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, c
 int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                            const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* Two chained pointwise layers in one launch, the second fed from the first one's accumulators (csrc/conv_pw_chain.hip):
+ *   y1 = act1(x Wa^T * sa + ta (+ residual))   -- a bottleneck's conv3 + FrozenBN + shortcut add + ReLU,
+ *   y2 = act2(y1 Wb^T * sb + tb)               -- the next bottleneck's conv1 + FrozenBN + ReLU,
+ * detectron2/modeling/backbone/resnet.py:205-211 of block i followed by :195-197 of block i+1; both results are stored, y1 is never
+ * read back.  x [M][ldx] (K1 channels), residual [M][ldr] or NULL, y1 [M][ldy1] (N1), y2 [M][ldy2] (N2).  wa [2][wa_rows][K1] /
+ * wb [2][wb_rows][N1]: fp16 planes of lvc_split_weights_rowscaled over weights whose contraction index is permuted within every
+ * 16 entries (0-3, 8-11, 4-7, 12-15); sa / sb = (per-channel scale or 1) x that call's row factors (never NULL); ta / tb shifts
+ * or NULL; relu1 / relu2: 0 none, 1 ReLU.  (K1, N1, N2) in {(64,256,64), (128,256,64), (128,512,128)}.  |x| or |y1| > 4094 (or
+ * NaN) sets bit 1 of the workspace error word. */
+int lvc_conv1x1_chain_nhwc_f16s1(const float* x, int ldx, const unsigned short* wa, int wa_rows, const float* sa, const float* ta,
+                                 const float* residual, int ldr, float* y1, int ldy1, int relu1, const unsigned short* wb,
+                                 int wb_rows, const float* sb, const float* tb, float* y2, int ldy2, int relu2, int M, int K1,
+                                 int N1, int N2, void* workspace, void* stream);
 /* wp [rows][Kg] fp32 (lvc_pack_conv_weights) -> planes_out [2][rows][Kg] fp16: w1 = fp16(wp 2^e), w2 = fp16(wp 2^e - w1) with
  * e = 13 - floor(log2(max |wp[row][:]|)) per row (0 for an all-zero row); row_factor[row] = 2^-(e + 4). */
 int lvc_split_weights_rowscaled(const float* wp, int rows, int Kg, void* planes_out, float* row_factor, void* stream);

@@ -328,6 +328,9 @@ PW_S1 = int(_os.environ.get("LVC_PW_S1", "2"))
 _PW_S1_MIN_C = int(_os.environ.get("LVC_PW_S1_MIN_C", "64"))
 _PW_S1_ONE_MIN_C = int(_os.environ.get("LVC_PW_S1_ONE_MIN_C", "256"))
 _PW_S1_RES = int(_os.environ.get("LVC_PW_S1_RES", "1"))     # 1: layers with a residual / upsample-add operand qualify too
+# inference: conv3 (+ shortcut add + ReLU) of a bottleneck and conv1 (+ ReLU) of the next one as ONE launch (csrc/conv_pw_chain.hip;
+# modeling/backbone/resnet.py `BottleneckBlock.chain_to`); 0 = the two launches
+CHAIN = _os.environ.get("LVC_CHAIN", "1") != "0"
 _HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
@@ -474,6 +477,74 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
     elif act is not None:
         raise ValueError("unknown activation {!r}".format(act))
     return out
+
+
+class PackedChain:
+    """Weights of two chained pointwise layers for lvc_conv1x1_chain_nhwc_f16s1 (csrc/conv_pw_chain.hip)."""
+
+    __slots__ = ("wa", "sa", "ta", "wb", "sb", "tb", "K1", "N1", "N2")
+
+
+_PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+CHAIN_SHAPES = {(64, 256, 64), (128, 256, 64), (128, 512, 128)}
+
+
+def _chain_planes(pc):
+    """Row-scaled fp16 planes of a pointwise layer's packed weights with the contraction index permuted within every 16
+    (position p holds channel 16 * (p // 16) + _PERM16[p % 16]): the order in which an accumulator lane of the transposed MFMA
+    holds a block's channels (csrc/conv_pw_chain.hip)."""
+    assert pc.R == 1 and pc.S == 1 and pc.mode == 0 and pc.stride == 1 and pc.pad == 0
+    rows, Kg = pc.w.shape
+    idx = torch.arange(Kg, device=pc.w.device).view(-1, 16)[:, list(_PERM16)].reshape(-1)
+    wperm = pc.w[:, idx].contiguous()
+    planes = torch.empty((2, rows, Kg), device=pc.w.device, dtype=torch.float16)
+    fac = torch.empty(rows, device=pc.w.device, dtype=torch.float32)
+    check(_lib.lib().lvc_split_weights_rowscaled(ptr(wperm), c_int(rows), c_int(Kg), ptr(planes), ptr(fac), _stream(pc.w)),
+          "lvc_split_weights_rowscaled")
+    fac = fac[: pc.K]
+    return planes, (fac * pc.scale if pc.scale is not None else fac).contiguous()
+
+
+def pack_chain(pc_a, pc_b):
+    """pc_a: the first pointwise layer (K1 -> N1), pc_b: the second (N1 -> N2), both `pack_conv` results of 1x1 layers."""
+    assert pc_b.C == pc_a.K
+    ch = PackedChain()
+    ch.wa, ch.sa = _chain_planes(pc_a)
+    ch.wb, ch.sb = _chain_planes(pc_b)
+    ch.ta, ch.tb = pc_a.shift, pc_b.shift
+    ch.K1, ch.N1, ch.N2 = pc_a.C, pc_a.K, pc_b.K
+    return ch
+
+
+def conv1x1_chain(x, ch, residual=None, relu1=True, relu2=True, out1=None, out2=None):
+    """y1 = act1(x Wa^T * sa + ta (+ residual)), y2 = act2(y1 Wb^T * sb + tb) in one launch; x [..., ldx] NHWC whose first K1
+    channels are the first layer's input (a row stride wider than K1 is allowed).  Returns (y1, y2)."""
+    _req_cuda(x, residual)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] >= ch.K1
+    M = x.numel() // x.shape[-1]
+    lead = tuple(x.shape[:-1])
+    if out1 is None:
+        out1 = torch.empty(lead + (ch.N1,), device=x.device, dtype=torch.float32)
+    if out2 is None:
+        out2 = torch.empty(lead + (ch.N2,), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == torch.float32 and residual.numel() // residual.shape[-1] == M
+    timer = CONV_TIMER
+    if timer is not None and (not timer.active or (timer.only is not None and "f16s1_chain" not in timer.only)):
+        timer = None
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    st = _lib.lib().lvc_conv1x1_chain_nhwc_f16s1(
+        ptr(x), c_int(x.shape[-1]), ptr(ch.wa), c_int(ch.wa.shape[1]), ptr(ch.sa), ptr(ch.ta), ptr(residual),
+        c_int(residual.shape[-1] if residual is not None else 0), ptr(out1), c_int(out1.shape[-1]), c_int(1 if relu1 else 0),
+        ptr(ch.wb), c_int(ch.wb.shape[1]), ptr(ch.sb), ptr(ch.tb), ptr(out2), c_int(out2.shape[-1]), c_int(1 if relu2 else 0),
+        c_int(M), c_int(ch.K1), c_int(ch.N1), c_int(ch.N2), ptr(conv_workspace(x.device)), _stream(x))
+    check(st, "lvc_conv1x1_chain_nhwc_f16s1")
+    if timer is not None:
+        e1.record()
+        timer.records.append((2.0 * M * (ch.K1 * ch.N1 + ch.N1 * ch.N2), e0, e1, "f16s1_chain"))
+    return out1, out2
 
 
 def split_planes_f16x2(w):

@@ -84,17 +84,51 @@ class BottleneckBlock(CNNBlockBase):
             self._cache_fused = _PackedCache()
         return self._cache_fused.get([self.conv3.weight, self.shortcut.weight, a3[0], a3[1], asc[0], asc[1]], build)
 
+    def _grad_free(self):
+        return not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())
+
+    def chain_to(self, nxt, fused_projection):
+        """conv3 (+ shortcut add + ReLU) of this block and conv1 (+ ReLU) of `nxt` as ONE launch (csrc/conv_pw_chain.hip): the
+        4x-wide block output is written once and never read back by conv1.  Returns the packed pair, or None when the pair is
+        outside that kernel's range (gradient passes, a strided conv1, channel counts it has no instance for, a layer that must
+        keep two accumulators, the range-free split)."""
+        if not (K.CHAIN and K.CONV_ENGINE == "bf16x3" and K.CONV_SPLIT == "f16x2" and K.PW_S1 == 2 and nxt is not None
+                and self._grad_free() and nxt._grad_free() and nxt.conv1.stride == 1 and self.conv2.stride == 1
+                and not getattr(self.conv3, "two_acc", False) and not getattr(nxt.conv1, "two_acc", False)):
+            return None
+        k1 = self.conv2.out_channels + (self.in_channels if fused_projection else 0)
+        if (k1, self.out_channels, nxt.conv1.out_channels) not in K.CHAIN_SHAPES:
+            return None
+        if not hasattr(self, "_cache_chain"):
+            from ...layers.wrappers import _PackedCache
+            self._cache_chain = _PackedCache()
+        pa = self._fused_projection() if fused_projection else self.conv3.packed()
+        pb = nxt.conv1.packed()
+        return self._cache_chain.get([pa.w, pa.scale, pa.shift, pb.w, pb.scale, pb.shift], lambda: K.pack_chain(pa, pb))
+
+    def forward_chained(self, x, t, nxt, concat=None):
+        """One block of a stage walked with look-ahead.  x: the block's input; t: conv1's output when the PREVIOUS block's
+        tail already produced it (else None); nxt: the following block of the stage (or None).  Returns (block output,
+        conv1 output of `nxt` or None).  concat: as `forward_nhwc`."""
+        if t is None:
+            t = self.conv1.forward_nhwc(x)
+        if concat is not None:
+            K.conv2d_nhwc(t, self.conv2.packed(), relu=True, out=concat)      # channels [0, bottleneck), row stride = buffer
+            ch = self.chain_to(nxt, True)
+            if ch is not None and concat.numel() < (1 << 29):
+                return K.conv1x1_chain(concat, ch)
+            return K.conv2d_nhwc(concat, self._fused_projection(), relu=True), None
+        z = self.conv2.forward_nhwc(t)
+        shortcut = self.shortcut.forward_nhwc(x) if self.shortcut is not None else x
+        ch = self.chain_to(nxt, False)
+        if ch is not None and shortcut.numel() < (1 << 29):
+            return K.conv1x1_chain(z, ch, residual=shortcut)
+        # conv3 + FrozenBN + residual add + ReLU in one epilogue (reference resnet.py:205-211)
+        return self.conv3.forward_nhwc(z, residual=shortcut, res_mode=1, relu=True), None
+
     def forward_nhwc(self, x, concat=None):
         """concat: [N,H,W, bottleneck + in] buffer whose LAST in_channels already hold x (`can_fuse_projection`)."""
-        if concat is not None:
-            out = self.conv1.forward_nhwc(x)
-            K.conv2d_nhwc(out, self.conv2.packed(), relu=True, out=concat)      # channels [0, bottleneck), row stride = buffer
-            return K.conv2d_nhwc(concat, self._fused_projection(), relu=True)
-        out = self.conv1.forward_nhwc(x)
-        out = self.conv2.forward_nhwc(out)
-        shortcut = self.shortcut.forward_nhwc(x) if self.shortcut is not None else x
-        # conv3 + FrozenBN + residual add + ReLU in one epilogue (reference resnet.py:205-211)
-        return self.conv3.forward_nhwc(out, residual=shortcut, res_mode=1, relu=True)
+        return self.forward_chained(x, None, None, concat=concat)[0]
 
     def forward(self, x):
         return to_nchw_view(self.forward_nhwc(to_nhwc(x)))
@@ -179,11 +213,15 @@ class ResNet(Backbone):
         if "stem" in self._out_features:
             outputs["stem"] = x
         for stage, name in self.stages_and_names:
-            for blk in stage:
-                if blk is first and concat:
-                    x = blk.forward_nhwc(x, concat=concat[0])
-                    continue
-                x = blk.forward_nhwc(x)
+            blocks = list(stage)
+            t = None     # conv1 output of the next block when the previous block's tail launch produced it (BottleneckBlock.chain_to)
+            for i, blk in enumerate(blocks):
+                nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+                if isinstance(blk, BottleneckBlock):
+                    x, t = blk.forward_chained(x, t, nxt if isinstance(nxt, BottleneckBlock) else None,
+                                               concat=concat[0] if (blk is first and concat) else None)
+                else:
+                    x, t = blk.forward_nhwc(x), None
             if name in self._out_features:
                 outputs[name] = x
         return outputs
