@@ -49,7 +49,7 @@ struct ChainArgs {
   const float* tb;           // [N2] or null
   float* y2;                 // [M][ldy2]
   int* flags;
-  int M, ldx, ldr, ldy1, ldy2, relu1, relu2, ngroups, err_index, dbg;
+  int M, ldx, ldr, ldy1, ldy2, relu1, relu2, ngroups, err_index;
   long long wa_plane, wb_plane;   // elements per plane
 };
 
@@ -66,6 +66,12 @@ template <int IMM> __device__ __forceinline__ f32x4 load_untracked(u32x4 rsrc, u
   f32x4 v;
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff), "n"(IMM) : "memory");
   return v;
+}
+// Range tracking pinned in program order (volatile asm): written as plain fmaxf the compiler sank these maxima far below the
+// split, kept the raw input rows alive for them and SPILLED those registers right after the untracked loads were issued --
+// i.e. before their data had arrived.  (The build fails on any spill in this file: csrc/Makefile.)
+__device__ __forceinline__ void track_abs(float& big, float a, float b) {
+  asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(big) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ void tie(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
@@ -176,6 +182,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
   if (ngl == 0) return;
   const int total_stages = ngl * NB1;
   float big = 0.f;
+  // ReLU as ONE v_max against a uniform lower bound (0 or -inf) instead of compare / mask / select per element
+  const float lo1 = p.relu1 ? 0.f : -INFINITY, lo2 = p.relu2 ? 0.f : -INFINITY;
 #pragma unroll
   for (int s = 0; s < NSLOT - 1; ++s) dma_stage(s % NB1, s);
 
@@ -212,12 +220,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
     const unsigned pxn = pixel(gl + 1 < ngl ? gl + 1 : gl);
     // ---- the first layer's B operand: x in the permuted channel order, split once
     f16x8 zh[KS1], zl[KS1];
-    if (p.dbg & 8) {
-      load_x(px);
-      wait_vm<0>();
-    }
     if (gl > 0) {
-      if (p.dbg & 4) wait_vm<0>();
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_X) : "memory");
 #pragma unroll
       for (int s = 0; s < KS1; ++s) asm volatile("" : "+v"(xr[s][0]), "+v"(xr[s][1]));
@@ -249,7 +252,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
       const int slot = t % NSLOT;
       // stage t has landed (this wave's pieces; behind the barrier everybody's), and everybody is done with stage t - 1
       wait_vm<N_DMA>();
-      if (p.dbg & 1) wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       {
         const int tn = t + NSLOT - 1;
@@ -272,7 +274,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, zh[s], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, zh[s], acc, 0, 0, 0);
       }
-      if (p.dbg & 32) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
       if (LAST) {
         // the split planes of x are dead: the next pixel group's rows take their place while this block finishes
         __builtin_amdgcn_sched_barrier(0);
@@ -280,11 +281,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
         if (RES) load_r(rn, pxn, 0);
       }
       if (RES) {
-        if (p.dbg & 2) wait_vm<0>();
-        if (p.dbg & 16) {
-          load_r(rr, px, j);
-          wait_vm<0>();
-        }
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]) : "n"(N_RES + (LAST ? 2 * KS1 : 0)) : "memory");
       }
       // ---- epilogue of block j in the accumulator layout; the result is split into the second layer's B operand
@@ -298,14 +294,15 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
         for (int c = 0; c < 4; ++c) {
           float o = acc[4 * i + c] * sc[c] + sh[c];
           if (RES) o += rr[i][c];
-          if (p.relu1) o = o > 0.f ? o : 0.f;
+          o = fmaxf(o, lo1);
           v[c] = o;
           const float a = o * ACT_SCALE;
           const f16 hh = (f16)a;
           yh[i >> 1][4 * (i & 1) + c] = hh;
           yl[i >> 1][4 * (i & 1) + c] = (f16)(a - (float)hh);
-          big = fmaxf(big, fabsf(o));
         }
+        track_abs(big, v[0], v[1]);
+        track_abs(big, v[2], v[3]);
         store_b128(v, y1res, y1off + 128u * j + 32u * i);
       }
       // ---- second layer: acc2[cb] += Wb[32 cb .. +31][32 j .. +31] . y1_j^T
@@ -331,7 +328,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
     }
     block(NB1 - 1, P1{}, std::true_type{});
     // ---- the second layer's epilogue
-    if (p.dbg & 32) asm volatile("s_nop 15\n s_nop 15\n s_nop 15\n s_nop 15" ::: "memory");
     const unsigned y2off = px * (unsigned)p.ldy2 * 4u + fh * 16u;
 #pragma unroll
     for (int cb = 0; cb < NB2; ++cb)
@@ -343,7 +339,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float o = acc2[cb][4 * i + c] * sc[c] + sh[c];
-          if (p.relu2) o = o > 0.f ? o : 0.f;
+            o = fmaxf(o, lo2);
           v[c] = o;
         }
         store_b128(v, y2res, y2off + 128u * cb + 32u * i);
@@ -388,7 +384,6 @@ extern "C" int lvc_conv1x1_chain_nhwc_f16s1(const float* x, int ldx, const unsig
   a.wa_plane = (long long)wa_rows * K1; a.wb_plane = (long long)wb_rows * N1;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS;
-  { const char* e = getenv("LVC_CHAIN_DBG"); a.dbg = e ? atoi(e) : 0; }
   if (g_cus_chain == 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -396,16 +391,6 @@ extern "C" int lvc_conv1x1_chain_nhwc_f16s1(const float* x, int ldx, const unsig
     g_cus_chain = cus;
   }
   hipStream_t st = (hipStream_t)stream;
-  static const int nw_env = [] { const char* e = getenv("LVC_CHAIN_NW"); return e ? atoi(e) : 4; }();
-  if (nw_env == 8) {
-    constexpr int NW = 8;
-    a.ngroups = lvc_cdiv(M, 32 * NW);
-    if (K1 == 64 && N1 == 256 && N2 == 64) chain_launch<64, 256, 64, NW, 3>(a, 1, st);
-    else if (K1 == 128 && N1 == 256 && N2 == 64) chain_launch<128, 256, 64, NW, 3>(a, 1, st);
-    else if (K1 == 128 && N1 == 512 && N2 == 128) chain_launch<128, 512, 128, NW, 3>(a, 1, st);
-    LVC_CHECK_LAUNCH();
-    return LVC_OK;
-  }
   constexpr int NW = 4;
   a.ngroups = lvc_cdiv(M, 32 * NW);
   if (K1 == 64 && N1 == 256 && N2 == 64) chain_launch<64, 256, 64, NW, 3>(a, 2, st);
