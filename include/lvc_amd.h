@@ -56,6 +56,14 @@ void lvc_set_error(const char* fmt, ...);
  *                             stream-K decomposition); launches on different streams need different workspaces
  */
 long long lvc_conv_workspace_bytes(void);
+/* Per-layer range words.  The workspace ends in lvc_range_slots() int32 words behind the worker flags (byte offset
+ * 1024*256*128*4 + 1024*4).  Word 0 is the shared error word (bit 0: a stream-K worker timed out; bit 1: an operand left a
+ * two-way fp16 split kernel's range).  lvc_set_range_slot(s), 0 < s < lvc_range_slots(), makes the fp16-split conv/GEMM
+ * launches that follow ON THE CALLING THREAD raise their bits in word s instead, so the host can re-route exactly the layer
+ * that overflowed (lvc_amd.kernels.check_conv_error_word); 0 restores the shared word. */
+void lvc_set_range_slot(int slot);
+int lvc_range_slot(void);
+int lvc_range_slots(void);
 int lvc_conv2d_nhwc_f32(const float* x, const float* w_packed, const float* scale, const float* shift,
                         const float* residual, float* y, int N, int H, int W, int C, int K, int R, int S,
                         int stride, int pad, int Kg, int relu, int res_mode, int ldy, int ldr, int mode,

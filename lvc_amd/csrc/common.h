@@ -11,6 +11,7 @@
 #define LVC_ERR_DOMAIN 3    // data-dependent precondition violated (e.g. negative RoI size)
 
 extern "C" void lvc_set_error(const char* fmt, ...);
+extern "C" int lvc_range_slot(void);   // see common.cpp
 
 #define LVC_CHECK_ARG(cond, msg)                       \
   do {                                                 \

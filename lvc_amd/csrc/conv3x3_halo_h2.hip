@@ -459,7 +459,7 @@ extern "C" int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_sp
   a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker) * a.ngroup;
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
-  a.err_index = LVC_MAX_WORKERS;
+  a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
   if (ni == 1)
     hipLaunchKernelGGL((conv3x3_halo_h2_kernel<1>), dim3(a.nworkers), dim3(NT), 0, (hipStream_t)stream, a);
   else

@@ -414,7 +414,7 @@ static int worker_capacity() {
 // zero-initialised once by the caller and must not be shared by launches that run concurrently on
 // different streams.
 extern "C" long long lvc_conv_workspace_bytes(void) {
-  return (long long)LVC_MAX_WORKERS * 256 * 128 * 4 + (LVC_MAX_WORKERS + 1) * 4 + 256;
+  return (long long)LVC_MAX_WORKERS * 256 * 128 * 4 + (LVC_MAX_WORKERS + 1024) * 4 + 256;   // worker flags, then 1024 range / error words
 }
 
 // C ABI -- see include/lvc_amd.h for the contract of each argument.

@@ -383,7 +383,7 @@ extern "C" int lvc_conv1x1_chain_nhwc_f16s1(const float* x, int ldx, const unsig
   a.M = M; a.ldx = ldx; a.ldr = ldr; a.ldy1 = ldy1; a.ldy2 = ldy2; a.relu1 = relu1; a.relu2 = relu2;
   a.wa_plane = (long long)wa_rows * K1; a.wb_plane = (long long)wb_rows * N1;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
-  a.err_index = LVC_MAX_WORKERS;
+  a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
   if (g_cus_chain == 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)

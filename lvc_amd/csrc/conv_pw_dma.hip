@@ -485,7 +485,7 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker) * a.ngroup;
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
-  a.err_index = LVC_MAX_WORKERS;
+  a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
   // timeline stamps (experiments): the upper half of the partial-tile area is never used by <= 256 workers
   static const int timeline = [] { const char* e = getenv("LVC_PW_TIMELINE"); return e ? atoi(e) : 0; }();
   a.dbg = timeline ? (unsigned long long*)((char*)workspace + (size_t)512 * 256 * 128 * 4) : nullptr;

@@ -672,7 +672,7 @@ static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_spl
   a.nworkers = (int)((units + a.units_per_worker - 1) / a.units_per_worker) * a.ngroup;
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
-  a.err_index = LVC_MAX_WORKERS;
+  a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
   hipStream_t st = (hipStream_t)stream;
   if (oneacc) {
     if (ni == 1) hipLaunchKernelGGL((conv_pw_s1_kernel<1, true>), dim3(a.nworkers), dim3(NT), 0, st, a);

@@ -21,9 +21,10 @@ from .modeling.roi_heads.roi_heads import CandidateOverflow, instances_from_batc
 
 
 def _limits(model):
-    """The widenable limits a pass is launched under (`roi_heads.widen_limits`): (candidate-list capacity, operand split)."""
+    """The widenable limits a pass is launched under (`roi_heads.widen_limits`): (candidate-list capacity, operand split, how often
+    layers have been re-routed to a wider range tier)."""
     heads = getattr(model, "roi_heads", None)
-    return (getattr(heads, "det_max_candidates", None), K.CONV_SPLIT)
+    return (getattr(heads, "det_max_candidates", None), K.CONV_SPLIT, K.RANGE_EPOCH)
 
 
 class PipelinedInference:
@@ -39,6 +40,9 @@ class PipelinedInference:
         uncollected batch at a time (its status / error words are per stream), so at most `depth` tickets are open.
         collectable=False: a throughput-only launch (timing loops) whose results are never read; no ticket."""
         k = self._n % len(self.streams)
+        if self._busy[k]:      # either kind of launch would share the open ticket's status / range words
+            raise RuntimeError("PipelinedInference: collect() the oldest ticket before submitting batch %d "
+                               "(depth %d)" % (self._n, len(self.streams)))
         if not collectable:
             s = self.streams[k]
             self._n += 1
@@ -46,9 +50,6 @@ class PipelinedInference:
             with torch.cuda.stream(s), torch.no_grad():
                 self.model.inference_batched(batched_inputs, do_postprocess)
             return None
-        if self._busy[k]:
-            raise RuntimeError("PipelinedInference: collect() the oldest ticket before submitting batch %d "
-                               "(depth %d)" % (self._n, len(self.streams)))
         s = self.streams[k]
         self._n += 1
         self._busy[k] = True
@@ -67,19 +68,20 @@ class PipelinedInference:
         (ob, osc, ocl, cnt, status), s, sizes, batched_inputs, do_postprocess, k, limits = ticket
         cur = torch.cuda.current_stream(self.model.device)
         rerun = False
-        with torch.cuda.stream(s):
-            try:
-                insts = instances_from_batched(ob, osc, ocl, cnt, sizes, status)   # one D2H read on that stream
-            except (CandidateOverflow, K.Fp16RangeError) as e:
-                # a limit the reference does not have was hit by this batch.  Widen it (a no-op when an earlier ticket
-                # already did) and run the batch again if it was LAUNCHED under narrower limits than the current ones --
-                # batches submitted before the widening overflow one after the other and each needs its own re-run.
-                widen_limits(self.model, e)
-                if _limits(self.model) == limits:
-                    self._busy[k] = False
-                    raise
-                rerun = True
-        self._busy[k] = False
+        try:
+            with torch.cuda.stream(s):
+                try:
+                    insts = instances_from_batched(ob, osc, ocl, cnt, sizes, status)   # one D2H read on that stream
+                except (CandidateOverflow, K.Fp16RangeError) as e:
+                    # a limit the reference does not have was hit by this batch.  Widen it (a no-op when an earlier ticket
+                    # already did) and run the batch again if it was LAUNCHED under narrower limits than the current ones --
+                    # batches submitted before the widening overflow one after the other and each needs its own re-run.
+                    widen_limits(self.model, e)
+                    if _limits(self.model) == limits:
+                        raise
+                    rerun = True
+        finally:
+            self._busy[k] = False      # whatever the read raised (timeout, status word): the stream is free for the next ticket
         # the results were allocated and written on the side stream: order the caller's stream behind it
         cur.wait_stream(s)
         if rerun:
@@ -145,8 +147,17 @@ class GraphedInference:
         return self.out
 
     def instances(self):
+        """One D2H read of the counts, the status word and the conv kernels' error words -- of the CAPTURE stream's workspace
+        (`kernels.conv_workspace` is per stream, and the graph baked that stream's pointer in)."""
         ob, osc, ocl, cnt, status = self.out
-        return [{"instances": r} for r in instances_from_batched(ob, osc, ocl, cnt, self.sizes, status)]
+        cur = torch.cuda.current_stream(self.model.device)
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_stream(cur)       # replay() was issued on the caller's stream
+            try:
+                insts = instances_from_batched(ob, osc, ocl, cnt, self.sizes, status)
+            finally:
+                cur.wait_stream(self.stream)
+        return [{"instances": r} for r in insts]
 
 
 def inference_on_dataset(model, data_loader, depth=2):

@@ -33,7 +33,8 @@ class PackedConv:
     scale/shift: y = conv * scale + shift  (FrozenBN fold and/or bias), or None.
     """
 
-    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h", "_w2s", "two_acc")
+    __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h", "_w2s", "two_acc",
+                 "slot", "state", "last_one", "__weakref__")
 
     def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
         self.w, self.scale, self.shift = w, scale, shift
@@ -42,6 +43,12 @@ class PackedConv:
         self._w2h = None
         self._w2s = None
         self.two_acc = False   # True: never the single-accumulator form of the 3x3 fp16-split kernel (see HALO_S1)
+        # range routing of THIS layer (`check_conv_error_word`): its own range word in the workspace, and the tier it runs on --
+        # 0: as configured (one accumulator where the policy allows it, |a| <= 4094), 1: two accumulators (|a| <= 65504),
+        # 2: the range-free bf16x3 kernels.  `state` may be a dict the owning module keeps across re-packs.
+        self.slot = _new_range_slot(self)
+        self.state = {"tier": 0}
+        self.last_one = False
 
     def _split(self, planes):
         n = self.w.numel()
@@ -81,6 +88,25 @@ class PackedConv:
             fac = fac[: self.K]
             self._w2s = (planes, (fac * self.scale if self.scale is not None else fac).contiguous())
         return self._w2s
+
+
+_RANGE_SLOTS = 1024
+_NEXT_SLOT = [0]
+_SLOT_OWNERS = {}
+RANGE_EPOCH = 0      # counts the re-routings: passes launched under an older epoch ran on the narrower kernels
+
+
+def _new_range_slot(owner):
+    """Slots 1 .. 1023, handed out round-robin; a slot shared by two layers (more than 1023 packed layers alive) only makes
+    the re-routing coarser (both move to the wider tier)."""
+    import weakref
+
+    _NEXT_SLOT[0] = _NEXT_SLOT[0] % (_RANGE_SLOTS - 1) + 1
+    slot = _NEXT_SLOT[0]
+    owners = [r for r in _SLOT_OWNERS.get(slot, []) if r() is not None]
+    owners.append(weakref.ref(owner))
+    _SLOT_OWNERS[slot] = owners
+    return slot
 
 
 def conv_affine(bias=None, bn=None, eps=1e-5):
@@ -196,26 +222,38 @@ def conv_workspace(device):
     return ws
 
 
+_ERR_OFF = 1024 * 256 * 128 * 4 + 1024 * 4      # byte offset of the range / error words: word 0 = shared, words 1.. = per layer
+
+
 def _conv_error_view(device):
     ws = conv_workspace(device)
-    return ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4]
+    return ws[_ERR_OFF: _ERR_OFF + 4]
+
+
+def _range_words(device):
+    ws = conv_workspace(device)
+    return ws[_ERR_OFF: _ERR_OFF + 4 * _RANGE_SLOTS].view(torch.int32)
 
 
 def conv_error_word(device):
-    """The kernel's spin-timeout word (0 = fine); reading it synchronises."""
-    ws = conv_workspace(device)
-    return int(ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4].view(torch.int32).item())
+    """OR of the kernels' error words (0 = fine; bit 0: spin timeout, bit 1: operand range); reading it synchronises."""
+    e = 0
+    for w in _range_words(device).tolist():
+        e |= w
+    return e
 
 
 def clear_conv_error_word(device):
-    ws = conv_workspace(device)
-    ws[1024 * 256 * 128 * 4 + 1024 * 4: 1024 * 256 * 128 * 4 + 1024 * 4 + 4].zero_()
+    _range_words(device).zero_()
 
 
 class Fp16RangeError(LvcNativeError):
-    """An operand beyond fp16's range (|a| > 65504, or NaN) reached a two-way fp16 split kernel: the results of that
-    pass are invalid.  The model entry points catch it, switch to the range-free three-way bf16 split
-    (`use_range_free_split`) and run the pass again."""
+    """An operand beyond the range of a two-way fp16 split kernel reached it (|a| > 4094 on the single-accumulator form,
+    > 65504 on the two-accumulator form, or NaN): the results of that pass are invalid.  `rerouted`: the layers that raised
+    their own range word were moved to the next wider form (`check_conv_error_word`); the model entry points run the pass
+    again.  Otherwise (shared word: stem, weights, descriptor network) they switch the process to the bf16x3 kernels."""
+
+    rerouted = False
 
 
 _RANGE_FALLBACK_LOGGED = False
@@ -232,7 +270,9 @@ def _log_once(key, msg, *args):
 
 def use_range_free_split(reason=""):
     """Switch every conv/GEMM of this process from the two-way fp16 split to the exact three-way bf16 split (no range
-    limit, ~1.5x slower); logged once.  Packed layers keep both plane sets lazily, so this takes effect at the next call."""
+    limit, ~1.5x slower); logged once.  Packed layers keep both plane sets lazily, so this takes effect at the next call.
+    Only for conditions that cannot be pinned on one layer (the shared error word); a layer that overflows its own range
+    word is re-routed alone (`check_conv_error_word`)."""
     global CONV_SPLIT, _RANGE_FALLBACK_LOGGED
     CONV_SPLIT = "bf16x3"
     if not _RANGE_FALLBACK_LOGGED:
@@ -240,21 +280,53 @@ def use_range_free_split(reason=""):
         import logging
 
         logging.getLogger("lvc_amd").warning(
-            "an operand beyond fp16's range (|a| > 65504 or NaN) reached the fp16x2 conv kernels%s; re-running on the "
-            "range-free bf16x3 kernels and keeping them for the rest of the process", (" (" + reason + ")") if reason else "")
+            "an operand beyond fp16's range (|a| > 65504 or NaN) reached an fp16x2 kernel that has no per-layer range word%s; "
+            "re-running on the range-free bf16x3 kernels and keeping them for the rest of the process", (" (" + reason + ")") if reason else "")
 
 
 def check_conv_error_word(device):
-    """Raise for a set bit of the conv workspace error word (bit 0: a stream-K worker timed out waiting for a partial
-    tile; bit 1: an operand beyond fp16's range reached a two-way fp16 split kernel -> Fp16RangeError, which the model
-    entry points turn into a re-run on the bf16x3 kernels).  Synchronises: call it where the results are read anyway."""
-    e = conv_error_word(device)
-    if e & 1:
+    """Raise for a set bit of the conv workspace's error words.  Bit 0 (any word): a stream-K worker timed out waiting for a
+    partial tile.  Bit 1 of a LAYER's word: an activation left the range of the form that layer ran on -> the layer moves to
+    the next wider one -- single accumulator (|a| <= 4094) -> two accumulators (|a| <= 65504) -> bf16x3 (no limit) -- and
+    stays there; every other layer keeps its kernels.  Bit 1 of the shared word: `Fp16RangeError` without `rerouted`
+    (process-wide bf16x3, `use_range_free_split`).  The words are cleared: every pass is judged on its own.
+    Synchronises: call it where the results are read anyway."""
+    global RANGE_EPOCH
+    words = _range_words(device).tolist()
+    if not any(words):
+        return
+    if any(w & 1 for w in words):
         raise LvcNativeError("conv/GEMM kernel: a stream-K worker timed out waiting for a partial tile")
-    if e & 2:
-        clear_conv_error_word(device)
-        raise Fp16RangeError("conv/GEMM kernel: an operand with |a| > 65504 (or NaN) reached the fp16x2 split; "
-                             "set LVC_CONV_SPLIT=bf16x3 for range-free kernels")
+    clear_conv_error_word(device)
+    moved = []
+    for slot in range(1, _RANGE_SLOTS):
+        if words[slot] & 2:
+            for ref in _SLOT_OWNERS.get(slot, []):
+                o = ref()
+                if o is None:
+                    continue
+                if isinstance(o, PackedChain):
+                    if not o.state.get("off"):
+                        o.state["off"] = True
+                        moved.append("chained pair %dx%d->%d->%d: two launches" % (o.K1, o.N1, o.N1, o.N2))
+                    continue
+                tier = o.state["tier"]
+                new = 1 if (o.last_one and tier < 1) else 2
+                if new > tier:
+                    o.state["tier"] = new
+                    moved.append("%dx%d %d->%d: |a| > %s -> %s" % (o.R, o.S, o.C, o.K, "4094" if o.last_one else "65504",
+                                                                   "two accumulators" if new == 1 else "bf16x3"))
+    if moved:
+        RANGE_EPOCH += 1
+        import logging
+
+        logging.getLogger("lvc_amd").warning("activation range: %d layer(s) re-routed and kept there (%s); re-running the pass",
+                                             len(moved), "; ".join(moved[:8]))
+    e = Fp16RangeError("conv/GEMM kernel: an operand beyond the range of the fp16 split form it ran on (|a| > 4094 single-accumulator, "
+                       "> 65504 two-accumulator, or NaN)" + ("; the layers concerned were moved to the next wider form" if moved else
+                                                             "; set LVC_CONV_SPLIT=bf16x3 for range-free kernels"))
+    e.rerouted = bool(moved) and not (words[0] & 2)
+    raise e
 
 
 class LaunchTimer:
@@ -368,6 +440,12 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
                         out=out[n0:n1], split=split, act=act)
         return out
     ldr = residual.shape[-1] if residual is not None else 0
+    # this layer's range tier (check_conv_error_word): 1 = two accumulators, 2 = the range-free bf16x3 kernels
+    tier = pc.state["tier"] if split is None else 0
+    two_acc = pc.two_acc or tier >= 1
+    if tier >= 2:
+        split = "bf16x3"
+    slotted = False
     engine = "f32"
     halo = CONV_HALO and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C % 32 == 0
     # narrow 1x1 layers (256 -> 64 reductions, the 15-channel RPN predictors) go to the 64- / 32-channel tiles of the
@@ -379,6 +457,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         h2_pw = (not halo and (split or CONV_SPLIT) == "f16x2" and pc.R == 1 and pc.S == 1 and pc.pad == 0 and pc.C >= _H2_PW_MIN_C
                  and N * Ho * Wo >= 2048)   # the 256-row pointwise shape; 64-channel streams stay bf16x3 (f16x2 there: 0.312 vs 0.335 ms alone, no gain end to end)
         engine = "f16x2_halo" if h2_halo else "f16x2_pw" if h2_pw else "bf16x3_halo" if halo else "bf16x3"
+        if engine.startswith("f16x2") and tier < 2 and split is None:
+            _lib.lib().lvc_set_range_slot(c_int(pc.slot))     # this launch raises the LAYER's range word
+            slotted = True
+            pc.last_one = False
         if (engine == "f16x2_pw" and PW_S1 and split is None and pc.C >= _PW_S1_MIN_C and pc.K >= 64 and (residual is None or _PW_S1_RES)
                 and out.numel() < (1 << 29)):
             engine = "f16x2_pws1"     # >= 64 input channels: the pipelined pointwise kernel (csrc/conv_pw_s1.hip)
@@ -389,8 +471,9 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not pc.two_acc:
+        if engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not two_acc:
             planes, scale2 = pc.split2s()
+            pc.last_one = True
             st = _lib.lib().lvc_conv3x3_nhwc_f16s1(
                 ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(residual), ptr(out),
                 c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0),
@@ -419,7 +502,8 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
             # conv1 -10..15 %, the memory-bound res2 / res3 conv3 -2..9 % since its epilogue stopped serialising rows:
             # scripts/probe_pw_set.py); precision policy as for the 3x3 layers, and the layers with < 256 input channels keep the
             # two-accumulator form -- bit-identical to the LDS-DMA kernel they ran on before (they are memory-bound: the form costs nothing)
-            one = PW_S1 == 2 and not pc.two_acc and C >= _PW_S1_ONE_MIN_C
+            one = PW_S1 == 2 and not two_acc and C >= _PW_S1_ONE_MIN_C
+            pc.last_one = one
             fused_act = act == "gelu" and not relu
             if fused_act:
                 act = None
@@ -468,6 +552,8 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
             c_int(pc.stride), c_int(pc.pad), c_int(pc.Kg), c_int(1 if relu else 0), c_int(res_mode),
             c_int(out.shape[-1]), c_int(ldr), c_int(pc.mode), ptr(conv_workspace(x.device)), _stream(x))
         check(st, "lvc_conv2d_nhwc_f32")
+    if slotted:
+        _lib.lib().lvc_set_range_slot(c_int(0))
     if timer is not None:
         e1.record()
         c_real = 3 if pc.mode == 1 else C
@@ -482,7 +568,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
 class PackedChain:
     """Weights of two chained pointwise layers for lvc_conv1x1_chain_nhwc_f16s1 (csrc/conv_pw_chain.hip)."""
 
-    __slots__ = ("wa", "sa", "ta", "wb", "sb", "tb", "K1", "N1", "N2")
+    __slots__ = ("wa", "sa", "ta", "wb", "sb", "tb", "K1", "N1", "N2", "slot", "state", "__weakref__")
 
 
 _PERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
@@ -505,10 +591,14 @@ def _chain_planes(pc):
     return planes, (fac * pc.scale if pc.scale is not None else fac).contiguous()
 
 
-def pack_chain(pc_a, pc_b):
-    """pc_a: the first pointwise layer (K1 -> N1), pc_b: the second (N1 -> N2), both `pack_conv` results of 1x1 layers."""
+def pack_chain(pc_a, pc_b, state=None):
+    """pc_a: the first pointwise layer (K1 -> N1), pc_b: the second (N1 -> N2), both `pack_conv` results of 1x1 layers.
+    state: a dict the owner keeps across re-packs; state["off"] is set when the pair overflowed the kernel's range
+    (|a| > 4094 for its input or the intermediate: `check_conv_error_word`) and must run as two launches from then on."""
     assert pc_b.C == pc_a.K
     ch = PackedChain()
+    ch.slot = _new_range_slot(ch)
+    ch.state = state if state is not None else {"off": False}
     ch.wa, ch.sa = _chain_planes(pc_a)
     ch.wb, ch.sb = _chain_planes(pc_b)
     ch.ta, ch.tb = pc_a.shift, pc_b.shift
@@ -535,11 +625,13 @@ def conv1x1_chain(x, ch, residual=None, relu1=True, relu2=True, out1=None, out2=
     if timer is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    _lib.lib().lvc_set_range_slot(c_int(ch.slot))
     st = _lib.lib().lvc_conv1x1_chain_nhwc_f16s1(
         ptr(x), c_int(x.shape[-1]), ptr(ch.wa), c_int(ch.wa.shape[1]), ptr(ch.sa), ptr(ch.ta), ptr(residual),
         c_int(residual.shape[-1] if residual is not None else 0), ptr(out1), c_int(out1.shape[-1]), c_int(1 if relu1 else 0),
         ptr(ch.wb), c_int(ch.wb.shape[1]), ptr(ch.sb), ptr(ch.tb), ptr(out2), c_int(out2.shape[-1]), c_int(1 if relu2 else 0),
         c_int(M), c_int(ch.K1), c_int(ch.N1), c_int(ch.N2), ptr(conv_workspace(x.device)), _stream(x))
+    _lib.lib().lvc_set_range_slot(c_int(0))
     check(st, "lvc_conv1x1_chain_nhwc_f16s1")
     if timer is not None:
         e1.record()

@@ -60,6 +60,7 @@ class Conv2d(nn.Module):
         self._cache = _PackedCache()
         self._cache_dgrad = _PackedCache()
         self._cache_affine = _PackedCache()
+        self._range_state = {"tier": 0}      # this layer's range tier survives re-packs (kernels.check_conv_error_word)
 
     def _affine(self):
         """FrozenBN fold / bias of the epilogue; rebuilt only when one of ITS tensors changes (not on every
@@ -81,6 +82,7 @@ class Conv2d(nn.Module):
         # precision policy of the 3x3 fp16-split kernel (kernels.HALO_S1): a layer whose output feeds discrete decisions sets
         # `two_acc` and keeps the main + cross accumulator form (the RPN head: objectness / deltas -> top-k, NMS)
         pc.two_acc = bool(getattr(self, "two_acc", False))
+        pc.state = self._range_state
         return pc
 
     def packed_dgrad(self):
@@ -194,9 +196,12 @@ class Linear(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features)) if bias else None
         nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
         self._cache = _PackedCache()
+        self._range_state = {"tier": 0}
 
     def packed(self):
-        return self._cache.get([self.weight, self.bias], lambda: K.pack_linear(self.weight, self.bias))   # two_acc: kernels.pack_linear
+        pc = self._cache.get([self.weight, self.bias], lambda: K.pack_linear(self.weight, self.bias))   # two_acc: kernels.pack_linear
+        pc.state = self._range_state
+        return pc
 
     def forward(self, x, relu=False):
         require_device(x, "Linear")

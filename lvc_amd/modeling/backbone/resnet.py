@@ -102,9 +102,12 @@ class BottleneckBlock(CNNBlockBase):
         if not hasattr(self, "_cache_chain"):
             from ...layers.wrappers import _PackedCache
             self._cache_chain = _PackedCache()
+            self._chain_state = {"off": False}
+        if self._chain_state["off"] or self.conv3._range_state["tier"] or nxt.conv1._range_state["tier"]:
+            return None     # the pair left the chain kernel's range once (|a| > 4094): two launches on their own tiers from then on
         pa = self._fused_projection() if fused_projection else self.conv3.packed()
         pb = nxt.conv1.packed()
-        return self._cache_chain.get([pa.w, pa.scale, pa.shift, pb.w, pb.scale, pb.shift], lambda: K.pack_chain(pa, pb))
+        return self._cache_chain.get([pa.w, pa.scale, pa.shift, pb.w, pb.scale, pb.shift], lambda: K.pack_chain(pa, pb, self._chain_state))
 
     def forward_chained(self, x, t, nxt, concat=None):
         """One block of a stage walked with look-ahead.  x: the block's input; t: conv1's output when the PREVIOUS block's

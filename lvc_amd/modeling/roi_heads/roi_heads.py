@@ -302,6 +302,8 @@ def widen_limits(model, exc):
         heads.det_max_candidates = None
         return True
     if isinstance(exc, K.Fp16RangeError):
+        if exc.rerouted:       # the layers that overflowed were moved to their next wider form (kernels.check_conv_error_word)
+            return True
         if K.CONV_SPLIT == "bf16x3":
             return False
         K.use_range_free_split()
@@ -312,7 +314,7 @@ def widen_limits(model, exc):
 def run_with_fallbacks(model, fn):
     """Run fn() (one pass that ends by reading the status words); on CandidateOverflow / Fp16RangeError widen the limit
     (`widen_limits`) and run again -- the pass degrades (one repeated batch, slower kernels) instead of failing."""
-    for _ in range(2):
+    for _ in range(8):     # a pass may move layers up one tier at a time (one accumulator -> two -> bf16x3), a few layers per pass
         try:
             return fn()
         except (CandidateOverflow, K.Fp16RangeError) as e:

@@ -1,0 +1,130 @@
+"""Activation range of the two-way fp16 split kernels, per layer (kernels.check_conv_error_word).
+
+The reference computes in fp32 (detectron2/layers/wrappers.py:41-99): no activation range.  Here a layer runs on the
+single-accumulator fp16 split (|a| <= 4094), and when ITS range word is raised it alone moves to the two-accumulator form
+(|a| <= 65504), then to the range-free bf16x3 kernels -- and stays there; every other layer keeps its kernels; the pass is
+repeated; the words are cleared per pass.  Planted here: a 5000 in one channel of res4's output (consumers: res5.0.conv1, the
+res5.0 projection shortcut, FPN lateral 4) and a 1e5 in one channel of res5's output (consumer: FPN lateral 5); the consumers'
+weights for that channel are scaled down so that everything behind them stays O(1)."""
+import time
+
+import pytest
+import torch
+
+from helpers import match_fraction, r50_state_dict
+
+pytestmark = pytest.mark.gpu
+
+CH4, CH5 = 37, 1001       # the planted channels of res4 / res5 outputs
+
+
+def _planted_state_dict():
+    sd = {k: v.clone() for k, v in r50_state_dict().items()}
+    bu = "backbone.bottom_up."
+    # FrozenBN bias of the last conv3 of res4 / res5: the block output (after the shortcut add and ReLU) gains +5000 / +1e5
+    sd[bu + "res4.5.conv3.norm.bias"][CH4] += 5000.0
+    sd[bu + "res5.2.conv3.norm.bias"][CH5] += 1.0e5
+    # consumers: keep what they make of that channel O(1)
+    for k in (bu + "res5.0.conv1.weight", bu + "res5.0.shortcut.weight", "backbone.fpn_lateral4.weight"):
+        sd[k][:, CH4] *= 1e-4
+    sd["backbone.fpn_lateral5.weight"][:, CH5] *= 1e-6
+    return sd
+
+
+def _model(sd):
+    from test_gpu_e2e import _model as base
+
+    m = base()
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def _tiers(model):
+    from lvc_amd.layers.wrappers import Conv2d, Linear
+
+    return {n: mod._range_state["tier"] for n, mod in model.named_modules() if isinstance(mod, (Conv2d, Linear)) and mod._range_state["tier"]}
+
+
+def test_only_the_overflowing_layers_are_rerouted_and_results_match_the_oracle():
+    from lvc_amd import kernels as K
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+
+    sd = _planted_state_dict()
+    model = _model(sd)
+    # full-size images: on small maps (fewer than 2048 output pixels) these layers run on the bf16x3 kernels, which have no range
+    inputs = [{"image": syn.synthetic_image(1), "height": 800, "width": 1333}, {"image": syn.synthetic_image(2), "height": 800, "width": 1333}]
+    split0, epoch0 = K.CONV_SPLIT, K.RANGE_EPOCH
+    with torch.no_grad():
+        out = model(inputs)
+    assert K.CONV_SPLIT == split0, "the process-wide fallback must not fire for a layer-local overflow"
+    assert K.RANGE_EPOCH > epoch0
+    tiers = _tiers(model)
+    print("re-routed layers:", tiers)
+    assert tiers == {"backbone.bottom_up.res5.0.conv1": 1, "backbone.bottom_up.res5.0.shortcut": 1, "backbone.fpn_lateral4": 1,
+                     "backbone.fpn_lateral5": 2}, tiers
+    # a second pass: nothing moves, nothing is repeated
+    epoch1 = K.RANGE_EPOCH
+    with torch.no_grad():
+        out2 = model(inputs)
+    assert K.RANGE_EPOCH == epoch1 and _tiers(model) == tiers
+    ref = orc.generalized_rcnn_inference({k: v.cpu() for k, v in sd.items()}, orc.RCNNSpec(), inputs)
+    for o, o2, r in zip(out, out2, ref):
+        inst = o["instances"].to("cpu")
+        assert torch.equal(inst.pred_boxes.tensor, o2["instances"].to("cpu").pred_boxes.tensor)
+        frac, wb, ws = match_fraction(inst.pred_boxes.tensor, inst.scores, inst.pred_classes, r["pred_boxes"], r["scores"],
+                                      r["pred_classes"], box_tol=0.1, score_tol=2e-3)
+        print("planted model: %d detections, %.0f%% matched vs the CPU oracle (worst box %.1e px, score %.1e)" % (len(inst), 100 * frac, wb, ws))
+        assert len(inst) == len(r["scores"]) and frac >= 0.9
+
+
+def test_steady_state_speed_with_rerouted_layers():
+    """Four re-routed layers cost a few percent at most: the rest of the network stays on its kernels."""
+    from lvc_amd.utils import synthetic as syn
+
+    batch = [{"image": syn.synthetic_image(1 + i), "height": 800, "width": 1333} for i in range(2)]
+
+    def rate(model):
+        with torch.no_grad():
+            for _ in range(3):
+                model.inference_batched(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                model.inference_batched(batch)
+            torch.cuda.synchronize()
+        return 10 * len(batch) / (time.perf_counter() - t0)
+
+    clean = _model(r50_state_dict())
+    with torch.no_grad():
+        clean(batch)
+    r_clean = rate(clean)
+    planted = _model(_planted_state_dict())
+    with torch.no_grad():
+        planted(batch)            # re-routes
+    assert len(_tiers(planted)) == 4
+    r_planted = rate(planted)
+    r_clean2 = rate(clean)
+    print("img/s clean %.1f / %.1f, with four re-routed layers %.1f" % (r_clean, r_clean2, r_planted))
+    assert r_planted >= 0.97 * min(r_clean, r_clean2)
+
+
+def test_graphed_replay_reports_an_out_of_range_activation():
+    """the captured kernels write the error words of the CAPTURE stream's workspace; `instances()` must read those."""
+    from lvc_amd import kernels as K
+    from lvc_amd.evaluation import GraphedInference
+    from lvc_amd.utils import synthetic as syn
+
+    model = _model(r50_state_dict())
+    batch = [{"image": syn.synthetic_image(3, 240, 320), "height": 240, "width": 320}]
+    g = GraphedInference(model, batch)
+    g.replay()
+    assert len(g.instances()) == 1
+    # the same graph, an image that drives the stem's successors far out of range
+    hot = [{"image": batch[0]["image"] * 1.0e6, "height": 240, "width": 320}]
+    g.replay(hot)
+    with pytest.raises(K.Fp16RangeError):
+        g.instances()
+    # the words were cleared with the report: the next in-range replay is clean again
+    g.replay(batch)
+    assert len(g.instances()) == 1
