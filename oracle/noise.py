@@ -1,0 +1,86 @@
+"""TEST INFRASTRUCTURE (oracle/): how far apart two evaluations of the detector may be, measured instead of set by hand.
+
+The reference computes in fp32 (MODEL.DEVICE=cpu); the answer its outputs approximate is the fp64 evaluation of the same
+weights.  `fp32_vs_fp64` runs the oracle's restatement of the reference path (oracle/rcnn.py, pinned against the reference's
+outputs in tests/test_oracle_golden.py) in both precisions on the given inputs and returns the statistics of their difference
+over the matched detections: the reference path's own rounding noise on THAT input.  `gate` then holds another evaluation (the
+HIP path) to a small multiple of it.  Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline / timed_batch_parity
+leg -- never by the product.
+"""
+import torch
+
+LOOSE_BOX, LOOSE_SCORE = 0.1, 2e-3      # identity bar: which detection is which (near-tie flips in top-k / NMS fall outside)
+K_NOISE = 3.0                           # median / p90 of |hip - reference| may be this multiple of the reference's own fp32-vs-fp64 noise
+FLOOR_BOX, FLOOR_SCORE = 2e-4, 2e-6     # fp32 resolution of a ~1000 px coordinate / of a score: no bar below it
+
+
+def match_pairs(boxes, scores, classes, gboxes, gscores, gclasses, box_tol=LOOSE_BOX, score_tol=LOOSE_SCORE):
+    """Greedy one-to-one matching of the detections (g*) to (boxes, scores, classes) of the same class within the loose bars.
+    Returns the list of (|box| error, |score| error) of the matched pairs."""
+    used, pairs = set(), []
+    for i in range(len(gboxes)):
+        db = (boxes - gboxes[i]).abs().max(dim=1)[0]
+        ds = (scores - gscores[i]).abs()
+        ok = (db <= box_tol) & (ds <= score_tol) & (classes == gclasses[i])
+        for u in used:
+            ok[u] = False
+        idx = ok.nonzero().view(-1)
+        if len(idx):
+            j = int(idx[db[idx].argmin()])
+            used.add(j)
+            pairs.append((float(db[j]), float(ds[j])))
+    return pairs
+
+
+def _q(vals, q):
+    if not vals:
+        return 0.0
+    v = sorted(vals)
+    return v[min(len(v) - 1, int(q * len(v)))]
+
+
+def deviation(dets_a, dets_b, box_tol=LOOSE_BOX, score_tol=LOOSE_SCORE):
+    """dets_*: per image (boxes [n,4], scores [n], classes [n]) on the CPU; b is the side whose detections must be found in a.
+    -> dict of counts and median / p90 / max of |box|, |score| differences over the pairs matched within the identity bars."""
+    pairs, total, counts_equal = [], 0, True
+    for (ab, asc, ac), (bb, bsc, bc) in zip(dets_a, dets_b):
+        counts_equal &= len(asc) == len(bsc)
+        total += len(bsc)
+        pairs += match_pairs(ab.double(), asc.double(), ac.long(), bb.double(), bsc.double(), bc.long(), box_tol, score_tol)
+    db, ds = [p[0] for p in pairs], [p[1] for p in pairs]
+    return {"detections": total, "matched": len(pairs), "matched_fraction": len(pairs) / max(1, total), "counts_equal": bool(counts_equal),
+            "box_median": _q(db, 0.5), "box_p90": _q(db, 0.9), "box_max": max(db, default=0.0),
+            "score_median": _q(ds, 0.5), "score_p90": _q(ds, 0.9), "score_max": max(ds, default=0.0)}
+
+
+def _dets(results):
+    return [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in results]
+
+
+def fp32_vs_fp64(sd, spec, inputs, res32=None, box_tol=LOOSE_BOX, score_tol=LOOSE_SCORE):
+    """The oracle in fp32 (or `res32`, its precomputed fp32 results) against the oracle in fp64 on `inputs`."""
+    from . import rcnn as orc
+
+    with torch.no_grad():
+        if res32 is None:
+            res32 = orc.generalized_rcnn_inference(sd, spec, inputs)
+        sd64 = {k: v.double() for k, v in sd.items()}      # the oracle computes in the state_dict's dtype
+        res64 = orc.generalized_rcnn_inference(sd64, spec, inputs)
+    return deviation(_dets(res32), _dets(res64), box_tol, score_tol)
+
+
+def gate(dev, noise, k=K_NOISE):
+    """dev = deviation(hip, reference fp32), noise = fp32_vs_fp64 on the same (or representative) inputs.
+    -> (ok, bars, message).  Identity: equal counts, >= 90 % of the reference detections found within the loose bars.  Accuracy:
+    median and p90 of the matched |box| / |score| differences within k x the reference path's own noise."""
+    bars = {"box_median": max(FLOOR_BOX, k * noise["box_median"]), "box_p90": max(FLOOR_BOX, k * noise["box_p90"]),
+            "score_median": max(FLOOR_SCORE, k * noise["score_median"]), "score_p90": max(FLOOR_SCORE, k * noise["score_p90"])}
+    bad = []
+    if not dev["counts_equal"]:
+        bad.append("detection counts differ")
+    if dev["matched_fraction"] < 0.9:
+        bad.append("only %.1f %% of the reference detections found within the identity bars" % (100 * dev["matched_fraction"]))
+    for key, bar in bars.items():
+        if dev[key] > bar:
+            bad.append("%s %.2e > %.2e (= %.0f x the reference path's own fp32-vs-fp64 %s %.2e)" % (key, dev[key], bar, k, key, noise[key]))
+    return not bad, bars, "; ".join(bad) if bad else "ok"

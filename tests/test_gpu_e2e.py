@@ -48,9 +48,28 @@ def _model():
 
 
 def _check(name, inputs, model, box_tol=0.1, score_tol=2e-3):
+    """Identity: equal counts, >= 90 % of the reference's detections found (class, 0.1 px, 2e-3) -- what is left are near-tie flips in
+    top-k / NMS.  Accuracy: median and p90 of the matched |box| / |score| differences within 3 x the reference path's OWN fp32-vs-fp64
+    noise on these inputs (oracle/noise.py: ~3e-3 px median at 800x1333), so that a kernel regression worth a few 1e-2 px fails."""
+    from oracle import noise as onoise
+    from oracle import rcnn as orc
+
     g = gold(name)
     with torch.no_grad():
         out = model(inputs)
+    cpu_in = [dict(b, image=b["image"].cpu()) for b in inputs]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    depth = 101 if "backbone.bottom_up.res4.22.conv1.weight" in sd else 50
+    nz = onoise.fp32_vs_fp64(sd, orc.RCNNSpec(depth=depth), cpu_in, box_tol=box_tol, score_tol=score_tol)
+    hip = [(o["instances"].pred_boxes.tensor.cpu(), o["instances"].scores.cpu(), o["instances"].pred_classes.cpu()) for o in out]
+    refd = [(g["det_boxes%d" % i], g["det_scores%d" % i], g["det_classes%d" % i]) for i in range(len(inputs))]
+    dev = onoise.deviation(hip, refd, box_tol, score_tol)
+    ok, bars, msg = onoise.gate(dev, nz)
+    print("%s: |hip - reference| box median %.2e p90 %.2e max %.2e px, score median %.2e p90 %.2e | reference fp32-vs-fp64 noise: box "
+          "median %.2e p90 %.2e, score median %.2e p90 %.2e | bars %s" % (name, dev["box_median"], dev["box_p90"], dev["box_max"],
+          dev["score_median"], dev["score_p90"], nz["box_median"], nz["box_p90"], nz["score_median"], nz["score_p90"],
+          {k: "%.1e" % v for k, v in bars.items()}))
+    assert ok, msg
     for i in range(len(inputs)):
         inst = out[i]["instances"].to("cpu")
         assert len(inst) == len(g["det_scores%d" % i])
@@ -173,7 +192,9 @@ def test_r101_e2e_small_matches_reference_cpu():
     The 101-layer trunk with these conditioned random weights has a 5-6x higher fp32 noise floor than R50
     (scripts/debug_r101.py on MI355X: CPU fp32 vs fp64 1.5e-4 (p2) .. 3.9e-4 (p5) of the feature scale, this build vs
     fp64 0.9e-4 .. 2.5e-4, i.e. closer to fp64 than the reference's own CPU path), so the detection tolerances of the
-    R50 test are scaled by 5: box 0.5 px, score 1e-2, and the features must agree to 8e-4 (2x the CPU path's own error)."""
+    R50 test are scaled by 5: box 0.5 px, score 1e-2 as IDENTITY bars (which detection is which); the accuracy bars are not set by
+    hand: median / p90 of the matched differences within 3 x the CPU path's own fp32-vs-fp64 noise for THESE weights (`_check`,
+    oracle/noise.py); the features must agree to 8e-4 (2x the CPU path's own error)."""
     from lvc_amd.config.presets import base_rcnn_fpn
     from lvc_amd.modeling import build_model
     from lvc_amd.utils import synthetic as syn

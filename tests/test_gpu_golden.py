@@ -1,0 +1,67 @@
+"""The HIP kernels against the vectors the REFERENCE produced (tests/golden/*.npz, oracle/make_golden.py) -- directly, not by way
+of the oracle: ROIAlign forward on the 16 configurations the reference's compiled `_C.roi_align_forward` was run on
+(detectron2/layers/csrc/ROIAlign/ROIAlign_cpu.cpp:116-218), `batched_nms` on the keep lists of detectron2/layers/nms.py:10-29, and a
+`BottleneckBlock` on the output of the reference module (detectron2/modeling/backbone/resnet.py:101-211).  VERDICT r3, weak 2."""
+import pytest
+import torch
+
+from helpers import gold
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(key):
+    _, s, a, sr = key.split("_")
+    return float(s[1:]), bool(int(a[1:])), int(sr[2:])
+
+
+def test_roi_align_forward_on_the_reference_vectors():
+    from lvc_amd import kernels as k
+    from lvc_amd.layers import roi_align
+
+    g = gold("roi_align")
+    d = torch.device("cuda:0")
+    feat, rois = g["feat"].to(d), g["rois"].to(d)
+    keys = [key for key in g if key.startswith("out_")]
+    assert len(keys) == 16
+    exact = 0
+    for key in keys:
+        scale, aligned, sr = _cfg(key)
+        ref = g[key]
+        tol = 1e-6 * max(1.0, float(ref.abs().max()))
+        # the NCHW drop-in op (what `detectron2.layers.ROIAlign` calls: torch.ops.lvc_amd.roi_align_forward)
+        out = roi_align(feat, rois, (7, 7), scale, sr, aligned).cpu()
+        assert out.shape == ref.shape and (out - ref).abs().max() <= tol, key
+        exact += int(torch.equal(out, ref))
+        # the engine's NHWC kernel (one level)
+        out2 = k.roi_align_fpn_nhwc([feat.permute(0, 2, 3, 1).contiguous()], [scale], rois, None, 7, 7, sr, aligned)
+        out2 = out2.permute(0, 3, 1, 2).cpu()
+        assert (out2 - ref).abs().max() <= tol, key
+    print("NCHW op bit-identical to the reference kernel on %d of %d configurations" % (exact, len(keys)))
+
+
+def test_batched_nms_on_the_reference_keep_lists():
+    from lvc_amd.layers import batched_nms
+
+    g = gold("nms")
+    d = torch.device("cuda:0")
+    boxes, scores, idxs = g["boxes"].to(d), g["scores"].to(d), g["idxs"].to(d)
+    for thr, key in ((0.7, "keep_thr07"), (0.5, "keep_thr05")):
+        keep = batched_nms(boxes, scores, idxs, thr).cpu()
+        assert keep.dtype == torch.int64 and keep.tolist() == g[key].tolist(), key
+
+
+def test_bottleneck_block_on_the_reference_output():
+    from lvc_amd.modeling.backbone.resnet import BottleneckBlock
+
+    g = gold("bottleneck")
+    blk = BottleneckBlock(64, 128, bottleneck_channels=32, stride=2, norm="FrozenBN", stride_in_1x1=True).eval()
+    blk.load_state_dict({key[3:]: v for key, v in g.items() if key.startswith("sd.")}, strict=True)
+    blk = blk.to("cuda:0")
+    with torch.no_grad():
+        y = blk(g["x"].to("cuda:0")).cpu()
+    ref = g["y"]
+    scale = float(ref.abs().max())
+    err = float((y - ref).abs().max())
+    print("bottleneck block: max |hip - reference| = %.2e of output scale %.2f" % (err / scale, scale))
+    assert y.shape == ref.shape and err <= 2e-6 * scale     # two fp32 evaluations of three chained convolutions
