@@ -98,6 +98,30 @@ def allreduce_gradients_(params, average=True):
     return flat.numel() * flat.element_size()
 
 
+def _reduce_scatter_sum(shard, flat):
+    """shard <- this rank's 1/world slice of the sum of `flat` over ranks.  RCCL: one reduce_scatter_tensor (async handle
+    returned).  gloo has no reduce-scatter: the same result as `world` rooted reductions of the slices (the rs_ag path then runs
+    its padding / shard / all-gather logic on CPU test worlds exactly as under RCCL); returns None (already complete)."""
+    world, rank = get_world_size(), get_rank()
+    if dist.get_backend() != "gloo":
+        return dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, async_op=True)
+    n = shard.numel()
+    for r in range(world):
+        piece = flat[r * n: (r + 1) * n].clone()
+        dist.reduce(piece, dst=r, op=dist.ReduceOp.SUM)
+        if r == rank:
+            shard.copy_(piece)
+    return None
+
+
+def _all_gather_shards(flat, shard):
+    if dist.get_backend() != "gloo":
+        dist.all_gather_into_tensor(flat, shard)
+        return
+    n = shard.numel()
+    dist.all_gather([flat[r * n: (r + 1) * n] for r in range(get_world_size())], shard)
+
+
 class GradientBuckets:
     """Bucketed, backward-overlapped gradient all-reduce (mean) for data-parallel training.
 
@@ -174,12 +198,13 @@ class GradientBuckets:
                         b["flat"][off: off + p.numel()].zero_()
                         p.grad = b["flat"][off: off + p.numel()].view_as(p)
             if get_world_size() > 1 or (self.mode == "rs_ag" and dist.is_available() and dist.is_initialized()):
-                if self.mode == "rs_ag" and dist.get_backend() != "gloo":
+                if self.mode == "rs_ag":
                     world = get_world_size()
                     if b["shard"] is None:
                         b["shard"] = torch.empty(b["flat"].numel() // world, device=b["flat"].device, dtype=b["flat"].dtype)
-                    b["work"] = dist.reduce_scatter_tensor(b["shard"], b["flat"], op=dist.ReduceOp.SUM, async_op=True)
-                else:   # gloo (CPU tests) has no reduce_scatter_tensor: same result through the all-reduce
+                    b["work"] = _reduce_scatter_sum(b["shard"], b["flat"])
+                    b["scattered"] = True
+                else:
                     b["work"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, async_op=True)
             b["launched"] = True
             self.bytes_reduced += b["flat"].numel() * b["flat"].element_size()
@@ -193,8 +218,9 @@ class GradientBuckets:
             if b["work"] is not None:
                 b["work"].wait()
                 b["work"] = None
-                if self.mode == "rs_ag" and dist.get_backend() != "gloo":
-                    dist.all_gather_into_tensor(b["flat"], b["shard"])
+            if b.get("scattered"):
+                b["scattered"] = False
+                _all_gather_shards(b["flat"], b["shard"])
             if self.average and world > 1:
                 b["flat"] /= world
             b["pending"], b["launched"] = len(b["params"]), False
