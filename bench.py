@@ -186,6 +186,9 @@ def _knn_inputs(c, rows, seed, classes=None, centers=None, spread=0.0, D=None):
     return centers[classes] + spread * x + 0.3
 
 
+KNN_INPUTS = None
+
+
 def knn_leg(c, steps, warmup, sample_check=2048):
     """BASELINE configs[3]: Q = 120 000 queries (sharded over the ranks: strong scaling), S = 2400 shots of 80 classes,
     D = 1024, cosine, k = 10.  Every rank contributes S / world shots to ONE RCCL all-gather, sweeps its own queries,
@@ -229,7 +232,7 @@ def knn_leg(c, steps, warmup, sample_check=2048):
         dt, _ = _max_and_all(c, time.perf_counter() - t0)
         return dt / n, res
 
-    only = os.environ.get("LVC_BENCH_KNN_ONLY")      # profiler runs: one kind of input per trace ("randn" | "structured")
+    only = KNN_INPUTS                                # --knn-inputs: one kind of input per profiler trace ("randn" | "structured")
     per, (top, keep) = timed(*inputs[only or "randn"], steps)
     if only:
         per_s, top_s, keep_s = per, top, keep
@@ -808,7 +811,7 @@ def _live_conv_pmc(timeout_s=90):
         cyc = agg.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         alg = 8 * 200 * 336 * 256 * 4 * 2 + 256 * 2304 * 4      # the p2 activation tensor read once and written once + the weights
         out = {"source": "live: rocprofv3 --pmc passes of scripts/probe_one.py 8 256 200 336 256 3 1 1 on this box, inside this bench run",
-               "launch": "the 3x3 fp16-split kernel (conv3x3_halo_s1_kernel unless LVC_HALO_S1=0), 3x3 256 -> 256 on [8,200,336,256]: the largest 3x3 launch, 2 per step",
+               "launch": "the 3x3 fp16-split kernel (conv3x3_halo_s1_kernel), 3x3 256 -> 256 on [8,200,336,256]: the largest 3x3 launch, 2 per step",
                "hbm_bytes_per_launch": int(2 * agg["FETCH_SIZE"] * 1024 + agg["WRITE_SIZE"] * 1024),
                "correction": "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM), WRITE_SIZE as is",
                "algorithmic_bytes_per_launch": alg,
@@ -966,6 +969,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=("infer", "train", "knn"), default="infer")
+    ap.add_argument("--knn-inputs", choices=("randn", "structured"), default=None,
+                    help="kNN leg: time one kind of query / shot rows only (profiler traces); default both")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the bandwidth_kernels / knn / dp_legs objects")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc subprocess passes (the committed profile is quoted)")
@@ -973,6 +978,8 @@ def main():
     ap.add_argument("--pipeline-depth", type=int, default=2,
                     help="streams of the extra pipelined pass reported as `pipelined` (1 = skip it); the timed region is always one stream")
     args = ap.parse_args()
+    global KNN_INPUTS
+    KNN_INPUTS = args.knn_inputs
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))

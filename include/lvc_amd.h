@@ -156,14 +156,12 @@ int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w_split, con
                           void* stream);
 
 /* BasicStem in one launch (detectron2/modeling/backbone/resnet.py:588-592): conv 7x7 s2 p3 (3 -> 64) -> FrozenBN fold
- * (scale/shift, NULL = identity) -> ReLU -> max_pool2d 3x3 s2 p1, on the split-precision bf16 MFMA path
- * (csrc/stem_pool.hip).  x [N,H,W,4] NHWC4 (the layout lvc_preprocess_nhwc4 writes), w_split = the three bf16 planes
- * [3][Kpad][224] of the mode-1 packed stem weights of lvc_conv2d_nhwc_f32 (k = r*32 + s*4 + c), Kpad >= 64 rows per
- * plane; y [N,Hp,Wp,64] with Ho = (H-1)/2+1, Hp = (Ho-1)/2+1 (same for W). */
-int lvc_stem_conv_pool_nhwc4(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                             float* y, int N, int H, int W, int Kpad, int relu, void* stream);
-/* The same with the two-way fp16 operand split (csrc/stem_pool_h2.hip): w_split = [2][Kpad][224] fp16 planes;
- * d_error_word: device int whose bit 1 is set when an input beyond fp16's range is met (may be NULL). */
+ * (scale/shift, NULL = identity) -> ReLU -> max_pool2d 3x3 s2 p1, with the two-way fp16 operand split (csrc/stem_pool_h2.hip).
+ * x [N,H,W,4] NHWC4 (the layout lvc_preprocess_nhwc4 writes), w_split = the [2][Kpad][224] fp16 planes of the mode-1 packed
+ * stem weights of lvc_conv2d_nhwc_f32 (k = r*32 + s*4 + c), Kpad >= 64 rows per plane; y [N,Hp,Wp,64] with Ho = (H-1)/2+1,
+ * Hp = (Ho-1)/2+1 (same for W).  d_error_word: device int whose bit 1 is set when an input beyond fp16's range is met (may be
+ * NULL).  (The three-way bf16 form of this kernel was removed in round 4: under the range-free split the stem runs as conv +
+ * max-pool, two launches.) */
 int lvc_stem_conv_pool_nhwc4_f16x2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                                    float* y, int N, int H, int W, int Kpad, int relu, int* d_error_word,
                                    float* y2 /* optional second copy of y, rows of ldy2 floats */, int ldy2, void* stream);
@@ -441,7 +439,9 @@ int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const fl
  *                      softmax(q k^T * scale) v per (image, head); head_dim must be 64 (one thread per query, fp32 VALU)
  *   lvc_mha_mfma     : the same result on the matrix cores (csrc/vit.hip: both products as fp32-accurate two-way fp16 splits, the
  *                      probabilities stay in registers between them); workspace = lvc_mha_workspace_bytes(B, N, H) bytes,
- *                      16-byte aligned (fp16 operand planes of q, k, v) */
+ *                      16-byte aligned (fp16 operand planes of q, k, v); d_error_word (may be NULL): device int whose bit 1 is
+ *                      set when q * scale * log2(e), k or v leaves fp16's range (|x| > 65504) or is NaN -- the result is
+ *                      then invalid and the caller falls back to lvc_mha */
 int lvc_vit_patchify(const float* img, float* out, int B, int C, int H, int W, int ps, void* stream);
 /* lvc_vit_patchify of (img - mean[c]) / std[c] (tools/run_nearest_neighbours.py:95-99 preprocess_crops fused into the gather);
  * mean / std: HOST arrays of C <= 8 floats. */
@@ -453,7 +453,7 @@ int lvc_layernorm(const float* x, int ldx, const float* w, const float* b, float
 int lvc_gelu(const float* x, float* y, long long n, void* stream);
 int lvc_mha(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, void* stream);
 long long lvc_mha_workspace_bytes(int B, int N, int H);
-int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, void* stream);
+int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, int* d_error_word, void* stream);
 
 #ifdef __cplusplus
 }

@@ -363,54 +363,6 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) {  // torch
   return v > hi ? hi : v;
 }
 
-// RPN step 2: decode the candidates, drop non-finite, clip, drop empty (ordered compaction)
-__global__ __launch_bounds__(1024) void rpn_decode_kernel(RpnLevels lv, const float* __restrict__ cand_score,
-                                                          const int* __restrict__ cand_idx, int Ntot,
-                                                          const int* __restrict__ image_sizes,
-                                                          float scale_clamp, float min_box_size,
-                                                          float* __restrict__ cboxes,
-                                                          float* __restrict__ cscores,
-                                                          int* __restrict__ clevels,
-                                                          int* __restrict__ ccount) {
-  __shared__ int sh[20];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float img_h = (float)image_sizes[b * 2 + 0], img_w = (float)image_sizes[b * 2 + 1];
-  int base = 0;
-  for (int c0 = 0; c0 < Ntot; c0 += 1024) {
-    const int c = c0 + tid;
-    bool ok = false;
-    float box[4] = {0, 0, 0, 0};
-    float score = 0.f;
-    int l = 0;
-    if (c < Ntot) {
-      while (l + 1 < lv.L && c >= lv.cand_off[l + 1]) ++l;
-      const int i = cand_idx[(size_t)b * Ntot + c];
-      score = cand_score[(size_t)b * Ntot + c];
-      const int A = lv.A, W = lv.W[l], HW = lv.H[l] * W;
-      const int p = i / A, a = i - p * A;
-      const int y = p / W, x = p - y * W;
-      const float sx = (float)(x * lv.stride[l]), sy = (float)(y * lv.stride[l]);
-      const float* ca = lv.cell_anchors[l] + a * 4;
-      const float ax1 = sx + ca[0], ay1 = sy + ca[1], ax2 = sx + ca[2], ay2 = sy + ca[3];
-      const float* d = lv.deltas[l] + ((size_t)b * HW + p) * lv.ld_delta[l] + a * 4;
-      apply_deltas(ax1, ay1, ax2, ay2, d[0], d[1], d[2], d[3], 1.f, 1.f, 1.f, 1.f, scale_clamp, box);
-      ok = isfinite(box[0]) && isfinite(box[1]) && isfinite(box[2]) && isfinite(box[3]) && isfinite(score);
-      box[0] = clampf(box[0], 0.f, img_w); box[1] = clampf(box[1], 0.f, img_h);
-      box[2] = clampf(box[2], 0.f, img_w); box[3] = clampf(box[3], 0.f, img_h);
-      ok = ok && (box[2] - box[0] > min_box_size) && (box[3] - box[1] > min_box_size);
-    }
-    int tot;
-    int pos = base + block_excl_scan_1024(ok ? 1 : 0, sh, &tot);
-    if (ok) {
-      float* o = cboxes + ((size_t)b * Ntot + pos) * 4;
-      o[0] = box[0]; o[1] = box[1]; o[2] = box[2]; o[3] = box[3];
-      cscores[(size_t)b * Ntot + pos] = score;
-      clevels[(size_t)b * Ntot + pos] = l;
-    }
-    base += tot;
-  }
-  if (tid == 0) ccount[b] = base;
-}
 
 // RPN steps 2-4, per-level form.  `batched_nms` with the level as group id (proposal_utils.py:104) never lets boxes of
 // different levels suppress each other, so NMS is L independent problems per image: one segment per (image, level) --
@@ -521,23 +473,6 @@ __global__ __launch_bounds__(1024) void rpn_merge_levels_kernel(const float* __r
   if (tid == 0) out_count[b] = nout;
 }
 
-// RPN step 4: gather the kept candidates into the fixed-size proposal arrays (rows past count = 0)
-__global__ void gather_proposals_kernel(const float* __restrict__ cboxes, const float* __restrict__ cscores,
-                                        const int* __restrict__ keep, const int* __restrict__ num_keep,
-                                        int Ntot, int post_topk, float* __restrict__ pboxes,
-                                        float* __restrict__ plogits) {
-  const int b = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= post_topk) return;
-  float4 bx = {0, 0, 0, 0};
-  float s = 0.f;
-  if (r < num_keep[b]) {
-    const int i = keep[(size_t)b * Ntot + r];
-    bx = *reinterpret_cast<const float4*>(cboxes + ((size_t)b * Ntot + i) * 4);
-    s = cscores[(size_t)b * Ntot + i];
-  }
-  *reinterpret_cast<float4*>(pboxes + ((size_t)b * post_topk + r) * 4) = bx;
-  plogits[(size_t)b * post_topk + r] = s;
-}
 
 static long long align16(long long x) { return (x + 15) & ~15ll; }
 
@@ -626,14 +561,7 @@ extern "C" int lvc_rpn_proposals(const float* const* logits, const int* ld_logit
   unsigned int* keys = (unsigned int*)(ws + p.off_keys);
   float* cand_score = (float*)(ws + p.off_cscore);
   int* cand_idx = (int*)(ws + p.off_cidx);
-  float* cboxes = (float*)(ws + p.off_cboxes);
-  float* cscores = (float*)(ws + p.off_cscores2);
-  int* clevels = (int*)(ws + p.off_clevels);
-  int* ccount = (int*)(ws + p.off_ccount);
-  int* keep = (int*)(ws + p.off_keep);
-  static int topk_multi = -1;   // LVC_TOPK_MULTI=0: single-workgroup selection for every level (experiments)
-  if (topk_multi < 0) { const char* e = getenv("LVC_TOPK_MULTI"); topk_multi = e ? atoi(e) : 1; }
-  const bool multi = topk_multi && p.max_slices > 0;
+  const bool multi = p.max_slices > 0;
   if (multi) {
     int* hist = (int*)(ws + p.off_hist);
     u64* ckeys = (u64*)(ws + p.off_ckeys);
@@ -651,34 +579,23 @@ extern "C" int lvc_rpn_proposals(const float* const* logits, const int* ld_logit
   hipLaunchKernelGGL(rpn_topk_kernel, dim3(L, B), dim3(1024), 0, st, lv, pre_nms_topk, keys, cand_score,
                      cand_idx, p.Ntot, multi ? TK_SLICE : 0x7FFFFFFF);
   LVC_CHECK_LAUNCH();
-  static int seg_nms = -1;   // LVC_RPN_NMS_SEG=0: NMS over the concatenated levels with level ids (the reference's shape)
-  if (seg_nms < 0) { const char* e = getenv("LVC_RPN_NMS_SEG"); seg_nms = e ? atoi(e) : 1; }
-  if (seg_nms) {
-    float* sboxes = (float*)(ws + p.off_sboxes);
-    float* sscores = (float*)(ws + p.off_sscores);
-    int* scount = (int*)(ws + p.off_scount);
-    int* skeep = (int*)(ws + p.off_skeep);
-    int* snk = (int*)(ws + p.off_snk);
-    hipLaunchKernelGGL(rpn_decode_seg_kernel, dim3(L, B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
-                       d_image_sizes, scale_clamp, min_box_size, p.SN, sboxes, sscores, scount);
-    LVC_CHECK_LAUNCH();
-    const int keep_per_level = post_nms_topk < p.SN ? post_nms_topk : p.SN;
-    int rc = lvc_batched_nms(sboxes, sscores, nullptr, scount, B * L, p.SN, nms_thresh, keep_per_level, skeep, snk,
-                             ws + p.off_snms, p.snms_bytes, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(rpn_merge_levels_kernel, dim3(B), dim3(1024), 0, st, sboxes, sscores, skeep, snk, L, p.SN,
-                       post_nms_topk, out_boxes, out_logits, d_out_count);
-    LVC_CHECK_LAUNCH();
-    return LVC_OK;
-  }
-  hipLaunchKernelGGL(rpn_decode_kernel, dim3(B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
-                     d_image_sizes, scale_clamp, min_box_size, cboxes, cscores, clevels, ccount);
+  // NMS per (image, level) segment -- levels never interact under `batched_nms` -- and a rank merge of the kept lists in the
+  // order the concatenated form keeps them (136 instead of 2 926 mask blocks per image; the concatenated form lost the A/B in
+  // round 1 and was removed in round 4)
+  float* sboxes = (float*)(ws + p.off_sboxes);
+  float* sscores = (float*)(ws + p.off_sscores);
+  int* scount = (int*)(ws + p.off_scount);
+  int* skeep = (int*)(ws + p.off_skeep);
+  int* snk = (int*)(ws + p.off_snk);
+  hipLaunchKernelGGL(rpn_decode_seg_kernel, dim3(L, B), dim3(1024), 0, st, lv, cand_score, cand_idx, p.Ntot,
+                     d_image_sizes, scale_clamp, min_box_size, p.SN, sboxes, sscores, scount);
   LVC_CHECK_LAUNCH();
-  int rc = lvc_batched_nms(cboxes, cscores, clevels, ccount, B, p.Ntot, nms_thresh, post_nms_topk, keep,
-                           d_out_count, ws + p.off_nms, p.total - p.off_nms, stream);
+  const int keep_per_level = post_nms_topk < p.SN ? post_nms_topk : p.SN;
+  int rc = lvc_batched_nms(sboxes, sscores, nullptr, scount, B * L, p.SN, nms_thresh, keep_per_level, skeep, snk,
+                           ws + p.off_snms, p.snms_bytes, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(gather_proposals_kernel, dim3(lvc_cdiv(post_nms_topk, 256), B), dim3(256), 0, st, cboxes,
-                     cscores, keep, d_out_count, p.Ntot, post_nms_topk, out_boxes, out_logits);
+  hipLaunchKernelGGL(rpn_merge_levels_kernel, dim3(B), dim3(1024), 0, st, sboxes, sscores, skeep, snk, L, p.SN,
+                     post_nms_topk, out_boxes, out_logits, d_out_count);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

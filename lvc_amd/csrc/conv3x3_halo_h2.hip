@@ -445,10 +445,9 @@ extern "C" int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_sp
   int cap = g_cus_halo_h;  // one worker per CU: 150 KB of LDS per workgroup
   if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
   // Two or four output-channel tiles: the workers of a group share their pixel tiles (see HaloArgsH::ngroup); the unit
-  // space is then pixel tiles x chunks only.  LVC_HALO_NGROUP=0 restores the one-worker-walks-all-channel-tiles order.
+  // space is then pixel tiles x chunks only.
   a.ngroup = 1;
-  static const int ngroup_on = [] { const char* e = getenv("LVC_HALO_NGROUP"); return e ? atoi(e) : 1; }();
-  if (ngroup_on && (a.tiles_n == 2 || a.tiles_n == 4) && cap % a.tiles_n == 0 && units / a.tiles_n >= cap / a.tiles_n) {
+  if ((a.tiles_n == 2 || a.tiles_n == 4) && cap % a.tiles_n == 0 && units / a.tiles_n >= cap / a.tiles_n) {
     a.ngroup = a.tiles_n;
     units /= a.tiles_n;
     cap /= a.tiles_n;

@@ -569,8 +569,7 @@ static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_s
   int cap = g_cus_halo_s;  // one worker per CU (154 KB of LDS per workgroup)
   if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
   a.ngroup = 1;
-  static const int ngroup_on = [] { const char* e = getenv("LVC_HALO_NGROUP"); return e ? atoi(e) : 1; }();
-  if (ngroup_on && (a.tiles_n == 2 || a.tiles_n == 4) && cap % a.tiles_n == 0 && units / a.tiles_n >= cap / a.tiles_n) {
+  if ((a.tiles_n == 2 || a.tiles_n == 4) && cap % a.tiles_n == 0 && units / a.tiles_n >= cap / a.tiles_n) {
     a.ngroup = a.tiles_n;
     units /= a.tiles_n;
     cap /= a.tiles_n;

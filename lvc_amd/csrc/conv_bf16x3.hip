@@ -1043,18 +1043,15 @@ extern "C" int lvc_conv2d_nhwc_bf16x3(const float* x, const unsigned short* w_sp
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
   // kernel shape: 0 = general implicit GEMM (128 x 128 tiles), 1 = pointwise, short reduction (conv_pw_bf16x3_kernel),
-  // 2 = pointwise, long reduction (conv_pw256_bf16x3_kernel, 256 x 128 tiles).  LVC_CONV_PW: 0 disables both pointwise
-  // shapes, 1 only the 256-row one (experiments).
-  static int pw_mode = -1;
-  if (pw_mode < 0) { const char* e = getenv("LVC_CONV_PW"); pw_mode = e ? atoi(e) : 2; }
+  // 2 = pointwise, long reduction (conv_pw256_bf16x3_kernel, 256 x 128 tiles).
+  constexpr int pw_mode = 2;
   a.nk = Kg / BK;
   int shape = 0;
   if (R == 1 && S == 1 && pad == 0) {
     // measured on the R50-FPN layer set (scripts/probe_layers_list.py): with its residual rows requested before the
     // LDS transpose the 256-row shape wins from 128 input channels up; the 64-channel layers (2 chunks per tile) are
     // pure HBM streams and keep the 128-row shape with its deeper activation run-ahead
-    static int min_nk256 = -1;
-    if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 4; }
+    constexpr int min_nk256 = 4;
     if (pw_mode >= 2 && a.M >= 2048 && a.nk >= min_nk256) shape = 2;
     else if (a.nk <= 16) shape = pw_mode >= 1 ? 1 : 0;
   }

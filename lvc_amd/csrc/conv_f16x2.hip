@@ -763,18 +763,15 @@ extern "C" int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_spl
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
   // kernel shape: 0 = general implicit GEMM (128 x 128 tiles), 1 = pointwise, short reduction (conv_pw_f16x2_kernel),
-  // 2 = pointwise, long reduction (conv_pw256_f16x2_kernel, 256 x 128 tiles).  LVC_CONV_PW: 0 disables both pointwise
-  // shapes, 1 only the 256-row one (experiments).
-  static int pw_mode = -1;
-  if (pw_mode < 0) { const char* e = getenv("LVC_CONV_PW"); pw_mode = e ? atoi(e) : 2; }
+  // 2 = pointwise, long reduction (conv_pw256_f16x2_kernel, 256 x 128 tiles).
+  constexpr int pw_mode = 2;
   a.nk = Kg / BK;
   int shape = 0;
   if (R == 1 && S == 1 && pad == 0) {
     // measured on the R50-FPN layer set (scripts/probe_layers_list.py): with its residual rows requested before the
     // LDS transpose the 256-row shape wins from 128 input channels up; the 64-channel layers (2 chunks per tile) are
     // pure HBM streams and keep the 128-row shape with its deeper activation run-ahead
-    static int min_nk256 = -1;
-    if (min_nk256 < 0) { const char* e = getenv("LVC_PW256_MIN_NK"); min_nk256 = e ? atoi(e) : 4; }
+    constexpr int min_nk256 = 4;
     if (pw_mode >= 2 && a.M >= 2048 && a.nk >= min_nk256) shape = 2;
     else if (a.nk <= 16) shape = pw_mode >= 1 ? 1 : 0;
   }
@@ -803,10 +800,9 @@ extern "C" int lvc_conv2d_nhwc_f16x2(const float* x, const unsigned short* w_spl
   // two output-channel tiles on a chip-filling layer: pair the workers (ConvArgsH::ngroup); the unit space is then row
   // tiles x chunks.  Measured per layer (scripts/probe_layers_list.py): pairs gain 2 % on the 256-channel outputs (FPN
   // laterals, res4 reductions); groups of 4 / 8 / 16 lose 1-7 % (sixteen workers in step on one row tile serialise on
-  // its loads), so wider layers keep the one-worker-walks-all-channel-tiles order.  LVC_PW_NGROUP=0: never group,
-  // =2: group every power-of-two tile count up to 16.
+  // its loads), so wider layers keep the one-worker-walks-all-channel-tiles order.
   a.ngroup = 1;
-  static const int ngroup_on = [] { const char* e = getenv("LVC_PW_NGROUP"); return e ? atoi(e) : 1; }();
+  constexpr int ngroup_on = 1;
   const int tn = a.tiles_n;
   if (ngroup_on && shape == 2 && workers == cap && (tn == 2 || (ngroup_on > 1 && tn <= 16 && (tn & (tn - 1)) == 0)) && cap % tn == 0 &&
       units / tn >= (long long)(cap / tn) * min_units) {

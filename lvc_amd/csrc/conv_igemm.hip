@@ -401,9 +401,7 @@ static int worker_capacity() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
       cus = 256;
-    int per_cu = 2;
-    const char* e = getenv("LVC_CONV_WORKERS_PER_CU");  // tuning knob (1 or 2); 2 = the LDS/VGPR residency limit
-    if (e && e[0] == '1') per_cu = 1;
+    const int per_cu = 2;     // the LDS / VGPR residency limit
     g_capacity = per_cu * cus;
   }
   return g_capacity;

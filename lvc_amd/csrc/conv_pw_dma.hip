@@ -44,7 +44,7 @@ struct ConvArgsD {
   int* flags;
   int H, W, C, K, stride, Ho, Wo, M, Kg, relu, res_mode, ldy, ldr;
   int tiles_n, nk, total_units, units_per_worker, nworkers, err_index, ngroup, y_bytes;
-  unsigned long long* dbg;   // LVC_PW_TIMELINE=1 (scripts/probe_pw_timeline.py): s_memtime stamps of every 64th workgroup, else null
+  unsigned long long* dbg;   // -DPW_DMA_TIMELINE build (scripts/probe_pw_timeline.py): cycle stamps of every 64th workgroup, else null
   long long w_plane_elems;
 };
 
@@ -472,7 +472,7 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   int workers = (int)((units + min_units - 1) / min_units);
   if (workers > cap) workers = cap;
   a.ngroup = 1;
-  static const int ngroup_on = [] { const char* e = getenv("LVC_PW_NGROUP"); return e ? atoi(e) : 1; }();
+  constexpr int ngroup_on = 1;
   const int tn = a.tiles_n;
   if (ngroup_on && workers == cap && (tn == 2 || (ngroup_on > 1 && tn <= 16 && (tn & (tn - 1)) == 0)) && cap % tn == 0 &&
       units / tn >= (long long)(cap / tn) * min_units) {
@@ -486,9 +486,11 @@ extern "C" int lvc_conv2d_nhwc_f16x2_dma(const float* x, const unsigned short* w
   a.partials = (float*)workspace;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
-  // timeline stamps (experiments): the upper half of the partial-tile area is never used by <= 256 workers
-  static const int timeline = [] { const char* e = getenv("LVC_PW_TIMELINE"); return e ? atoi(e) : 0; }();
-  a.dbg = timeline ? (unsigned long long*)((char*)workspace + (size_t)512 * 256 * 128 * 4) : nullptr;
+#ifdef PW_DMA_TIMELINE     // diagnostics build only: stamps into the upper half of the partial-tile area (never used by <= 256 workers)
+  a.dbg = (unsigned long long*)((char*)workspace + (size_t)512 * 256 * 128 * 4);
+#else
+  a.dbg = nullptr;
+#endif
   hipStream_t st = (hipStream_t)stream;
 #define PW_LAUNCH(NI_, NW_, NS_) hipLaunchKernelGGL((conv_pw_dma_kernel<NI_, NW_, NS_, 1>), dim3(a.nworkers), dim3(NW_ * 64), 0, st, a)
   (void)nw;

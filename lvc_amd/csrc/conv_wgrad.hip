@@ -166,7 +166,7 @@ extern "C" int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float*
   const int nchunks = lvc_cdiv(p.M, 32);
   // every workgroup ends with 128x128 atomic adds (64 KB), the traffic of two 32-pixel chunks: a pixel range must be
   // long enough to amortise it, even if that leaves fewer workgroups than the chip has slots
-  static const int min_chunks = getenv("LVC_WGRAD_MIN_CHUNKS") ? atoi(getenv("LVC_WGRAD_MIN_CHUNKS")) : 16;
+  constexpr int min_chunks = 16;
   int splits = lvc_cdiv(1024, tiles);                 // ~4 workgroups per CU
   const int max_splits = lvc_cdiv(nchunks, min_chunks);
   if (splits > max_splits) splits = max_splits;
@@ -526,7 +526,7 @@ extern "C" int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const 
   const int nchunks = lvc_cdiv(p.M, 32);
   // two workgroups fit a CU (250 VGPRs): four rounds of them (measured over the layer set on one box: 1024 -> 8.88 ms,
   // 1536 -> 8.65, 2048 -> 8.54, 2560 -> 8.47, 3072 -> 8.40; the whole training step does not resolve 2048 from 3072)
-  static const int target_h = [] { const char* e = getenv("LVC_WGRAD_F16_TARGET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 2048; }();
+  constexpr int target_h = 2048;
   int splits = lvc_cdiv(target_h, tiles);
   const int max_splits = lvc_cdiv(nchunks, 16);
   if (splits > max_splits) splits = max_splits;
@@ -753,8 +753,7 @@ extern "C" int lvc_conv_wgrad_nhwc_bf16x3(const float* x, const float* dy, const
   const int nchunks = lvc_cdiv(p.M, 16);
   // three workgroups fit a CU (146 VGPRs, 48 KB of LDS): aim at three full rounds of them (2304 on 256 CUs; measured over
   // the layer set: 1024 -> 12.4 ms, 1536 -> 12.1, 2304 -> 10.5, 3072 -> 11.0, 4608 -> 10.6)
-  static const int target_wgs = [] { const char* e = getenv("LVC_WGRAD_TARGET_WGS"); return e && atoi(e) > 0 ? atoi(e) : 2304; }();
-  static const int min_chunks = [] { const char* e = getenv("LVC_WGRAD_BF16_MIN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 32; }();
+  constexpr int target_wgs = 2304, min_chunks = 32;
   int splits = lvc_cdiv(target_wgs, tiles);
   const int max_splits = lvc_cdiv(nchunks, min_chunks);   // at least 32 chunks (512 pixels) per slice
   if (splits > max_splits) splits = max_splits;

@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
 // lvc_rownorm for the two-stage kNN sweep: the normalised rows rounded to fp16 (round to nearest even; the operand of the
 // pre-filter GEMM, gemm_h.hip), the denominators den [M] (so that a consumer can redo (x - mu) / den bit for bit), the
 // 2-norm of each row's fp16 rounding residual resid [M] (what bounds the pre-filter's error for that row) and -- optionally --
-// the fp32 rows themselves (bit-identical to rownorm_kernel: same summation order, same division).
+// the fp32 rows themselves (bit-identical to rownorm_kernel -- same summation order, same division -- for the widths this file
+// vectorises here, D <= 2048 with 16-byte aligned rows, and for unaligned rows; wider aligned rows are summed in the scalar order
+// here and in the vectorised order there: equal to fp32 rounding, not bit for bit).
 template <int NV, bool VEC>   // VEC: NV * 256 >= D, the centred row stays in registers between the two passes; else it is read twice
 __global__ __launch_bounds__(256) void rownorm_h_kernel(const float* __restrict__ x, const float* __restrict__ mu,
                                                         float* __restrict__ y, _Float16* __restrict__ yh, float* __restrict__ dens,

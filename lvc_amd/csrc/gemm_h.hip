@@ -237,10 +237,9 @@ static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int
   g.nk = C / 32;
   g.tiles_m = lvc_cdiv(M, 256);
   g.tiles_n = lvc_cdiv(N, 256);
-  static const int ngroup_env = [] { const char* e = getenv("LVC_GH_NGROUP"); return e ? atoi(e) : 0; }();
   // measured on 120000 x 2400 x 1024 (scripts/probe_gemm_h_pmc.sh): all ten column tiles in one sweep 1.89 GB of fabric reads per
   // launch, groups of five 1.11 GB at the same speed (0.855 vs 0.861 ms), narrower groups no less traffic and 4 - 6 % slower
-  g.ngroup = ngroup_env > 0 ? ngroup_env : 5;
+  g.ngroup = 5;
   if (g.ngroup > g.tiles_n) g.ngroup = g.tiles_n;
   if (g_cus_h == 0) {
     int dev = 0, cus = 0;

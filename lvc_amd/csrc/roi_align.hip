@@ -344,7 +344,7 @@ static int launch(RoiAlignArgs& a, void* stream) {
   for (int l = 0; l < LVC_MAX_LEVELS; ++l)
     if (a.feat[l] && (long long)a.H[l] * a.W[l] * a.C >= (1ll << 31)) small = false;
   if (a.nhwc && (a.C & 255) == 0 && a.pw <= 8 && a.num_valid == nullptr && a.so_c == 1 && small) {
-    static const int xcd_rows = [] { const char* e = getenv("LVC_ROI_XCD_ROWS"); return e ? atoi(e) : 1; }();
+    constexpr int xcd_rows = 1;
     a.xcd_rows = xcd_rows;
     dim3 gridl(xcd_rows ? lvc_cdiv(a.K, 8) * 8 * a.ph : a.K * a.ph, a.C / 256), blockl(512);
     hipLaunchKernelGGL(roi_align_fwd_nhwc_lds_kernel, gridl, blockl, 0, (hipStream_t)stream, a);
@@ -659,9 +659,7 @@ extern "C" int lvc_roi_align_fpn_backward_nhwc(const float* grad, float* const* 
   a.so_k = (long long)C * pooled_h * pooled_w; a.so_c = 1;
   a.so_h = (long long)pooled_w * C; a.so_w = C;
   a.status = d_status;
-  static int rows_form = -1;
-  if (rows_form < 0) { const char* e = getenv("LVC_ROI_BWD_ROWS"); rows_form = e ? atoi(e) : 1; }
-  if (rows_form && pooled_h == 7 && pooled_w == 7)
+  if (pooled_h == 7 && pooled_w == 7)      // the separable form: one atomic per footprint pixel
     hipLaunchKernelGGL((roi_align_bwd_rows_kernel<7, 7>), dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(K, lvc_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, a);

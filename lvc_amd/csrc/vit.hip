@@ -257,7 +257,8 @@ typedef __attribute__((address_space(3))) at_fp16x4 at_lds_fp16x4;
 #define AT_TK 64
 
 __global__ __launch_bounds__(256) void mha_split_kernel(const float* __restrict__ qkv, h16* __restrict__ ws, int B, int N, int H,
-                                                        int Npad, float qscale) {
+                                                        int Npad, float qscale, int* __restrict__ err) {
+  float big = 0.f;      // largest |operand| rounded to fp16: beyond 65504 (or NaN) the planes would carry inf / NaN silently
   const long long total = (long long)B * Npad * 3 * H * 16;
   const size_t PS = (size_t)B * H * Npad * 64;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -271,6 +272,8 @@ __global__ __launch_bounds__(256) void mha_split_kernel(const float* __restrict_
     if (n < N) {
       v = *reinterpret_cast<const f32x4*>(qkv + ((size_t)b * N + n) * (3 * H * 64) + which * H * 64 + h * 64 + d4 * 4);
       if (which == 0) v *= qscale;
+      big = fmaxf(big, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+      if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) big = INFINITY;
     }
     h16x4 hi, lo;
 #pragma unroll
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(256) void mha_split_kernel(const float* __restrict_
     *reinterpret_cast<h16x4*>(ws + (size_t)(2 * which) * PS + o) = hi;
     *reinterpret_cast<h16x4*>(ws + (size_t)(2 * which + 1) * PS + o) = lo;
   }
+  if (err && !(big <= 65504.f)) atomicOr(err, 2);
 }
 
 __global__ __launch_bounds__(256, 2) void mha_mfma_kernel(const h16* __restrict__ ws, float* __restrict__ out, int B, int N, int H,
@@ -445,7 +449,8 @@ extern "C" long long lvc_mha_workspace_bytes(int B, int N, int H) {
 
 // lvc_mha on the matrix cores: same arguments and result (to fp32 rounding), plus `workspace` (lvc_mha_workspace_bytes, 16-byte
 // aligned) for the fp16 operand planes.  head_dim is 64.
-extern "C" int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, void* stream) {
+extern "C" int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, int* d_error_word,
+                            void* stream) {
   LVC_CHECK_ARG(B >= 0 && N > 0 && H > 0, "bad sizes");
   if (B == 0) return LVC_OK;
   LVC_CHECK_ARG(qkv && out && workspace && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
@@ -455,7 +460,7 @@ extern "C" int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B
   const long long total = (long long)B * Npad * 3 * H * 16;
   const int blocks = (int)((total + 255) / 256 < 1048576 ? (total + 255) / 256 : 1048576);
   hipLaunchKernelGGL(mha_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qkv, (h16*)workspace, B, N, H, Npad,
-                     scale * 1.44269504088896340736f);
+                     scale * 1.44269504088896340736f, d_error_word);
   LVC_CHECK_LAUNCH();
   hipLaunchKernelGGL(mha_mfma_kernel, dim3(Npad / AT_TQ, H, B), dim3(256), 0, (hipStream_t)stream, (const h16*)workspace, out, B, N, H,
                      Npad);

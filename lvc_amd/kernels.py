@@ -363,13 +363,13 @@ CONV_TIMER = None  # set to a LaunchTimer to instrument lvc_conv2d_nhwc_f32 laun
 import os as _os
 
 CONV_ENGINE = _os.environ.get("LVC_CONV_ENGINE", "bf16x3")
-_BF16X3_MIN_K = int(_os.environ.get("LVC_BF16X3_MIN_K", "128"))
+_BF16X3_MIN_K = 128
 # 3x3 / stride 1 / pad 1 layers of the bf16x3 engine go to the halo kernel (csrc/conv3x3_halo.hip)
-CONV_HALO = _os.environ.get("LVC_CONV_HALO", "1") != "0"
+CONV_HALO = True       # False: the generic kernels (tests compare the two)
 # BasicStem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2) as one fused split-precision kernel (csrc/stem_pool.hip)
-STEM_FUSED = _os.environ.get("LVC_STEM_FUSED", "1") != "0"
-_PW_NARROW = _os.environ.get("LVC_PW_NARROW", "1") != "0"
-_PW_NARROW_MIN_C = int(_os.environ.get("LVC_PW_NARROW_MIN_C", "64"))
+STEM_FUSED = True
+_PW_NARROW = True
+_PW_NARROW_MIN_C = 64
 # operand split of the split-precision kernels that have both forms: "f16x2" = two fp16 planes, 3 MFMAs per block
 # (Ootomo & Yokota; csrc/conv3x3_halo_h2.hip), "bf16x3" = three bf16 planes, 6 MFMAs per block (no range limit)
 CONV_SPLIT = _os.environ.get("LVC_CONV_SPLIT", "f16x2")
@@ -382,9 +382,7 @@ DGRAD_SPLIT = _os.environ.get("LVC_DGRAD_SPLIT", "bf16x3")
 WGRAD_ENGINE = _os.environ.get("LVC_WGRAD_ENGINE", "bf16x3")
 # inference: conv3 + stride-1 projection shortcut of res2.0 as one GEMM over [conv2 output | block input] (resnet.py)
 FUSE_PROJECTION = _os.environ.get("LVC_FUSE_PROJECTION", "1") != "0"
-_H2_PW_MIN_C = int(_os.environ.get("LVC_H2_PW_MIN_C", "64"))   # 64-channel streams too since the LDS-DMA kernel (0.32 -> 0.27 ms on res2 conv3)
-# pointwise fp16x2 layers on the LDS-DMA kernel (csrc/conv_pw_dma.hip); 0 = the register-staged conv_pw256_f16x2_kernel
-PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
+_H2_PW_MIN_C = 64   # 64-channel streams too since the LDS-DMA kernel (0.32 -> 0.27 ms on res2 conv3)
 # 3x3 fp16x2 layers of the FORWARD pass on the software-pipelined kernel (csrc/conv3x3_halo_s1.hip):
 #   2 (default) = its single-accumulator form (row-scaled weight planes, activations x 2^4: |a| <= 4094; ~7 % faster on the 3x3
 #       set -- the accumulate of the small cross products into the large sum costs the matrix pipe less power than a second full
@@ -393,17 +391,17 @@ PW_DMA = _os.environ.get("LVC_PW_DMA", "1") != "0"
 #       head: its outputs feed top-k / NMS decisions and the post-trunk chain is held to the literal 1e-3, tests/test_gpu_chain.py);
 #   1 = the numerics of conv3x3_halo_h2.hip everywhere (main + cross accumulators, same weight planes, |a| <= 65504);
 #   0 = the round-1 kernel (conv3x3_halo_h2.hip), which data gradients (explicit `split`) always use.
-HALO_S1 = int(_os.environ.get("LVC_HALO_S1", "2"))
+HALO_S1 = 2
 # pointwise fp16x2 layers with at least LVC_PW_S1_MIN_C input channels on the pipelined kernel (csrc/conv_pw_s1.hip): 2 = its
 # single-accumulator form except `two_acc` layers, 1 = two accumulators everywhere, 0 = off (the LDS-DMA kernel for all of them)
-PW_S1 = int(_os.environ.get("LVC_PW_S1", "2"))
-_PW_S1_MIN_C = int(_os.environ.get("LVC_PW_S1_MIN_C", "64"))
-_PW_S1_ONE_MIN_C = int(_os.environ.get("LVC_PW_S1_ONE_MIN_C", "256"))
-_PW_S1_RES = int(_os.environ.get("LVC_PW_S1_RES", "1"))     # 1: layers with a residual / upsample-add operand qualify too
+PW_S1 = 2
+_PW_S1_MIN_C = 64
+_PW_S1_ONE_MIN_C = 256
+_PW_S1_RES = 1     # 1: layers with a residual / upsample-add operand qualify too
 # inference: conv3 (+ shortcut add + ReLU) of a bottleneck and conv1 (+ ReLU) of the next one as ONE launch (csrc/conv_pw_chain.hip;
 # modeling/backbone/resnet.py `BottleneckBlock.chain_to`); 0 = the two launches
 CHAIN = _os.environ.get("LVC_CHAIN", "1") != "0"
-_HALO_H2_MIN_TILES = int(_os.environ.get("LVC_HALO_H2_MIN_TILES", "128"))   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
+_HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None, act=None):
@@ -524,11 +522,11 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
             # the LDS-DMA kernel addresses outputs / residuals through 32-bit buffer descriptors (< 2^29 elements) and moves
             # residual rows in 32-channel chunks; anything else stays on the register-staged kernel (logged once)
             dma_ok = out.numel() < (1 << 29) and (residual is None or (residual.numel() < (1 << 29) and pc.K % 32 == 0))
-            if PW_DMA and not dma_ok:
+            if not dma_ok:
                 _log_once("pw_dma_fallback", "pointwise layer %dx%d->%d (%d output elements, residual %s) is outside the LDS-DMA "
                           "kernel's range; it runs on the register-staged fp16x2 kernel", N * H * W, C, pc.K, out.numel(),
                           "yes" if residual is not None else "no")
-            fn = "lvc_conv2d_nhwc_f16x2_dma" if PW_DMA and dma_ok else "lvc_conv2d_nhwc_f16x2"
+            fn = "lvc_conv2d_nhwc_f16x2_dma" if dma_ok else "lvc_conv2d_nhwc_f16x2"
             fused_act = act == "gelu" and fn.endswith("_dma") and not relu
             if fused_act:
                 act = None
@@ -671,13 +669,7 @@ def stem_conv_pool(x4, pc, relu=True, second=None):
                                                        c_int(y2.stride(2) if y2 is not None else 0), _stream(x4))
         check(st, "lvc_stem_conv_pool_nhwc4_f16x2")
         return out
-    st = _lib.lib().lvc_stem_conv_pool_nhwc4(ptr(x4), ptr(pc.split3()), ptr(pc.scale), ptr(pc.shift), ptr(out),
-                                             c_int(N), c_int(H), c_int(W), c_int(pc.w.shape[0]), c_int(1 if relu else 0),
-                                             _stream(x4))
-    check(st, "lvc_stem_conv_pool_nhwc4")
-    if y2 is not None:
-        y2.copy_(out)
-    return out
+    raise RuntimeError("the fused stem exists for the fp16 split only; BasicStem runs conv + max-pool as two launches otherwise")
 
 
 def linear(x, pc, relu=False, split=None):
@@ -1461,21 +1453,23 @@ def gelu(x):
     return y
 
 
-MHA_MFMA = _os.environ.get("LVC_MHA_MFMA", "1") != "0"   # 0: the one-thread-per-query fp32 VALU kernel of round 2 (lvc_mha)
+MHA_MFMA = True   # 0: the one-thread-per-query fp32 VALU kernel of round 2 (lvc_mha)
 
 
 def mha(qkv, B, N, num_heads, head_dim, scale, mfma=None):
     """qkv [B*N, 3*H*head_dim] -> [B*N, H*head_dim] (softmax(q k^T scale) v per image and head).  Default: the matrix-core
     kernel (lvc_mha_mfma: fp32-accurate two-way fp16 split, probabilities kept in registers between the two products);
-    mfma=False (or LVC_MHA_MFMA=0): the scalar fp32 kernel."""
+    mfma=False, or the range-free split (CONV_SPLIT "bf16x3"): the scalar fp32 kernel.  q * scale, k or v beyond fp16's range
+    (or NaN) raises bit 1 of the shared conv error word, like the conv kernels' operands (`check_conv_error_word`)."""
     _req_cuda(qkv)
     qkv = qkv.contiguous()
     out = torch.empty(B * N, num_heads * head_dim, device=qkv.device, dtype=torch.float32)
-    if (MHA_MFMA if mfma is None else mfma) and head_dim == 64:
+    if ((MHA_MFMA and CONV_SPLIT == "f16x2") if mfma is None else mfma) and head_dim == 64:
         lib = _lib.lib()
         lib.lvc_mha_workspace_bytes.restype = c_longlong
         ws = torch.empty(max(16, lib.lvc_mha_workspace_bytes(c_int(B), c_int(N), c_int(num_heads))), dtype=torch.uint8, device=qkv.device)
-        check(lib.lvc_mha_mfma(ptr(qkv), ptr(out), ptr(ws), c_int(B), c_int(N), c_int(num_heads), c_float(scale), _stream(qkv)), "lvc_mha_mfma")
+        check(lib.lvc_mha_mfma(ptr(qkv), ptr(out), ptr(ws), c_int(B), c_int(N), c_int(num_heads), c_float(scale),
+                                   ptr(_conv_error_view(qkv.device)), _stream(qkv)), "lvc_mha_mfma")
         return out
     check(_lib.lib().lvc_mha(ptr(qkv), ptr(out), c_int(B), c_int(N), c_int(num_heads), c_int(head_dim), c_float(scale), _stream(qkv)),
           "lvc_mha")

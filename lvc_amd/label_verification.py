@@ -15,7 +15,7 @@ from . import kernels as K
 # LVC_KNN_TWO_STAGE=0: materialise the full-precision similarity matrix (three MFMAs per block) and rank it directly
 KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
 # LVC_KNN_ROW_MARGINS=0: the worst-case margin 2^-9 for every row instead of the per-row bound from the measured rounding residuals
-KNN_ROW_MARGINS = os.environ.get("LVC_KNN_ROW_MARGINS", "1") != "0"
+KNN_ROW_MARGINS = True
 # unit-norm rows: |fp16 dot - exact| <= 2^-11 (|q| rounding) + 2^-11 (|s| rounding) + 2^-22 + fp32 accumulation
 # < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
 VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16

@@ -148,7 +148,8 @@ class BasicStem(CNNBlockBase):
     def forward_nhwc(self, x4, second=None):
         """x4: [N,H,W,4] (RGB + zero slot).  second: optional callable shape -> [N,Hp,Wp,64] strided view that receives
         a copy of the output (the concat buffer of a fused projection block)."""
-        if K.CONV_ENGINE == "bf16x3" and K.STEM_FUSED and self.conv1.out_channels == 64 and self.conv1.norm is not None:
+        if (K.CONV_ENGINE == "bf16x3" and K.CONV_SPLIT == "f16x2" and K.STEM_FUSED and self.conv1.out_channels == 64
+                and self.conv1.norm is not None):
             return K.stem_conv_pool(x4, self.conv1.packed(), relu=True, second=second)   # conv + FrozenBN + ReLU + max-pool, one launch
         y = self.conv1.forward_nhwc(x4)
         y = K.maxpool2d_nhwc(y, 3, 2, 1)

@@ -2,8 +2,8 @@
 # kNN sweep kernels: kernel trace + stats, then FETCH_SIZE / WRITE_SIZE / busy counters in separate --pmc passes (kernel trace only)
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/knn_pmc
-export LVC_BENCH_KNN_ONLY=${LVC_BENCH_KNN_ONLY:-randn}
-CMD="python $GRAFT_REPO_ROOT/bench.py --workload knn --steps 5 --warmup 2 --no-extras"
+KNN_INPUTS=${KNN_INPUTS:-randn}
+CMD="python $GRAFT_REPO_ROOT/bench.py --workload knn --knn-inputs $KNN_INPUTS --steps 5 --warmup 2 --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- $CMD > /dev/null 2>&1
 i=0
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY"; do

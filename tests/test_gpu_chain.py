@@ -142,11 +142,26 @@ def test_post_trunk_chain_exact_decisions_and_1e3(seeds, hw):
             v = (rb[:, b] - rb[:, a]).double() * scale / 7.0
             edge |= (v - v.round()).abs() <= 2.0 * box_tol * scale / 7.0 + 1e-7
         kg, kr = ~edge[src], ~edge[r["rows"]]
-        m2 = min(int(kg.sum()), int(kr.sum()))
-        g_cl, g_src, g_sc, g_bx = ocl[i, :n][kg][:m2], src[kg][:m2], osc[i, :n][kg][:m2], ob[i, :n][kg][:m2]
-        r_cl, r_rows, r_sc, r_bx = r["pred_classes"][kr][:m2], r["rows"][kr][:m2], r["scores"][kr][:m2], r["pred_boxes"][kr][:m2]
         n_edge = int(edge.sum())
-        assert n - m2 <= 4 * n_edge, (n, m2, n_edge)       # only those proposals' detections were set aside
+        # the SAME (class, source row) entries must be left on both sides (the lists used to be cut to a common length);
+        # an entry present on one side only may only be one that trades places at the 100-detection cut-off, i.e. whose score is
+        # within TIE of the last kept score
+        set_g = {(int(c), int(q)) for c, q in zip(ocl[i, :n][kg].tolist(), src[kg].tolist())}
+        set_r = {(int(c), int(q)) for c, q in zip(r["pred_classes"][kr].tolist(), r["rows"][kr].tolist())}
+        cut = float(r["scores"][-1])
+        for side, only, cls_l, row_l, sc_l in (("GPU", set_g - set_r, ocl[i, :n].tolist(), src.tolist(), osc[i, :n].tolist()),
+                                               ("oracle", set_r - set_g, r["pred_classes"].tolist(), r["rows"].tolist(), r["scores"].tolist())):
+            for c_, q_, s_ in zip(cls_l, row_l, sc_l):
+                if (int(c_), int(q_)) in only:
+                    assert abs(s_ - cut) <= tie_s, "%s-only detection (class %d, proposal %d, score %.6f) is not at the cut-off (%.6f)" % (side, c_, q_, s_, cut)
+        common = set_g & set_r
+        mg = torch.tensor([(int(c), int(q)) in common for c, q in zip(ocl[i, :n].tolist(), src.tolist())]) & kg
+        mr = torch.tensor([(int(c), int(q)) in common for c, q in zip(r["pred_classes"].tolist(), r["rows"].tolist())]) & kr
+        m2 = int(mg.sum())
+        assert m2 == int(mr.sum())
+        g_cl, g_src, g_sc, g_bx = ocl[i, :n][mg], src[mg], osc[i, :n][mg], ob[i, :n][mg]
+        r_cl, r_rows, r_sc, r_bx = r["pred_classes"][mr], r["rows"][mr], r["scores"][mr], r["pred_boxes"][mr]
+        assert n - m2 <= 4 * n_edge + len(set_g ^ set_r), (n, m2, n_edge)       # only those proposals' detections were set aside
         key_g = torch.stack([g_cl.double(), g_src.double()], 1)
         key_r = torch.stack([r_cl.double(), r_rows.double()], 1)
         dperm, dmoved = _tie_aware_order(key_g, g_sc, key_r, r_sc, 0.0, 1e-3, tie_s)

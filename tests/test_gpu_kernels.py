@@ -278,14 +278,13 @@ def test_conv_stem_7x7():
     assert (y - ref).abs().max() <= 2e-5 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("N,H,W", [(1, 64, 96), (2, 70, 134), (1, 37, 41), (1, 800, 1344)])
-def test_stem_conv_pool_fused_matches_cpu(N, H, W, split, monkeypatch):
-    """csrc/stem_pool.hip: conv 7x7/2 + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch vs the same chain on the
+def test_stem_conv_pool_fused_matches_cpu(N, H, W, monkeypatch):
+    """csrc/stem_pool_h2.hip: conv 7x7/2 + FrozenBN + ReLU + max_pool2d(3, 2, 1) in one launch vs the same chain on the
     CPU (reference BasicStem.forward, resnet.py:588-592), including odd sizes whose patches straddle the borders."""
     from lvc_amd import kernels as k
 
-    monkeypatch.setattr(k, "CONV_SPLIT", split)
+    monkeypatch.setattr(k, "CONV_SPLIT", "f16x2")
     g = torch.Generator().manual_seed(H * 7 + W)
     x = torch.randn(N, 3, H, W, generator=g) * 50
     w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
@@ -698,3 +697,49 @@ def test_pointwise_pipelined_forms_vs_fp64(N, H, W, C, K, stride, act, monkeypat
     if N * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) >= 2048 and C >= 64:     # both on a two-way fp16 kernel: same bits
         assert torch.equal(out[0], out[1]) or float((out[0] - out[1]).abs().max()) <= 2e-6 * sc
     assert rms[2] <= max(1.5 * rms_cpu, 2.0 * rms[0])
+
+
+@pytest.mark.parametrize("shape", ["res2", "res2.0", "res3"])
+def test_chained_conv3_conv1_matches_two_launches_and_fp64(shape):
+    """csrc/conv_pw_chain.hip (kernels.CHAIN / LVC_CHAIN): a bottleneck's conv3 + FrozenBN + shortcut add + ReLU and the next block's
+    conv1 + FrozenBN + ReLU as one launch (reference resnet.py:205-211 then :195-197) against the two launches and an fp64
+    evaluation; a row count that is not a multiple of the 128-pixel workgroup, a row stride wider than the contraction (the
+    res2.0 concat buffer), and the range word for an input beyond 4094."""
+    from lvc_amd import kernels as k
+
+    K1, N1, N2, res, ldx = {"res2": (64, 256, 64, True, 64), "res2.0": (128, 256, 64, False, 128), "res3": (128, 512, 128, True, 160)}[shape]
+    M = 128 * 37 + 45
+    g = torch.Generator().manual_seed(K1 + N1)
+    x = torch.randn(M, 1, 1, ldx, generator=g).relu_()
+    r = torch.randn(M, 1, 1, N1, generator=g).relu_() if res else None
+    wa = torch.randn(N1, K1, 1, 1, generator=g) * (2.0 / K1) ** 0.5
+    wb = torch.randn(N2, N1, 1, 1, generator=g) * (2.0 / N1) ** 0.5
+    bna = (torch.rand(N1, generator=g) + 0.5, torch.randn(N1, generator=g) * 0.1, torch.randn(N1, generator=g) * 0.1, torch.rand(N1, generator=g) + 0.5)
+    bnb = (torch.rand(N2, generator=g) + 0.5, torch.randn(N2, generator=g) * 0.1, torch.randn(N2, generator=g) * 0.1, torch.rand(N2, generator=g) + 0.5)
+    d = _dev()
+    pa, pb = k.pack_conv(wa.to(d), bn=[t.to(d) for t in bna]), k.pack_conv(wb.to(d), bn=[t.to(d) for t in bnb])
+    ch = k.pack_chain(pa, pb)
+    xd, rd = x.to(d), (r.to(d) if res else None)
+    y1, y2 = k.conv1x1_chain(xd, ch, residual=rd)
+    z1 = k.conv2d_nhwc(xd[..., :K1].contiguous(), pa, relu=True, residual=rd, res_mode=1 if res else 0)
+    z2 = k.conv2d_nhwc(z1, pb, relu=True)
+    sa, ta = k.conv_affine(None, bna)
+    sb, tb = k.conv_affine(None, bnb)
+    r1 = x.view(M, ldx)[:, :K1].double() @ wa.view(N1, K1).double().t() * sa.double() + ta.double()
+    if res:
+        r1 = r1 + r.view(M, N1).double()
+    r1 = r1.relu()
+    r2 = (r1 @ wb.view(N2, N1).double().t() * sb.double() + tb.double()).relu()
+    for got, two, ref in ((y1, z1, r1), (y2, z2, r2)):
+        scale = float(ref.abs().max())
+        e_one = float((got.cpu().view(M, -1).double() - ref).abs().max()) / scale
+        e_two = float((two.cpu().view(M, -1).double() - ref).abs().max()) / scale
+        assert e_one <= 2e-6 and e_one <= 2.0 * e_two + 2e-7, (e_one, e_two)
+    assert k.conv_error_word(d) == 0
+    # the range word: one input element beyond 4094 (a legal fp32 activation) must be reported, for this launch's own slot
+    xd2 = xd.clone()
+    xd2[7, 0, 0, 3] = 5000.0
+    k.conv1x1_chain(xd2, ch, residual=rd)
+    with pytest.raises(k.Fp16RangeError):
+        k.check_conv_error_word(d)
+    assert ch.state["off"] and k.conv_error_word(d) == 0
