@@ -6,22 +6,26 @@
 N > 1 without a launcher re-executes itself under `python -m torch.distributed.run --nproc-per-node N` (one rank per
 GPU over RCCL); launched BY torch.distributed.run (RANK / WORLD_SIZE in the environment) it runs as that rank.
 
-Default workload `infer` (BASELINE.json configs[1]): one "step" = one pass of the hot path over one batch of 8
-synthetic 3x800x1333 images per GPU; inputs are resident in HBM before the timed region; weights are the conditioned
+Default workload `infer` (BASELINE.json configs[1]): one "step" = one call of the drop-in surface, `GeneralizedRCNN.forward(
+batched_inputs) -> list[{"instances": Instances}]` (reference rcnn.py:100-125), on one batch of 8 synthetic 3x800x1333 images per GPU,
+including the step's one device->host read; inputs are resident in HBM before the timed region; weights are the conditioned
 random-init R50-FPN (lvc_amd/utils/synthetic.py).  Images shard data-parallel across ranks with no data-path collective
 (reference InferenceSampler semantics), so scaling is "weak" and value = all images of all ranks / max-over-ranks time.
 Rank 0 prints ONE JSON line carrying
-  roofline            the dominant conv kernel, HIP events around its launches inside the timed region
+  roofline            the dominant conv kernel, HIP events around its launches inside the timed region; plus `backbone_mfma_busy`
+                      (matrix-pipe occupancy of the whole backbone, duration-weighted) and `step_traffic` (fabric bytes of the whole
+                      step) from live rocprofv3 --pmc passes, against `step_algorithmic_bytes`
   bandwidth_kernels   ROIAlign / batched NMS / kNN top-k: event-timed ms, algorithmic bytes, GB/s and fraction of 8 TB/s
   knn                 BASELINE configs[3] on this GPU: 120k x 2400 x 1024 cosine sweep (ms, TF/s, GB/s, oracle agreement)
-  value_through_forward   the same K steps through `model(batch)` (adds the one D2H read + Instances slicing)
+  value_inference_batched the same K steps through `inference_batched` (device tensors out, no host read in the loop)
   pipelined           the same K steps with two batches in flight on two HIP streams
   cpu_baseline        the CPU oracle timed on this host (rank 0, N = 1 only), 5 warm-up + 20 timed images
   rccl / per_rank     (N > 1 or under a launcher) the RCCL world and every rank's own rate
   dp_legs             (N > 1) short RCCL legs: cfg-3 fine-tune steps with the gradient all-reduce, sharded kNN sweep
   train               (N = 1) cfg-3 fine-tune step (bs 8), cfg-5 R101 box-corrector step (bs 2) with ms forward / backward /
                       optimizer, and R101-FPN inference img/s
-  timed_batch_parity  the timed batch's detections against the CPU oracle's (the run exits non-zero below 0.9 matched)
+  timed_batch_parity  the timed batch's detections against the CPU oracle's; bars = 3 x the oracle's own fp32-vs-fp64 noise on the
+                      batch (oracle/noise.py); the run exits non-zero when a bar is missed
 `--workload train` / `--workload knn` time those two data-parallel legs as the main metric instead.
 """
 import argparse
@@ -561,8 +565,14 @@ def infer_main(c, args):
         with torch.no_grad():
             return model.inference_batched(batch)
 
+    def step_forward():
+        # the drop-in surface (reference lvc/modeling/meta_arch/rcnn.py:100-125): list[{"image", ...}] -> list[{"instances": Instances}];
+        # = inference_batched + the step's ONE device->host read (counts, status, range words) + per-image slicing.  This is `value`.
+        with torch.no_grad():
+            return model(batch)
+
     for _ in range(args.warmup):
-        out = step()
+        res = step_forward()
     _barrier(c)
     # HIP events on the launch stream: the timed region brackets only the launches of the DOMINANT kernel (picked from
     # one fully bracketed untimed step; ~150 event records per step cost ~0.7 ms of host time inside the timed region),
@@ -587,7 +597,7 @@ def infer_main(c, args):
     for _ in range(args.steps):
         if timer is not None:
             timer.next_step()
-        out = step()
+        res = step_forward()
     _barrier(c)
     dt = time.perf_counter() - t0
     K.CONV_TIMER = None
@@ -601,24 +611,24 @@ def infer_main(c, args):
         K.CONV_TIMER = None
     from lvc_amd.modeling.roi_heads.roi_heads import check_status
 
+    out = step()      # the raw device outputs of the same batch (what forward() slices): parity check and detection counts below
     check_status(int(out[4].item()))
     K.check_conv_error_word(c.dev)   # stream-K timeout / fp16x2 operand-range word of the conv kernels
     n_det = out[3].tolist()
+    assert [len(r["instances"]) for r in res] == n_det
 
-    # the drop-in surface itself: model(batch) = inference_batched + ONE D2H read (counts, status) + Instances slicing
+    # the same K steps WITHOUT the host read: inference_batched returns device tensors, nothing synchronises inside the loop
     with torch.no_grad():
-        for _ in range(2):
-            res = model(batch)
         _barrier(c)
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            res = model(batch)
+            step()
         _barrier(c)
         fdt, _ = _max_and_all(c, time.perf_counter() - t1)
     through_forward = {"value": round(c.world * BATCH_PER_GPU * args.steps / fdt, 2), "unit": "img/s",
                        "ms_per_step": round(1e3 * fdt / args.steps, 3),
-                       "note": "same K steps through GeneralizedRCNN.forward(batched_inputs) -> list[{'instances': Instances}] "
-                               "(reference rcnn.py:100-125 signature): adds the step's one device->host read and the per-image slicing"}
+                       "note": "same K steps through GeneralizedRCNN.inference_batched (device tensors out, no device->host read inside the loop): what "
+                               "`value` was in rounds 1-3; `value` is now the reference-signature forward(batched_inputs) -> list[{'instances': Instances}]"}
 
     # Extra, separately timed pass (not `value`): the same K steps issued round-robin on two HIP streams
     # (lvc_amd/evaluation.py): the latency-bound tail of batch i overlaps the trunk of batch i+1.  Kept out of the timed
@@ -675,9 +685,10 @@ def infer_main(c, args):
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_F16X2_TFLOPS if dom.startswith("f16x2") else PEAK_BF16X3_TFLOPS
         traffic = pmc = None
-        live = None
+        live = step_pmc = None
         if c.rank == 0 and c.world == 1 and not args.no_live_pmc:
             live = _live_conv_pmc()
+            step_pmc = _live_step_pmc()
         if live is not None:
             traffic = live["hbm_bytes_per_launch"]
             pmc = live
@@ -715,6 +726,18 @@ def infer_main(c, args):
         other["whole_step"] = {"tflops": round(fl_all / 2 / (dt_max / args.steps) / 1e12, 2),
                                "frac_of_f16x2_peak": round(fl_all / 2 / (dt_max / args.steps) / 1e12 / PEAK_F16X2_TFLOPS, 4)}
         roofline["breakdown_untimed_pass"] = other
+        # north_star: MFMA utilisation of the BACKBONE (not of one launch) and the whole step's traffic against its algorithmic bytes
+        alg_conv = full.algorithmic_bytes() / 2
+        alg_other = BATCH_PER_GPU * (3 * 800 * 1333 * 4 + 800 * 1344 * 16) + BATCH_PER_GPU * (1000 * 49 * 256 * 4 + 91.4e6)   # preprocess in / out; ROIAlign out + pyramid once
+        roofline["step_algorithmic_bytes"] = int(alg_conv + alg_other)
+        if step_pmc is not None:
+            roofline["backbone_mfma_busy"] = step_pmc["backbone_mfma_busy"]
+            roofline["step_traffic"] = step_pmc["step_hbm_bytes"]
+            roofline["step_traffic_over_algorithmic"] = round(step_pmc["step_hbm_bytes"] / (alg_conv + alg_other), 3)
+            roofline["step_pmc"] = step_pmc
+        else:
+            roofline["backbone_mfma_busy"] = roofline["step_traffic"] = None
+            roofline["step_pmc"] = "not measured in this run (--no-live-pmc or rocprofv3 unavailable); the committed pass: profiles/r04_step_pmc.json"
 
     extras = {}
     if c.rank == 0 and not args.no_extras:
@@ -752,7 +775,7 @@ def infer_main(c, args):
 
     if c.rank == 0:
         line = {
-            "metric": "img/s COCO 800x1333 R50-FPN inference (GeneralizedRCNN forward, 1000 proposals, 100 detections)",
+            "metric": "img/s COCO 800x1333 R50-FPN inference (GeneralizedRCNN.forward(batched_inputs) -> Instances, 1000 proposals, 100 detections)",
             "value": round(value, 2), "unit": "img/s", "n_gpus": c.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 (conv/GEMM inner products on the fp16 / bf16 matrix cores through fp32-accurate operand splits: two-way fp16 with main + cross fp32 accumulators for the 3x3 and wide 1x1 / FC layers, three-way bf16 for the rest; final boxes/scores closer to the fp64 evaluation than the reference's fp32 CPU path, tests/test_gpu_chain.py)", "data": "synthetic",
@@ -762,7 +785,7 @@ def infer_main(c, args):
                        "detections_per_image": n_det},
             "rccl": c.rccl, "per_rank": {"img_per_s": [round(BATCH_PER_GPU * args.steps / t, 2) for t in dt_all],
                                          "seconds": [round(t, 4) for t in dt_all], "max_over_ranks_s": round(dt_max, 4)},
-            "roofline": roofline, "value_through_forward": through_forward, "pipelined": pipelined, "graphed": graphed,
+            "roofline": roofline, "value_inference_batched": through_forward, "pipelined": pipelined, "graphed": graphed,
             "cpu_baseline": cpu_baseline, "timed_batch_parity": parity,
         }
         line.update(extras)
@@ -820,6 +843,75 @@ def _live_conv_pmc(timeout_s=90):
                "mfma_busy_fraction": round(agg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (cyc * 1024), 4) if cyc else None,
                "clock_GHz_under_load": round(cyc / ms / 1e6, 3) if (cyc and ms) else None}
         return out
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _live_step_pmc(timeout_s=150):
+    """Matrix-pipe occupancy of the WHOLE backbone and fabric traffic of the WHOLE step, measured on this box: three rocprofv3
+    passes (--pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES; each with --kernel-trace only, as
+    MI355X_MICROARCH.md prescribes) of scripts/probe_step_pmc.py, which runs one step and one backbone-only pass between marker
+    launches.  Busy fraction = sum of SQ_VALU_MFMA_BUSY_CYCLES / sum of (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) over the launches,
+    i.e. weighted by each launch's duration.  None when rocprofv3 is missing or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    probe = os.path.join(ROOT, "scripts", "probe_step_pmc.py")
+    if not os.path.exists(exe) or not os.path.exists(probe):
+        return None
+    tmp = tempfile.mkdtemp(prefix="lvc_step_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        seg = {}       # counter -> [rows of the step, rows of the backbone pass]; a row = (kernel name, value)
+        for i, ctr in enumerate(["FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"]):
+            cmd = [exe, "--pmc"] + ctr.split() + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "s%d" % i, "--", sys.executable, probe, str(BATCH_PER_GPU)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            rows = []
+            for f in glob.glob(os.path.join(tmp, "**", "s%d*counter_collection.csv" % i), recursive=True):
+                rows += list(csv.DictReader(open(f)))
+            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+            for name in ctr.split():
+                mine = [x for x in rows if x["Counter_Name"] == name]
+                marks = [j for j, x in enumerate(mine) if "gelu" in x["Kernel_Name"]]
+                if len(marks) < 3:
+                    return None
+                a, b, e = marks[-3], marks[-2], marks[-1]
+                seg[name] = [[(x["Kernel_Name"].split("(")[0], float(x["Counter_Value"])) for x in mine[a + 1:b]],
+                             [(x["Kernel_Name"].split("(")[0], float(x["Counter_Value"])) for x in mine[b + 1:e]]]
+        step_bytes = 2 * 1024 * sum(v for _, v in seg["FETCH_SIZE"][0]) + 1024 * sum(v for _, v in seg["WRITE_SIZE"][0])
+        bb_bytes = 2 * 1024 * sum(v for _, v in seg["FETCH_SIZE"][1]) + 1024 * sum(v for _, v in seg["WRITE_SIZE"][1])
+
+        def busy(rows_busy, rows_act, pred):
+            bsum = sum(v for n, v in rows_busy if pred(n))
+            asum = sum(v for n, v in rows_act if pred(n)) / 8.0 * 1024.0
+            return (bsum / asum) if asum else None
+
+        conv = lambda n: any(t in n for t in ("conv", "stem_pool", "gemm"))
+        per = {}
+        for n, v in seg["GRBM_GUI_ACTIVE"][1]:
+            per.setdefault(n, [0.0, 0.0, 0])
+            per[n][1] += v / 8.0 * 1024.0
+            per[n][2] += 1
+        for n, v in seg["SQ_VALU_MFMA_BUSY_CYCLES"][1]:
+            per.setdefault(n, [0.0, 0.0, 0])[0] += v
+        tot_act = sum(v[1] for v in per.values())
+        return {"source": "live: three rocprofv3 --pmc passes of scripts/probe_step_pmc.py (one step, one backbone-only pass, batch %d) on this box, inside this bench run" % BATCH_PER_GPU,
+                "backbone_mfma_busy": round(busy(seg["SQ_VALU_MFMA_BUSY_CYCLES"][1], seg["GRBM_GUI_ACTIVE"][1], lambda n: True), 4),
+                "backbone_mfma_busy_conv_kernels_only": round(busy(seg["SQ_VALU_MFMA_BUSY_CYCLES"][1], seg["GRBM_GUI_ACTIVE"][1], conv), 4),
+                "whole_step_mfma_busy": round(busy(seg["SQ_VALU_MFMA_BUSY_CYCLES"][0], seg["GRBM_GUI_ACTIVE"][0], lambda n: True), 4),
+                "backbone_launches": len(seg["GRBM_GUI_ACTIVE"][1]), "step_launches": len(seg["GRBM_GUI_ACTIVE"][0]),
+                "backbone_by_kernel": {n: {"launches": v[2], "share_of_backbone_cycles": round(v[1] / tot_act, 4), "mfma_busy": round(v[0] / v[1], 4) if v[1] else None}
+                                       for n, v in sorted(per.items(), key=lambda kv: -kv[1][1])[:8]},
+                "step_hbm_bytes": int(step_bytes), "backbone_hbm_bytes": int(bb_bytes),
+                "correction": "FETCH_SIZE x 2 (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE, KiB -> bytes",
+                "weighting": "sum of busy cycles / sum of active SIMD cycles over the launches (each launch weighs its own duration under the profiler)"}
     except Exception:
         return None
     finally:

@@ -348,6 +348,9 @@ class LaunchTimer:
     def steps_timed(self):
         return (self.step + self.every - 1) // self.every
 
+    def algorithmic_bytes(self, engine=None):
+        return sum(r[4] for r in self.records if (engine is None or r[3] == engine) and len(r) > 4)
+
     def flops_and_ms(self, engine=None):
         torch.cuda.synchronize()
         recs = [r for r in self.records if engine is None or r[3] == engine]
@@ -555,7 +558,10 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
     if timer is not None:
         e1.record()
         c_real = 3 if pc.mode == 1 else C
-        timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1, engine))
+        # algorithmic bytes of the launch: the input pixels it needs, its output, the residual operand, the weights -- each once
+        nbytes = 4.0 * (N * (Ho * Wo if (pc.R == 1 and pc.S == 1) else H * W) * c_real + N * Ho * Wo * pc.K
+                        + (residual.numel() if residual is not None else 0) + pc.K * c_real * pc.R * pc.S)
+        timer.records.append((2.0 * N * Ho * Wo * pc.K * c_real * pc.R * pc.S, e0, e1, engine, nbytes))
     if act == "gelu":
         check(_lib.lib().lvc_gelu(ptr(out), ptr(out), c_longlong(out.numel()), _stream(out)), "lvc_gelu")
     elif act is not None:
@@ -633,7 +639,8 @@ def conv1x1_chain(x, ch, residual=None, relu1=True, relu2=True, out1=None, out2=
     check(st, "lvc_conv1x1_chain_nhwc_f16s1")
     if timer is not None:
         e1.record()
-        timer.records.append((2.0 * M * (ch.K1 * ch.N1 + ch.N1 * ch.N2), e0, e1, "f16s1_chain"))
+        nbytes = 4.0 * (M * (ch.K1 + ch.N1 + ch.N2 + (ch.N1 if residual is not None else 0)) + ch.K1 * ch.N1 + ch.N1 * ch.N2)
+        timer.records.append((2.0 * M * (ch.K1 * ch.N1 + ch.N1 * ch.N2), e0, e1, "f16s1_chain", nbytes))
     return out1, out2
 
 
