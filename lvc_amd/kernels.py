@@ -235,6 +235,13 @@ def _range_words(device):
     return ws[_ERR_OFF: _ERR_OFF + 4 * _RANGE_SLOTS].view(torch.int32)
 
 
+def range_summary(device):
+    """[1] int32 device tensor, non-zero iff any error / range word of this stream's workspace is set: lets a caller fold the
+    check into a device->host read it does anyway (`roi_heads.instances_from_batched`) and call `check_conv_error_word` only
+    when something is up."""
+    return _range_words(device).amax().view(1)
+
+
 def conv_error_word(device):
     """OR of the kernels' error words (0 = fine; bit 0: spin timeout, bit 1: operand range); reading it synchronises."""
     e = 0

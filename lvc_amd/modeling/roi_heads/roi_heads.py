@@ -326,10 +326,12 @@ def run_with_fallbacks(model, fn):
 def instances_from_batched(boxes, scores, classes, count, image_sizes, status=None):
     """One device->host read (counts + status), then per-image `Instances` of device tensors."""
     if status is not None:
-        meta = torch.cat([count, status]).tolist()
-        counts, st = meta[:-1], meta[-1]
+        # ONE read: counts, the status word and whether any of the conv kernels' error / range words is set
+        meta = torch.cat([count, status, K.range_summary(count.device)]).tolist()
+        counts, st, flagged = meta[:-2], meta[-2], meta[-1]
         check_status(st)
-        K.check_conv_error_word(count.device)   # spin timeout / fp16x2 range word of the conv kernels (already synced)
+        if flagged:
+            K.check_conv_error_word(count.device)   # spin timeout / a layer beyond its fp16 split's range: re-routes and raises
     else:
         counts = count.tolist()
     out = []
