@@ -118,6 +118,7 @@ __global__ __launch_bounds__(1024) void nms_prep_kernel(const float* __restrict_
 // ---------------------------------------------------------------- 2. suppression mask via ballot
 #define NMS_MASK_STRIDE 96
 #define NMS_TILE 16384   // rows of one block of the blocked form = keys of one LDS sort tile
+#define NMS_HEAD_MIN 2048   // lists longer than this with max_keep << Nmax run the greedy pass on a HEAD block of sorted rows first
 // Rows / columns are the sorted positions [row0, min(n, row0 + rows_cap)) of the image (row0 = 0 and rows_cap >= n:
 // the whole image, the usual case); mask row (i - row0) holds nwords column words relative to the block.
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ sboxes,
@@ -434,6 +435,8 @@ extern "C" long long lvc_batched_nms_workspace_bytes(int B, int Nmax) {
                   (long long)Nmax * 4 /*sidx*/ + rows * nwords * 8 /*mask (one block)*/;
   if (Nmax > NMS_TILE)   // blocked form: kept positions, initial removed words, global sort keys, max key
     per += (long long)Nmax * 4 + NMS_MAX_WORDS * 8 + pad_pow2_ll(Nmax) * 8 + 16;
+  else if (Nmax > NMS_HEAD_MIN)   // head-block form (max_keep << Nmax): kept positions, initial removed words
+    per += (long long)Nmax * 4 + NMS_MAX_WORDS * 8 + 16;
   return (long long)B * per + 512;
 }
 
@@ -489,6 +492,41 @@ extern "C" int lvc_batched_nms(const float* boxes, const float* scores, const in
     }
 #undef LAUNCH_PREP
     LVC_CHECK_LAUNCH();
+    // Head-block form.  The detection stage asks for the 100 best of ~10 000 sorted candidates per image: the greedy pass ends
+    // as soon as max_keep boxes are kept, typically inside the first few hundred rows, but the mask kernel used to evaluate the
+    // whole upper triangle (thousands of 64 x 64 blocks per image).  Here the pass runs on the first `head` sorted rows alone
+    // (mask + reduce over a 1024-row block); the rest of the list follows as a second block of the blocked form below --
+    // suppression by the boxes kept so far (nms_cross_kernel), mask, reduce -- whose kernels return at once for every image
+    // that already has its max_keep boxes.  Same kernels, same decisions as the one-pass form.
+    int head = ((8 * max_keep + 63) / 64) * 64;
+    if (head < 1024) head = 1024;
+    if (Nmax > NMS_HEAD_MIN && head * 2 <= Nmax) {
+      int* kept_pos = (int*)ws; ws += (size_t)B * Nmax * 4;
+      ws = (char*)(((uintptr_t)ws + 15) & ~(uintptr_t)15);
+      u64* removed_init = (u64*)ws;
+      if (hipMemsetAsync(d_num_keep, 0, sizeof(int) * B, st) != hipSuccess) {
+        lvc_set_error("%s: hipMemsetAsync failed", __func__);
+        return LVC_ERR_HIP;
+      }
+      const int hw = head / 64;
+      hipLaunchKernelGGL(nms_mask_kernel, dim3(hw < NMS_MASK_STRIDE ? hw : NMS_MASK_STRIDE, hw, B), dim3(64), 0, st, sboxes, sidx,
+                         d_counts, Nmax, hw, iou_threshold, mask, 0, head, (const int*)nullptr, max_keep);
+      LVC_CHECK_LAUNCH();
+      hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, st, mask, order, d_counts, Nmax, hw, max_keep, keep,
+                         d_num_keep, 0, head, removed_init, kept_pos, 1);
+      LVC_CHECK_LAUNCH();
+      const int rest = Nmax - head, rw = (rest + 63) / 64;
+      hipLaunchKernelGGL(nms_cross_kernel, dim3(lvc_cdiv(rw, 4), B), dim3(256), 0, st, sboxes, sidx, d_counts, Nmax, rw,
+                         iou_threshold, kept_pos, d_num_keep, max_keep, head, rest, removed_init);
+      LVC_CHECK_LAUNCH();
+      hipLaunchKernelGGL(nms_mask_kernel, dim3(rw < NMS_MASK_STRIDE ? rw : NMS_MASK_STRIDE, rw, B), dim3(64), 0, st, sboxes, sidx,
+                         d_counts, Nmax, rw, iou_threshold, mask, head, rest, (const int*)d_num_keep, max_keep);
+      LVC_CHECK_LAUNCH();
+      hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, st, mask, order, d_counts, Nmax, rw, max_keep, keep,
+                         d_num_keep, head, rest, removed_init, kept_pos, 1);
+      LVC_CHECK_LAUNCH();
+      return LVC_OK;
+    }
     hipLaunchKernelGGL(nms_mask_kernel, mask_grid, dim3(64), 0, st, sboxes, sidx, d_counts, Nmax, nwords, iou_threshold,
                        mask, 0, rows_cap, (const int*)nullptr, max_keep);
     LVC_CHECK_LAUNCH();

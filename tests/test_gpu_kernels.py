@@ -743,3 +743,36 @@ def test_chained_conv3_conv1_matches_two_launches_and_fp64(shape):
     with pytest.raises(k.Fp16RangeError):
         k.check_conv_error_word(d)
     assert ch.state["off"] and k.conv_error_word(d) == 0
+
+
+@pytest.mark.parametrize("jitter,nidx,thr,max_keep", [(4.0, 80, 0.5, 100), (0.02, 3, 0.5, 100), (4.0, 80, 0.5, 1000), (0.5, 1, 0.3, 64)])
+def test_batched_nms_head_block_form_bit_exact(jitter, nidx, thr, max_keep):
+    """lvc_batched_nms with max_keep << Nmax (the detection stage: 100 of ~10 000 candidates): the greedy pass runs on a head block of
+    the sorted rows first and on the rest only for images that still lack boxes (csrc/nms.hip).  Keep lists must equal the oracle's
+    first max_keep entries -- with counts below / inside / far beyond the head block, with so much overlap that the head block keeps
+    fewer than max_keep boxes (the second block has to finish the list), and with score ties."""
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(int(jitter * 100) + nidx)
+    B, Nmax = 5, 12000
+    counts = torch.tensor([12000, 900, 3000, 0, 7777], dtype=torch.int32)
+    boxes = torch.zeros(B, Nmax, 4)
+    scores = torch.zeros(B, Nmax)
+    idxs = torch.zeros(B, Nmax, dtype=torch.int32)
+    for b in range(B):
+        bb, ss, ii = _nms_case(g, Nmax, nidx, jitter)
+        ss[::11] = ss[3]
+        if b == 2:      # 30 clusters of near-identical boxes: the head block keeps a few dozen, the rest of the list has to be walked
+            few = bb[:30]
+            bb = few[torch.randint(0, 30, (Nmax,), generator=g)] + torch.randn(Nmax, 4, generator=g) * 0.01
+            ii = torch.zeros(Nmax, dtype=torch.int64)
+        boxes[b], scores[b], idxs[b] = bb, ss, ii.int()
+    d = _dev()
+    keep, nk = k.batched_nms_batch(boxes.to(d), scores.to(d), idxs.to(d), counts.to(d), thr, max_keep=max_keep)
+    keep, nk = keep.cpu(), nk.cpu()
+    for b in range(B):
+        n = int(counts[b])
+        ref = oops.batched_nms(boxes[b, :n], scores[b, :n], idxs[b, :n].long(), thr)[:max_keep]
+        assert int(nk[b]) == len(ref), (b, int(nk[b]), len(ref))
+        assert keep[b, : len(ref)].tolist() == ref.tolist(), b
