@@ -32,6 +32,7 @@ struct GemmHArgs {
   float* y;
   int M, N, C, ldb, ldy, nk, tiles_m, tiles_n, nworkers, ngroup;
   unsigned y_bytes;
+  int q15;      // 1: y is int16, y[m][n] = rint(32767 * value) (|value| <= 1: cosine similarities), NaN -> -32768
 };
 
 typedef __attribute__((address_space(3))) void* gh_lds_ptr_t;
@@ -173,6 +174,20 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) {
         const int col = n0 + ni * 32 + fi;
+        if (p.q15) {
+          // 16-bit fixed point (step 2^-15: 1.5e-5 of quantisation error against the pre-filter's own ~6e-4): half the bytes of the
+          // matrix that this kernel writes and lvc_knn_verify_topk_vote_q15 reads back
+          const unsigned cb16 = col < p.N ? (rbase >> 1) + (unsigned)col * 2u : 0x80000000u;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float v = acc[mi][ni][e];
+            float t = __builtin_rintf(v * 32767.f);
+            t = t > 32767.f ? 32767.f : t < -32767.f ? -32767.f : t;
+            const int qv = v != v ? -32768 : (int)t;
+            __builtin_amdgcn_raw_buffer_store_b16((short)qv, yres, cb16 + (unsigned)((e & 3) + 8 * (e >> 2)) * (ldy4 >> 1), 0, 0);
+          }
+          continue;
+        }
         const unsigned cbase = col < p.N ? rbase + (unsigned)col * 4u : 0x80000000u;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -220,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 static int g_cus_h = 0;
 
 static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
-                           void* stream) {
+                           void* stream, int q15 = 0) {
   LVC_CHECK_ARG(M >= 0 && N > 0 && C > 0, "bad shape");
   if (M == 0) return LVC_OK;
   LVC_CHECK_ARG(a && b && y, "null pointer");
@@ -231,9 +246,11 @@ static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int
   LVC_CHECK_ARG(g.ldb >= C && g.ldb % 8 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0, "operands must be 16-byte aligned (ldb % 8 == 0)");
   g.ldy = ldy > 0 ? ldy : N;
   LVC_CHECK_ARG(g.ldy >= N, "ldy < N");
-  const long long yb = (long long)M * g.ldy * 4;
+  const long long yb = (long long)M * g.ldy * (q15 ? 2 : 4);
   LVC_CHECK_ARG(yb < (1ll << 31), "output must be smaller than 2 GiB");
+  LVC_CHECK_ARG(!q15 || g.ldy % 2 == 0, "16-bit rows must be 4-byte aligned");
   g.y_bytes = (unsigned)yb;
+  g.q15 = q15;
   g.nk = C / 32;
   g.tiles_m = lvc_cdiv(M, 256);
   g.tiles_n = lvc_cdiv(N, 256);
@@ -260,4 +277,11 @@ static int gemm_f16_launch(const unsigned short* a, const unsigned short* b, int
 extern "C" int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, int ldb, float* y, int M, int N, int C, int ldy,
                             void* stream) {
   return gemm_f16_launch(a, b, ldb, y, M, N, C, ldy, stream);
+}
+
+// lvc_gemm_f16 with a 16-bit fixed-point result: y [M, ldy] int16, y[m][n] = rint(32767 * sum_c a[m][c] b[n][c]) clamped to +-32767,
+// NaN -> -32768.  For operands with |dot product| <= 1 (unit-norm rows: the kNN pre-filter): |y / 32767 - dot| <= 1.6e-5.  ldy even.
+extern "C" int lvc_gemm_f16_q15(const unsigned short* a, const unsigned short* b, int ldb, short* y, int M, int N, int C, int ldy,
+                                void* stream) {
+  return gemm_f16_launch(a, b, ldb, (float*)y, M, N, C, ldy, stream, 1);
 }

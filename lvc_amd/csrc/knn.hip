@@ -525,8 +525,11 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
 //      smallest maximum with fewer than KTOP above it is T): a lower bound of A10, the row's KTOP-th largest value;
 //   2. ONE pass over the registers compacts the values >= T - margin into LDS (a superset of the candidates);
 //   3. A10 = the KTOP-th largest of those (every value >= T is among them); the entries below A10 - margin are dropped.
-template <int KTOP, int PER, int NSL, bool VEC>
-__global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* __restrict__ approx, int ld, int Q, int S,
+// Q15: the matrix is lvc_gemm_f16_q15's 16-bit fixed point (value = q / 32767, -32768 = NaN): half the bytes of the scan every row
+// pays; the caller's margin carries the 1.6e-5 of quantisation error.  Register j of lane l then holds column
+// (j / 8) * 512 + l * 8 + j % 8 (one dwordx4 = eight values per lane and 512 columns; PER % 8 == 0).
+template <int KTOP, int PER, int NSL, bool VEC, bool Q15 = false>
+__global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const void* __restrict__ approx_, int ld, int Q, int S,
                                                                    const float* __restrict__ q, int ldq, const float* __restrict__ mu,
                                                                    const float* __restrict__ den, const float* __restrict__ sn,
                                                                    int D, float margin_all, const float* __restrict__ margins,
@@ -539,12 +542,27 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const float* 
   if (row >= Q) return;     // whole waves leave; nothing below synchronises across waves
   const float margin = margins ? margins[row] : margin_all;
   KvLds<KTOP>& L = s_L[w];
-  const float* ar = approx + (size_t)row * ld;
+  const float* ar = reinterpret_cast<const float*>(approx_) + (Q15 ? 0 : (size_t)row * ld);
   float v[PER];
   float lmax = -INFINITY;
   // register j of lane l holds column col_of(j): one dwordx4 per lane and 256 columns when the rows are 16-byte aligned
-  auto col_of = [&](int j) { return VEC ? (j >> 2) * 256 + lane * 4 + (j & 3) : j * 64 + lane; };
-  if constexpr (VEC) {
+  auto col_of = [&](int j) { return Q15 ? (j >> 3) * 512 + lane * 8 + (j & 7) : VEC ? (j >> 2) * 256 + lane * 4 + (j & 3) : j * 64 + lane; };
+  if constexpr (Q15) {
+    static_assert(!Q15 || PER % 8 == 0, "eight 16-bit values per lane and load");
+    const short* as = reinterpret_cast<const short*>(approx_) + (size_t)row * ld;
+#pragma unroll
+    for (int jj = 0; jj < PER / 8; ++jj) {
+      const int i = jj * 512 + lane * 8;
+      int4 x = {0, 0, 0, 0};
+      if (i < S) x = *reinterpret_cast<const int4*>(as + i);      // rows are 16-byte aligned and padded to a multiple of 8 columns
+      const int wv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int qv = (wv[e >> 1] << (e & 1 ? 0 : 16)) >> 16;      // sign-extended half
+        v[8 * jj + e] = i + e < S ? (qv == -32768 ? INFINITY : (float)qv * (1.f / 32767.f)) : -INFINITY;
+      }
+    }
+  } else if constexpr (VEC) {
 #pragma unroll
     for (int jj = 0; jj < PER / 4; ++jj) {
       const int i = jj * 256 + lane * 4;
@@ -636,11 +654,43 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
-#define KV_LAUNCH_V(P, N, V) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N, V>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, \
+#define KV_LAUNCH_V(P, N, V) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N, V>), grid, block, 0, st, (const void*)approx, ldd, Q, S, q, ldqq, mu, \
                                                 den, sn, D, margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
 #define KV_LAUNCH_N(P, N) do { if (vec) KV_LAUNCH_V(P, N, true); else KV_LAUNCH_V(P, N, false); } while (0)
 #define KV_LAUNCH(P) do { if (D <= 512) KV_LAUNCH_N(P, 2); else if (D <= 1024) KV_LAUNCH_N(P, 4); else KV_LAUNCH_N(P, 8); } while (0)
   const bool vec = ldd % 4 == 0 && (((uintptr_t)approx) & 15) == 0;     // rows that dwordx4 loads can walk
+  if (per <= 8) KV_LAUNCH(8);
+  else if (per <= 16) KV_LAUNCH(16);
+  else if (per <= 24) KV_LAUNCH(24);
+  else if (per <= 32) KV_LAUNCH(32);
+  else if (per <= 40) KV_LAUNCH(40);
+  else if (per <= 48) KV_LAUNCH(48);
+  else KV_LAUNCH(64);
+#undef KV_LAUNCH_N
+#undef KV_LAUNCH_V
+#undef KV_LAUNCH
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// The same over lvc_gemm_f16_q15's 16-bit fixed-point matrix (approx [Q, ld] int16, value = q / 32767, -32768 = NaN; ld % 8 == 0, rows
+// 16-byte aligned): `margin` / `margins` must include 2 x 1.6e-5 for the quantisation (lvc_amd.label_verification.Q15_MARGIN).
+extern "C" int lvc_knn_verify_topk_vote_q15(const short* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
+                                        const float* den, const float* sn, int D, float margin, const float* margins,
+                                        const long long* shot_classes, const long long* det_classes, int kvote,
+                                        long long* top_classes, long long* keep, void* stream) {
+  KV_CHECKS();
+  LVC_CHECK_ARG(approx, "null pointer");
+  LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
+  const int per = lvc_cdiv(S, 64);
+  const dim3 grid(lvc_cdiv(Q, 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  const int ldd = ld > 0 ? ld : S;
+#define KV_LAUNCH_V(P, N, V) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N, true, true>), grid, block, 0, st, (const void*)approx, ldd, Q, S, q, ldqq, mu, \
+                                                den, sn, D, margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
+#define KV_LAUNCH_N(P, N) KV_LAUNCH_V(P, N, true)
+#define KV_LAUNCH(P) do { if (D <= 512) KV_LAUNCH_N(P, 2); else if (D <= 1024) KV_LAUNCH_N(P, 4); else KV_LAUNCH_N(P, 8); } while (0)
+  LVC_CHECK_ARG(ldd % 8 == 0 && (((uintptr_t)approx) & 15) == 0, "16-bit rows must be 16-byte aligned (ld % 8 == 0)");
   if (per <= 8) KV_LAUNCH(8);
   else if (per <= 16) KV_LAUNCH(16);
   else if (per <= 24) KV_LAUNCH(24);

@@ -1128,15 +1128,23 @@ def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True, want_resid=False):
     return (y, yh, den, resid) if want_resid else (y, yh, den)
 
 
-def gemm_f16(a, b, n=None, ldb=None):
+def gemm_f16(a, b, n=None, ldb=None, q15=False):
     """a [M,C] . b^T on fp16 operands with fp32 accumulation -> [M,N] fp32 (lvc_gemm_f16): the pre-filter of the two-stage
-    kNN sweep.  n / ldb: use n rows of b that lie ldb elements apart (a strided subset of a contiguous [*, C] tensor)."""
+    kNN sweep.  n / ldb: use n rows of b that lie ldb elements apart (a strided subset of a contiguous [*, C] tensor).
+    q15: the result as 16-bit fixed point, rint(32767 * value) (lvc_gemm_f16_q15; rows padded to a multiple of 8 columns,
+    returned as the [M, N] view)."""
     _req_cuda(a, b)
     M, C = a.shape
     assert a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float16 and b.dtype == torch.float16 and b.shape[1] == C
     N = b.shape[0] if n is None else n
     ldb = C if ldb is None else ldb
     assert (N - 1) * ldb + C <= b.numel()
+    if q15:
+        ld = (N + 7) // 8 * 8
+        y = torch.empty(M, ld, device=a.device, dtype=torch.int16)
+        rc = _lib.lib().lvc_gemm_f16_q15(ptr(a), ptr(b), c_int(ldb), ptr(y), c_int(M), c_int(N), c_int(C), c_int(ld), _stream(a))
+        check(rc, "lvc_gemm_f16_q15")
+        return y[:, :N]
     y = torch.empty(M, N, device=a.device, dtype=torch.float32)
     rc = _lib.lib().lvc_gemm_f16(ptr(a), ptr(b), c_int(ldb), ptr(y), c_int(M), c_int(N), c_int(C), c_int(N), _stream(a))
     check(rc, "lvc_gemm_f16")
@@ -1160,9 +1168,11 @@ def knn_verify_topk_vote(approx, q, sn, margin, shot_classes, det_classes, k, mu
     if det_classes is not None:
         det_classes = det_classes.contiguous()
         assert det_classes.dtype == torch.int64
-    rc = _lib.lib().lvc_knn_verify_topk_vote(ptr(approx), c_int(approx.stride(0)), c_int(Q), c_int(S), ptr(q), c_int(q.stride(0)),
-                                             ptr(mu), ptr(den), ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(margins),
-                                             ptr(shot_classes), ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(approx))
+    fn = _lib.lib().lvc_knn_verify_topk_vote_q15 if approx.dtype == torch.int16 else _lib.lib().lvc_knn_verify_topk_vote
+    assert approx.dtype in (torch.int16, torch.float32)
+    rc = fn(ptr(approx), c_int(approx.stride(0)), c_int(Q), c_int(S), ptr(q), c_int(q.stride(0)),
+            ptr(mu), ptr(den), ptr(sn), c_int(sn.shape[1]), c_float(margin), ptr(margins),
+            ptr(shot_classes), ptr(det_classes), c_int(k), ptr(top), ptr(keep), _stream(approx))
     check(rc, "lvc_knn_verify_topk_vote")
     return top, keep
 

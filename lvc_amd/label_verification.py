@@ -16,6 +16,10 @@ from . import kernels as K
 KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
 # LVC_KNN_ROW_MARGINS=0: the worst-case margin 2^-9 for every row instead of the per-row bound from the measured rounding residuals
 KNN_ROW_MARGINS = True
+# the pre-filter similarities as 16-bit fixed point (lvc_gemm_f16_q15: half the matrix round trip between the two stages);
+# its quantisation error (half a step of 1 / 32767, twice: containment argument of csrc/knn.hip) joins every margin
+KNN_Q15 = True
+Q15_MARGIN = 2.0 * (0.5 / 32767.0) + 1e-6
 # unit-norm rows: |fp16 dot - exact| <= 2^-11 (|q| rounding) + 2^-11 (|s| rounding) + 2^-22 + fp32 accumulation
 # < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
 VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16
@@ -136,7 +140,10 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
             _, qh, den, qres = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False, want_resid=True)
             margins = pre_filter_margins(qres, sh_max, sres_max, D)
-            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh), qc, sn, VERIFY_MARGIN, shot_classes, dc, k, mu=mu, den=den,
+            extra = Q15_MARGIN if KNN_Q15 else 0.0
+            if extra:
+                margins = margins + extra
+            t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh, q15=KNN_Q15), qc, sn, VERIFY_MARGIN + extra, shot_classes, dc, k, mu=mu, den=den,
                                            margins=margins if KNN_ROW_MARGINS else None)
         else:
             qn = K.rownorm(qc, mu=mu, eps=1e-8, mode=1) if cosine else qc
