@@ -938,15 +938,18 @@ def _knn_kernels_alone(c):
     sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
     _, qh, den = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False)
     nq = min(KNN_Q, (2 ** 31 - 1) // (4 * KNN_S))
-    ms = _event_ms(lambda: K.gemm_f16(qh[:nq], sh), 10)
+    q15 = bool(LV.KNN_Q15)       # what the sweep runs: the similarity matrix as 16-bit fixed point between the two stages
+    eb = 2 if q15 else 4
+    ms = _event_ms(lambda: K.gemm_f16(qh[:nq], sh, q15=q15), 10)
     fl = 2.0 * nq * KNN_S * KNN_D
-    out["knn_gemm_f16"] = {"kernel": "gemm_f16_dma_kernel, %d x %d x %d fp16 operands -> fp32" % (nq, KNN_S, KNN_D), "ms": round(ms, 4),
+    out["knn_gemm_f16"] = {"kernel": "gemm_f16_dma_kernel, %d x %d x %d fp16 operands -> %s" % (nq, KNN_S, KNN_D, "int16 (q15)" if q15 else "fp32"), "ms": round(ms, 4),
                            "tflops": round(fl / ms / 1e9, 1), "frac_of_fp16_mfma_peak_2500": round(fl / ms / 1e9 / 2500.0, 4),
-                           "algorithmic_bytes": nq * KNN_D * 2 + KNN_S * KNN_D * 2 + nq * KNN_S * 4}
+                           "algorithmic_bytes": nq * KNN_D * 2 + KNN_S * KNN_D * 2 + nq * KNN_S * eb}
     out["knn_gemm_f16"]["GBps"] = round(out["knn_gemm_f16"]["algorithmic_bytes"] / ms / 1e6, 1)
-    ap = K.gemm_f16(qh[:nq], sh)
-    ms = _event_ms(lambda: K.knn_verify_topk_vote(ap, q[:nq], sn, LV.VERIFY_MARGIN, cls, qcls[:nq], 10, mu=mu, den=den), 10)
-    alg = nq * KNN_S * 4 + nq * 10 * 8 + nq * 8
+    ap = K.gemm_f16(qh[:nq], sh, q15=q15)
+    mg = LV.VERIFY_MARGIN + (LV.Q15_MARGIN if q15 else 0.0)
+    ms = _event_ms(lambda: K.knn_verify_topk_vote(ap, q[:nq], sn, mg, cls, qcls[:nq], 10, mu=mu, den=den), 10)
+    alg = nq * KNN_S * eb + nq * 10 * 8 + nq * 8
     out["knn_verify_topk_vote"] = {"kernel": "knn_verify_topk_vote_kernel, %d x %d pre-filter similarities -> exact top-10 class ids + keep" % (nq, KNN_S),
                                    "ms": round(ms, 4), "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1),
                                    "frac_of_hbm_peak": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4)}
