@@ -129,16 +129,18 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
   // grid (NMS_MASK_STRIDE, nwords, B): workgroup (x, ci) walks the column words wj = ci + x, ci + x + STRIDE, ... of its
   // 64-row chunk (upper triangle only).  The grid is sized for Nmax, the loop for this image's n: the detection stage
   // (Nmax = 16 384, a few thousand real candidates) no longer dispatches 256 x 256 mostly empty workgroups per image.
-  const int ci = blockIdx.y, img = blockIdx.z;
+  const int img = blockIdx.z;
   int n = counts ? counts[img] : Nmax;
   if (n > Nmax) n = Nmax;
   const int nend = n < row0 + rows_cap ? n : row0 + rows_cap;
-  if (row0 + ci * 64 >= nend) return;
   if (num_keep && num_keep[img] >= max_keep) return;   // later blocks of the blocked form: the image is done
-  const int nchunks = (nend - row0 + 63) >> 6;
+  const int nchunks = nend > row0 ? (nend - row0 + 63) >> 6 : 0;
   const int lane = threadIdx.x;
   const float* sb = sboxes + (size_t)img * Nmax * 4;
   const int* si = sidx + (size_t)img * Nmax;
+  // gridDim.y may be smaller than the number of 64-row chunks (the second block of the head-block form is launched for the worst
+  // case and mostly returns at once: 184 000 empty workgroups cost 39 us): a workgroup walks chunks ci, ci + gridDim.y, ...
+  for (int ci = blockIdx.y; ci < nchunks; ci += gridDim.y) {
   const int i_me = row0 + ci * 64 + lane;
   // row box held by lane i (broadcast later), column box held by lane j
   float ix1 = 0, iy1 = 0, ix2 = 0, iy2 = 0; int iid = -1;
@@ -174,6 +176,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
       if (lane == r) my_word = word;
     }
     if (i_me < nend) mask[((size_t)img * rows_cap + (i_me - row0)) * nwords + wj] = my_word;
+  }
   }
 }
 
@@ -519,7 +522,7 @@ extern "C" int lvc_batched_nms(const float* boxes, const float* scores, const in
       hipLaunchKernelGGL(nms_cross_kernel, dim3(lvc_cdiv(rw, 4), B), dim3(256), 0, st, sboxes, sidx, d_counts, Nmax, rw,
                          iou_threshold, kept_pos, d_num_keep, max_keep, head, rest, removed_init);
       LVC_CHECK_LAUNCH();
-      hipLaunchKernelGGL(nms_mask_kernel, dim3(rw < NMS_MASK_STRIDE ? rw : NMS_MASK_STRIDE, rw, B), dim3(64), 0, st, sboxes, sidx,
+      hipLaunchKernelGGL(nms_mask_kernel, dim3(rw < NMS_MASK_STRIDE ? rw : NMS_MASK_STRIDE, rw < 16 ? rw : 16, B), dim3(64), 0, st, sboxes, sidx,
                          d_counts, Nmax, rw, iou_threshold, mask, head, rest, (const int*)d_num_keep, max_keep);
       LVC_CHECK_LAUNCH();
       hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, st, mask, order, d_counts, Nmax, rw, max_keep, keep,
