@@ -935,8 +935,9 @@ def _knn_kernels_alone(c):
     shots = _knn_inputs(c, KNN_S, 7, cls, centers, 2.0)
     q = _knn_inputs(c, KNN_Q, 100, qcls, centers, 2.5)
     mu = K.colmean(shots)
-    sn, sh, _ = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1)
-    _, qh, den = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False)
+    sn, sh, _, sres = K.rownorm_h(shots, mu=mu, eps=1e-8, mode=1, want_resid=True)
+    _, qh, den, qres = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False, want_resid=True)
+    sres_max = K.max_f32(sres)
     nq = min(KNN_Q, (2 ** 31 - 1) // (4 * KNN_S))
     q15 = bool(LV.KNN_Q15)       # what the sweep runs: the similarity matrix as 16-bit fixed point between the two stages
     eb = 2 if q15 else 4
@@ -948,9 +949,12 @@ def _knn_kernels_alone(c):
     out["knn_gemm_f16"]["GBps"] = round(out["knn_gemm_f16"]["algorithmic_bytes"] / ms / 1e6, 1)
     ap = K.gemm_f16(qh[:nq], sh, q15=q15)
     mg = LV.VERIFY_MARGIN + (LV.Q15_MARGIN if q15 else 0.0)
-    ms = _event_ms(lambda: K.knn_verify_topk_vote(ap, q[:nq], sn, mg, cls, qcls[:nq], 10, mu=mu, den=den), 10)
-    alg = nq * KNN_S * eb + nq * 10 * 8 + nq * 8
-    out["knn_verify_topk_vote"] = {"kernel": "knn_verify_topk_vote_kernel, %d x %d pre-filter similarities -> exact top-10 class ids + keep" % (nq, KNN_S),
+    # the per-row margins the sweep hands in (label_verification.knn_sweep)
+    margins = (LV.pre_filter_margins(qres, 1.0 + 1e-6 + sres_max, sres_max, KNN_D) + (LV.Q15_MARGIN if q15 else 0.0))[:nq].contiguous()
+    ms = _event_ms(lambda: K.knn_verify_topk_vote(ap, q[:nq], sn, mg, cls, qcls[:nq], 10, mu=mu, den=den, margins=margins), 10)
+    alg = nq * KNN_S * eb + nq * KNN_D * 4 + nq * 10 * 8 + nq * 8
+    out["knn_verify_topk_vote"] = {"kernel": "%s, %d x %d pre-filter similarities + the raw query rows -> exact top-10 class ids + keep" % (
+                                       "knn_verify_q15_kernel" if q15 else "knn_verify_topk_vote_kernel", nq, KNN_S),
                                    "ms": round(ms, 4), "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1),
                                    "frac_of_hbm_peak": round(alg / ms / 1e6 / PEAK_HBM_GBPS, 4)}
     ms = _event_ms(lambda: K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_rows=False), 10)

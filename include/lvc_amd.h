@@ -425,7 +425,7 @@ int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const fl
                              const long long* shot_classes, const long long* det_classes, int kvote, long long* top_classes,
                              long long* keep, void* stream);
 /* 16-bit fixed-point form of the two-stage sweep's similarity matrix (tools/run_nearest_neighbours.py:146-151 keeps it in fp32; here
- * it only pre-filters): lvc_gemm_f16_q15 writes y[m][n] = rint(32767 * dot) as int16 (NaN -> -32768; ldy even), and
+ * it only pre-filters): lvc_gemm_f16_q15 writes y[m][n] = rint(32766 * dot) clamped to +-32766 as int16 (NaN -> 32767; ldy even), and
  * lvc_knn_verify_topk_vote_q15 reads it (ld % 8 == 0, rows 16-byte aligned) -- half the bytes of the matrix round trip; the margin
  * handed in must include 2 x 1.6e-5 for the quantisation. */
 int lvc_gemm_f16_q15(const unsigned short* a, const unsigned short* b, int ldb, short* y, int M, int N, int C, int ldy, void* stream);

@@ -32,7 +32,7 @@ struct GemmHArgs {
   float* y;
   int M, N, C, ldb, ldy, nk, tiles_m, tiles_n, nworkers, ngroup;
   unsigned y_bytes;
-  int q15;      // 1: y is int16, y[m][n] = rint(32767 * value) (|value| <= 1: cosine similarities), NaN -> -32768
+  int q15;      // 1: y is int16, y[m][n] = rint(32766 * value) clamped to +-32766 (cosine similarities), NaN -> 32767
 };
 
 typedef __attribute__((address_space(3))) void* gh_lds_ptr_t;
@@ -181,9 +181,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const float v = acc[mi][ni][e];
-            float t = __builtin_rintf(v * 32767.f);
-            t = t > 32767.f ? 32767.f : t < -32767.f ? -32767.f : t;
-            const int qv = v != v ? -32768 : (int)t;
+            // NaN takes the largest code so that it sorts first, as in torch.topk; -32768 is never written ("no value" for the reader)
+            const float t = __builtin_amdgcn_fmed3f(__builtin_rintf(v * 32766.f), -32766.f, 32766.f);
+            const int qv = v != v ? 32767 : (int)t;
             __builtin_amdgcn_raw_buffer_store_b16((short)qv, yres, cb16 + (unsigned)((e & 3) + 8 * (e >> 2)) * (ldy4 >> 1), 0, 0);
           }
           continue;
@@ -279,8 +279,9 @@ extern "C" int lvc_gemm_f16(const unsigned short* a, const unsigned short* b, in
   return gemm_f16_launch(a, b, ldb, y, M, N, C, ldy, stream);
 }
 
-// lvc_gemm_f16 with a 16-bit fixed-point result: y [M, ldy] int16, y[m][n] = rint(32767 * sum_c a[m][c] b[n][c]) clamped to +-32767,
-// NaN -> -32768.  For operands with |dot product| <= 1 (unit-norm rows: the kNN pre-filter): |y / 32767 - dot| <= 1.6e-5.  ldy even.
+// lvc_gemm_f16 with a 16-bit fixed-point result: y [M, ldy] int16, y[m][n] = rint(32766 * sum_c a[m][c] b[n][c]) clamped to +-32766,
+// NaN -> 32767.  For operands with |dot product| <= 1 (unit-norm rows: the kNN pre-filter): |y / 32766 - dot| <= 1.6e-5 (a dot product
+// that rounding pushed beyond +-1 is clamped TOWARDS the true value).  ldy even.
 extern "C" int lvc_gemm_f16_q15(const unsigned short* a, const unsigned short* b, int ldb, short* y, int M, int N, int C, int ldy,
                                 void* stream) {
   return gemm_f16_launch(a, b, ldb, (float*)y, M, N, C, ldy, stream, 1);

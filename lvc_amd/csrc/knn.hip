@@ -525,10 +525,8 @@ __device__ __forceinline__ void kv_finish(KvLds<KTOP>& L, const int lane, const 
 //      smallest maximum with fewer than KTOP above it is T): a lower bound of A10, the row's KTOP-th largest value;
 //   2. ONE pass over the registers compacts the values >= T - margin into LDS (a superset of the candidates);
 //   3. A10 = the KTOP-th largest of those (every value >= T is among them); the entries below A10 - margin are dropped.
-// Q15: the matrix is lvc_gemm_f16_q15's 16-bit fixed point (value = q / 32767, -32768 = NaN): half the bytes of the scan every row
-// pays; the caller's margin carries the 1.6e-5 of quantisation error.  Register j of lane l then holds column
-// (j / 8) * 512 + l * 8 + j % 8 (one dwordx4 = eight values per lane and 512 columns; PER % 8 == 0).
-template <int KTOP, int PER, int NSL, bool VEC, bool Q15 = false>
+// (The 16-bit fixed-point matrix of lvc_gemm_f16_q15 has a kernel of its own: knn_verify_q15_kernel below.)
+template <int KTOP, int PER, int NSL, bool VEC>
 __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const void* __restrict__ approx_, int ld, int Q, int S,
                                                                    const float* __restrict__ q, int ldq, const float* __restrict__ mu,
                                                                    const float* __restrict__ den, const float* __restrict__ sn,
@@ -542,27 +540,12 @@ __global__ __launch_bounds__(256) void knn_verify_topk_vote_kernel(const void* _
   if (row >= Q) return;     // whole waves leave; nothing below synchronises across waves
   const float margin = margins ? margins[row] : margin_all;
   KvLds<KTOP>& L = s_L[w];
-  const float* ar = reinterpret_cast<const float*>(approx_) + (Q15 ? 0 : (size_t)row * ld);
+  const float* ar = reinterpret_cast<const float*>(approx_) + (size_t)row * ld;
   float v[PER];
   float lmax = -INFINITY;
   // register j of lane l holds column col_of(j): one dwordx4 per lane and 256 columns when the rows are 16-byte aligned
-  auto col_of = [&](int j) { return Q15 ? (j >> 3) * 512 + lane * 8 + (j & 7) : VEC ? (j >> 2) * 256 + lane * 4 + (j & 3) : j * 64 + lane; };
-  if constexpr (Q15) {
-    static_assert(!Q15 || PER % 8 == 0, "eight 16-bit values per lane and load");
-    const short* as = reinterpret_cast<const short*>(approx_) + (size_t)row * ld;
-#pragma unroll
-    for (int jj = 0; jj < PER / 8; ++jj) {
-      const int i = jj * 512 + lane * 8;
-      int4 x = {0, 0, 0, 0};
-      if (i < S) x = *reinterpret_cast<const int4*>(as + i);      // rows are 16-byte aligned and padded to a multiple of 8 columns
-      const int wv[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int qv = (wv[e >> 1] << (e & 1 ? 0 : 16)) >> 16;      // sign-extended half
-        v[8 * jj + e] = i + e < S ? (qv == -32768 ? INFINITY : (float)qv * (1.f / 32767.f)) : -INFINITY;
-      }
-    }
-  } else if constexpr (VEC) {
+  auto col_of = [&](int j) { return VEC ? (j >> 2) * 256 + lane * 4 + (j & 3) : j * 64 + lane; };
+  if constexpr (VEC) {
 #pragma unroll
     for (int jj = 0; jj < PER / 4; ++jj) {
       const int i = jj * 256 + lane * 4;
@@ -673,34 +656,358 @@ extern "C" int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int 
   return LVC_OK;
 }
 
-// The same over lvc_gemm_f16_q15's 16-bit fixed-point matrix (approx [Q, ld] int16, value = q / 32767, -32768 = NaN; ld % 8 == 0, rows
-// 16-byte aligned): `margin` / `margins` must include 2 x 1.6e-5 for the quantisation (lvc_amd.label_verification.Q15_MARGIN).
+// ---------------------------------------------------------------------------------------------------------------------
+// The same verification over lvc_gemm_f16_q15's 16-bit fixed-point matrix (gemm_h.hip: y = rint(32766 * dot) clamped to +-32766,
+// NaN -> 32767 so that it sorts first as in torch.topk; -32768 is never written and stands for "no value" here).  The float kernel
+// above is bound by VALU issue, not by memory (0.61 ms for 576 MB on the cfg-4 sweep, 0.37 ms of it before the first exact dot
+// product: scripts/probe_knn_verify.py): it unpacks and tests every one of the S values of a row in fp32.  Here
+//   * the scan stays in the 16-bit domain: lane maxima with v_pk_max_i16 on the packed words as loaded (eight values per dwordx4),
+//     T = the KTOP-th largest lane maximum by a bisection over the value range with one ballot per step (scalar work), the
+//     compaction tests each packed word with two integer compares against T - margin (margin rounded UP to steps of 1 / 32766: a
+//     superset of the float test) and converts nothing but the candidates;
+//   * a candidate is one packed key (value << 16 | 65535 - column: signed order = value descending, column ascending) next to its
+//     class, read back as ONE 64-bit broadcast per step of the ranking loops;
+//   * the exact re-evaluation works on q - mu (not normalised) with two-wide fmas and divides the finished dot product by the row's
+//     norm once -- sixteen divisions per row become one per dot product; the sum order is fixed (lane l: the x/y and the z/w halves
+//     of its float4 slices as two chains, added, then the lane tree of the float kernel), identical shots still tie exactly;
+//   * the query row is requested at the top of the kernel, under the scan.
+// The containment / flagging argument is the float kernel's (header above); candidates carrying the NaN code are never flagged
+// (they keep +inf and order by shot index).  More than KQ_MAX_CAND candidates: every shot exactly, as there.
+#define KQ_MAX_CAND 192
+#define KQ_SCALE 32766.f
+#ifndef KQ_WAVES
+#define KQ_WAVES
+#endif
+#ifndef KQ_CH
+#define KQ_CH 4     // 256-element slices of four shot rows in flight per round of exact dot products
+#endif
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float kq_f32x2 __attribute__((ext_vector_type(2)));
+
+struct KqLds {
+  int2 ent[KQ_MAX_CAND];      // x: approximate value in steps (32767 = NaN code), y: class
+  int2 rk[KQ_MAX_CAND];       // x: bits of the sort key (exact similarity where evaluated, else the approximate one), y: shot
+  short alist[KQ_MAX_CAND];   // positions of the flagged candidates
+  int cls[16];
+};
+
+__device__ __forceinline__ int kq_prefix(unsigned long long m) {     // set bits of m below this lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+__device__ __forceinline__ int kq_count(bool p) {     // lanes with p, as a 32-bit scalar (the compiler's own 64-bit count is compared on the VALU)
+  int n;
+  const unsigned long long m = __ballot(p);
+  asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+  return n;
+}
+
+template <int KTOP, int NJ, int NSL>
+__global__ __launch_bounds__(256) KQ_WAVES void knn_verify_q15_kernel(const short* __restrict__ approx, int ld, int Q, int S,
+                                                             const float* __restrict__ q, int ldq, const float* __restrict__ mu,
+                                                             const float* __restrict__ den, const float* __restrict__ sn, int D,
+                                                             float margin_all, const float* __restrict__ margins,
+                                                             const long long* __restrict__ shot_classes,
+                                                             const long long* __restrict__ det_classes, int kvote,
+                                                             long long* __restrict__ top_classes, long long* __restrict__ keep) {
+  __shared__ KqLds s_L[4];
+  // wave-uniform values are made scalar by hand (readfirstlane): row pointers and shot rows then address as SGPR base + lane offset
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= Q) return;     // whole waves leave; nothing below synchronises across waves
+  KqLds& L = s_L[w];
+  constexpr int PADW = (int)0x80008000u;      // two "no value" halves
+  constexpr int NW = 4 * NJ;
+  // ---- the row's packed values: word d of lane l holds columns (d / 4) * 512 + l * 8 + (d % 4) * 2 and + 1
+  const short* as = approx + (size_t)row * ld;
+  int xw[NW];
+  // (NJ = ceil(S / 512): only the last group of 512 columns can be partial.  Its loads are clamped to the row and masked without
+  // branches -- rows are padded to a multiple of 8 columns, so a dwordx4 that starts below S stays inside the row.)
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int i = jj * 512 + lane * 8;
+    if (jj < NJ - 1) {
+      const int4 x = *reinterpret_cast<const int4*>(as + i);
+      xw[4 * jj + 0] = x.x; xw[4 * jj + 1] = x.y; xw[4 * jj + 2] = x.z; xw[4 * jj + 3] = x.w;
+    } else {
+      const int4 x = *reinterpret_cast<const int4*>(as + (i < S ? i : 0));
+      const int t[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int rem = S - (i + 2 * k);      // valid halves of this word: >= 2 both, 1 the low one, <= 0 none
+        xw[4 * jj + k] = rem >= 2 ? t[k] : rem == 1 ? ((t[k] & 0xffff) | (int)0x80000000u) : PADW;
+      }
+    }
+  }
+  // ---- the raw query row, requested now and used by the first exact dot product
+  float4 xq[NSL];
+  {
+    const float* qr = q + (size_t)row * ldq;
+#pragma unroll
+    for (int sl = 0; sl < NSL; ++sl) {
+      const int d = sl * 256 + lane * 4;
+      xq[sl] = *reinterpret_cast<const float4*>(qr + (d < D ? d : 0));
+    }
+  }
+  const float dn = den ? den[row] : 1.f;
+  const float margin = margins ? margins[row] : margin_all;
+  const int mq = (int)fminf(ceilf(margin * KQ_SCALE), 65535.f);      // margin in steps, rounded up
+
+  // largest t in [-32768, 32767] with at least KTOP of the listed values >= t (there are at least KTOP values): built bit by bit from
+  // the top in offset binary, one ballot per bit -- sixteen steps of scalar work, no loop, whatever the values
+  auto kth = [&](auto count_ge_biased) {
+    unsigned u = 0;
+#pragma unroll
+    for (int b = 15; b >= 0; --b) {
+      const unsigned c = u | (1u << b);
+      if (count_ge_biased(c) >= KTOP) u = c;
+    }
+    return (int)u - 32768;
+  };
+  // ---- T: the KTOP-th largest of the 64 lane maxima (with multiplicity), a lower bound of the row's KTOP-th largest value
+  s16x2 pm = __builtin_bit_cast(s16x2, PADW);
+#pragma unroll
+  for (int d = 0; d < NW; ++d) pm = __builtin_elementwise_max(pm, __builtin_bit_cast(s16x2, xw[d]));
+  const int lmax = max((int)pm.x, (int)pm.y);
+  const unsigned lmax_b = (unsigned)(lmax + 32768);
+  const int T = kth([&](unsigned t) { return kq_count(lmax_b >= t); });
+  const int Tm = max(T - mq, -32767);
+  // ---- candidates: the values >= T - margin, as (steps, shot) in LDS
+  const int TmH = Tm * 65536;
+  int total = 0;
+#pragma unroll
+  for (int d = 0; d < NW; ++d) {
+    const int x = xw[d];
+    const bool hl = (int)((unsigned)x << 16) >= TmH;
+    const bool hh = x >= TmH;
+    const unsigned long long ml = __ballot(hl), mh = __ballot(hh);
+    if (ml | mh) {
+      const int col = (d >> 2) * 512 + lane * 8 + (d & 3) * 2;
+      if (ml) {
+        const int pos = total + kq_prefix(ml);
+        if (hl && pos < KQ_MAX_CAND) L.ent[pos] = int2{(int)(short)(x & 0xffff), col};
+        total += __popcll(ml);
+      }
+      if (mh) {
+        const int pos = total + kq_prefix(mh);
+        if (hh && pos < KQ_MAX_CAND) L.ent[pos] = int2{x >> 16, col + 1};
+        total += __popcll(mh);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+
+  // exact similarities of the n shots listed through pos_of(k) -> position in L.rk, four shot rows per round (see the float kernel)
+  bool have_q = false;
+  auto exact_dots = [&](int n, auto pos_of) {
+    if (!have_q) {
+      if (mu) {       // every slice of mu is requested before the first is used
+        float4 m4[NSL];
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) m4[sl] = *reinterpret_cast<const float4*>(mu + (sl * 256 + lane * 4 < D ? sl * 256 + lane * 4 : 0));
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) { xq[sl].x -= m4[sl].x; xq[sl].y -= m4[sl].y; xq[sl].z -= m4[sl].z; xq[sl].w -= m4[sl].w; }
+      }
+#pragma unroll
+      for (int sl = 0; sl < NSL; ++sl)
+        if (!(sl * 256 + lane * 4 < D)) xq[sl] = float4{0.f, 0.f, 0.f, 0.f};
+      have_q = true;
+    }
+    constexpr int CH = NSL < KQ_CH ? NSL : KQ_CH;
+    const int t_mine = lane >> 4;
+    for (int k0 = 0; k0 < n; k0 += 4) {
+      const float* sr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) sr[t] = sn + (size_t)__builtin_amdgcn_readfirstlane(L.rk[pos_of(min(k0 + t, n - 1))].y) * D + lane * 4;
+      const int mypos = pos_of(min(k0 + t_mine, n - 1));
+      kq_f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int c0 = 0; c0 < NSL; c0 += CH) {
+        if (c0) __builtin_amdgcn_sched_barrier(0);      // the next slices' loads stay behind this round's fmas (register budget)
+        float4 sv[4][CH];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+            sv[t][c] = (c0 + c) * 256 + lane * 4 < D ? *reinterpret_cast<const float4*>(sr[t] + (c0 + c) * 256) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 x = xq[c0 + c];
+            acc[t] = __builtin_elementwise_fma(kq_f32x2{x.x, x.y}, kq_f32x2{sv[t][c].x, sv[t][c].y}, acc[t]);
+            acc[t] = __builtin_elementwise_fma(kq_f32x2{x.z, x.w}, kq_f32x2{sv[t][c].z, sv[t][c].w}, acc[t]);
+          }
+      }
+      float a1[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a1[t] = acc[t].x + acc[t].y;
+      const auto p02 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1[0]), __float_as_uint(a1[2]), false, false);
+      const auto p13 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1[1]), __float_as_uint(a1[3]), false, false);
+      const float s02 = __uint_as_float(p02[0]) + __uint_as_float(p02[1]);     // lanes 0..31: shot 0, lanes 32..63: shot 2
+      const float s13 = __uint_as_float(p13[0]) + __uint_as_float(p13[1]);     //              shot 1,               shot 3
+      const auto pr = __builtin_amdgcn_permlane16_swap(__float_as_uint(s02), __float_as_uint(s13), false, false);
+      float u = __uint_as_float(pr[0]) + __uint_as_float(pr[1]);               // 16-lane row t: shot t
+      u = kv_add_ror<0x128>(u); u = kv_add_ror<0x124>(u); u = kv_add_ror<0x122>(u); u = kv_add_ror<0x121>(u);
+      if ((lane & 15) == 0) L.rk[mypos].x = (int)__float_as_uint(den ? u / dn : u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  };
+  // rank of entry c among the first n of L.rk by (key descending, shot ascending)
+  auto rank_of = [&](int c, int n) {
+    const int2 me = L.rk[c];
+    const float mv = __uint_as_float((unsigned)me.x);
+    int r = 0;
+#pragma unroll 2
+    for (int l = 0; l < n; ++l) {
+      const int2 o = L.rk[l];
+      const float ov = __uint_as_float((unsigned)o.x);
+      r += (ov > mv || (ov == mv && o.y < me.y)) ? 1 : 0;
+    }
+    return r;
+  };
+
+  if (total <= KQ_MAX_CAND) {
+    // ---- A10 = the KTOP-th largest candidate value; the candidates below A10 - margin go
+    constexpr int NC = KQ_MAX_CAND / 64;
+    int2 e[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) e[ch] = ch * 64 + lane < total ? L.ent[ch * 64 + lane] : int2{-32768, 0};
+    unsigned eb[NC];
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) eb[ch] = (unsigned)(e[ch].x + 32768);
+    const int A10 = total <= 64 ? kth([&](unsigned t) { return kq_count(eb[0] >= t); })
+                                : kth([&](unsigned t) {
+                                    int n = 0;
+#pragma unroll
+                                    for (int ch = 0; ch < NC; ++ch) n += kq_count(eb[ch] >= t);
+                                    return n;
+                                  });
+    const int Tv = max(A10 - mq, -32767);
+    int ncand = 0;
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+      if (ch * 64 < total) {
+        const bool live = e[ch].x >= Tv;
+        const unsigned long long m = __ballot(live);
+        if (live) {
+          const int pos = ncand + kq_prefix(m);
+          const int cl = (int)shot_classes[e[ch].y];
+          L.ent[pos] = int2{e[ch].x, cl};
+          L.rk[pos] = int2{(int)__float_as_uint(e[ch].x == 32767 ? INFINITY : (float)e[ch].x * (1.f / KQ_SCALE)), e[ch].y};
+        }
+        ncand += __popcll(m);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    // ---- flagged: a candidate of another class within margin (NaN codes excepted); their positions compacted
+    int nflag = 0;
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+      const int c = c0 + lane;
+      bool fl = false;
+      if (c < ncand) {
+        const int2 me = L.ent[c];
+        const int base = me.x - mq;
+        const unsigned span = 2u * (unsigned)mq;
+#pragma unroll 2
+        for (int l = 0; l < ncand; ++l) {
+          const int2 o = L.ent[l];
+          fl = fl || ((unsigned)(o.x - base) <= span && o.y != me.y);
+        }
+        fl = fl && me.x != 32767;
+      }
+      const unsigned long long m = __ballot(fl);
+      if (fl) L.alist[nflag + kq_prefix(m)] = (short)c;
+      nflag += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (nflag) exact_dots(nflag, [&](int k) { return (int)L.alist[k]; });
+    // ---- ranks below KTOP write their class to the output slot of that rank
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+      const int c = c0 + lane;
+      if (c < ncand) {
+        const int r = rank_of(c, ncand);
+        if (r < KTOP) {
+          const int cl = L.ent[c].y;
+          L.cls[r] = cl;
+          top_classes[(size_t)row * KTOP + r] = cl;
+        }
+      }
+    }
+  } else {
+    // every shot exactly, in blocks of KQ_MAX_CAND - KTOP next to the running best (kept in slots 0 .. nbest - 1)
+    int nbest = 0;
+    for (int s0 = 0; s0 < S; s0 += KQ_MAX_CAND - KTOP) {
+      const int nb = min(KQ_MAX_CAND - KTOP, S - s0);
+      for (int c = lane; c < nb; c += 64) L.rk[nbest + c].y = s0 + c;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      const int base = nbest;
+      exact_dots(nb, [&](int k) { return base + k; });
+      const int n = nbest + nb;
+      for (int c0 = 0; c0 < n; c0 += 64) {     // winners park in L.ent (unused on this path), then move to the front
+        const int c = c0 + lane;
+        if (c < n) {
+          const int r = rank_of(c, n);
+          if (r < KTOP) L.ent[r] = L.rk[c];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      nbest = n < KTOP ? n : KTOP;
+      if (lane < nbest) L.rk[lane] = L.ent[lane];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    if (lane < KTOP) {
+      const int cl = (int)shot_classes[L.rk[lane].y];
+      L.cls[lane] = cl;
+      top_classes[(size_t)row * KTOP + lane] = cl;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  if (keep) {
+    // mode of the first kvote classes, ties -> smallest class id: lane a counts its class, then the best (count, -class)
+    const int mycl = lane < KTOP ? L.cls[lane] : -1;
+    int cnt = 0;
+    if (lane < kvote)
+      for (int b = 0; b < kvote; ++b) cnt += (L.cls[b] == mycl);
+    int best = cnt;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    int cand = (lane < kvote && cnt == best) ? mycl : 0x7fffffff;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+    if (lane == 0) keep[row] = (det_classes && det_classes[row] == (long long)cand) ? 1 : 0;
+  }
+}
+
+// approx [Q, ld] int16 from lvc_gemm_f16_q15 (value = steps / 32766, 32767 = NaN; ld % 8 == 0, rows 16-byte aligned); `margin` /
+// `margins` must include 2 x 1.6e-5 for the quantisation (lvc_amd.label_verification.Q15_MARGIN).  Other arguments as above.
 extern "C" int lvc_knn_verify_topk_vote_q15(const short* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
                                         const float* den, const float* sn, int D, float margin, const float* margins,
                                         const long long* shot_classes, const long long* det_classes, int kvote,
                                         long long* top_classes, long long* keep, void* stream) {
   KV_CHECKS();
   LVC_CHECK_ARG(approx, "null pointer");
-  LVC_CHECK_ARG(S <= 64 * KNN_MAX_PER_LANE, "at most 4096 shots per call");
-  const int per = lvc_cdiv(S, 64);
+  LVC_CHECK_ARG(S <= 4096, "at most 4096 shots per call");
+  const int nj = lvc_cdiv(S, 512);
   const dim3 grid(lvc_cdiv(Q, 4)), block(256);
   hipStream_t st = (hipStream_t)stream;
   const int ldd = ld > 0 ? ld : S;
-#define KV_LAUNCH_V(P, N, V) hipLaunchKernelGGL((knn_verify_topk_vote_kernel<10, P, N, true, true>), grid, block, 0, st, (const void*)approx, ldd, Q, S, q, ldqq, mu, \
-                                                den, sn, D, margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
-#define KV_LAUNCH_N(P, N) KV_LAUNCH_V(P, N, true)
-#define KV_LAUNCH(P) do { if (D <= 512) KV_LAUNCH_N(P, 2); else if (D <= 1024) KV_LAUNCH_N(P, 4); else KV_LAUNCH_N(P, 8); } while (0)
-  LVC_CHECK_ARG(ldd % 8 == 0 && (((uintptr_t)approx) & 15) == 0, "16-bit rows must be 16-byte aligned (ld % 8 == 0)");
-  if (per <= 8) KV_LAUNCH(8);
-  else if (per <= 16) KV_LAUNCH(16);
-  else if (per <= 24) KV_LAUNCH(24);
-  else if (per <= 32) KV_LAUNCH(32);
-  else if (per <= 40) KV_LAUNCH(40);
-  else if (per <= 48) KV_LAUNCH(48);
-  else KV_LAUNCH(64);
-#undef KV_LAUNCH_N
-#undef KV_LAUNCH_V
-#undef KV_LAUNCH
+  LVC_CHECK_ARG(ldd % 8 == 0 && ldd >= S && (((uintptr_t)approx) & 15) == 0, "16-bit rows must be 16-byte aligned (ld % 8 == 0)");
+#define KQ_LAUNCH_N(J, N) hipLaunchKernelGGL((knn_verify_q15_kernel<10, J, N>), grid, block, 0, st, approx, ldd, Q, S, q, ldqq, mu, den, sn, D, \
+                                             margin, margins, shot_classes, det_classes, kvote, top_classes, keep)
+#define KQ_LAUNCH(J) do { if (D <= 512) KQ_LAUNCH_N(J, 2); else if (D <= 1024) KQ_LAUNCH_N(J, 4); else KQ_LAUNCH_N(J, 8); } while (0)
+  switch (nj) {      // exactly ceil(S / 512): the kernel masks only its last group of columns
+    case 1: KQ_LAUNCH(1); break;
+    case 2: KQ_LAUNCH(2); break;
+    case 3: KQ_LAUNCH(3); break;
+    case 4: KQ_LAUNCH(4); break;
+    case 5: KQ_LAUNCH(5); break;
+    case 6: KQ_LAUNCH(6); break;
+    case 7: KQ_LAUNCH(7); break;
+    default: KQ_LAUNCH(8); break;
+  }
+#undef KQ_LAUNCH_N
+#undef KQ_LAUNCH
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -1131,7 +1131,7 @@ def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True, want_resid=False):
 def gemm_f16(a, b, n=None, ldb=None, q15=False):
     """a [M,C] . b^T on fp16 operands with fp32 accumulation -> [M,N] fp32 (lvc_gemm_f16): the pre-filter of the two-stage
     kNN sweep.  n / ldb: use n rows of b that lie ldb elements apart (a strided subset of a contiguous [*, C] tensor).
-    q15: the result as 16-bit fixed point, rint(32767 * value) (lvc_gemm_f16_q15; rows padded to a multiple of 8 columns,
+    q15: the result as 16-bit fixed point, rint(32766 * value), NaN -> 32767 (lvc_gemm_f16_q15; rows padded to a multiple of 8 columns,
     returned as the [M, N] view)."""
     _req_cuda(a, b)
     M, C = a.shape

@@ -17,9 +17,9 @@ KNN_TWO_STAGE = os.environ.get("LVC_KNN_TWO_STAGE", "1") != "0"
 # LVC_KNN_ROW_MARGINS=0: the worst-case margin 2^-9 for every row instead of the per-row bound from the measured rounding residuals
 KNN_ROW_MARGINS = True
 # the pre-filter similarities as 16-bit fixed point (lvc_gemm_f16_q15: half the matrix round trip between the two stages);
-# its quantisation error (half a step of 1 / 32767, twice: containment argument of csrc/knn.hip) joins every margin
+# its quantisation error (half a step of 1 / 32766, twice: containment argument of csrc/knn.hip) joins every margin
 KNN_Q15 = True
-Q15_MARGIN = 2.0 * (0.5 / 32767.0) + 1e-6
+Q15_MARGIN = 2.0 * (0.5 / 32766.0) + 1e-6
 # unit-norm rows: |fp16 dot - exact| <= 2^-11 (|q| rounding) + 2^-11 (|s| rounding) + 2^-22 + fp32 accumulation
 # < 2^-10 (Cauchy-Schwarz on sum |q_i s_i|); the candidate window is twice that plus slack for the accumulation order
 VERIFY_MARGIN = 2.0 ** -9 + 2.0 ** -16

@@ -1,54 +1,64 @@
-"""Does running the early (memory-bound) ResNet stages per sub-batch keep their streams in the Infinity Cache?
-Times res2 / res3 / res4 on the bench's batch of 8 against the same work in sub-batches of 4 / 2 / 1 images."""
+"""Does the trunk run faster per image when a sub-batch's activations fit the 256 MB Infinity Cache?  The bottom-up stages and the
+whole backbone timed at 1, 2, 4 and 8 images per call, all scaled to 8 images."""
 import os, sys
-import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from lvc_amd.config import set_global_cfg
+import torch
 from lvc_amd.config.presets import base_rcnn_fpn
 from lvc_amd.modeling import build_model
 from lvc_amd.utils import synthetic as syn
-
-cfg = base_rcnn_fpn(num_classes=80, device="cuda:0")
-set_global_cfg(cfg)
-model = build_model(cfg)
+dev = torch.device("cuda:0")
+model = build_model(base_rcnn_fpn(depth=50, num_classes=80, device="cuda:0")).eval()
 syn.conditioned_r50_fpn_(model)
-model.eval()
-bu = model.backbone.bottom_up
-D = "cuda:0"
-g = torch.Generator(device=D).manual_seed(0)
-shapes = {"res2": (8, 200, 336, 64), "res3": (8, 200, 336, 256), "res4": (8, 100, 168, 512)}
+batch = [{"image": syn.synthetic_image(1 + i).to(dev), "height": 800, "width": 1333} for i in range(8)]
 
 
-def timeit(f, n=10):
+def timed(fn, n=20):
     for _ in range(3):
-        f()
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    a.record()
     for _ in range(n):
-        f()
-    e1.record()
+        fn()
+    b.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / n
+    return a.elapsed_time(b) / n
 
 
 with torch.no_grad():
+    images = model.preprocess_image(batch)
+    from lvc_amd.modeling.backbone.resnet import _as_nhwc4
+    x4 = _as_nhwc4(images.tensor)
+    bu = model.backbone.bottom_up
+    stem = bu.stem.forward_nhwc(x4)
+    feats = {"stem": stem}
+    x = stem
     for stage, name in bu.stages_and_names:
-        if name not in shapes:
-            continue
-        x = torch.randn(*shapes[name], device=D, generator=g).abs().contiguous()
+        for blk in stage:
+            x = blk.forward_nhwc(x)
+        feats[name] = x
 
-        def run(sub):
-            outs = []
-            for i in range(0, 8, sub):
-                y = x[i: i + sub]
-                for blk in stage:
-                    y = blk.forward_nhwc(y) if hasattr(blk, "forward_nhwc") else blk(y)
-                outs.append(y)
-            return outs
+    def run_stage(stage, xin):
+        blocks = list(stage)
+        t = None
+        x = xin
+        for i, blk in enumerate(blocks):
+            nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+            x, t = blk.forward_chained(x, t, nxt)
+        return x
 
-        ref = torch.cat(run(8))
-        for sub in (8, 4, 2, 1):
-            t = timeit(lambda: run(sub))
-            got = torch.cat(run(sub))
-            print("%s sub-batch %d: %.3f ms   max|diff| vs batch 8 %.2e" % (name, sub, t, (got - ref).abs().max().item()))
+    prev = "stem"
+    for stage, name in bu.stages_and_names:
+        xin = feats[prev]
+        row = []
+        for nb in (1, 2, 4, 8):
+            parts = [xin[i:i + nb] for i in range(0, 8, nb)]
+            row.append(timed(lambda: [run_stage(stage, p) for p in parts]))
+        print("%s (input %s, %.0f MB): 8 images as 8x1 %.3f ms | 4x2 %.3f | 2x4 %.3f | 1x8 %.3f" %
+              (name, tuple(xin.shape), xin.numel() * 4 / 1e6, *row))
+        prev = name
+    row = []
+    for nb in (1, 2, 4, 8):
+        parts = [x4[i:i + nb] for i in range(0, 8, nb)]
+        row.append(timed(lambda: [model.backbone.forward_nhwc(p) for p in parts]))
+    print("backbone + FPN: 8x1 %.3f ms | 4x2 %.3f | 2x4 %.3f | 1x8 %.3f" % tuple(row))

@@ -115,8 +115,9 @@ def _unit_rows(n, d, g):
     return x / x.norm(dim=1, keepdim=True)
 
 
+@pytest.mark.parametrize("q15", [False, True])
 @pytest.mark.parametrize("Dm,clustered", [(64, False), (384, False), (1024, False), (2048, False), (384, True), (1024, True)])
-def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm, clustered):
+def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm, clustered, q15):
     """knn_verify_topk_vote_kernel with a pre-filter matrix perturbed by the WORST noise its contract allows (+-2^-10,
     uniformly random per entry -- far rougher than the fp16 GEMM): the class sequence of the exact ten best (fp64 ranking of
     the same rows) must come back wherever fp32 can tell the shots apart.  Random classes make nearly every candidate
@@ -146,8 +147,19 @@ def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm, clustered):
     sims = qn @ sn.t()
     approx = (sims + (torch.rand(Q, S, generator=g, dtype=torch.float64) * 2 - 1) * 2.0 ** -10).float()
     det = torch.randint(0, 50, (Q,), generator=g)
-    top, keep = K.knn_verify_topk_vote(approx.to(D), qn.float().contiguous().to(D), sn.float().contiguous().to(D),
-                                       2.0 ** -9 + 2.0 ** -16, shot_classes.to(D), det.to(D), 10)
+    margin = 2.0 ** -9 + 2.0 ** -16
+    if q15:
+        # the 16-bit fixed-point form of the matrix (lvc_gemm_f16_q15's encoding) in rows padded to a multiple of 8 columns, the pad
+        # columns holding values that would win if they were read; knn_verify_q15_kernel behind the same entry point
+        from lvc_amd.label_verification import Q15_MARGIN
+        pad = torch.full((Q, (S + 7) // 8 * 8), 32000, dtype=torch.int16)
+        pad[:, :S] = (approx * 32766.0).round().clamp(-32766, 32766).to(torch.int16)
+        approx_dev = pad.to(D)[:, :S]
+        margin += Q15_MARGIN
+    else:
+        approx_dev = approx.to(D)
+    top, keep = K.knn_verify_topk_vote(approx_dev, qn.float().contiguous().to(D), sn.float().contiguous().to(D),
+                                       margin, shot_classes.to(D), det.to(D), 10)
     qs, ss = qn.float().double(), sn.float().double()      # the fp32 rows the kernel reads, evaluated in fp64
     s64 = qs @ ss.t()
     val, order = torch.sort(s64, dim=1, descending=True, stable=True)
@@ -166,8 +178,9 @@ def test_verify_kernel_recovers_exact_top10_from_noisy_prefilter(Dm, clustered):
 
 
 def test_verify_kernel_normalises_raw_queries_like_rownorm():
-    """Raw descriptors + (mu, den) from rownorm_h give the same answer as the pre-normalised rows: the kernel redoes
-    (q - mu) / den bit for bit."""
+    """Raw descriptors + (mu, den) from rownorm_h give the same answer as the pre-normalised rows: the float kernel redoes
+    (q - mu) / den bit for bit; the q15 kernel divides the finished dot product of q - mu by den instead (one more rounding
+    than on pre-normalised rows: rows whose neighbours tie to fp32 rounding may swap)."""
     from lvc_amd import kernels as K
 
     g = torch.Generator().manual_seed(3)
@@ -187,6 +200,14 @@ def test_verify_kernel_normalises_raw_queries_like_rownorm():
     a = K.knn_verify_topk_vote(ap, qn, sn, m, classes, det, 10)
     b = K.knn_verify_topk_vote(ap, q, sn, m, classes, det, 10, mu=mu, den=den)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    from lvc_amd.label_verification import Q15_MARGIN
+    ap16 = K.gemm_f16(qh, sh, q15=True)
+    assert ap16.dtype == torch.int16 and ap16.stride(0) % 8 == 0
+    assert (ap16.float() / 32766.0 - ap).abs().max().item() <= 0.5 / 32766.0 + 1e-7
+    c = K.knn_verify_topk_vote(ap16, qn, sn, m + Q15_MARGIN, classes, det, 10)
+    d = K.knn_verify_topk_vote(ap16, q, sn, m + Q15_MARGIN, classes, det, 10, mu=mu, den=den)
+    for other in (c, d):     # fp32 evaluations of the same dot products in another sum order: only fp32-level ties may swap
+        assert (a[0] != other[0]).any(dim=1).float().mean() <= 1e-3 and (a[1] != other[1]).float().mean() <= 1e-3
 
 
 def test_two_stage_equals_single_stage(monkeypatch):
