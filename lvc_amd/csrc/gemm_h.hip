@@ -22,7 +22,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef GH_NS
 #define GH_NS 4
+#endif
 #define GH_A_BYTES (256 * 64)
 #define GH_STAGE (2 * GH_A_BYTES)
 
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
   auto wait_landed = [&](int g) {
     if (g < landed) return;
     const int younger = issued - g - 1;
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (younger >= 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (younger == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (younger == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -181,9 +184,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_dma_kernel(GemmHArgs p) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const float v = acc[mi][ni][e];
-            // NaN takes the largest code so that it sorts first, as in torch.topk; -32768 is never written ("no value" for the reader)
-            const float t = __builtin_amdgcn_fmed3f(__builtin_rintf(v * 32766.f), -32766.f, 32766.f);
-            const int qv = v != v ? 32767 : (int)t;
+            // rint by the 1.5 x 2^23 trick: the low 16 bits of clamp(v, -1, 1) * 32766 + 12582912 are the rounded value in two's
+            // complement (one fma instead of multiply, round, clamp, convert).  NaN takes the largest code so that it sorts first, as
+            // in torch.topk; -32768 is never written ("no value" for the reader)
+            const float c = __builtin_fminf(__builtin_fmaxf(v, -1.f), 1.f);
+            const unsigned qv = v != v ? 32767u : __float_as_uint(__builtin_fmaf(c, 32766.f, 12582912.f));
             __builtin_amdgcn_raw_buffer_store_b16((short)qv, yres, cb16 + (unsigned)((e & 3) + 8 * (e >> 2)) * (ldy4 >> 1), 0, 0);
           }
           continue;

@@ -254,6 +254,16 @@ def test_fp16_gemm_error_bound_and_exactness():
         y = K.gemm_f16(ah, bh)
         exact = an.double() @ bn.double().t()
         assert (y.double() - exact).abs().max().item() <= 2.0 ** -10
+        # the 16-bit fixed-point form of the same products: rint(32766 x) of the value clamped to [-1, 1], rows padded to 8 columns
+        y16 = K.gemm_f16(ah, bh, q15=True)
+        assert y16.dtype == torch.int16 and y16.shape == y.shape and y16.stride(0) % 8 == 0
+        want = y.double().clamp(-1.0, 1.0) * 32766.0
+        assert (y16.double() - want).abs().max().item() <= 0.5 + 1e-6 and int(y16.min()) >= -32766 and int(y16.max()) <= 32766
+    # NaN operands take the code that sorts first; the rest of the matrix is untouched
+    ah2 = ah.clone()
+    ah2[5, 7] = float("nan")
+    y16n = K.gemm_f16(ah2, bh, q15=True)
+    assert (y16n[5] == 32767).all() and torch.equal(y16n[:5], y16[:5]) and torch.equal(y16n[6:], y16[6:])
 
 
 @pytest.mark.parametrize("cosine", [True, False])
