@@ -35,7 +35,6 @@ struct RoiAlignArgs {
   float* out;
   long long so_k, so_c, so_h, so_w;  // output strides (elements)
   int* status;                   // device status word (bit 0: negative RoI size with aligned=true)
-  int xcd_rows;                  // LDS-staged forward: the output rows of a RoI on one XCD (LVC_ROI_XCD_ROWS, default 1)
 };
 
 __global__ __launch_bounds__(256) void roi_align_fwd_kernel(RoiAlignArgs p) {
@@ -186,41 +185,33 @@ __global__ __launch_bounds__(64) void roi_align_fwd_nhwc4_kernel(RoiAlignArgs p)
   }
 }
 
-// NHWC LDS-staged path: one 512-thread workgroup per (RoI, output row ph), 256 channels (wave = bin, lane = 4 channels).  The feature window that
-// the 7 bins of that output row can touch -- rows [floor(y_first), floor(y_last)+1] x columns [floor(x_first),
-// floor(x_last)+1] -- is copied ONCE into LDS with fully coalesced 1-KiB pixel segments (64 lanes x dwordx4), then
-// every thread (bin pw = tid/64, 4 channels = tid%64) walks its bin's samples reading the four bilinear taps from
-// LDS (a wave reads one contiguous 1-KiB pixel: conflict-free ds_read_b128).  A small RoI touches each
-// feature pixel ~10 times (49 bins x g^2 samples x 4 taps over <= 9x9 pixels); after staging it is fetched from
-// L2/HBM once per output row (~3 rows each), which cuts the L2 read volume by ~3x.  Windows larger than
-// ROI_LDS_MAX_PIX pixels (very elongated boxes) take the direct-from-L2 loop: same arithmetic, same order.
-#ifndef ROI_LDS_MAX_PIX
-#define ROI_LDS_MAX_PIX 24
+// NHWC engine path: one WAVE per (RoI, output row ph) and 256-channel slice -- no LDS, no barrier; a workgroup is the ph waves of a
+// RoI.  A bin's value is sum over samples (iy, ix) of sum over the four taps of weight x pixel; a sample is in range when its row
+// AND its column are, and a tap's weight is (hy or ly) x (hx or lx): the double sum factors into
+//     sum_r sum_c Wy[r] Wx[c] pixel[r][c],   Wy[r] = sum over in-range iy of (hy if y_low == r) + (ly if y_high == r),  Wx alike.
+// The wave computes Wy once (one register, lane = window row) and Wx of each of its seven bins (seven registers, lane = window
+// column), then reads every pixel of the row's window -- rows [floor(y_first), floor(y_last)+1] x columns [floor(x_first),
+// floor(x_last)+1] -- ONCE (1 KiB per pixel and wave, coalesced, ROI_WAVE_MLP pixels in flight) and adds it into the bins whose
+// Wx is not zero in that column (weights are read with v_readlane at wave-uniform indices; the test is scalar).  The sum is formed
+// in another order than the reference's (rows outer, columns inner; weights pre-summed): the same value to fp32 rounding (the
+// tests' 1e-6), not the same bits -- the NCHW drop-in kernel above keeps the reference's order.
+// History (profiles/README.md, round 4): the workgroup-per-(RoI, row) form with the window staged in LDS and per-sample taps ran
+// 0.60 - 0.66 ms on the bench batch's 8000 proposals (47 % of the windows fitted its 24-pixel buffer, the rest read 10.6 GB of
+// taps from L1 / L2); the separable sums in that form cut the L2 reads to 2.5 GB and did not change its time (four items in flight
+// per CU, each a chain of dependent latencies); a wave per item with the bins walked one after the other: 0.95 - 0.99 ms (every
+// column re-read per bin, L1 far smaller than 28 waves' windows); this form 0.53 - 0.57 ms.
+// Items beyond the registers' reach (more than 64 window rows or columns; empty grids) take the per-sample loop.
+#define ROI_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#ifndef ROI_WAVE_MLP
+#define ROI_WAVE_MLP 8
 #endif
-#ifndef ROI_TAB
-#define ROI_TAB 32      // samples per pass of a wave's weight / offset table
-#endif
-__global__ __launch_bounds__(512, 8) void roi_align_fwd_nhwc_lds_kernel(RoiAlignArgs p) {
-  __shared__ __attribute__((aligned(16))) float win[ROI_LDS_MAX_PIX * 256];
-  __shared__ float4 tab_w[8][ROI_TAB];     // per wave (bin): the four bilinear weights of up to 64 in-range samples ...
-  __shared__ int4 tab_o[8][ROI_TAB];       // ... and the element offsets of their four taps (into win when staged, else into the level's image)
-  const int tid = threadIdx.x;
-  // workgroup -> (RoI, output row).  The hardware deals consecutive workgroups to the 8 XCDs in turn; the rows of one RoI read
-  // overlapping feature rows and the same columns, so they are kept on ONE XCD (one fetch of the window into that L2 instead of
-  // one per XCD): groups of p.ph consecutive slots of an XCD form a RoI, RoIs are dealt to the XCDs round robin
-  int k, ph;
-  if (p.xcd_rows) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int g = slot / p.ph;
-    ph = slot - g * p.ph;
-    k = g * 8 + xcd;
-    if (k >= p.K) return;
-  } else {
-    k = blockIdx.x / p.ph;
-    ph = blockIdx.x - k * p.ph;
-  }
+template <int PW>
+__global__ __launch_bounds__(512) void roi_align_fwd_nhwc_wave_kernel(RoiAlignArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int ph = ROI_UNI((int)(threadIdx.x >> 6));
+  const int k = blockIdx.x;
+  if (ph >= p.ph) return;
   const int cbase = blockIdx.y * 256;
-  const int cq = tid & 63, bin = tid >> 6;   // bin = pw (8 slots, p.pw <= 8 used)
   const float* r = p.rois + (long long)k * 5;
   const int lvl = p.levels ? p.levels[k] : 0;
   const int H = p.H[lvl], W = p.W[lvl];
@@ -235,7 +226,7 @@ __global__ __launch_bounds__(512, 8) void roi_align_fwd_nhwc_lds_kernel(RoiAlign
   float roi_height = roi_end_h - roi_start_h;
   if (p.aligned) {
     if (!(roi_width >= 0 && roi_height >= 0)) {
-      if (p.status && tid == 0 && blockIdx.y == 0 && ph == 0) atomicOr(p.status, 1);
+      if (p.status && lane == 0 && blockIdx.y == 0 && ph == 0) atomicOr(p.status, 1);
     }
   } else {
     roi_width = roi_width > 1.f ? roi_width : 1.f;
@@ -243,99 +234,122 @@ __global__ __launch_bounds__(512, 8) void roi_align_fwd_nhwc_lds_kernel(RoiAlign
   }
   const float bin_h = roi_height / (float)p.ph;
   const float bin_w = roi_width / (float)p.pw;
-  const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_height / (float)p.ph);
-  const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_width / (float)p.pw);
+  const int gh = ROI_UNI(p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_height / (float)p.ph));
+  const int gw = ROI_UNI(p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(roi_width / (float)p.pw));
   const int cnt = gh * gw > 1 ? gh * gw : 1;
   const float count = (float)cnt;
   const long long C = p.C;
-  const float* in = p.feat[lvl] + (long long)b * p.sb[lvl] + cbase + cq * 4;
+  const bool c_ok = cbase + lane * 4 < p.C;
+  const float* in = p.feat[lvl] + (long long)b * p.sb[lvl] + (c_ok ? cbase + lane * 4 : 0);
+  float* outp = p.out + (long long)k * p.so_k + ph * p.so_h + cbase + lane * 4;
 
-  // window of this output row (conservative: every tap of every in-range sample lies inside)
   const float yf = roi_start_h + ph * bin_h, yl = roi_start_h + (ph + 1) * bin_h;
-  int y0 = (int)floorf(fmaxf(yf, 0.f)), y1 = (int)floorf(fmaxf(yl, 0.f)) + 1;
-  int x0 = (int)floorf(fmaxf(roi_start_w, 0.f)), x1 = (int)floorf(fmaxf(roi_start_w + roi_width, 0.f)) + 1;
-  y0 = min(y0, H - 1); y1 = min(y1, H - 1); x0 = min(x0, W - 1); x1 = min(x1, W - 1);
+  const int y0 = ROI_UNI(min((int)floorf(fmaxf(yf, 0.f)), H - 1)), y1 = ROI_UNI(min((int)floorf(fmaxf(yl, 0.f)) + 1, H - 1));
+  const int x0 = ROI_UNI(min((int)floorf(fmaxf(roi_start_w, 0.f)), W - 1));
+  const int x1 = ROI_UNI(min((int)floorf(fmaxf(roi_start_w + roi_width, 0.f)) + 1, W - 1));
   const int nrows = y1 - y0 + 1, ncols = x1 - x0 + 1;
-  const bool staged = (nrows > 0) && (ncols > 0) && (nrows * ncols <= ROI_LDS_MAX_PIX) && (cbase + 256 <= p.C);
-  if (staged) {
-    const int npix = nrows * ncols;
-    for (int px = bin; px < npix; px += 8) {   // 8 pixels per pass, one wave (64 lanes x 16 B) each
-      const int yy = px / ncols, xx = px - yy * ncols;
-      const float4 v = *reinterpret_cast<const float4*>(in + (long long)((y0 + yy) * W + x0 + xx) * C);
-      *reinterpret_cast<float4*>(win + px * 256 + cq * 4) = v;
+  const bool sep = gh > 0 && gw > 0 && nrows >= 1 && nrows <= 64 && ncols >= 1 && ncols <= 64;
+  if (!sep) {
+    // the reference's loop, sample by sample (every bin of the row)
+    for (int pw = 0; pw < p.pw; ++pw) {
+      float4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int y_low = (int)y, x_low = (int)x, y_high, x_high;
+          if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+          if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+          const float ly = y - y_low, lx = x - x_low;
+          const float hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const float4 v1 = *reinterpret_cast<const float4*>(in + (long long)(y_low * W + x_low) * C);
+          const float4 v2 = *reinterpret_cast<const float4*>(in + (long long)(y_low * W + x_high) * C);
+          const float4 v3 = *reinterpret_cast<const float4*>(in + (long long)(y_high * W + x_low) * C);
+          const float4 v4 = *reinterpret_cast<const float4*>(in + (long long)(y_high * W + x_high) * C);
+          acc.x += w1 * v1.x + w2 * v2.x + w3 * v3.x + w4 * v4.x;
+          acc.y += w1 * v1.y + w2 * v2.y + w3 * v3.y + w4 * v4.y;
+          acc.z += w1 * v1.z + w2 * v2.z + w3 * v3.z + w4 * v4.z;
+          acc.w += w1 * v1.w + w2 * v2.w + w3 * v3.w + w4 * v4.w;
+        }
+      }
+      if (c_ok) *reinterpret_cast<float4*>(outp + pw * p.so_w) = float4{acc.x / count, acc.y / count, acc.z / count, acc.w / count};
     }
-    __syncthreads();
+    return;
   }
-  if (bin >= p.pw) return;        // nothing below synchronises across waves
-  const int pw = bin;
-  float4 acc = {0.f, 0.f, 0.f, 0.f};
-  // The sample positions, clamps and bilinear weights depend on (RoI, ph, pw, iy, ix) only -- the same for the 64 lanes of this
-  // wave.  64 samples at a time, lane = SAMPLE computes its four weights and tap offsets once (the reference's arithmetic), the
-  // in-range samples are compacted in order (iy outer, ix inner) into this wave's LDS table, and the channel loop below reads a
-  // sample as two broadcast ds_read_b128: ~25 instead of ~60 vector instructions per sample and wave, the sums term by term as
-  // the reference forms them.
-  const int nsamp = gh * gw;
-  float4* tw = tab_w[bin];
-  int4* to = tab_o[bin];
-  const bool c_ok = cbase + cq * 4 < p.C;
-  for (int s0 = 0; s0 < nsamp; s0 += ROI_TAB) {
-    const int smp = s0 + cq;
-    bool valid = smp < nsamp && cq < ROI_TAB;
-    float4 wv = {0.f, 0.f, 0.f, 0.f};
-    int4 ov = {0, 0, 0, 0};
-    if (valid) {
-      const int iy = smp / gw, ix = smp - iy * gw;
+  // Wy: lane = window row, the samples in the reference's order
+  float wy = 0.f;
+  {
+    const int ymine = y0 + lane;
+    for (int iy = 0; iy < gh; ++iy) {
       const float yy = roi_start_h + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+      if (yy < -1.0f || yy > (float)H) continue;
+      float y = yy <= 0 ? 0.f : yy;
+      int y_low = (int)y, y_high;
+      if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+      const float ly = y - y_low, hy = 1.f - ly;
+      wy += (y_low == ymine ? hy : 0.f) + (y_high == ymine ? ly : 0.f);
+    }
+  }
+  // Wx of every bin of the row: lane = window column
+  float wx[PW];
+#pragma unroll
+  for (int pw = 0; pw < PW; ++pw) {
+    const int xmine = x0 + lane;
+    float a = 0.f;
+    for (int ix = 0; ix < gw; ++ix) {
       const float xx = roi_start_w + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
-      float x = xx, y = yy;
-      if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) valid = false;
-      else {
-        if (y <= 0) y = 0;
-        if (x <= 0) x = 0;
-        int y_low = (int)y, x_low = (int)x, y_high, x_high;
-        if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
-        if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
-        const float ly = y - y_low, lx = x - x_low;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        wv = float4{hy * hx, hy * lx, ly * hx, ly * lx};
-        if (staged)
-          ov = int4{((y_low - y0) * ncols + (x_low - x0)) * 256, ((y_low - y0) * ncols + (x_high - x0)) * 256,
-                    ((y_high - y0) * ncols + (x_low - x0)) * 256, ((y_high - y0) * ncols + (x_high - x0)) * 256};
-        else
-          ov = int4{(y_low * W + x_low) * (int)C, (y_low * W + x_high) * (int)C, (y_high * W + x_low) * (int)C, (y_high * W + x_high) * (int)C};
+      if (xx < -1.0f || xx > (float)W) continue;
+      float x = xx <= 0 ? 0.f : xx;
+      int x_low = (int)x, x_high;
+      if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+      const float lx = x - x_low, hx = 1.f - lx;
+      a += (x_low == xmine ? hx : 0.f) + (x_high == xmine ? lx : 0.f);
+    }
+    wx[pw] = a;
+  }
+  // every pixel of the window once (rows outer, columns inner, ROI_WAVE_MLP in flight), into the bins whose Wx is not zero there
+  float4 acc[PW];
+#pragma unroll
+  for (int pw = 0; pw < PW; ++pw) acc[pw] = float4{0.f, 0.f, 0.f, 0.f};
+  const float* base = in + ((long long)y0 * W + x0) * C;
+  const int total = nrows * ncols;
+  int rr = 0, cc = 0;
+  for (int t = 0; t < total; t += ROI_WAVE_MLP) {
+    float4 v[ROI_WAVE_MLP];
+    int rs[ROI_WAVE_MLP], cs[ROI_WAVE_MLP];
+#pragma unroll
+    for (int u = 0; u < ROI_WAVE_MLP; ++u) {
+      const bool live = t + u < total;
+      rs[u] = live ? rr : -1;
+      cs[u] = live ? cc : 0;
+      v[u] = *reinterpret_cast<const float4*>(base + ((long long)(live ? rr : 0) * W + cs[u]) * C);
+      if (++cc == ncols) { cc = 0; ++rr; }
+    }
+#pragma unroll
+    for (int u = 0; u < ROI_WAVE_MLP; ++u) {
+      if (rs[u] < 0) continue;
+      const float wyr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wy), rs[u]));
+#pragma unroll
+      for (int pw = 0; pw < PW; ++pw) {
+        const float wxc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wx[pw]), cs[u]));
+        if (wxc != 0.f) {      // wave-uniform: a bin touches two to five of the window's columns
+          const float w = wyr * wxc;
+          acc[pw].x = __builtin_fmaf(w, v[u].x, acc[pw].x); acc[pw].y = __builtin_fmaf(w, v[u].y, acc[pw].y);
+          acc[pw].z = __builtin_fmaf(w, v[u].z, acc[pw].z); acc[pw].w = __builtin_fmaf(w, v[u].w, acc[pw].w);
+        }
       }
     }
-    const unsigned long long m = __ballot(valid);
-    const int n = __popcll(m);
-    if (valid) {
-      const int pos = __popcll(m & ((1ull << cq) - 1ull));
-      tw[pos] = wv;
-      to[pos] = ov;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    if (c_ok) {
-      // one sample per iteration: rounds of four samples with their sixteen taps in flight together measured slower (0.70 vs 0.66 ms on
-      // the bench batch's proposals): the kernel is bound by the taps' LDS / L1 throughput, not by their latency
-      auto run = [&](const float* base) {
-        for (int e = 0; e < n; ++e) {
-          const float4 w = tw[e];
-          const int4 o = to[e];
-          const float4 v1 = *reinterpret_cast<const float4*>(base + o.x), v2 = *reinterpret_cast<const float4*>(base + o.y);
-          const float4 v3 = *reinterpret_cast<const float4*>(base + o.z), v4 = *reinterpret_cast<const float4*>(base + o.w);
-          acc.x += w.x * v1.x + w.y * v2.x + w.z * v3.x + w.w * v4.x;
-          acc.y += w.x * v1.y + w.y * v2.y + w.z * v3.y + w.w * v4.y;
-          acc.z += w.x * v1.z + w.y * v2.z + w.z * v3.z + w.w * v4.z;
-          acc.w += w.x * v1.w + w.y * v2.w + w.z * v3.w + w.w * v4.w;
-        }
-      };
-      if (staged) run(win + cq * 4);
-      else run(in);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   }
-  if (!c_ok) return;
-  float4 o = {acc.x / count, acc.y / count, acc.z / count, acc.w / count};
-  *reinterpret_cast<float4*>(p.out + (long long)k * p.so_k + ph * p.so_h + pw * p.so_w + cbase + cq * 4) = o;
+  if (c_ok) {
+#pragma unroll
+    for (int pw = 0; pw < PW; ++pw)
+      *reinterpret_cast<float4*>(outp + pw * p.so_w) = float4{acc[pw].x / count, acc[pw].y / count, acc[pw].z / count, acc[pw].w / count};
+  }
 }
 
 static int launch(RoiAlignArgs& a, void* stream) {
@@ -343,11 +357,8 @@ static int launch(RoiAlignArgs& a, void* stream) {
   bool small = true;     // the staged kernel keeps tap offsets inside one image of a level as 32-bit element counts
   for (int l = 0; l < LVC_MAX_LEVELS; ++l)
     if (a.feat[l] && (long long)a.H[l] * a.W[l] * a.C >= (1ll << 31)) small = false;
-  if (a.nhwc && (a.C & 255) == 0 && a.pw <= 8 && a.num_valid == nullptr && a.so_c == 1 && small) {
-    constexpr int xcd_rows = 1;
-    a.xcd_rows = xcd_rows;
-    dim3 gridl(xcd_rows ? lvc_cdiv(a.K, 8) * 8 * a.ph : a.K * a.ph, a.C / 256), blockl(512);
-    hipLaunchKernelGGL(roi_align_fwd_nhwc_lds_kernel, gridl, blockl, 0, (hipStream_t)stream, a);
+  if (a.nhwc && (a.C & 3) == 0 && a.ph <= 8 && a.pw == 7 && a.num_valid == nullptr && a.so_c == 1 && small) {
+    hipLaunchKernelGGL(roi_align_fwd_nhwc_wave_kernel<7>, dim3(a.K, lvc_cdiv(a.C, 256)), dim3(64 * a.ph), 0, (hipStream_t)stream, a);
     LVC_CHECK_LAUNCH();
     return LVC_OK;
   }
