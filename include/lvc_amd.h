@@ -205,13 +205,19 @@ int lvc_rownorm(const float* x, const float* mu, float* y, int M, int D, int ldx
 int lvc_rownorm_backward(const float* x, const float* dy, float* dx, int M, int D, float eps, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * ROIAlign forward.  Same arithmetic and operation order as ROIAlign_cpu.cpp:20-218 / ROIAlign_cuda.cu:65-139.
+ * ROIAlign forward.  Same arithmetic as ROIAlign_cpu.cpp:20-218 / ROIAlign_cuda.cu:65-139 (and the same operation order in the NCHW form).
  * lvc_roi_align_forward_nchw has the reference op's shape contract (csrc/vision.cpp:96):
  *   input [B,C,H,W], rois [K,5] = (batch index, x1, y1, x2, y2), output [K,C,pooled_h,pooled_w].
  * lvc_roi_align_fpn_nhwc is the engine form: L pyramid levels [B,H_l,W_l,C] (feats/Hs/Ws/scales are [host]
  * arrays of L entries), per-RoI level ids [K] int32 (NULL if L == 1), output [K,pooled_h,pooled_w,C];
  * replaces the per-level gather/ROIAlign/scatter loop of detectron2/modeling/poolers.py:236-246.
+ *   The engine form sums a bin in the separable order (weights of a row and of a column pre-summed, every window pixel read once:
+ *   csrc/roi_align.hip): the reference's value to fp32 rounding (1e-6 of the output scale in the tests), not its bits; the NCHW
+ *   form keeps the reference's order.
  * d_num_valid (device int, may be NULL): rows >= *d_num_valid are zero-filled.
+ * lvc_roi_work_order writes d_order [K], a permutation of the RoIs with the largest windows first; lvc_roi_align_fpn_nhwc_ordered
+ *   lets workgroup i pool RoI d_order[i] (output row k is RoI k either way; NULL = RoI order): the launch no longer ends on a few
+ *   large RoIs that started last.
  */
 int lvc_roi_align_forward_nchw(const float* input, const float* rois, float* output, int B, int C, int H, int W,
                                int K, int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio,
@@ -220,6 +226,12 @@ int lvc_roi_align_fpn_nhwc(const float* const* feats, const int* Hs, const int* 
                            int B, int C, const float* rois, const int* levels, const int* d_num_valid, int K,
                            int pooled_h, int pooled_w, int sampling_ratio, int aligned, float* output,
                            int* d_status, void* stream);
+int lvc_roi_work_order(const float* rois, const int* levels, const float* scales, int L, int K, int pooled_h, int* d_order,
+                       void* stream);
+int lvc_roi_align_fpn_nhwc_ordered(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int L,
+                                   int B, int C, const float* rois, const int* levels, const int* d_num_valid, int K,
+                                   int pooled_h, int pooled_w, int sampling_ratio, int aligned, float* output,
+                                   int* d_status, const int* d_order, void* stream);
 
 /* ROIAlign backward (csrc/vision.cpp:97 roi_align_backward; ROIAlign_cuda.cu:142-306 / ROIAlign_cpu.cpp:219-406):
  *   grad [K,C,pooled_h,pooled_w] contiguous -> grad_input [B,C,H,W], zeroed by the call (the reference returns a

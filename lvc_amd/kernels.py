@@ -715,6 +715,9 @@ def roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_r
     return out
 
 
+ROI_ORDER_MIN = 1024     # RoIs per launch from which a work order is computed (lvc_roi_work_order: one small launch)
+
+
 def roi_align_fpn_nhwc(feats, scales, rois, levels, pooled_h, pooled_w, sampling_ratio, aligned,
                        num_valid=None, status=None):
     """feats: list of NHWC level tensors [B,H_l,W_l,C]; rois [K,5]; levels [K] int32 (or None when one
@@ -736,10 +739,17 @@ def roi_align_fpn_nhwc(feats, scales, rois, levels, pooled_h, pooled_w, sampling
         assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[0] == B and f.shape[3] == C
     if levels is not None:
         assert levels.dtype == torch.int32 and levels.is_contiguous()
-    st = _lib.lib().lvc_roi_align_fpn_nhwc(
+    order = None
+    if K >= ROI_ORDER_MIN:
+        # the workgroups take the RoIs largest window first (the launch's time follows the window area; in proposal order a few
+        # large RoIs start last and finish alone)
+        order = torch.empty(K, device=rois.device, dtype=torch.int32)
+        check(_lib.lib().lvc_roi_work_order(ptr(rois), ptr(levels), sc, c_int(L), c_int(K), c_int(pooled_h), ptr(order), _stream(rois)),
+              "lvc_roi_work_order")
+    st = _lib.lib().lvc_roi_align_fpn_nhwc_ordered(
         fp, hs, ws, sc, c_int(L), c_int(B), c_int(C), ptr(rois), ptr(levels), ptr(num_valid), c_int(K),
         c_int(pooled_h), c_int(pooled_w), c_int(sampling_ratio), c_int(1 if aligned else 0), ptr(out),
-        ptr(status), _stream(rois))
+        ptr(status), ptr(order), _stream(rois))
     check(st, "lvc_roi_align_fpn_nhwc")
     return out
 

@@ -37,8 +37,16 @@ with torch.no_grad():
         return e0.elapsed_time(e1) / n
 
     print("all %d RoIs: %.4f ms; same RoIs sorted by size: %.4f ms" % (len(rois), timed(rois, levels), timed(rois[order].contiguous(), levels[order].contiguous())))
+    desc = torch.flip(order, [0])
+    print("sorted descending: %.4f ms" % timed(rois[desc].contiguous(), levels[desc].contiguous()))
+    bucket = torch.log2(area.clamp(min=1)).floor()
+    for name, key in (("bucket log2(area) ascending (stable)", bucket), ("bucket log2(area) descending (stable)", -bucket),
+                      ("half-octave buckets descending", -(2 * torch.log2(area.clamp(min=1))).floor())):
+        o = torch.sort(key, stable=True)[1]
+        print("%s: %.4f ms" % (name, timed(rois[o].contiguous(), levels[o].contiguous())))
+    print("all again: %.4f ms" % timed(rois, levels))
     K_ = len(rois)
-    for d in range(10):
+    for d in range(0):
         sel = order[d * K_ // 10:(d + 1) * K_ // 10]
         r, l = rois[sel].contiguous(), levels[sel].contiguous()
         print("decile %d: window area %6.0f..%6.0f px  %.4f ms" % (d, float(area[sel].min()), float(area[sel].max()), timed(r, l)))

@@ -381,6 +381,42 @@ def test_roi_align_fpn_nhwc_matches_oracle(sr, aligned):
         assert (out[sel] - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
 
 
+def test_roi_align_work_order_is_a_permutation_and_changes_no_value(monkeypatch):
+    """lvc_roi_work_order (largest windows first) + lvc_roi_align_fpn_nhwc_ordered: the order is a permutation of the RoIs, its
+    window areas fall bucket by bucket, and the pooled features are bit-identical to the launch in RoI order (NaN / degenerate
+    boxes included: they land in the smallest bucket)."""
+    import ctypes
+
+    from lvc_amd import _lib
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(77)
+    B, C = 2, 256
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [torch.randn(B, int(800 * s), int(1344 * s), C, generator=g) for s in scales]
+    rois = _rand_rois(g, 3000, B, 1333, 800)
+    rois[5, 1:] = torch.tensor([10.0, 10.0, 10.0, 10.0])          # zero area
+    rois[6, 1:] = torch.tensor([0.0, 0.0, 1333.0, 800.0])         # the whole image
+    levels = torch.randint(0, 4, (3000,), generator=g).int()
+    d = _dev()
+    fd, rd, ld = [f.to(d) for f in feats], rois.to(d), levels.to(d)
+    order = torch.full((3000,), -1, device=d, dtype=torch.int32)
+    sc = (ctypes.c_float * 4)(*scales)
+    rc = _lib.lib().lvc_roi_work_order(k.ptr(rd), k.ptr(ld), sc, ctypes.c_int(4), ctypes.c_int(3000), ctypes.c_int(7), k.ptr(order), None)
+    assert rc == 0
+    o = order.cpu().long()
+    assert torch.equal(torch.sort(o)[0], torch.arange(3000))
+    s_ = torch.tensor(scales)[levels.long()]
+    area = ((rois[:, 3] - rois[:, 1]) * s_ + 2) * ((rois[:, 4] - rois[:, 2]) * s_ + 14)
+    bucket = (2 * torch.log2(area)).floor()[o]
+    assert (bucket[1:] <= bucket[:-1]).all() and o[0] != 5 and o[-1] != 6
+    monkeypatch.setattr(k, "ROI_ORDER_MIN", 1 << 30)
+    plain = k.roi_align_fpn_nhwc(fd, scales, rd, ld, 7, 7, 0, True)
+    monkeypatch.setattr(k, "ROI_ORDER_MIN", 1)
+    ordered = k.roi_align_fpn_nhwc(fd, scales, rd, ld, 7, 7, 0, True)
+    assert torch.equal(plain, ordered)
+
+
 @pytest.mark.parametrize("scale,aligned,sr", [(0.25, True, 0), (1 / 32, True, 0), (0.0625, False, 2)])
 def test_roi_align_backward_nchw_matches_oracle(scale, aligned, sr):
     """lvc_roi_align_backward_nchw (atomic scatter, like ROIAlign_cuda.cu) vs the oracle's restatement of the
