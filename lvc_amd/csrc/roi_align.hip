@@ -314,12 +314,16 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_wave_kernel(RoiAlignAr
     wx[pw] = a;
   }
   // every pixel of the window once (rows outer, columns inner, ROI_WAVE_MLP in flight), into the bins whose Wx is not zero there
+  unsigned amask = 0;
+#pragma unroll
+  for (int pw = 0; pw < PW; ++pw) amask |= wx[pw] != 0.f ? 1u << pw : 0u;
   float4 acc[PW];
 #pragma unroll
   for (int pw = 0; pw < PW; ++pw) acc[pw] = float4{0.f, 0.f, 0.f, 0.f};
   const float* base = in + ((long long)y0 * W + x0) * C;
   const int total = nrows * ncols;
-  int rr = 0, cc = 0;
+  const int Ci = (int)C, rowskip = (W - ncols) * Ci;      // element offsets inside one image of a level fit 32 bits (checked at launch)
+  int rr = 0, cc = 0, off = 0;                            // off = (rr * W + cc) * C, kept incrementally (scalar adds)
   for (int t = 0; t < total; t += ROI_WAVE_MLP) {
     float4 v[ROI_WAVE_MLP];
     int rs[ROI_WAVE_MLP], cs[ROI_WAVE_MLP];
@@ -328,18 +332,19 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_wave_kernel(RoiAlignAr
       const bool live = t + u < total;
       rs[u] = live ? rr : -1;
       cs[u] = live ? cc : 0;
-      v[u] = *reinterpret_cast<const float4*>(base + ((long long)(live ? rr : 0) * W + cs[u]) * C);
-      if (++cc == ncols) { cc = 0; ++rr; }
+      v[u] = *reinterpret_cast<const float4*>(base + (live ? off : 0));
+      off += Ci;
+      if (++cc == ncols) { cc = 0; ++rr; off += rowskip; }
     }
 #pragma unroll
     for (int u = 0; u < ROI_WAVE_MLP; ++u) {
       if (rs[u] < 0) continue;
       const float wyr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wy), rs[u]));
+      const unsigned am = __builtin_amdgcn_readlane(amask, cs[u]);      // the bins with a weight in this column
 #pragma unroll
       for (int pw = 0; pw < PW; ++pw) {
-        const float wxc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wx[pw]), cs[u]));
-        if (wxc != 0.f) {      // wave-uniform: a bin touches two to five of the window's columns
-          const float w = wyr * wxc;
+        if (am & (1u << pw)) {      // wave-uniform: a bin touches two to five of the window's columns
+          const float w = wyr * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wx[pw]), cs[u]));
           acc[pw].x = __builtin_fmaf(w, v[u].x, acc[pw].x); acc[pw].y = __builtin_fmaf(w, v[u].y, acc[pw].y);
           acc[pw].z = __builtin_fmaf(w, v[u].z, acc[pw].z); acc[pw].w = __builtin_fmaf(w, v[u].w, acc[pw].w);
         }
@@ -347,9 +352,10 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_wave_kernel(RoiAlignAr
     }
   }
   if (c_ok) {
+    const float inv = 1.f / count;      // one division per item instead of 28 (the bins' sums are not the reference's bit for bit anyway)
 #pragma unroll
     for (int pw = 0; pw < PW; ++pw)
-      *reinterpret_cast<float4*>(outp + pw * p.so_w) = float4{acc[pw].x / count, acc[pw].y / count, acc[pw].z / count, acc[pw].w / count};
+      *reinterpret_cast<float4*>(outp + pw * p.so_w) = float4{acc[pw].x * inv, acc[pw].y * inv, acc[pw].z * inv, acc[pw].w * inv};
   }
 }
 
