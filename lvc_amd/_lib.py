@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liblvc_amd.so")
+# LVC_AMD_LIB: another build of the same library (A/B measurements of one kernel against its predecessor in alternating processes)
+_SO = os.environ.get("LVC_AMD_LIB") or os.path.join(_HERE, "liblvc_amd.so")
 _lib = None
 
 c_void_p = ctypes.c_void_p

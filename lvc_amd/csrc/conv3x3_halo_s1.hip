@@ -88,9 +88,69 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 #else
 #define HALO_PRIO(first) do { } while (0)
 #endif
+// The two groups of a k16 step that read fragments, written out (NI = 2).  Left to the compiler, nearly every fragment wait of the tap
+// loop is `s_waitcnt lgkmcnt(0)` placed in front of the group that uses the reads -- also the read issued one instruction earlier -- so a
+// wave that runs alone on its SIMD (its partner waiting at the tap's barrier: the older wave of a SIMD is served first and runs ahead)
+// stalls a full LDS round trip per group of four MFMAs.  Here the four reads of a group go out FIRST, in the order of their use, and
+// every MFMA waits with a COUNT: LDS operations of a wave retire in order, so `lgkmcnt(n)` = "all but the youngest n have landed".
+// The counts name only reads of these two blocks; anything the compiler adds to the queue in between (the halo stores) makes a wait
+// stricter, never weaker.  The accumulation order per block (G1, G2, G3) is the compiler-scheduled loop's: bit-identical results.
+//   halo_g1: late reads of THIS step (alo0, bhi0, alo1, bhi1) + G1 = a1 b2 into (c00, c01, c10, c11); the early fragments ahi / blo
+//            were requested by the previous step's halo_g2 as (blo0, blo1, ahi0, ahi1), oldest first.
+//   halo_g2: early reads of the NEXT step (blo_n0, blo_n1, ahi_n0, ahi_n1) + G2 = a2 b1 into (c00, c10, c01, c11).
+// OA / OB: immediate byte offsets (fragment's k16 step and operand plane) on top of the per-lane LDS addresses.
+template <int OA, int OB>
+__device__ __forceinline__ void halo_g1(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, const f16x8& ah0, const f16x8& ah1,
+                                        const f16x8& bl0, const f16x8& bl1, f16x8& al0, f16x8& al1, f16x8& bh0, f16x8& bh1,
+                                        unsigned aA0, unsigned aA1, unsigned aB) {
+  asm volatile(
+      "ds_read_b128 %[al0], %[aA0] offset:%[oa]\n\t"
+      "ds_read_b128 %[bh0], %[aB] offset:%[ob0]\n\t"
+      "ds_read_b128 %[al1], %[aA1] offset:%[oa]\n\t"
+      "ds_read_b128 %[bh1], %[aB] offset:%[ob1]\n\t"
+      "s_waitcnt lgkmcnt(5)\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c00], %[ah0], %[bl0], %[c00]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c01], %[ah0], %[bl1], %[c01]\n\t"
+      "s_waitcnt lgkmcnt(4)\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c10], %[ah1], %[bl0], %[c10]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c11], %[ah1], %[bl1], %[c11]"
+      : [al0] "=&v"(al0), [al1] "=&v"(al1), [bh0] "=&v"(bh0), [bh1] "=&v"(bh1), [c00] "+v"(c00), [c01] "+v"(c01), [c10] "+v"(c10),
+        [c11] "+v"(c11)
+      : [ah0] "v"(ah0), [ah1] "v"(ah1), [bl0] "v"(bl0), [bl1] "v"(bl1), [aA0] "v"(aA0), [aA1] "v"(aA1), [aB] "v"(aB), [oa] "n"(OA),
+        [ob0] "n"(OB), [ob1] "n"(OB + 2048));
+}
+// (bh0 / bh1 are in-out operands of halo_g2 although it only reads them: halo_g1 leaves while its reads are still in flight, and
+// the G3 MFMAs the compiler schedules -- which read bh -- must not be placed before the waits in here.)
+template <int OA, int OB>
+__device__ __forceinline__ void halo_g2(f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11, const f16x8& al0, const f16x8& al1,
+                                        f16x8& bh0, f16x8& bh1, f16x8& bln0, f16x8& bln1, f16x8& ahn0, f16x8& ahn1,
+                                        unsigned aAn0, unsigned aAn1, unsigned aBn) {
+  asm volatile(
+      "ds_read_b128 %[bln0], %[aBn] offset:%[ob0]\n\t"
+      "ds_read_b128 %[bln1], %[aBn] offset:%[ob1]\n\t"
+      "ds_read_b128 %[ahn0], %[aAn0] offset:%[oa]\n\t"
+      "ds_read_b128 %[ahn1], %[aAn1] offset:%[oa]\n\t"
+      "s_waitcnt lgkmcnt(6)\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c00], %[al0], %[bh0], %[c00]\n\t"
+      "s_waitcnt lgkmcnt(5)\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c10], %[al1], %[bh0], %[c10]\n\t"
+      "s_waitcnt lgkmcnt(4)\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c01], %[al0], %[bh1], %[c01]\n\t"
+      "v_mfma_f32_32x32x16_f16 %[c11], %[al1], %[bh1], %[c11]"
+      : [bln0] "=&v"(bln0), [bln1] "=&v"(bln1), [ahn0] "=&v"(ahn0), [ahn1] "=&v"(ahn1), [c00] "+v"(c00), [c01] "+v"(c01),
+        [c10] "+v"(c10), [c11] "+v"(c11), [bh0] "+v"(bh0), [bh1] "+v"(bh1)
+      : [al0] "v"(al0), [al1] "v"(al1), [aAn0] "v"(aAn0), [aAn1] "v"(aAn1), [aBn] "v"(aBn), [oa] "n"(OA),
+        [ob0] "n"(OB), [ob1] "n"(OB + 2048));
+}
+
 template <int NI, bool ONEACC>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
   constexpr int HN = 64 * NI;
+  // the fragment groups written out with counted waits (halo_g1 / halo_g2): the one-accumulator instance with 128-channel tiles -- the
+  // trunk and FPN layers.  The two-accumulator instance needs every register and spills a few (loop-invariant values); a spill of a
+  // register with a read in flight would be silent corruption, so it keeps the compiler-scheduled groups (the Makefile fails the build
+  // if the instance below ever spills a vector register).
+  constexpr bool ASM_GROUPS = NI == 2 && ONEACC;
   constexpr int PLANE_A = HALO_S1 * LROW;          // halves
   constexpr int A_BUF = 2 * PLANE_A;               // halves per halo buffer (two planes)
   constexpr int A_BYTES = 2 * A_BUF * 2;           // two buffers
@@ -233,8 +293,38 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       return *reinterpret_cast<const f16x8*>(B + pl * PLANE_B + b_row + ni * 32 * 64 + b_g[s2]);
     };
     // one k16 step: (A, toff, s2, B) = this step's operands; (An, toffn, s2n, Bn) = the next step's
-    auto step_body = [&](const f16* A, int toff, int s2, const unsigned char* B, const f16* An, int toffn, int s2n,
+    const unsigned ldsA = (unsigned)(size_t)(lds_ptr_t)(void*)sA, ldsB = (unsigned)(size_t)(lds_ptr_t)(void*)sB;
+    auto step_body = [&](const f16* A, int toff, auto s2_tag, const unsigned char* B, const f16* An, int toffn, auto s2n_tag,
                          const unsigned char* Bn) {
+      constexpr int s2 = decltype(s2_tag)::value, s2n = decltype(s2n_tag)::value;
+      if constexpr (ASM_GROUPS) {
+        // per-lane LDS byte addresses: A fragments of this step / of the next, B rows of this step / of the next
+        const unsigned aoff = (unsigned)((A - sA) + toff) * 2u, aoffn = (unsigned)((An - sA) + toffn) * 2u;
+        const unsigned aA0 = ldsA + aoff + (unsigned)a_frag[0] * 2u, aA1 = ldsA + aoff + (unsigned)a_frag[1] * 2u;
+        const unsigned aAn0 = ldsA + aoffn + (unsigned)a_frag[0] * 2u, aAn1 = ldsA + aoffn + (unsigned)a_frag[1] * 2u;
+        const unsigned aB = ldsB + (unsigned)(B - sB) + (unsigned)(b_row + b_g[s2]);
+        const unsigned aBn = ldsB + (unsigned)(Bn - sB) + (unsigned)(b_row + b_g[s2n]);
+        f32x16& g00 = ONEACC ? acc[0][0] : accx[0][0];
+        f32x16& g01 = ONEACC ? acc[0][1] : accx[0][ONEACC ? 0 : 1];
+        f32x16& g10 = ONEACC ? acc[1][0] : accx[ONEACC ? 0 : 1][0];
+        f32x16& g11 = ONEACC ? acc[1][1] : accx[ONEACC ? 0 : 1][ONEACC ? 0 : 1];
+        f16x8 blo_n[2], ahi_n[2];
+        // late reads (a2 of this step: plane 1 of A; b1: plane 0 of B) + G1
+        halo_g1<PLANE_A * 2 + s2 * 32, 0>(g00, g01, g10, g11, ahi[0], ahi[1], blo[0], blo[1], alo[0], alo[1], bhi[0], bhi[1], aA0, aA1, aB);
+        // early reads of the next step (b2: plane 1 of B; a1: plane 0 of A) + G2
+        halo_g2<s2n * 32, PLANE_B>(g00, g01, g10, g11, alo[0], alo[1], bhi[0], bhi[1], blo_n[0], blo_n[1], ahi_n[0], ahi_n[1], aAn0, aAn1, aBn);
+        // G3: a1 b1
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) ahi[mi] = ahi_n[mi];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) blo[ni] = blo_n[ni];
+        return;
+      }
       // late reads of this step, in the order G2 needs them
       alo[0] = rdA(A, 1, 0, toff, s2);
       bhi[0] = rdB(B, 0, 0, s2);
@@ -273,8 +363,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) blo[ni] = blo_n[ni];
     };
+    // every fragment read of the written-out groups has landed (before anything may copy or reuse their registers: the chunk
+    // loop's back edge, the end of the tile)
+    auto drain_frags = [&]() {
+      if constexpr (ASM_GROUPS)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ahi[0]), "+v"(ahi[1]), "+v"(blo[0]), "+v"(blo[1]));
+    };
     // MFMA, DS read, MFMA, DS read ... for the 4 + 2 NI reads of a step, the remaining MFMAs behind
     auto interleave = [&]() {
+      if constexpr (ASM_GROUPS) return;      // the written-out groups fix their own order
 #pragma unroll
       for (int i = 0; i < 4 + 2 * NI; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -319,7 +416,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
         const unsigned char* Bnext = sB + ((tap + 1) % 3) * B_BUF;
         // ---- phase A: k16 step 0 of this tap; its early reads are step 1's (same buffers)
         HALO_PRIO(true);
-        step_body(Acur, toff, 0, Bcur, Acur, toff, 1, Bcur);
+        step_body(Acur, toff, std::integral_constant<int, 0>{}, Bcur, Acur, toff, std::integral_constant<int, 1>{}, Bcur);
         if (tap == 4) store_A_piece(Anext, 0);
         if (tap == 5) store_A_piece(Anext, 2);
         if (tap == 6) store_A_piece(Anext, 4);
@@ -344,7 +441,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
         // instruction stream has no data-dependent branch
         dma_B(min(step + 2, last_step), (tap + 2) % 3);
         HALO_PRIO(false);
-        step_body(Acur, toff, 1, Bcur, tap == 8 ? Anext : Acur, toff_n, 0, Bnext);
+        step_body(Acur, toff, std::integral_constant<int, 1>{}, Bcur, tap == 8 ? Anext : Acur, toff_n, std::integral_constant<int, 0>{}, Bnext);
         if (tap == 1) load_A(min(cc + 1, cc1 - 1));
         if (tap == 4) store_A_piece(Anext, 1);
         if (tap == 5) store_A_piece(Anext, 3);
@@ -352,6 +449,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
         interleave();
         __builtin_amdgcn_sched_barrier(0);
       }
+      drain_frags();
     }
     wait_vm<0>();
     __syncthreads();
