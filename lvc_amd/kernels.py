@@ -411,7 +411,7 @@ _PW_S1_RES = 1     # 1: layers with a residual / upsample-add operand qualify to
 # inference: conv3 (+ shortcut add + ReLU) of a bottleneck and conv1 (+ ReLU) of the next one as ONE launch (csrc/conv_pw_chain.hip;
 # modeling/backbone/resnet.py `BottleneckBlock.chain_to`); 0 = the two launches
 CHAIN = _os.environ.get("LVC_CHAIN", "1") != "0"
-_HALO_H2_MIN_TILES = 128   # smaller 3x3 layers (p5 / p6, one image) use the bf16 kernels (tests set 0)
+_HALO_H2_MIN_TILES = 64    # smaller 3x3 layers (p6; p5 of fewer than seven images) use the bf16 kernels (tests set 0): scripts/probe_small_maps.py -- p5 of the batch of eight (80 tiles) 0.052 / 0.056 ms on the fp16-split kernel against 0.077 / 0.069, p6 (32 tiles) 0.041 / 0.050 against 0.040
 
 
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None, act=None):
