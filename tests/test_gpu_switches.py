@@ -1,6 +1,7 @@
 """Every surviving LVC_* switch is exercised on the device: the ones without a test of their own elsewhere.
   LVC_CONV_ENGINE=f32  -> kernels.CONV_ENGINE  (every conv / GEMM on the exact fp32 MFMA kernel)
   LVC_CHAIN=0          -> kernels.CHAIN        (conv3 -> next conv1 as two launches)
+  rpn.MERGE_LEVELS     (module constant)      (the RPN predictor of all levels as one launch)
 and the attention's range report (kernels.mha -> the shared error word)."""
 import pytest
 import torch
@@ -59,6 +60,32 @@ def test_chain_switch_two_launches_equal_one(monkeypatch):
     for k in res[True]:
         scale = float(res[False][k].abs().max())
         assert float((res[True][k] - res[False][k]).abs().max()) <= 2e-5 * scale, k
+
+
+def test_rpn_predictor_of_all_levels_in_one_launch(monkeypatch):
+    """StandardRPNHead: the five hidden maps in one buffer and ONE predictor launch over it (rpn.MERGE_LEVELS, default) against a
+    predictor launch per level -- four launches fewer, the same products per pixel (the contraction of a tile may be split over
+    workers at other points when the launch has other dimensions: fp32 summation order, 1e-6 of the output scale)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.proposal_generator import rpn as R
+    from test_gpu_e2e import _model
+
+    model = _model()
+    g = torch.Generator().manual_seed(2)
+    feats = [torch.randn(2, h, w, 256, generator=g).cuda() for h, w in ((104, 152), (52, 76), (26, 38), (13, 19), (7, 10))]
+    res, n = {}, {}
+    for merge in (True, False):
+        monkeypatch.setattr(R, "MERGE_LEVELS", merge)
+        timer = K.LaunchTimer()
+        monkeypatch.setattr(K, "CONV_TIMER", timer)
+        with torch.no_grad():
+            res[merge] = [t.clone() for t in model.proposal_generator.rpn_head.forward_nhwc(feats)]
+        monkeypatch.setattr(K, "CONV_TIMER", None)
+        n[merge] = len(timer.records)
+    assert n[False] - n[True] == 4
+    for a, b, f in zip(res[True], res[False], feats):
+        assert a.shape == b.shape == (2, f.shape[1], f.shape[2], 16) and a.is_contiguous()
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
 
 
 def test_mha_reports_operands_beyond_fp16():
