@@ -110,6 +110,18 @@ int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_split, const 
 int lvc_conv3x3_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                                 const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                                 int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* L <= 6 maps [N,Hs[l],Ws[l],C] through the SAME 3x3 / stride 1 / pad 1 layer in ONE launch of that kernel (ys[l] [N,Hs[l],Ws[l],K]; xs / ys /
+ * Hs / Ws are [host] arrays): one stream-K split over the row tiles of all maps -- StandardRPNHead.conv over the pyramid levels
+ * (detectron2/modeling/proposal_generator/rpn.py:112-120 calls it once per level).  oneacc: 1 = the arguments of lvc_conv3x3_nhwc_f16s1,
+ * 0 = those of lvc_conv3x3_nhwc_f16x2_pipe.  No residual.  Per output pixel the arithmetic is the single-map launch's. */
+int lvc_conv3x3_nhwc_f16_levels(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                                const unsigned short* w_split, const float* scale, const float* shift, int N, int C, int K, int Kg,
+                                int relu, void* workspace, void* stream);
+/* The same with a LAYER per map (L layers of one shape and form: the FPN output convs, detectron2/modeling/backbone/fpn.py:128-141): ws /
+ * scales / shifts are [host] arrays of L device pointers (shift entries may be NULL). */
+int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                                const unsigned short* const* ws, const float* const* scales, const float* const* shifts, int N, int C,
+                                int K, int Kg, int relu, void* workspace, void* stream);
 /* Pointwise (R = S = 1, pad 0) layers with a long contraction on the pipelined loop of the 3x3 kernel (csrc/conv_pw_s1.hip; the conv1
  * / FC layers of detectron2/modeling/backbone/resnet.py:195-211, roi_heads/box_head.py:80-93 and the ViT linears): y = act(conv(x,
  * w) * scale + shift (+ residual)), x [N,H,W,C] fp32 NHWC with C % 32 == 0, stride >= 1, relu: 0 none / 1 ReLU / 2 exact GELU,

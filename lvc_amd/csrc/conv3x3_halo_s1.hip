@@ -42,6 +42,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 #define SPIN_LIMIT (1 << 24)
 #define ACT_SCALE 16.f    // activations x 2^4 before the split (see the header)
 #define ACT_MAX 4094.f    // 65504 / 16
+#define HALO_MAX_LEVELS 6
 
 struct HaloArgsS {
   const float* x;
@@ -59,6 +60,17 @@ struct HaloArgsS {
   int ngroup;
   int x_bytes;
   long long w_plane_elems;
+  // several maps in one launch (same weights, same channel counts, no residual: the RPN head over the pyramid levels): map l owns
+  // the row tiles [lv_tile0[l], lv_tile0[l + 1]); nlev = 0: the one map above
+  int nlev;
+  const float* lv_x[HALO_MAX_LEVELS];
+  float* lv_y[HALO_MAX_LEVELS];
+  int lv_H[HALO_MAX_LEVELS], lv_W[HALO_MAX_LEVELS], lv_tx[HALO_MAX_LEVELS], lv_ty[HALO_MAX_LEVELS], lv_xbytes[HALO_MAX_LEVELS];
+  int lv_tile0[HALO_MAX_LEVELS + 1];
+  // ... or L layers of one shape, a map each (the FPN output convs): per-map weight planes, scale and shift (lv_w[0] == nullptr: p.w, p.scale, p.shift)
+  const unsigned short* lv_w[HALO_MAX_LEVELS];
+  const float* lv_scale[HALO_MAX_LEVELS];
+  const float* lv_shift[HALO_MAX_LEVELS];
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -182,7 +194,6 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
   int u = wq * p.units_per_worker;
   const int u_end = min(u + p.units_per_worker, p.total_units);
 
-  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
 
   // fragment offsets.  A (halves): halo pixel of output pixel m at tap (0,0); rows past the patch read pixel 0.
   // B (bytes within a plane): row * 64 + swizzled granule of k16 step s2: ((s2 * 2 + fh) ^ ((row >> 2) & 3)) * 16
@@ -214,10 +225,27 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     const int cc1 = min(p.nk, cc0 + (u_end - u));
     const int tile_n = p.ngroup > 1 ? wsel : tile % p.tiles_n;
     const int tile_m = p.ngroup > 1 ? tile : tile / p.tiles_n;
-    const int tx = tile_m % p.tiles_x;
-    const int t2 = tile_m / p.tiles_x;
-    const int ty = t2 % p.tiles_y;
-    const int img = t2 / p.tiles_y;
+    // the map this row tile belongs to (one map: the launch's own fields)
+    int Hl = p.H, Wl = p.W, txl = p.tiles_x, tyl = p.tiles_y, xbl = p.x_bytes, tml = tile_m;
+    const float* xl = p.x;
+    float* yl = p.y;
+    const unsigned short* wl = p.w;
+    const float* scl = p.scale;
+    const float* shl = p.shift;
+    if (p.nlev > 0) {
+      int lv = 0;
+#pragma unroll
+      for (int l = 1; l < HALO_MAX_LEVELS; ++l) lv += (l < p.nlev && tile_m >= p.lv_tile0[l]) ? 1 : 0;
+      Hl = p.lv_H[lv]; Wl = p.lv_W[lv]; txl = p.lv_tx[lv]; tyl = p.lv_ty[lv]; xbl = p.lv_xbytes[lv];
+      xl = p.lv_x[lv]; yl = p.lv_y[lv];
+      if (p.lv_w[0]) { wl = p.lv_w[lv]; scl = p.lv_scale[lv]; shl = p.lv_shift[lv]; }
+      tml = tile_m - p.lv_tile0[lv];
+    }
+    const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)xl, 0, xbl, 0x00020000);
+    const int tx = tml % txl;
+    const int t2 = tml / txl;
+    const int ty = t2 % tyl;
+    const int img = t2 / tyl;
     const int y0 = ty * p.PH, x0 = tx * p.PW;
     const int n0 = tile_n * HN;
 
@@ -229,8 +257,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       const int h = min(hrow + 64 * j, p.HP - 1);
       const int hy = h / p.HW, hx = h - hy * p.HW;
       const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool ok = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      a_off[j] = ok ? (unsigned)(((img * p.H + yy) * p.W + xx) * p.C + q * 4) * 4u : 0x80000000u;
+      const bool ok = yy >= 0 && yy < Hl && xx >= 0 && xx < Wl;
+      a_off[j] = ok ? (unsigned)(((img * Hl + yy) * Wl + xx) * p.C + q * 4) * 4u : 0x80000000u;
     }
     // weight DMA: piece idx = wave * NI + j -> plane idx / RBLK, rows (idx % RBLK) * 16 + (lane >> 2), source granule swizzled
     const unsigned short* bsrc[NI];
@@ -241,7 +269,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       const int pl = idx / RBLK, rb = idx - pl * RBLK;
       const int row = rb * 16 + (lane >> 2);
       const int G = (lane & 3) ^ ((row >> 2) & 3);
-      bsrc[j] = p.w + (size_t)pl * p.w_plane_elems + (size_t)(n0 + row) * (9 * p.C) + G * 8;
+      bsrc[j] = wl + (size_t)pl * p.w_plane_elems + (size_t)(n0 + row) * (9 * p.C) + G * 8;
       bdst[j] = pl * PLANE_B + rb * 16 * 64;
     }
     auto dma_B = [&](int step, int buf) {
@@ -547,12 +575,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     const int col = n0 + c4 * 4;
     if (col < p.K) {
       f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + col);
+      if (scl) sc = *reinterpret_cast<const f32x4*>(scl + col);
       f32x4 sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + col);
-      const size_t origin = (size_t)(img * p.H + y0) * p.W + x0;          // pixel index of the patch's corner
-      float* const ybase = p.y + origin * p.ldy + col;
-      const int ylim = p.H - y0, xlim = p.W - x0;
+      if (shl) sh = *reinterpret_cast<const f32x4*>(shl + col);
+      const size_t origin = (size_t)(img * Hl + y0) * Wl + x0;          // pixel index of the patch's corner
+      float* const ybase = yl + origin * p.ldy + col;
+      const int ylim = Hl - y0, xlim = Wl - x0;
       const float* cs = Cs + rsub * CS_STRIDE + c4 * 4;
       // one copy of the loop per (residual mode, ReLU): with the modes tested inside, every iteration ended in the compiler's
       // vmcnt(0) lgkmcnt(0) -- the LDS read of a row and the acknowledgement of the previous row's store, one after the other,
@@ -565,14 +593,14 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
           const int r = it * RPI + rsub;
           const int py = (r * p.inv_pw) >> 16, px = r - py * p.PW;
           if (r < p.MP && py < ylim && px < xlim) {
-            const unsigned pix = (unsigned)(py * p.W + px);
+            const unsigned pix = (unsigned)(py * Wl + px);
             f32x4 v = *reinterpret_cast<const f32x4*>(cs + it * RPI * CS_STRIDE);
             v = v * sc + sh;
             if (RM == 1) {
               v += *reinterpret_cast<const f32x4*>(p.res + (origin + pix) * p.ldr + col);
             } else if (RM == 2) {
               const int yy = y0 + py, xx = x0 + px;
-              const size_t ro = ((size_t)(img * (p.H >> 1) + (yy >> 1)) * (p.W >> 1) + (xx >> 1));
+              const size_t ro = ((size_t)(img * (Hl >> 1) + (yy >> 1)) * (Wl >> 1) + (xx >> 1));
               v += *reinterpret_cast<const f32x4*>(p.res + ro * p.ldr + col);
             }
             if (RELU) {
@@ -600,7 +628,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
     d[8] = tl_hand; d[9] = tl_cs;
   }
 #endif
-  if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);
+  // bit 1: a FINITE activation beyond the form's range; bit 2: a non-finite one (usually what an upstream layer that left ITS range
+  // in this pass handed down: kernels.check_conv_error_word does not move this layer for it while another layer reports bit 1)
+  if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);
 }
 
 #define LVC_MAX_WORKERS 1024
@@ -623,41 +653,16 @@ static void pick_patch_s(int H, int W, int* PH, int* PW) {
   *PH = bh; *PW = bw;
 }
 
-static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
-                          const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu, int res_mode,
-                          int ldy, int ldr, void* workspace, void* stream) {
-  LVC_CHECK_ARG(x && w_split && workspace && y, "null pointer");
-  LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
-  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
-  LVC_CHECK_ARG(C % 32 == 0 && Kg == 9 * C, "needs C % 32 == 0 and Kg == 9*C");
-  LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
-  if (res_mode == 2) LVC_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "upsample-add needs even output size");
-  HaloArgsS a;
-  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.relu = relu; a.res_mode = res_mode;
-  a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
-  LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
-  LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
-                    ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)scale & 15) == 0, "pointers must be 16-byte aligned");
-  pick_patch_s(H, W, &a.PH, &a.PW);
-  if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
-    int ph = 0, pw = 0;
-    if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_S1) { a.PH = ph; a.PW = pw; }
-  }
-  a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
-  a.inv_pw = (65536 + a.PW - 1) / a.PW;
-  a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
-  const int ni = K <= 64 ? 1 : 2;
+// tiles_m_total row tiles (all maps); fills the stream-K split and launches
+static int halo_s1_finish(HaloArgsS& a, bool oneacc, long long tiles_m_total, int Kg, void* workspace, void* stream) {
+  const int ni = a.K <= 64 ? 1 : 2;
   const int HN = 64 * ni;
-  a.tiles_n = lvc_cdiv(K, HN);
-  a.nk = C / 32;
-  long long units = (long long)N * a.tiles_x * a.tiles_y * a.tiles_n * a.nk;
+  a.tiles_n = lvc_cdiv(a.K, HN);
+  a.nk = a.C / 32;
+  long long units = tiles_m_total * a.tiles_n * a.nk;
   LVC_CHECK_ARG(units < (1ll << 31), "iteration space too large");
   a.total_units = (int)units;
-  const long long xb = (long long)N * H * W * C * 4;
-  LVC_CHECK_ARG(xb < (1ll << 31), "input tensor must be smaller than 2 GiB");
-  a.x_bytes = (int)xb;
-  a.w_plane_elems = (long long)(lvc_cdiv(K, 128) * 128) * Kg;   // planes are padded to 128 rows
+  a.w_plane_elems = (long long)(lvc_cdiv(a.K, 128) * 128) * Kg;   // planes are padded to 128 rows
   if (g_cus_halo_s == 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
@@ -689,6 +694,101 @@ static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_s
   }
   LVC_CHECK_LAUNCH();
   return LVC_OK;
+}
+
+static void halo_s1_patch(HaloArgsS& a, int H, int W) {
+  pick_patch_s(H, W, &a.PH, &a.PW);
+  if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
+    int ph = 0, pw = 0;
+    if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_S1) { a.PH = ph; a.PW = pw; }
+  }
+  a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
+  a.inv_pw = (65536 + a.PW - 1) / a.PW;
+}
+
+static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                          const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu, int res_mode,
+                          int ldy, int ldr, void* workspace, void* stream) {
+  LVC_CHECK_ARG(x && w_split && workspace && y, "null pointer");
+  LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
+  LVC_CHECK_ARG(C % 32 == 0 && Kg == 9 * C, "needs C % 32 == 0 and Kg == 9*C");
+  LVC_CHECK_ARG(res_mode >= 0 && res_mode <= 2 && (res_mode == 0 || residual), "bad residual");
+  if (res_mode == 2) LVC_CHECK_ARG(H % 2 == 0 && W % 2 == 0, "upsample-add needs even output size");
+  HaloArgsS a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.w = w_split; a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.relu = relu; a.res_mode = res_mode;
+  a.ldy = ldy > 0 ? ldy : K; a.ldr = ldr > 0 ? ldr : K;
+  LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
+  LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
+                    ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)scale & 15) == 0, "pointers must be 16-byte aligned");
+  halo_s1_patch(a, H, W);
+  a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
+  const long long xb = (long long)N * H * W * C * 4;
+  LVC_CHECK_ARG(xb < (1ll << 31), "input tensor must be smaller than 2 GiB");
+  a.x_bytes = (int)xb;
+  return halo_s1_finish(a, oneacc, (long long)N * a.tiles_x * a.tiles_y, Kg, workspace, stream);
+}
+
+// L maps [N, Hs[l], Ws[l], C] through the SAME 3x3 layer in one launch (outputs ys[l] [N, Hs[l], Ws[l], K], rows of K floats): the
+// RPN head over the pyramid levels.  One stream-K split over the row tiles of all maps (the largest map first), one patch shape
+// (chosen for map 0): the small maps no longer pay a launch each that cannot fill the chip.  Per output pixel the arithmetic is
+// the single-map launch's.  oneacc as above; no residual.
+static int halo_s1_levels(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                          const unsigned short* w_split, const float* scale, const float* shift, const unsigned short* const* ws,
+                          const float* const* scales, const float* const* shifts, int N, int C, int K, int Kg, int relu, void* workspace,
+                          void* stream) {
+  LVC_CHECK_ARG(xs && ys && Hs && Ws && L >= 1 && L <= HALO_MAX_LEVELS, "1..6 maps");
+  if (ws) {
+    LVC_CHECK_ARG(scales && shifts, "null pointer");
+    w_split = ws[0]; scale = scales[0]; shift = shifts[0];
+  }
+  LVC_CHECK_ARG(w_split && workspace, "null pointer");
+  LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
+  LVC_CHECK_ARG(N > 0 && C > 0 && K > 0 && C % 32 == 0 && Kg == 9 * C && (K & 3) == 0, "bad shape");
+  HaloArgsS a;
+  memset(&a, 0, sizeof a);
+  a.w = w_split; a.scale = scale; a.shift = shift; a.res = nullptr;
+  a.N = N; a.C = C; a.K = K; a.relu = relu; a.res_mode = 0; a.ldy = K; a.ldr = K;
+  LVC_CHECK_ARG(((uintptr_t)w_split & 15) == 0 && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)scale & 15) == 0, "pointers must be 16-byte aligned");
+  halo_s1_patch(a, Hs[0], Ws[0]);
+  long long tiles = 0;
+  a.nlev = L;
+  for (int l = 0; l < L; ++l) {
+    LVC_CHECK_ARG(xs[l] && ys[l] && Hs[l] > 0 && Ws[l] > 0, "bad map");
+    LVC_CHECK_ARG(((uintptr_t)xs[l] & 15) == 0 && ((uintptr_t)ys[l] & 15) == 0, "pointers must be 16-byte aligned");
+    const long long xb = (long long)N * Hs[l] * Ws[l] * C * 4;
+    LVC_CHECK_ARG(xb < (1ll << 31), "input tensor must be smaller than 2 GiB");
+    a.lv_x[l] = xs[l]; a.lv_y[l] = ys[l]; a.lv_H[l] = Hs[l]; a.lv_W[l] = Ws[l]; a.lv_xbytes[l] = (int)xb;
+    if (ws) {
+      LVC_CHECK_ARG(ws[l] && (!oneacc || scales[l]) && ((uintptr_t)ws[l] & 15) == 0 && ((uintptr_t)scales[l] & 15) == 0 && ((uintptr_t)shifts[l] & 15) == 0,
+                    "per-map weights: null or misaligned pointer");
+      a.lv_w[l] = ws[l]; a.lv_scale[l] = scales[l]; a.lv_shift[l] = shifts[l];
+    }
+    a.lv_tx[l] = lvc_cdiv(Ws[l], a.PW); a.lv_ty[l] = lvc_cdiv(Hs[l], a.PH);
+    a.lv_tile0[l] = (int)tiles;
+    tiles += (long long)N * a.lv_tx[l] * a.lv_ty[l];
+    LVC_CHECK_ARG(tiles < (1ll << 30), "too many tiles");
+  }
+  a.lv_tile0[L] = (int)tiles;
+  a.x = xs[0]; a.y = ys[0]; a.H = Hs[0]; a.W = Ws[0]; a.tiles_x = a.lv_tx[0]; a.tiles_y = a.lv_ty[0]; a.x_bytes = a.lv_xbytes[0];
+  return halo_s1_finish(a, oneacc != 0, tiles, Kg, workspace, stream);
+}
+
+extern "C" int lvc_conv3x3_nhwc_f16_levels(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                                            const unsigned short* w_split, const float* scale, const float* shift, int N, int C, int K,
+                                            int Kg, int relu, void* workspace, void* stream) {
+  return halo_s1_levels(oneacc, xs, ys, Hs, Ws, L, w_split, scale, shift, nullptr, nullptr, nullptr, N, C, K, Kg, relu, workspace, stream);
+}
+
+// The same with a LAYER per map (L layers of one shape: the FPN output convs): ws / scales / shifts are [host] arrays of L device
+// pointers (weight planes, per-channel scale, per-channel shift or NULL).
+extern "C" int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                                            const unsigned short* const* ws, const float* const* scales, const float* const* shifts, int N,
+                                            int C, int K, int Kg, int relu, void* workspace, void* stream) {
+  LVC_CHECK_ARG(ws && scales && shifts, "null pointer");
+  return halo_s1_levels(oneacc, xs, ys, Hs, Ws, L, nullptr, nullptr, nullptr, ws, scales, shifts, N, C, K, Kg, relu, workspace, stream);
 }
 
 // Single-accumulator form.  Same arguments as lvc_conv3x3_nhwc_f16x2 except the weights: w_split = the [2][Kpad][Kg] fp16 planes

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_pw_chain_kernel(ChainArgs p) 
     px = pxn;
   }
   wait_vm<0>();
-  if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, 2);
+  if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
 }
 
 static int g_cus_chain = 0;

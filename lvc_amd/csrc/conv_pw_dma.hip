@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NW * 64, MI == 2 ? 1 : 2) void conv_pw_dma_kernel(C
   }
   STAMP(9);
 #undef STAMP
-  if (!(big <= 65504.f)) atomicOr(p.flags + p.err_index, 2);
+  if (!(big <= 65504.f)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
 }
 
 static int g_cus_d = 0;

@@ -610,7 +610,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     d[0] = tl_pro; d[1] = tl_loop; d[2] = tl_hand; d[3] = tl_cs; d[4] = tl_rows; d[5] = tl_tiles; d[6] = tl_chunks; d[7] = __builtin_readcyclecounter() - tl_t0; d[8] = 1; d[9] = tl_wa; d[10] = tl_wv; d[11] = tl_wb;
   }
 #endif
-  if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, 2);
+  if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
 }
 
 #define LVC_MAX_WORKERS 1024

@@ -243,7 +243,8 @@ def range_summary(device):
 
 
 def conv_error_word(device):
-    """OR of the kernels' error words (0 = fine; bit 0: spin timeout, bit 1: operand range); reading it synchronises."""
+    """OR of the kernels' error words (0 = fine; bit 0: spin timeout, bit 1: a finite operand beyond the range of the form, bit 2: a
+    non-finite operand in a range-checked kernel); reading it synchronises."""
     e = 0
     for w in _range_words(device).tolist():
         e |= w
@@ -306,8 +307,12 @@ def check_conv_error_word(device):
         raise LvcNativeError("conv/GEMM kernel: a stream-K worker timed out waiting for a partial tile")
     clear_conv_error_word(device)
     moved = []
+    # bit 1: a finite operand beyond the form's range -- that layer moves.  bit 2 alone: the layer saw inf (NaN is not tracked); when
+    # another layer reports bit 1 in the same pass that is what the overflowing layer handed down, and the layer stays where it is
+    # (the repeated pass will tell); with no bit 1 anywhere the non-finite values are the data's own and the layers move as before
+    finite_somewhere = any(w & 2 for w in words[1:])
     for slot in range(1, _RANGE_SLOTS):
-        if words[slot] & 2:
+        if words[slot] & 2 or (words[slot] & 4 and not finite_somewhere):
             for ref in _SLOT_OWNERS.get(slot, []):
                 o = ref()
                 if o is None:
@@ -332,7 +337,7 @@ def check_conv_error_word(device):
     e = Fp16RangeError("conv/GEMM kernel: an operand beyond the range of the fp16 split form it ran on (|a| > 4094 single-accumulator, "
                        "> 65504 two-accumulator, or NaN)" + ("; the layers concerned were moved to the next wider form" if moved else
                                                              "; set LVC_CONV_SPLIT=bf16x3 for range-free kernels"))
-    e.rerouted = bool(moved) and not (words[0] & 2)
+    e.rerouted = bool(moved) and not (words[0] & 6)
     raise e
 
 
@@ -600,6 +605,92 @@ def _chain_planes(pc):
           "lvc_split_weights_rowscaled")
     fac = fac[: pc.K]
     return planes, (fac * pc.scale if pc.scale is not None else fac).contiguous()
+
+
+_GROUP_SLOTS = {}
+
+
+def _group_slot(pcs):
+    """One range slot owned by all layers of a grouped launch: a raised word moves every one of them to the next wider form."""
+    key = tuple(id(pc.state) for pc in pcs)
+    ent = _GROUP_SLOTS.get(key)
+    if ent is None or any(r() is None for r in ent[1]):
+        import weakref
+
+        slot = _new_range_slot(pcs[0])
+        for pc in pcs[1:]:
+            _SLOT_OWNERS[slot].append(weakref.ref(pc))
+        if len(_GROUP_SLOTS) > 64:
+            _GROUP_SLOTS.clear()
+        ent = _GROUP_SLOTS[key] = (slot, [weakref.ref(pc) for pc in pcs])
+    else:
+        # the packed layers may have been rebuilt (new objects, same range state): keep the slot's owners current
+        import weakref
+
+        _SLOT_OWNERS[ent[0]] = [weakref.ref(pc) for pc in pcs]
+    return ent[0]
+
+
+def conv3x3_levels(xs, pc, relu=False, outs=None):
+    """A 3x3 / stride 1 / pad 1 layer over several maps xs[l] [N,H_l,W_l,C] in ONE launch of the pipelined fp16-split kernel (one
+    stream-K split over the row tiles of all maps: the small maps no longer pay a launch each that cannot fill the chip).  `pc`: one
+    PackedConv -- the SAME layer on every map (the RPN head over the pyramid levels, lvc_conv3x3_nhwc_f16_levels) -- or a list with a
+    layer per map, all of one shape and precision form (the FPN output convs, lvc_conv3x3_nhwc_f16_layers).  outs[l] (optional):
+    [N,H_l,W_l,K] contiguous buffers to write.  Falls back to one conv2d_nhwc call per map where that kernel is not the layers'
+    route (another engine or split, a range tier on the bf16x3 kernels, mixed forms, maps of 2 GiB)."""
+    _req_cuda(*xs)
+    pcs = list(pc) if isinstance(pc, (list, tuple)) else [pc] * len(xs)
+    shared = not isinstance(pc, (list, tuple))
+    p0 = pcs[0]
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    if outs is None:
+        outs = [torch.empty(x.shape[0], x.shape[1], x.shape[2], q.K, device=x.device, dtype=torch.float32) for x, q in zip(xs, pcs)]
+    forms = {(q.two_acc or q.state["tier"] >= 1) for q in pcs}
+    ok = (len(xs) > 1 and len(xs) <= 6 and len(pcs) == len(xs) and CONV_ENGINE == "bf16x3" and CONV_SPLIT == "f16x2" and CONV_HALO and HALO_S1 >= 1
+          and len(forms) == 1 and all(q.state["tier"] < 2 and q.mode == 0 and q.R == 3 and q.S == 3 and q.stride == 1 and q.pad == 1 and q.C == C
+                                      and q.K == p0.K and q.Kg == p0.Kg for q in pcs)
+          and C % 32 == 0 and p0.K >= 64 and p0.K % 4 == 0
+          and all(x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == N and x.shape[3] == C
+                  and x.numel() < (1 << 29) for x in xs)
+          and all(o.is_contiguous() and o.shape == (x.shape[0], x.shape[1], x.shape[2], p0.K) for o, x in zip(outs, xs))
+          and N * ((xs[0].shape[1] * xs[0].shape[2] + 255) // 256) * ((p0.K + 127) // 128) >= _HALO_H2_MIN_TILES)
+    if not ok:
+        for x, q, o in zip(xs, pcs, outs):
+            conv2d_nhwc(x, q, relu=relu, out=o)
+        return outs
+    L = len(xs)
+    one = HALO_S1 == 2 and not forms.pop()
+    timer = CONV_TIMER
+    if timer is not None and (not timer.active or (timer.only is not None and "f16x2_halo" not in timer.only)):
+        timer = None
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    XP, IP = c_void_p * L, c_int * L
+    xp, yp = XP(*[x.data_ptr() for x in xs]), XP(*[o.data_ptr() for o in outs])
+    hs, ws = IP(*[x.shape[1] for x in xs]), IP(*[x.shape[2] for x in xs])
+    for q in pcs:
+        q.last_one = one
+    ops = [q.split2s() if one else (q.split2h(), q.scale) for q in (pcs[:1] if shared else pcs)]
+    _lib.lib().lvc_set_range_slot(c_int(p0.slot if shared else _group_slot(pcs)))
+    if shared:
+        st = _lib.lib().lvc_conv3x3_nhwc_f16_levels(c_int(1 if one else 0), xp, yp, hs, ws, c_int(L), ptr(ops[0][0]), ptr(ops[0][1]), ptr(p0.shift),
+                                                    c_int(N), c_int(C), c_int(p0.K), c_int(p0.Kg), c_int(1 if relu else 0),
+                                                    ptr(conv_workspace(xs[0].device)), _stream(xs[0]))
+    else:
+        def table(ts):
+            return XP(*[0 if t is None else t.data_ptr() for t in ts])
+        st = _lib.lib().lvc_conv3x3_nhwc_f16_layers(c_int(1 if one else 0), xp, yp, hs, ws, c_int(L), table([o[0] for o in ops]),
+                                                    table([o[1] for o in ops]), table([q.shift for q in pcs]),
+                                                    c_int(N), c_int(C), c_int(p0.K), c_int(p0.Kg), c_int(1 if relu else 0),
+                                                    ptr(conv_workspace(xs[0].device)), _stream(xs[0]))
+    _lib.lib().lvc_set_range_slot(c_int(0))
+    check(st, "lvc_conv3x3_nhwc_f16_levels")
+    if timer is not None:
+        e1.record()
+        px = sum(x.shape[0] * x.shape[1] * x.shape[2] for x in xs)
+        timer.records.append((2.0 * px * p0.K * C * 9, e0, e1, "f16x2_halo", 4.0 * (px * C + px * p0.K + (1 if shared else L) * p0.K * C * 9)))
+    return outs
 
 
 def pack_chain(pc_a, pc_b, state=None):

@@ -51,6 +51,9 @@ class LastLevelMaxPool(nn.Module):
         return [to_nchw_view(t) for t in self.forward_nhwc(to_nhwc(x))]
 
 
+MERGE_OUTPUT_CONVS = True      # the 3x3 output convs of all levels as one launch (FPN.forward_nhwc)
+
+
 class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
@@ -97,11 +100,22 @@ class FPN(Backbone):
         bottom_up = self.bottom_up.forward_nhwc(x4)
         x = [bottom_up[f] for f in self.in_features[::-1]]
         results = []
-        prev = self.lateral_convs[0].forward_nhwc(x[0])
-        results.append(self.output_convs[0].forward_nhwc(prev))
-        for feat, lateral, output in zip(x[1:], self.lateral_convs[1:], self.output_convs[1:]):
-            prev = lateral.forward_nhwc(feat, residual=prev, res_mode=2)  # lateral + upsample(prev)
-            results.insert(0, output.forward_nhwc(prev))
+        grad_free = not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())
+        if grad_free and MERGE_OUTPUT_CONVS and all(c.norm is None and c.activation is None for c in self.output_convs):
+            # the top-down path first (lateral + upsample-add, coarse to fine), then the output convs of ALL levels as one launch
+            # (kernels.conv3x3_levels: a layer per map; the small levels no longer pay a launch each that cannot fill the chip)
+            prevs = [self.lateral_convs[0].forward_nhwc(x[0])]
+            for feat, lateral in zip(x[1:], self.lateral_convs[1:]):
+                prevs.append(lateral.forward_nhwc(feat, residual=prevs[-1], res_mode=2))
+            order = list(range(len(prevs)))[::-1]          # finest (largest) map first
+            outs = K.conv3x3_levels([prevs[i] for i in order], [self.output_convs[i].packed() for i in order], relu=False)
+            results = list(outs)                           # fine to coarse, the order of self._out_features
+        else:
+            prev = self.lateral_convs[0].forward_nhwc(x[0])
+            results.append(self.output_convs[0].forward_nhwc(prev))
+            for feat, lateral, output in zip(x[1:], self.lateral_convs[1:], self.output_convs[1:]):
+                prev = lateral.forward_nhwc(feat, residual=prev, res_mode=2)  # lateral + upsample(prev)
+                results.insert(0, output.forward_nhwc(prev))
         if self.top_block is not None:
             src = bottom_up.get(self.top_block.in_feature, None)
             if src is None:

@@ -32,6 +32,7 @@ def build_rpn_head(cfg, input_shape):
 
 
 MERGE_LEVELS = True      # the predictor of all pyramid levels as one launch (StandardRPNHead.forward_nhwc)
+MERGE_LEVELS_CONV = True     # ... and the head's 3x3 conv over the levels as one launch
 
 
 @RPN_HEAD_REGISTRY.register()
@@ -85,10 +86,16 @@ class StandardRPNHead(nn.Module):
             ms = [x.shape[0] * x.shape[1] * x.shape[2] for x in feats]
             if sum(ms) * C * 4 < (1 << 31):
                 hid = torch.empty(sum(ms), C, device=feats[0].device, dtype=torch.float32)
-                off = 0
+                views, off = [], 0
                 for x, m in zip(feats, ms):
-                    K.conv2d_nhwc(x, self.conv.packed(), relu=True, out=hid[off:off + m].view(x.shape[0], x.shape[1], x.shape[2], C))
+                    views.append(hid[off:off + m].view(x.shape[0], x.shape[1], x.shape[2], C))
                     off += m
+                # ... and the 3x3 conv itself is one launch over the levels where its kernel allows (kernels.conv3x3_levels)
+                if MERGE_LEVELS_CONV:
+                    K.conv3x3_levels(list(feats), self.conv.packed(), relu=True, outs=views)
+                else:
+                    for x, v in zip(feats, views):
+                        K.conv2d_nhwc(x, self.conv.packed(), relu=True, out=v)
                 y = K.conv2d_nhwc(hid.view(1, sum(ms), 1, C), pc).view(sum(ms), -1)
                 out, off = [], 0
                 for x, m in zip(feats, ms):

@@ -57,11 +57,11 @@ class LossScaler:
             K.check_conv_error_word(device)        # stream-K timeout: not a scaling matter
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             # data parallel: every rank must take the same decision (one rank's overflow skips the step everywhere)
-            flag = torch.tensor([float(word & 2)], device=device)
+            flag = torch.tensor([float(word & 6)], device=device)     # bit 1: finite operand out of range, bit 2: non-finite
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
             if float(flag.item()) > 0:
                 word |= 2
-        if word & 2:
+        if word & 6:
             K.clear_conv_error_word(device)
             for p in params:
                 p.grad = None

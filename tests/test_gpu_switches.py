@@ -1,7 +1,7 @@
 """Every surviving LVC_* switch is exercised on the device: the ones without a test of their own elsewhere.
   LVC_CONV_ENGINE=f32  -> kernels.CONV_ENGINE  (every conv / GEMM on the exact fp32 MFMA kernel)
   LVC_CHAIN=0          -> kernels.CHAIN        (conv3 -> next conv1 as two launches)
-  rpn.MERGE_LEVELS     (module constant)      (the RPN predictor of all levels as one launch)
+  fpn.MERGE_OUTPUT_CONVS, rpn.MERGE_LEVELS / MERGE_LEVELS_CONV (module constants)  (the RPN head's predictor / 3x3 conv over all levels as one launch each)
 and the attention's range report (kernels.mha -> the shared error word)."""
 import pytest
 import torch
@@ -62,10 +62,12 @@ def test_chain_switch_two_launches_equal_one(monkeypatch):
         assert float((res[True][k] - res[False][k]).abs().max()) <= 2e-5 * scale, k
 
 
-def test_rpn_predictor_of_all_levels_in_one_launch(monkeypatch):
-    """StandardRPNHead: the five hidden maps in one buffer and ONE predictor launch over it (rpn.MERGE_LEVELS, default) against a
-    predictor launch per level -- four launches fewer, the same products per pixel (the contraction of a tile may be split over
-    workers at other points when the launch has other dimensions: fp32 summation order, 1e-6 of the output scale)."""
+def test_rpn_head_over_all_levels_in_two_launches(monkeypatch):
+    """StandardRPNHead: the 3x3 conv over the five levels as ONE launch (kernels.conv3x3_levels, rpn.MERGE_LEVELS_CONV) writing one
+    hidden buffer, and ONE predictor launch over it (rpn.MERGE_LEVELS) -- against a launch per level and layer: eight launches fewer,
+    the same products per output (a tile's contraction may be split over workers at other points, and p5 / p6 run on the fp16-split
+    kernel inside the grouped launch: fp32 summation order, within the conv tolerance of 2e-5 of the output scale; the predictor
+    alone 1e-6)."""
     from lvc_amd import kernels as K
     from lvc_amd.modeling.proposal_generator import rpn as R
     from test_gpu_e2e import _model
@@ -74,18 +76,50 @@ def test_rpn_predictor_of_all_levels_in_one_launch(monkeypatch):
     g = torch.Generator().manual_seed(2)
     feats = [torch.randn(2, h, w, 256, generator=g).cuda() for h, w in ((104, 152), (52, 76), (26, 38), (13, 19), (7, 10))]
     res, n = {}, {}
-    for merge in (True, False):
+    for merge, merge_conv in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(R, "MERGE_LEVELS", merge)
+        monkeypatch.setattr(R, "MERGE_LEVELS_CONV", merge_conv)
         timer = K.LaunchTimer()
         monkeypatch.setattr(K, "CONV_TIMER", timer)
         with torch.no_grad():
-            res[merge] = [t.clone() for t in model.proposal_generator.rpn_head.forward_nhwc(feats)]
+            res[merge, merge_conv] = [t.clone() for t in model.proposal_generator.rpn_head.forward_nhwc(feats)]
+        monkeypatch.setattr(K, "CONV_TIMER", None)
+        n[merge, merge_conv] = len(timer.records)
+    assert n[False, False] == 10 and n[True, False] == 6 and n[True, True] == 2
+    for a, b, c, f in zip(res[True, True], res[True, False], res[False, False], feats):
+        assert a.shape == b.shape == c.shape == (2, f.shape[1], f.shape[2], 16) and a.is_contiguous()
+        scale = max(1.0, float(c.abs().max()))
+        assert float((b - c).abs().max()) <= 1e-6 * scale
+        assert float((a - c).abs().max()) <= 2e-5 * scale
+    assert K.conv_error_word(feats[0].device) == 0
+
+
+def test_fpn_output_convs_of_all_levels_in_one_launch(monkeypatch):
+    """FPN: the four 3x3 output convs (a layer per level) as ONE launch (kernels.conv3x3_levels with a list of layers,
+    fpn.MERGE_OUTPUT_CONVS) against a launch per level: three launches fewer, outputs within the conv tolerance (p5 moves from the
+    bf16x3 kernel to the fp16-split one inside the grouped launch)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.backbone import fpn as F_
+    from test_gpu_e2e import _model
+
+    model = _model()
+    x = torch.randn(2, 3, 416, 608, generator=torch.Generator().manual_seed(1)).cuda() * 40
+    res, n = {}, {}
+    for merge in (True, False):
+        monkeypatch.setattr(F_, "MERGE_OUTPUT_CONVS", merge)
+        timer = K.LaunchTimer()
+        monkeypatch.setattr(K, "CONV_TIMER", timer)
+        with torch.no_grad():
+            res[merge] = {k: v.clone() for k, v in model.backbone(x).items()}
         monkeypatch.setattr(K, "CONV_TIMER", None)
         n[merge] = len(timer.records)
-    assert n[False] - n[True] == 4
-    for a, b, f in zip(res[True], res[False], feats):
-        assert a.shape == b.shape == (2, f.shape[1], f.shape[2], 16) and a.is_contiguous()
-        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    assert n[False] - n[True] == 3
+    assert list(res[True]) == list(res[False]) == ["p2", "p3", "p4", "p5", "p6"]
+    for k in res[True]:
+        scale = float(res[False][k].abs().max())
+        assert res[True][k].shape == res[False][k].shape
+        assert float((res[True][k] - res[False][k]).abs().max()) <= 2e-5 * scale, k
+    assert K.conv_error_word(x.device) == 0
 
 
 def test_mha_reports_operands_beyond_fp16():
