@@ -381,6 +381,32 @@ def test_roi_align_fpn_nhwc_matches_oracle(sr, aligned):
         assert (out[sel] - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max()))
 
 
+def test_roi_align_wave_form_at_the_edges_of_its_tables():
+    """The engine kernel keeps a row's weights in one register (<= 64 window rows per output row) and a bin's in another (<= 64
+    window columns); RoIs just inside and just beyond those limits -- 62 / 63 / 64 / 65 / 66 window columns, 62 .. 66 window rows per
+    output row -- must agree with the oracle on either path (separable form / per-sample loop), as must RoIs hanging over the map."""
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(5)
+    H, W, C = 520, 120, 256
+    feat = torch.randn(1, C, H, W, generator=g)
+    rois = []
+    for wcols in (60.2, 61.2, 62.2, 63.2, 64.2):          # window columns = floor(x1) + 1 - floor(x0) + 1 = wcols + ~2
+        rois.append([0, 10.3, 20.0, 10.3 + wcols, 60.0])
+        rois.append([0, W - wcols - 0.7, 5.0, W + 3.0, 40.0])         # the same width, hanging over the right edge
+    for hrows in (60.2, 61.2, 62.2, 63.2, 64.2):          # window rows per output row = bin height + ~2
+        rois.append([0, 30.0, 8.4, 50.0, 8.4 + 7 * hrows])
+    rois.append([0, -5.0, -7.0, 20.0, 15.0])
+    rois.append([0, 100.0, 500.0, 130.0, 530.0])
+    rois = torch.tensor(rois, dtype=torch.float32)
+    d = _dev()
+    for sr, aligned in ((0, True), (2, True), (0, False)):
+        out = k.roi_align_fpn_nhwc([_nhwc(feat).to(d)], [1.0], rois.to(d), None, 7, 7, sr, aligned).cpu().permute(0, 3, 1, 2)
+        ref = oops.roi_align_forward(feat, rois, 1.0, 7, 7, sr, aligned)
+        assert (out - ref).abs().max() <= 1e-6 * max(1.0, float(ref.abs().max())), (sr, aligned)
+
+
 def test_roi_align_work_order_is_a_permutation_and_changes_no_value(monkeypatch):
     """lvc_roi_work_order (largest windows first) + lvc_roi_align_fpn_nhwc_ordered: the order is a permutation of the RoIs, its
     window areas fall bucket by bucket, and the pooled features are bit-identical to the launch in RoI order (NaN / degenerate
