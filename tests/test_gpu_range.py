@@ -128,3 +128,30 @@ def test_graphed_replay_reports_an_out_of_range_activation():
     # the words were cleared with the report: the next in-range replay is clean again
     g.replay(batch)
     assert len(g.instances()) == 1
+
+
+def test_grouped_launch_overflow_moves_its_layers():
+    """kernels.conv3x3_levels: an activation beyond 4094 in ONE of the maps of a grouped launch raises the launch's range word; the
+    shared layer (one PackedConv over all maps), or every layer of a launch with a layer per map, moves to two accumulators, the
+    repeated launch is clean and equals the per-map launches."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(9)
+    dev = torch.device("cuda:0")
+    xs = [torch.randn(2, h, w, 256, generator=g).to(dev) for h, w in ((96, 128), (48, 64), (24, 32))]
+    xs[1][1, 7, 9, 33] = 5000.0
+    ws = [torch.randn(256, 256, 3, 3, generator=g).to(dev) * (2.0 / (9 * 256)) ** 0.5 for _ in range(3)]
+    K.clear_conv_error_word(dev)
+    for pcs in (K.pack_conv(ws[0], stride=1, pad=1), [K.pack_conv(w, stride=1, pad=1) for w in ws]):
+        plist = pcs if isinstance(pcs, list) else [pcs]
+        assert all(q.state["tier"] == 0 for q in plist)
+        K.conv3x3_levels(xs, pcs, relu=True)
+        with pytest.raises(K.Fp16RangeError) as ei:
+            K.check_conv_error_word(dev)
+        assert ei.value.rerouted and all(q.state["tier"] == 1 for q in plist)
+        outs = K.conv3x3_levels(xs, pcs, relu=True)
+        assert K.conv_error_word(dev) == 0
+        for l, (x, o) in enumerate(zip(xs, outs)):
+            ref = K.conv2d_nhwc(x, plist[l] if isinstance(pcs, list) else pcs, relu=True)
+            assert float((o - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+        assert K.conv_error_word(dev) == 0
