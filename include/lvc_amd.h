@@ -452,6 +452,10 @@ int lvc_knn_verify_topk_vote(const float* approx, int ld, int Q, int S, const fl
  * it only pre-filters): lvc_gemm_f16_q15 writes y[m][n] = rint(32766 * dot) clamped to +-32766 as int16 (NaN -> 32767; ldy even), and
  * lvc_knn_verify_topk_vote_q15 reads it (ld % 8 == 0, rows 16-byte aligned) -- half the bytes of the matrix round trip; the margin
  * handed in must include 2 x 1.6e-5 for the quantisation. */
+/* The sweep's per-row margins in one launch: margins[i] = 2 (1 + 1e-4) (qres[i] (1 + 1e-6 + *d_sres_max) + *d_sres_max (1 + 1e-5) + acc) + extra
+ * (qres: the queries' rounding-residual norms from lvc_rownorm_h, d_sres_max: device scalar = lvc_max_f32 over the shots' residual
+ * norms, acc: the accumulation term, extra: the 16-bit matrix's quantisation margin or 0). */
+int lvc_knn_margins(const float* qres, const float* d_sres_max, float acc, float extra, int Q, float* margins, void* stream);
 int lvc_gemm_f16_q15(const unsigned short* a, const unsigned short* b, int ldb, short* y, int M, int N, int C, int ldy, void* stream);
 int lvc_knn_verify_topk_vote_q15(const short* approx, int ld, int Q, int S, const float* q, int ldq, const float* mu,
                              const float* den, const float* sn, int D, float margin, const float* margins,

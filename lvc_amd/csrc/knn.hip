@@ -306,6 +306,27 @@ extern "C" int lvc_max_f32(const float* x, long long n, float* out, void* stream
   return LVC_OK;
 }
 
+// margins[i] = 2 (1 + 1e-4) (qres[i] (1 + 1e-6 + sres_max) + sres_max (1 + 1e-5) + acc) + extra: the per-row pre-filter margin of the
+// two-stage sweep (lvc_amd.label_verification.pre_filter_margins states the bound) in one launch instead of five elementwise
+// ones, in the same fp32 operation order.  d_sres_max: device scalar (lvc_max_f32 over the shots' residual norms).
+__global__ __launch_bounds__(256) void knn_margins_kernel(const float* __restrict__ qres, const float* __restrict__ d_sres_max, float acc,
+                                                          float extra, int Q, float* __restrict__ margins) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= Q) return;
+  const float sres_max = d_sres_max[0];
+  const float sh_max = 1.0f + 1e-6f + sres_max;
+  const float eps = qres[i] * sh_max + sres_max * (1.0f + 1e-5f) + acc;
+  margins[i] = (2.0f * (1.0f + 1e-4f)) * eps + extra;
+}
+
+extern "C" int lvc_knn_margins(const float* qres, const float* d_sres_max, float acc, float extra, int Q, float* margins, void* stream) {
+  LVC_CHECK_ARG(Q >= 0 && (Q == 0 || (qres && d_sres_max && margins)), "bad arguments");
+  if (Q == 0) return LVC_OK;
+  hipLaunchKernelGGL(knn_margins_kernel, dim3(lvc_cdiv(Q, 256)), dim3(256), 0, (hipStream_t)stream, qres, d_sres_max, acc, extra, Q, margins);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Two-stage exact top-10: the [Q, S] matrix handed in is an APPROXIMATION of the similarities (lvc_gemm_f16, gemm_h.hip: every
 // operand rounded to fp16, one MFMA per block instead of three) with |approx - exact| <= eps for unit-norm rows

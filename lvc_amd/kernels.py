@@ -1213,6 +1213,18 @@ def max_f32(x):
     return out
 
 
+def knn_margins(qres, sres_max, acc, extra=0.0):
+    """The two-stage sweep's per-row margins (label_verification.pre_filter_margins + extra) in one launch (lvc_knn_margins).
+    qres [Q] fp32, sres_max [1] fp32 device tensor."""
+    _req_cuda(qres, sres_max)
+    qres = qres.contiguous()
+    assert qres.dtype == torch.float32 and sres_max.dtype == torch.float32 and sres_max.numel() == 1
+    out = torch.empty_like(qres)
+    check(_lib.lib().lvc_knn_margins(ptr(qres), ptr(sres_max), c_float(acc), c_float(extra), c_int(qres.numel()), ptr(out), _stream(qres)),
+          "lvc_knn_margins")
+    return out
+
+
 def rownorm_h(x, mu=None, eps=1e-5, mode=0, want_rows=True, want_resid=False):
     """`rownorm` for the two-stage kNN sweep: (y fp32 [M,D] or None, yh fp16 [M,D], den [M]); y is bit-identical to
     `rownorm`'s output and equals (x - mu) / den[:, None] exactly.  want_resid: also resid [M] = |row - fp16(row)|_2."""

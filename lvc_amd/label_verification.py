@@ -78,6 +78,11 @@ def assemble_tensors(shot_features):
     return classes[sorter], desc[sorter]
 
 
+def pre_filter_acc(D):
+    """The accumulation term of `pre_filter_margins`."""
+    return (2.0 * (D / 16.0 + 16.0) + 32.0) * 2.0 ** -24
+
+
 def pre_filter_margins(qres, sh_max, sres_max, D):
     """margin [Q] = 2 x the error bound of the fp16 pre-filter for each query row against ANY shot:
         |q.s - q_h.s_h| = |(q - q_h).s_h + q.(s - s_h)| <= |q - q_h| |s_h| + |q| |s - s_h|      (Cauchy-Schwarz, twice)
@@ -88,7 +93,7 @@ def pre_filter_margins(qres, sh_max, sres_max, D):
     unit, so that a truncating adder is covered); the exact re-evaluation of csrc/knn.hip sums 16 fmas per lane and a six-level
     tree (22 roundings of 2^-24, taken as 32).  About half of the worst case 2^-9 (`VERIFY_MARGIN`) on real rows: fewer shots
     inside the window, fewer exact dot products."""
-    acc = (2.0 * (D / 16.0 + 16.0) + 32.0) * 2.0 ** -24
+    acc = pre_filter_acc(D)
     eps = qres * sh_max + sres_max * (1.0 + 1e-5) + acc
     return (2.0 * (1.0 + 1e-4)) * eps
 
@@ -139,10 +144,8 @@ def knn_sweep(shot_classes, shot_descriptors, query_descriptors, detector_classe
             # fp16 similarities (one MFMA per block instead of three) as a pre-filter, exact fp32 re-evaluation of the few shots
             # that can reach the top ten (csrc/knn.hip: knn_verify_topk_vote_kernel states the containment argument)
             _, qh, den, qres = K.rownorm_h(qc, mu=mu, eps=1e-8, mode=1, want_rows=False, want_resid=True)
-            margins = pre_filter_margins(qres, sh_max, sres_max, D)
             extra = Q15_MARGIN if KNN_Q15 else 0.0
-            if extra:
-                margins = margins + extra
+            margins = K.knn_margins(qres, sres_max, pre_filter_acc(D), extra)      # pre_filter_margins(qres, sh_max, sres_max, D) + extra, one launch
             t, kp = K.knn_verify_topk_vote(K.gemm_f16(qh, sh, q15=KNN_Q15), qc, sn, VERIFY_MARGIN + extra, shot_classes, dc, k, mu=mu, den=den,
                                            margins=margins if KNN_ROW_MARGINS else None)
         else:

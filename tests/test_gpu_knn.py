@@ -341,6 +341,12 @@ def test_per_row_margins_bound_the_pre_filter_error(Dm):
     qn, qh, _, qres = K.rownorm_h(q, mu=mu, eps=1e-8, mode=1, want_resid=True)
     assert torch.allclose(qres, (qn - qh.float()).norm(dim=1), rtol=1e-5, atol=1e-12)
     margins = pre_filter_margins(qres, sh.float().norm(dim=1).max(), sres.max(), Dm)
+    # the sweep's one-launch form of the same numbers (lvc_knn_margins: the shots' largest fp16-row norm bounded by 1 + 1e-6 + max residual)
+    from lvc_amd import kernels as K_
+    from lvc_amd.label_verification import pre_filter_acc
+    sres_max = K_.max_f32(sres)
+    fused = K_.knn_margins(qres, sres_max, pre_filter_acc(Dm), 3.0e-5)
+    torch.testing.assert_close(fused, pre_filter_margins(qres, 1.0 + 1e-6 + sres_max, sres_max, Dm) + 3.0e-5, rtol=2e-6, atol=0.0)
     err = (K.gemm_f16(qh, sh).double() - qn.double() @ sn.double().t()).abs().max(dim=1)[0]
     assert (2.0 * err <= margins.double()).all()
     assert margins.max().item() < VERIFY_MARGIN and margins.median().item() < 0.7 * VERIFY_MARGIN
