@@ -240,6 +240,9 @@ int lvc_roi_align_fpn_nhwc(const float* const* feats, const int* Hs, const int* 
                            int* d_status, void* stream);
 int lvc_roi_work_order(const float* rois, const int* levels, const float* scales, int L, int K, int pooled_h, int* d_order,
                        void* stream);
+/* XCD-local order for B <= 16 images: position i holds a RoI of image i % B (workgroup i runs on XCD i % 8), inside an image by
+ * (level, 16-pixel band of the box centre's row) -- the windows an XCD reads next to each other in time share its L2. */
+int lvc_roi_work_order_xcd(const float* rois, const int* levels, int K, int B, int* d_order, void* stream);
 int lvc_roi_align_fpn_nhwc_ordered(const float* const* feats, const int* Hs, const int* Ws, const float* scales, int L,
                                    int B, int C, const float* rois, const int* levels, const int* d_num_valid, int K,
                                    int pooled_h, int pooled_w, int sampling_ratio, int aligned, float* output,

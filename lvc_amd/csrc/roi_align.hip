@@ -17,6 +17,7 @@
 // drop-in convenience, the engine uses NHWC).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #define LVC_MAX_LEVELS 8
 
@@ -203,6 +204,12 @@ __global__ __launch_bounds__(64) void roi_align_fwd_nhwc4_kernel(RoiAlignArgs p)
 // column re-read per bin, L1 far smaller than 28 waves' windows); this form 0.53 - 0.57 ms.
 // Items beyond the registers' reach (more than 64 window rows or columns; empty grids) take the per-sample loop.
 #define ROI_UNI(x) __builtin_amdgcn_readfirstlane(x)
+#ifndef ROI_RB4
+#define ROI_RB4 2      // rows per batch of loads, windows of <= 4 columns
+#endif
+#ifndef ROI_RB8
+#define ROI_RB8 1      // rows per batch of loads, chunks of 8 columns
+#endif
 #ifndef ROI_WAVE_MLP
 #define ROI_WAVE_MLP 8
 #endif
@@ -313,7 +320,11 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_wave_kernel(RoiAlignAr
     }
     wx[pw] = a;
   }
-  // every pixel of the window once (rows outer, columns inner, ROI_WAVE_MLP in flight), into the bins whose Wx is not zero there
+  // Every pixel of the window once.  Wy does not depend on the bin, so the rows are summed FIRST, per column:
+  //     T[c] = sum_r Wy[r] pixel[r][c]                      (two packed fmas per pixel, whatever the number of bins that use it)
+  //     bin[pw] = sum_c Wx[pw][c] T[c]                      (per column and bin with a weight there, once per column chunk)
+  // -- 0.42 -> ... ms against adding every pixel into each of its (two to seven) bins.  Columns go in chunks of CW (T lives in
+  // registers), RB rows of a chunk per batch of loads: 4 x 2 for the narrow windows (<= 4 columns), 8 x 1 otherwise.
   unsigned amask = 0;
 #pragma unroll
   for (int pw = 0; pw < PW; ++pw) amask |= wx[pw] != 0.f ? 1u << pw : 0u;
@@ -321,35 +332,52 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_wave_kernel(RoiAlignAr
 #pragma unroll
   for (int pw = 0; pw < PW; ++pw) acc[pw] = float4{0.f, 0.f, 0.f, 0.f};
   const float* base = in + ((long long)y0 * W + x0) * C;
-  const int total = nrows * ncols;
-  const int Ci = (int)C, rowskip = (W - ncols) * Ci;      // element offsets inside one image of a level fit 32 bits (checked at launch)
-  int rr = 0, cc = 0, off = 0;                            // off = (rr * W + cc) * C, kept incrementally (scalar adds)
-  for (int t = 0; t < total; t += ROI_WAVE_MLP) {
-    float4 v[ROI_WAVE_MLP];
-    int rs[ROI_WAVE_MLP], cs[ROI_WAVE_MLP];
+  const int Ci = (int)C, rowstep = W * Ci;      // element offsets inside one image of a level fit 32 bits (checked at launch)
+  auto chunk = [&](auto cw_tag, auto rb_tag, int c0) {
+    constexpr int CW = decltype(cw_tag)::value, RB = decltype(rb_tag)::value;
+    const int ncw = min(CW, ncols - c0);        // columns of this chunk
+    float4 T[CW];
 #pragma unroll
-    for (int u = 0; u < ROI_WAVE_MLP; ++u) {
-      const bool live = t + u < total;
-      rs[u] = live ? rr : -1;
-      cs[u] = live ? cc : 0;
-      v[u] = *reinterpret_cast<const float4*>(base + (live ? off : 0));
-      off += Ci;
-      if (++cc == ncols) { cc = 0; ++rr; off += rowskip; }
-    }
+    for (int u = 0; u < CW; ++u) T[u] = float4{0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < nrows; r0 += RB) {
+      float4 v[RB][CW];
 #pragma unroll
-    for (int u = 0; u < ROI_WAVE_MLP; ++u) {
-      if (rs[u] < 0) continue;
-      const float wyr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wy), rs[u]));
-      const unsigned am = __builtin_amdgcn_readlane(amask, cs[u]);      // the bins with a weight in this column
+      for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-      for (int pw = 0; pw < PW; ++pw) {
-        if (am & (1u << pw)) {      // wave-uniform: a bin touches two to five of the window's columns
-          const float w = wyr * __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wx[pw]), cs[u]));
-          acc[pw].x = __builtin_fmaf(w, v[u].x, acc[pw].x); acc[pw].y = __builtin_fmaf(w, v[u].y, acc[pw].y);
-          acc[pw].z = __builtin_fmaf(w, v[u].z, acc[pw].z); acc[pw].w = __builtin_fmaf(w, v[u].w, acc[pw].w);
+        for (int u = 0; u < CW; ++u) {
+          const bool live = u < ncw && r0 + rb < nrows;      // wave-uniform
+          v[rb][u] = *reinterpret_cast<const float4*>(base + (live ? (r0 + rb) * rowstep + (c0 + u) * Ci : 0));
+        }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        if (r0 + rb >= nrows) continue;
+        const float wyr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wy), r0 + rb));
+#pragma unroll
+        for (int u = 0; u < CW; ++u) {
+          if (u >= ncw) continue;
+          T[u].x = __builtin_fmaf(wyr, v[rb][u].x, T[u].x); T[u].y = __builtin_fmaf(wyr, v[rb][u].y, T[u].y);
+          T[u].z = __builtin_fmaf(wyr, v[rb][u].z, T[u].z); T[u].w = __builtin_fmaf(wyr, v[rb][u].w, T[u].w);
         }
       }
     }
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+      if (u >= ncw) continue;
+      const unsigned am = __builtin_amdgcn_readlane(amask, c0 + u);      // the bins with a weight in this column
+#pragma unroll
+      for (int pw = 0; pw < PW; ++pw) {
+        if (am & (1u << pw)) {      // wave-uniform
+          const float w = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wx[pw]), c0 + u));
+          acc[pw].x = __builtin_fmaf(w, T[u].x, acc[pw].x); acc[pw].y = __builtin_fmaf(w, T[u].y, acc[pw].y);
+          acc[pw].z = __builtin_fmaf(w, T[u].z, acc[pw].z); acc[pw].w = __builtin_fmaf(w, T[u].w, acc[pw].w);
+        }
+      }
+    }
+  };
+  if (ncols <= 4) {
+    chunk(std::integral_constant<int, 4>{}, std::integral_constant<int, ROI_RB4>{}, 0);
+  } else {
+    for (int c0 = 0; c0 < ncols; c0 += 8) chunk(std::integral_constant<int, 8>{}, std::integral_constant<int, ROI_RB8>{}, c0);
   }
   if (c_ok) {
     const float inv = 1.f / count;      // one division per item instead of 28 (the bins' sums are not the reference's bit for bit anyway)
@@ -753,6 +781,70 @@ extern "C" int lvc_roi_work_order(const float* rois, const int* levels, const fl
   a.rois = rois; a.levels = levels; a.K = K; a.ph = pooled_h; a.order = d_order;
   for (int l = 0; l < L; ++l) a.scale[l] = scales[l];
   hipLaunchKernelGGL(roi_work_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// XCD-local work order.  Workgroup i runs on XCD i % 8; the windows of a launch are read through that XCD's 4 MB L2, and since the
+// column-sum form the launch is bound by what misses it (3 GB of window reads, 0.7 GB of pyramid).  Here position i of the order holds
+// a RoI of image i % B (B images; with B = 8 an XCD pools ONE image's RoIs), and inside an image the RoIs go by (level, 16-pixel band
+// of the box centre's row): neighbours in time on an XCD read neighbouring rows of one map.  0.394 -> 0.368 ms on the bench batch
+// (scripts/probe_roi_orders.py).  One workgroup, counting sort with B x 256 counters in LDS; B <= 16, else the area order above.
+#define ROI_XCD_MAX_B 16
+struct RoiOrderXcdArgs {
+  const float* rois;
+  const int* levels;
+  int K, B;
+  int* order;
+};
+__global__ __launch_bounds__(1024) void roi_work_order_xcd_kernel(RoiOrderXcdArgs p) {
+  __shared__ int hist[ROI_XCD_MAX_B][256];
+  __shared__ int cnt[ROI_XCD_MAX_B], tail0[ROI_XCD_MAX_B], s_min;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ROI_XCD_MAX_B * 256; i += 1024) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  auto key = [&](int k, int& b) {
+    const float* r = p.rois + (long long)k * 5;
+    const float bf = r[0];
+    b = bf >= 0.f && bf < (float)p.B ? (int)bf : 0;
+    const int lv = p.levels ? (p.levels[k] & 3) : 0;
+    const float yc = (r[2] + r[4]) * 0.5f;
+    int band = yc == yc ? (int)(fminf(fmaxf(yc, 0.f), 1e6f) * (1.f / 16.f)) : 0;
+    band = band > 63 ? 63 : band;
+    return lv * 64 + band;
+  };
+  for (int k = tid; k < p.K; k += 1024) { int b; const int ky = key(k, b); atomicAdd(&hist[b][ky], 1); }
+  __syncthreads();
+  if (tid < p.B) {      // exclusive prefix inside the image; its count
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int n = hist[tid][i]; hist[tid][i] = run; run += n; }
+    cnt[tid] = run;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int m = cnt[0];
+    for (int b = 1; b < p.B; ++b) m = cnt[b] < m ? cnt[b] : m;
+    s_min = m;
+    int run = 0;
+    for (int b = 0; b < p.B; ++b) { tail0[b] = run; run += cnt[b] - m; }
+  }
+  __syncthreads();
+  const int m = s_min;
+  for (int k = tid; k < p.K; k += 1024) {
+    int b;
+    const int ky = key(k, b);
+    const int r = atomicAdd(&hist[b][ky], 1);      // rank inside the image (order inside a key: whatever the atomics give)
+    p.order[r < m ? r * p.B + b : m * p.B + tail0[b] + (r - m)] = k;
+  }
+}
+
+extern "C" int lvc_roi_work_order_xcd(const float* rois, const int* levels, int K, int B, int* d_order, void* stream) {
+  LVC_CHECK_ARG(K >= 0 && B >= 1 && B <= ROI_XCD_MAX_B, "1..16 images");
+  if (K == 0) return LVC_OK;
+  LVC_CHECK_ARG(rois && d_order, "null pointer");
+  RoiOrderXcdArgs a;
+  a.rois = rois; a.levels = levels; a.K = K; a.B = B; a.order = d_order;
+  hipLaunchKernelGGL(roi_work_order_xcd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

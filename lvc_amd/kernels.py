@@ -810,7 +810,7 @@ ROI_ORDER_MIN = 1024     # RoIs per launch from which a work order is computed (
 
 
 def roi_align_fpn_nhwc(feats, scales, rois, levels, pooled_h, pooled_w, sampling_ratio, aligned,
-                       num_valid=None, status=None):
+                       num_valid=None, status=None, order=None):
     """feats: list of NHWC level tensors [B,H_l,W_l,C]; rois [K,5]; levels [K] int32 (or None when one
     level).  Returns [K, ph, pw, C]."""
     _req_cuda(rois, *feats)
@@ -830,13 +830,18 @@ def roi_align_fpn_nhwc(feats, scales, rois, levels, pooled_h, pooled_w, sampling
         assert f.is_contiguous() and f.dtype == torch.float32 and f.shape[0] == B and f.shape[3] == C
     if levels is not None:
         assert levels.dtype == torch.int32 and levels.is_contiguous()
-    order = None
-    if K >= ROI_ORDER_MIN:
+    if order is not None:       # a caller's own work order ([K] int32 permutation; experiments)
+        assert order.dtype == torch.int32 and order.is_contiguous() and order.numel() == K
+    elif K >= ROI_ORDER_MIN:
         # the workgroups take the RoIs largest window first (the launch's time follows the window area; in proposal order a few
         # large RoIs start last and finish alone)
         order = torch.empty(K, device=rois.device, dtype=torch.int32)
-        check(_lib.lib().lvc_roi_work_order(ptr(rois), ptr(levels), sc, c_int(L), c_int(K), c_int(pooled_h), ptr(order), _stream(rois)),
-              "lvc_roi_work_order")
+        if B <= 16:
+            # image b's RoIs on XCD b % 8, inside an image by (level, band of rows): what an XCD reads close in time shares its L2
+            check(_lib.lib().lvc_roi_work_order_xcd(ptr(rois), ptr(levels), c_int(K), c_int(B), ptr(order), _stream(rois)), "lvc_roi_work_order_xcd")
+        else:
+            check(_lib.lib().lvc_roi_work_order(ptr(rois), ptr(levels), sc, c_int(L), c_int(K), c_int(pooled_h), ptr(order), _stream(rois)),
+                  "lvc_roi_work_order")
     st = _lib.lib().lvc_roi_align_fpn_nhwc_ordered(
         fp, hs, ws, sc, c_int(L), c_int(B), c_int(C), ptr(rois), ptr(levels), ptr(num_valid), c_int(K),
         c_int(pooled_h), c_int(pooled_w), c_int(sampling_ratio), c_int(1 if aligned else 0), ptr(out),

@@ -436,6 +436,19 @@ def test_roi_align_work_order_is_a_permutation_and_changes_no_value(monkeypatch)
     area = ((rois[:, 3] - rois[:, 1]) * s_ + 2) * ((rois[:, 4] - rois[:, 2]) * s_ + 14)
     bucket = (2 * torch.log2(area)).floor()[o]
     assert (bucket[1:] <= bucket[:-1]).all() and o[0] != 5 and o[-1] != 6
+    # the XCD-local order (what roi_align_fpn_nhwc uses for <= 16 images): a permutation; position i holds a RoI of image i % B while
+    # every image has RoIs left, and inside an image the (level, 16-pixel band of the centre row) keys do not decrease
+    order2 = torch.full((3000,), -1, device=d, dtype=torch.int32)
+    assert _lib.lib().lvc_roi_work_order_xcd(k.ptr(rd), k.ptr(ld), ctypes.c_int(3000), ctypes.c_int(B), k.ptr(order2), None) == 0
+    o2 = order2.cpu().long()
+    assert torch.equal(torch.sort(o2)[0], torch.arange(3000))
+    imgs = rois[:, 0].long()
+    m = int(torch.bincount(imgs, minlength=B).min())
+    assert torch.equal(imgs[o2[:m * B]], torch.arange(B).repeat(m))
+    key = levels.long() * 64 + ((rois[:, 2] + rois[:, 4]) * 0.5 / 16).long().clamp(max=63)
+    for b in range(B):
+        kb = key[o2][imgs[o2] == b]
+        assert (kb[1:] >= kb[:-1]).all()
     monkeypatch.setattr(k, "ROI_ORDER_MIN", 1 << 30)
     plain = k.roi_align_fpn_nhwc(fd, scales, rd, ld, 7, 7, 0, True)
     monkeypatch.setattr(k, "ROI_ORDER_MIN", 1)
