@@ -732,8 +732,8 @@ static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_s
 }
 
 // L maps [N, Hs[l], Ws[l], C] through the SAME 3x3 layer in one launch (outputs ys[l] [N, Hs[l], Ws[l], K], rows of K floats): the
-// RPN head over the pyramid levels.  One stream-K split over the row tiles of all maps (the largest map first), one patch shape
-// (chosen for map 0): the small maps no longer pay a launch each that cannot fill the chip.  Per output pixel the arithmetic is
+// RPN head over the pyramid levels.  One stream-K split over the row tiles of all maps (in the order given), one patch shape
+// (chosen for the largest map): the small maps no longer pay a launch each that cannot fill the chip.  Per output pixel the arithmetic is
 // the single-map launch's.  oneacc as above; no residual.
 static int halo_s1_levels(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
                           const unsigned short* w_split, const float* scale, const float* shift, const unsigned short* const* ws,
@@ -752,7 +752,10 @@ static int halo_s1_levels(int oneacc, const float* const* xs, float* const* ys, 
   a.w = w_split; a.scale = scale; a.shift = shift; a.res = nullptr;
   a.N = N; a.C = C; a.K = K; a.relu = relu; a.res_mode = 0; a.ldy = K; a.ldr = K;
   LVC_CHECK_ARG(((uintptr_t)w_split & 15) == 0 && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)scale & 15) == 0, "pointers must be 16-byte aligned");
-  halo_s1_patch(a, Hs[0], Ws[0]);
+  int big = 0;      // the patch shape is chosen for the largest map, wherever it stands in the list
+  for (int l = 1; l < L; ++l)
+    if ((long long)Hs[l] * Ws[l] > (long long)Hs[big] * Ws[big]) big = l;
+  halo_s1_patch(a, Hs[big], Ws[big]);
   long long tiles = 0;
   a.nlev = L;
   for (int l = 0; l < L; ++l) {

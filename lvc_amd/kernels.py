@@ -653,7 +653,7 @@ def conv3x3_levels(xs, pc, relu=False, outs=None):
           and all(x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == N and x.shape[3] == C
                   and x.numel() < (1 << 29) for x in xs)
           and all(o.is_contiguous() and o.shape == (x.shape[0], x.shape[1], x.shape[2], p0.K) for o, x in zip(outs, xs))
-          and N * ((xs[0].shape[1] * xs[0].shape[2] + 255) // 256) * ((p0.K + 127) // 128) >= _HALO_H2_MIN_TILES)
+          and N * ((max(x.shape[1] * x.shape[2] for x in xs) + 255) // 256) * ((p0.K + 127) // 128) >= _HALO_H2_MIN_TILES)
     if not ok:
         for x, q, o in zip(xs, pcs, outs):
             conv2d_nhwc(x, q, relu=relu, out=o)
