@@ -405,6 +405,9 @@ int lvc_conv_wgrad_nhwc_bf16x3(const float* x, const float* dy, const float* sca
 int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                               int K, int R, int S, int stride, int pad, int lddy, int* err_word, void* stream);
 int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* y[n, i, j, 0..C) = x[n, 2i, 2j, :], rows of ldy floats in y (0 = C): the sampling of a stride-2 1x1 convolution as a copy (the
+ * block input of res3.0 / res4.0 / res5.0 next to conv2's output: conv3 + projection shortcut as one GEMM, resnet.py:117-160). */
+int lvc_subsample2_nhwc(const float* x, float* y, int N, int H, int W, int C, int ldy, void* stream);
 int lvc_downsum2x2_nhwc(const float* x, float* y, int N, int Hs, int Ws, int C, void* stream);
 int lvc_colsum_atomic(const float* x, int M, int N, int ldx, float* out, void* stream);
 

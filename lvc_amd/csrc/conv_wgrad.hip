@@ -206,6 +206,34 @@ extern "C" int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, 
   return LVC_OK;
 }
 
+// y[n, i, j, 0..C) = x[n, 2i, 2j, :] with rows of ldy floats in y (ldy >= C: y may be the tail channels of a wider buffer).  The
+// sampling of a stride-2 1x1 convolution as a copy: the block input of res3.0 / res4.0 / res5.0 next to conv2's output, so that
+// conv3 and the projection shortcut run as ONE pointwise GEMM over [conv2 output | sampled input] (BottleneckBlock.can_fuse_projection).
+__global__ __launch_bounds__(256) void subsample2_kernel(const f32x4* __restrict__ x, float* __restrict__ y, int H, int W, int Hs,
+                                                         int Ws, int C4, int ldy, long long total) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i % C4);
+  long long q = i / C4;
+  const int ix = (int)(q % Ws); q /= Ws;
+  const int iy = (int)(q % Hs);
+  const int n = (int)(q / Hs);
+  const f32x4 v = x[(((long long)n * H + 2 * iy) * W + 2 * ix) * C4 + c];
+  *reinterpret_cast<f32x4*>(y + (((long long)n * Hs + iy) * Ws + ix) * ldy + c * 4) = v;
+}
+
+extern "C" int lvc_subsample2_nhwc(const float* x, float* y, int N, int H, int W, int C, int ldy, void* stream) {
+  LVC_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bad arguments");
+  const int ld = ldy > 0 ? ldy : C;
+  LVC_CHECK_ARG(ld >= C && ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0, "rows must be 16-byte aligned");
+  const int Hs = (H - 1) / 2 + 1, Ws = (W - 1) / 2 + 1;
+  const long long total = (long long)N * Hs * Ws * (C / 4);
+  hipLaunchKernelGGL(subsample2_kernel, dim3((unsigned)lvc_cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const f32x4*>(x), y, H, W, Hs, Ws, C / 4, ld, total);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
 // y[n, i, j, :] = sum of the 2x2 block x[n, 2i..2i+1, 2j..2j+1, :].  Backward of the nearest x2 upsample of the FPN
 // top-down path (fpn.py:131-133).  x [N,2Hs,2Ws,C] -> y [N,Hs,Ws,C].
 __global__ __launch_bounds__(256) void downsum2x2_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int Hs, int Ws,

@@ -1421,6 +1421,20 @@ def scatter_stride2(x, H, W):
     return y
 
 
+def subsample2_into(x, out):
+    """out[n, i, j, :C] = x[n, 2i, 2j, :] where out is a [N,Hs,Ws,C] view with unit channel stride (rows may be wider: the tail
+    channels of a concat buffer)."""
+    _req_cuda(x, out)
+    N, H, W, C = x.shape
+    Hs, Ws = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert x.is_contiguous() and x.dtype == torch.float32 and out.dtype == torch.float32 and out.shape == (N, Hs, Ws, C)
+    ld = out.stride(2)
+    assert out.stride(3) == 1 and out.stride(1) == Ws * ld and out.stride(0) == Hs * Ws * ld
+    check(_lib.lib().lvc_subsample2_nhwc(ptr(x), ptr(out), c_int(N), c_int(H), c_int(W), c_int(C), c_int(ld), _stream(x)),
+          "lvc_subsample2_nhwc")
+    return out
+
+
 def downsum2x2(x):
     """x [N,2Hs,2Ws,C] -> [N,Hs,Ws,C] sums of the 2x2 blocks."""
     _req_cuda(x)

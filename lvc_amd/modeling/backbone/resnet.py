@@ -32,6 +32,9 @@ class CNNBlockBase(nn.Module):
         return self
 
 
+FUSE_STRIDED_PROJECTION = True      # conv3 + a stride-2 projection shortcut as one GEMM (BottleneckBlock.can_fuse_projection)
+
+
 class BottleneckBlock(CNNBlockBase):
     def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
                  stride_in_1x1=False, dilation=1):
@@ -59,8 +62,12 @@ class BottleneckBlock(CNNBlockBase):
         stride-1 projection shortcut (res2.0: both 64 -> 256 at 1/4 resolution, both HBM streams) as ONE pointwise GEMM
         over the concatenated input [conv2 output | block input]."""
         grad_free = not torch.is_grad_enabled() or not any(p.requires_grad for p in self.parameters())
+        # stride 2 in the 1x1 layers (res3.0 / res4.0 / res5.0 with STRIDE_IN_1X1): the shortcut samples x[:, ::2, ::2]; that sampling is
+        # a copy into the buffer's tail channels (kernels.subsample2_into) -- the strided projection launch (168 us on res3.0 for 137 MB
+        # read + 275 MB written) and the residual round trip of its output go away
+        strided = self.shortcut is not None and self.shortcut.stride == 2 and self.conv1.stride == 2
         return (K.FUSE_PROJECTION and K.CONV_ENGINE == "bf16x3" and grad_free and self.shortcut is not None
-                and self.shortcut.stride == 1 and self.conv2.stride == 1
+                and (self.shortcut.stride == 1 or (strided and FUSE_STRIDED_PROJECTION)) and self.conv2.stride == 1
                 and (self.conv2.out_channels + self.in_channels) % 32 == 0 and self.conv2.out_channels % 4 == 0)
 
     def _fused_projection(self):
@@ -115,6 +122,12 @@ class BottleneckBlock(CNNBlockBase):
         conv1 output of `nxt` or None).  concat: as `forward_nhwc`."""
         if t is None:
             t = self.conv1.forward_nhwc(x)
+        if (concat is None and self.shortcut is not None and self.shortcut.stride == 2 and self.can_fuse_projection()
+                and self.chain_to(nxt, False) is None):      # res3.0 keeps its conv3 -> res3.1.conv1 chain (shortcut as the residual)
+            # a stage head with stride 2: [conv2 output | x sampled at the even pixels] built here (res2.0's buffer comes from the stem)
+            cb = self.conv2.out_channels
+            concat = torch.empty(t.shape[0], t.shape[1], t.shape[2], cb + self.in_channels, device=t.device, dtype=torch.float32)
+            K.subsample2_into(x, concat[..., cb:])
         if concat is not None:
             K.conv2d_nhwc(t, self.conv2.packed(), relu=True, out=concat)      # channels [0, bottleneck), row stride = buffer
             ch = self.chain_to(nxt, True)

@@ -4,7 +4,7 @@ The reference computes in fp32 (detectron2/layers/wrappers.py:41-99): no activat
 single-accumulator fp16 split (|a| <= 4094), and when ITS range word is raised it alone moves to the two-accumulator form
 (|a| <= 65504), then to the range-free bf16x3 kernels -- and stays there; every other layer keeps its kernels; the pass is
 repeated; the words are cleared per pass.  Planted here: a 5000 in one channel of res4's output (consumers: res5.0.conv1, the
-res5.0 projection shortcut, FPN lateral 4) and a 1e5 in one channel of res5's output (consumer: FPN lateral 5); the consumers'
+res5.0 projection shortcut -- fused with conv3 --, FPN lateral 4) and a 1e5 in one channel of res5's output (consumer: FPN lateral 5); the consumers'
 weights for that channel are scaled down so that everything behind them stays O(1)."""
 import time
 
@@ -61,8 +61,11 @@ def test_only_the_overflowing_layers_are_rerouted_and_results_match_the_oracle()
     assert K.RANGE_EPOCH > epoch0
     tiers = _tiers(model)
     print("re-routed layers:", tiers)
-    assert tiers == {"backbone.bottom_up.res5.0.conv1": 1, "backbone.bottom_up.res5.0.shortcut": 1, "backbone.fpn_lateral4": 1,
-                     "backbone.fpn_lateral5": 2}, tiers
+    # (res5.0's projection shortcut runs fused with conv3 -- resnet.FUSE_STRIDED_PROJECTION -- as one packed layer with a range state
+    # of its own: the planted channel arrives in its sampled-input half)
+    assert tiers == {"backbone.bottom_up.res5.0.conv1": 1, "backbone.fpn_lateral4": 1, "backbone.fpn_lateral5": 2}, tiers
+    assert model.backbone.bottom_up.res5[0]._fused_projection().state["tier"] == 1
+    assert model.backbone.bottom_up.res4[0]._fused_projection().state["tier"] == 0
     # a second pass: nothing moves, nothing is repeated
     epoch1 = K.RANGE_EPOCH
     with torch.no_grad():
@@ -102,7 +105,7 @@ def test_steady_state_speed_with_rerouted_layers():
     planted = _model(_planted_state_dict())
     with torch.no_grad():
         planted(batch)            # re-routes
-    assert len(_tiers(planted)) == 4
+    assert len(_tiers(planted)) == 3 and planted.backbone.bottom_up.res5[0]._fused_projection().state["tier"] == 1      # + the fused conv3 / shortcut of res5.0
     r_planted = rate(planted)
     r_clean2 = rate(clean)
     print("img/s clean %.1f / %.1f, with four re-routed layers %.1f" % (r_clean, r_clean2, r_planted))

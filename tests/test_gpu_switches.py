@@ -1,7 +1,7 @@
 """Every surviving LVC_* switch is exercised on the device: the ones without a test of their own elsewhere.
   LVC_CONV_ENGINE=f32  -> kernels.CONV_ENGINE  (every conv / GEMM on the exact fp32 MFMA kernel)
   LVC_CHAIN=0          -> kernels.CHAIN        (conv3 -> next conv1 as two launches)
-  fpn.MERGE_OUTPUT_CONVS, rpn.MERGE_LEVELS / MERGE_LEVELS_CONV (module constants)  (the RPN head's predictor / 3x3 conv over all levels as one launch each)
+  resnet.FUSE_STRIDED_PROJECTION, fpn.MERGE_OUTPUT_CONVS, rpn.MERGE_LEVELS / MERGE_LEVELS_CONV (module constants)  (the RPN head's predictor / 3x3 conv over all levels as one launch each)
 and the attention's range report (kernels.mha -> the shared error word)."""
 import pytest
 import torch
@@ -42,11 +42,13 @@ def test_chain_switch_two_launches_equal_one(monkeypatch):
     """The trunk with the conv3 -> conv1 pairs of res2 / res3 as one launch each (default) against the two-launch form, and which
     engine tags a step launches in either case."""
     from lvc_amd import kernels as K
+    from lvc_amd.modeling.backbone import resnet as R
     from test_gpu_e2e import _model
 
     model = _model()
     x = torch.randn(2, 3, 416, 608, generator=torch.Generator().manual_seed(1)).cuda() * 40
     res, tags = {}, {}
+    monkeypatch.setattr(R, "FUSE_STRIDED_PROJECTION", False)      # (without the chain res3.0 would take that form: one launch fewer)
     for chain in (True, False):
         monkeypatch.setattr(K, "CHAIN", chain)
         timer = K.LaunchTimer()
@@ -118,6 +120,32 @@ def test_fpn_output_convs_of_all_levels_in_one_launch(monkeypatch):
     for k in res[True]:
         scale = float(res[False][k].abs().max())
         assert res[True][k].shape == res[False][k].shape
+        assert float((res[True][k] - res[False][k]).abs().max()) <= 2e-5 * scale, k
+    assert K.conv_error_word(x.device) == 0
+
+
+def test_strided_projection_shortcut_fused_with_conv3(monkeypatch):
+    """res4.0 / res5.0 (res3.0 keeps its chained launch): conv3 and the stride-2 projection shortcut as ONE pointwise GEMM over [conv2
+    output | block input sampled at the even pixels] (resnet.FUSE_STRIDED_PROJECTION) against the two launches + residual: two conv launches fewer,
+    features within the conv tolerance (the FrozenBN scales go into the fused weights: one more fp32 rounding per weight)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.backbone import resnet as R
+    from test_gpu_e2e import _model
+
+    model = _model()
+    x = torch.randn(2, 3, 416, 608, generator=torch.Generator().manual_seed(1)).cuda() * 40
+    res, n = {}, {}
+    for fuse in (True, False):
+        monkeypatch.setattr(R, "FUSE_STRIDED_PROJECTION", fuse)
+        timer = K.LaunchTimer()
+        monkeypatch.setattr(K, "CONV_TIMER", timer)
+        with torch.no_grad():
+            res[fuse] = {k: v.clone() for k, v in model.backbone.bottom_up(x).items()}
+        monkeypatch.setattr(K, "CONV_TIMER", None)
+        n[fuse] = len(timer.records)
+    assert n[False] - n[True] == 2
+    for k in res[True]:
+        scale = float(res[False][k].abs().max())
         assert float((res[True][k] - res[False][k]).abs().max()) <= 2e-5 * scale, k
     assert K.conv_error_word(x.device) == 0
 
