@@ -117,6 +117,18 @@ int lvc_conv3x3_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, c
 int lvc_conv3x3_nhwc_f16_levels(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
                                 const unsigned short* w_split, const float* scale, const float* shift, int N, int C, int K, int Kg,
                                 int relu, void* workspace, void* stream);
+/* ... with a POINTWISE layer on top of act(conv), the hidden maps never written: StandardRPNHead.forward of the reference
+ * (detectron2/modeling/proposal_generator/rpn.py:112-120: t = relu(conv(x)); objectness_logits(t), anchor_deltas(t)) as one launch over
+ * the levels.  ys[l] [N,Hs[l],Ws[l],pred_ld] are the POINTWISE layer's outputs and must be ZEROED by the caller (every workgroup adds
+ * its 128-channel slice of the contraction atomically: K = 128 or 256 hidden channels -> at most two addends per element, the sum does
+ * not depend on their order).  oneacc must be 0 (w_split / scale / shift as for lvc_conv3x3_nhwc_f16x2_pipe).  pred_w: the
+ * [2][pred_rows >= 32][K] fp16 planes lvc_split_weights writes for the pointwise weights [pred_rows][K] (rows >= pred_K zero), pred_scale /
+ * pred_shift [pred_K] or NULL, 1 <= pred_K <= 32 <= pred_rows, pred_ld >= pred_K.  pred_slot: the pointwise layer's range word (a hidden
+ * value beyond 65504 raises it; the 3x3 layer's own word is the slot set by lvc_set_range_slot). */
+int lvc_conv3x3_nhwc_f16_levels_pred(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                                     const unsigned short* w_split, const float* scale, const float* shift, int N, int C, int K, int Kg,
+                                     int relu, const unsigned short* pred_w, const float* pred_scale, const float* pred_shift, int pred_K,
+                                     int pred_rows, int pred_ld, int pred_slot, void* workspace, void* stream);
 /* The same with a LAYER per map (L layers of one shape and form: the FPN output convs, detectron2/modeling/backbone/fpn.py:128-141): ws /
  * scales / shifts are [host] arrays of L device pointers (shift entries may be NULL). */
 int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,

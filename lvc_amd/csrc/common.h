@@ -12,6 +12,7 @@
 
 extern "C" void lvc_set_error(const char* fmt, ...);
 extern "C" int lvc_range_slot(void);   // see common.cpp
+extern "C" int lvc_range_slots(void);
 
 #define LVC_CHECK_ARG(cond, msg)                       \
   do {                                                 \

@@ -71,6 +71,14 @@ struct HaloArgsS {
   const unsigned short* lv_w[HALO_MAX_LEVELS];
   const float* lv_scale[HALO_MAX_LEVELS];
   const float* lv_shift[HALO_MAX_LEVELS];
+  // ... with a POINTWISE layer on top of act(conv) (the RPN predictor on the head's hidden map, pred_w != nullptr): y / lv_y are that
+  // layer's outputs (rows of ldy floats, ZEROED by the caller), the hidden map is never written.  pred_w: its [2][pred_rows][K] fp16
+  // planes (lvc_split_weights: w1 = fp16(w), w2 = fp16((w - w1) 2^11)), pred_K <= 32 outputs, pred_scale / pred_shift per output or null
+  const unsigned short* pred_w;
+  const float* pred_scale;
+  const float* pred_shift;
+  long long pred_plane_elems;
+  int pred_K, pred_err_index;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -155,7 +163,7 @@ __device__ __forceinline__ void halo_g2(f32x16& c00, f32x16& c01, f32x16& c10, f
         [ob0] "n"(OB), [ob1] "n"(OB + 2048));
 }
 
-template <int NI, bool ONEACC>
+template <int NI, bool ONEACC, bool PRED = false>
 __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
   constexpr int HN = 64 * NI;
   // the fragment groups written out with counted waits (halo_g1 / halo_g2): the one-accumulator instance with 128-channel tiles -- the
@@ -552,6 +560,83 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
 #endif
     // ---- epilogue through LDS: tile row r is patch pixel (r / PW, r % PW)
     float* Cs = reinterpret_cast<float*>(smem_raw);
+    if constexpr (PRED) {
+      // A pointwise layer on top (HaloArgsS::pred_w): this workgroup holds act(conv) for HN of the K hidden channels of its pixels --
+      // a HN-deep slice of the layer's contraction.  The slice's products go to the output by atomic adds: with K <= 2 HN there are at
+      // most two addends per element on a zeroed output, so the sum does not depend on their order.  Arithmetic of a slice: the
+      // two-accumulator fp16 split (main a1 b1, cross a2 b1 + a1 b2 with the residual planes x 2^11), as the pointwise kernels'.
+      float bigp = 0.f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = wn * 32 * NI + ni * 32 + fi;
+        const float sc1 = scl ? scl[n0 + col] : 1.f;
+        const float sh1 = shl ? shl[n0 + col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            float v = acc[mi][ni][e] * sc1 + sh1;
+            if (p.relu) v = v > 0.f ? v : 0.f;
+            bigp = (fabsf(v) > bigp || v != v) ? fabsf(v) : bigp;
+            Cs[row * CS_STRIDE + col] = v;
+          }
+      }
+      __syncthreads();
+      // B fragments from L1 / L2 (every workgroup reads the same 2 x 32 x HN halves), one k16 step ahead of their use
+      const unsigned short* bsrcp = p.pred_w + (size_t)fi * p.K + n0 + fh * 8;
+      f16x8 pbh = *reinterpret_cast<const f16x8*>(bsrcp), pbl = *reinterpret_cast<const f16x8*>(bsrcp + p.pred_plane_elems);
+      f32x16 pm, px2;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { pm[e] = 0.f; px2[e] = 0.f; }
+      const float* arow = Cs + (wave * 32 + fi) * CS_STRIDE + fh * 8;
+#pragma unroll 1
+      for (int ks = 0; ks < HN / 16; ++ks) {
+        const int kn = ks + 1 < HN / 16 ? ks + 1 : ks;
+        const f16x8 nbh = *reinterpret_cast<const f16x8*>(bsrcp + kn * 16);
+        const f16x8 nbl = *reinterpret_cast<const f16x8*>(bsrcp + p.pred_plane_elems + kn * 16);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + ks * 16);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + ks * 16 + 4);
+        f16x8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float a = j < 4 ? a0[j & 3] : a1[j & 3];
+          const f16 hh = (f16)a;
+          ah[j] = hh;
+          al[j] = (f16)((a - (float)hh) * 2048.f);
+        }
+        pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pbh, pm, 0, 0, 0);
+        px2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, pbh, px2, 0, 0, 0);
+        px2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pbl, px2, 0, 0, 0);
+        pbh = nbh; pbl = nbl;
+      }
+      // The 32 x 32 result block goes back through the wave's OWN rows of the LDS tile (no other wave reads or writes them), then
+      // out in a rolled loop, two pixels x 32 outputs per instruction: written out per accumulator element, the sixteen address
+      // computations were spilled and every reload -- a vmcnt(0) -- waited for the atomic before it (+0.36 ms on the RPN head).
+      float* rblk = Cs + wave * 32 * CS_STRIDE;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) rblk[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fi] = pm[e] + px2[e] * (1.f / 2048.f);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (fi < p.pred_K) {
+        const float psc = p.pred_scale ? p.pred_scale[fi] : 1.f;
+        const float psh = (n0 == 0 && p.pred_shift) ? p.pred_shift[fi] : 0.f;     // the bias once: with the first slice
+        const size_t origin = (size_t)(img * Hl + y0) * Wl + x0;
+        float* const ybase = yl + origin * p.ldy + fi;
+        const int ylim = Hl - y0, xlim = Wl - x0;
+#pragma unroll 2
+        for (int rr = 0; rr < 32; rr += 2) {
+          const int r = wave * 32 + rr + fh;
+          const int py = (r * p.inv_pw) >> 16, px = r - py * p.PW;
+          const float v = rblk[(rr + fh) * 32 + fi];
+          if (r < p.MP && py < ylim && px < xlim) unsafeAtomicAdd(ybase + (size_t)(unsigned)(py * Wl + px) * p.ldy, v * psc + psh);
+        }
+      }
+      // the pointwise layer's own range word: a hidden value beyond fp16
+      if (!(bigp <= 65504.f)) atomicOr(p.flags + p.pred_err_index, bigp < INFINITY ? 2 : 4);
+      __syncthreads();
+      continue;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -685,7 +770,10 @@ static int halo_s1_finish(HaloArgsS& a, bool oneacc, long long tiles_m_total, in
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
   hipStream_t st = (hipStream_t)stream;
-  if (oneacc) {
+  if (a.pred_w) {
+    LVC_CHECK_ARG(!oneacc && ni == 2, "pointwise layer on top: the two-accumulator form with >= 128 hidden channels");
+    hipLaunchKernelGGL((conv3x3_halo_s1_kernel<2, false, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+  } else if (oneacc) {
     if (ni == 1) hipLaunchKernelGGL((conv3x3_halo_s1_kernel<1, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((conv3x3_halo_s1_kernel<2, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
   } else {
@@ -695,6 +783,14 @@ static int halo_s1_finish(HaloArgsS& a, bool oneacc, long long tiles_m_total, in
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+// a pointwise layer on top of the 3x3 layer (lvc_conv3x3_nhwc_f16_levels_pred)
+struct HaloPred {
+  const unsigned short* w;
+  const float* scale;
+  const float* shift;
+  int K, rows, ld, slot;
+};
 
 static void halo_s1_patch(HaloArgsS& a, int H, int W) {
   pick_patch_s(H, W, &a.PH, &a.PW);
@@ -738,7 +834,7 @@ static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_s
 static int halo_s1_levels(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
                           const unsigned short* w_split, const float* scale, const float* shift, const unsigned short* const* ws,
                           const float* const* scales, const float* const* shifts, int N, int C, int K, int Kg, int relu, void* workspace,
-                          void* stream) {
+                          void* stream, const HaloPred* pred = nullptr) {
   LVC_CHECK_ARG(xs && ys && Hs && Ws && L >= 1 && L <= HALO_MAX_LEVELS, "1..6 maps");
   if (ws) {
     LVC_CHECK_ARG(scales && shifts, "null pointer");
@@ -752,6 +848,16 @@ static int halo_s1_levels(int oneacc, const float* const* xs, float* const* ys, 
   a.w = w_split; a.scale = scale; a.shift = shift; a.res = nullptr;
   a.N = N; a.C = C; a.K = K; a.relu = relu; a.res_mode = 0; a.ldy = K; a.ldr = K;
   LVC_CHECK_ARG(((uintptr_t)w_split & 15) == 0 && ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)scale & 15) == 0, "pointers must be 16-byte aligned");
+  if (pred) {
+    // at most two channel tiles per pixel tile: two addends per output element, whatever their order (see the kernel)
+    LVC_CHECK_ARG(pred->w && ((uintptr_t)pred->w & 15) == 0 && K % 128 == 0 && K <= 256, "pointwise layer on top: needs K = 128 or 256");
+    LVC_CHECK_ARG(pred->K >= 1 && pred->K <= 32 && pred->rows >= 32 && pred->ld >= pred->K, "pointwise layer on top: 1..32 outputs, planes of >= 32 rows");
+    LVC_CHECK_ARG(pred->slot > 0 && pred->slot < lvc_range_slots(), "pointwise layer on top: its range slot");
+    a.pred_w = pred->w; a.pred_scale = pred->scale; a.pred_shift = pred->shift; a.pred_K = pred->K;
+    a.pred_plane_elems = (long long)pred->rows * K;
+    a.pred_err_index = LVC_MAX_WORKERS + pred->slot;
+    a.ldy = pred->ld;
+  }
   int big = 0;      // the patch shape is chosen for the largest map, wherever it stands in the list
   for (int l = 1; l < L; ++l)
     if ((long long)Hs[l] * Ws[l] > (long long)Hs[big] * Ws[big]) big = l;
@@ -783,6 +889,19 @@ extern "C" int lvc_conv3x3_nhwc_f16_levels(int oneacc, const float* const* xs, f
                                             const unsigned short* w_split, const float* scale, const float* shift, int N, int C, int K,
                                             int Kg, int relu, void* workspace, void* stream) {
   return halo_s1_levels(oneacc, xs, ys, Hs, Ws, L, w_split, scale, shift, nullptr, nullptr, nullptr, N, C, K, Kg, relu, workspace, stream);
+}
+
+// ... with a pointwise layer on top, act(conv) never written (the RPN head: 3x3 conv + ReLU, then objectness | anchor deltas): ys[l] are
+// the POINTWISE layer's outputs [N, Hs[l], Ws[l], pred_ld floats per pixel], zeroed by the caller (the kernel adds the two 128-channel
+// slices of the contraction atomically: two addends, order-free).  pred_w: the [2][pred_rows][K] fp16 planes of lvc_split_weights,
+// pred_scale / pred_shift [pred_K] or null, pred_slot: that layer's range word (a hidden value beyond 65504 raises it).
+extern "C" int lvc_conv3x3_nhwc_f16_levels_pred(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
+                                                 const unsigned short* w_split, const float* scale, const float* shift, int N, int C,
+                                                 int K, int Kg, int relu, const unsigned short* pred_w, const float* pred_scale,
+                                                 const float* pred_shift, int pred_K, int pred_rows, int pred_ld, int pred_slot,
+                                                 void* workspace, void* stream) {
+  HaloPred pr = {pred_w, pred_scale, pred_shift, pred_K, pred_rows, pred_ld, pred_slot};
+  return halo_s1_levels(oneacc, xs, ys, Hs, Ws, L, w_split, scale, shift, nullptr, nullptr, nullptr, N, C, K, Kg, relu, workspace, stream, &pr);
 }
 
 // The same with a LAYER per map (L layers of one shape: the FPN output convs): ws / scales / shifts are [host] arrays of L device

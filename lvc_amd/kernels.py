@@ -693,6 +693,58 @@ def conv3x3_levels(xs, pc, relu=False, outs=None):
     return outs
 
 
+def conv3x3_levels_pred(xs, pc, pred, relu=True):
+    """act(conv3x3(xs[l])) through the pointwise layer `pred` (<= 32 outputs) in the ONE launch of `conv3x3_levels`: the hidden maps are
+    never written -- every workgroup of the 3x3 kernel contracts its 128 hidden channels with the pointwise weights in its epilogue and
+    adds the slice to the (zeroed) output atomically (two slices per element: order-free, csrc/conv3x3_halo_s1.hip).  The RPN head:
+    conv + ReLU, then objectness | anchor deltas.  Returns the list of [N,H_l,W_l,pred.K] outputs (views of one [sum of pixels, pred.K]
+    buffer), or None where the launch does not apply (the caller runs the two layers one after the other)."""
+    _req_cuda(*xs)
+    N, C = xs[0].shape[0], xs[0].shape[3]
+    ok = (1 <= len(xs) <= 6 and CONV_ENGINE == "bf16x3" and CONV_SPLIT == "f16x2" and CONV_HALO and HALO_S1 >= 1
+          and pc.state["tier"] < 2 and (pc.two_acc or pc.state["tier"] == 1 or HALO_S1 == 1)      # the two-accumulator instance
+          and pc.mode == 0 and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.C == C and C % 32 == 0
+          and pc.K in (128, 256) and pc.Kg == 9 * C
+          and pred.mode == 0 and pred.R == 1 and pred.S == 1 and pred.stride == 1 and pred.pad == 0 and pred.C == pc.K and pred.Kg == pc.K
+          and 1 <= pred.K <= 32 and pred.w.shape[0] >= 32 and pred.state["tier"] < 2
+          and all(x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32 and x.shape[0] == N and x.shape[3] == C
+                  and x.numel() < (1 << 29) for x in xs)
+          and N * ((max(x.shape[1] * x.shape[2] for x in xs) + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES)
+    if not ok:
+        return None
+    L = len(xs)
+    ms = [x.shape[0] * x.shape[1] * x.shape[2] for x in xs]
+    y = torch.zeros(sum(ms), pred.K, device=xs[0].device, dtype=torch.float32)
+    outs, off = [], 0
+    for x, m in zip(xs, ms):
+        outs.append(y[off:off + m].view(x.shape[0], x.shape[1], x.shape[2], pred.K))
+        off += m
+    timer = CONV_TIMER
+    if timer is not None and (not timer.active or (timer.only is not None and "f16x2_halo" not in timer.only)):
+        timer = None
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    XP, IP = c_void_p * L, c_int * L
+    xp, yp = XP(*[x.data_ptr() for x in xs]), XP(*[o.data_ptr() for o in outs])
+    hs, ws = IP(*[x.shape[1] for x in xs]), IP(*[x.shape[2] for x in xs])
+    pc.last_one = False
+    pred.last_one = False
+    planes, pplanes = pc.split2h(), pred.split2h()
+    _lib.lib().lvc_set_range_slot(c_int(pc.slot))
+    st = _lib.lib().lvc_conv3x3_nhwc_f16_levels_pred(c_int(0), xp, yp, hs, ws, c_int(L), ptr(planes), ptr(pc.scale), ptr(pc.shift), c_int(N),
+                                                     c_int(C), c_int(pc.K), c_int(pc.Kg), c_int(1 if relu else 0), ptr(pplanes),
+                                                     ptr(pred.scale), ptr(pred.shift), c_int(pred.K), c_int(pred.w.shape[0]),
+                                                     c_int(pred.K), c_int(pred.slot), ptr(conv_workspace(xs[0].device)), _stream(xs[0]))
+    _lib.lib().lvc_set_range_slot(c_int(0))
+    check(st, "lvc_conv3x3_nhwc_f16_levels_pred")
+    if timer is not None:
+        e1.record()
+        px = sum(ms)
+        timer.records.append((2.0 * px * pc.K * (C * 9 + pred.K), e0, e1, "f16x2_halo", 4.0 * (px * C + px * pred.K + pc.K * (C * 9 + pred.K))))
+    return outs
+
+
 def pack_chain(pc_a, pc_b, state=None):
     """pc_a: the first pointwise layer (K1 -> N1), pc_b: the second (N1 -> N2), both `pack_conv` results of 1x1 layers.
     state: a dict the owner keeps across re-packs; state["off"] is set when the pair overflowed the kernel's range

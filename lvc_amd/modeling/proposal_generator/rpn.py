@@ -33,6 +33,7 @@ def build_rpn_head(cfg, input_shape):
 
 MERGE_LEVELS = True      # the predictor of all pyramid levels as one launch (StandardRPNHead.forward_nhwc)
 MERGE_LEVELS_CONV = True     # ... and the head's 3x3 conv over the levels as one launch
+FUSE_PREDICTOR = True        # ... with the predictor in that launch's epilogue: the hidden maps are never written (kernels.conv3x3_levels_pred)
 
 
 @RPN_HEAD_REGISTRY.register()
@@ -84,6 +85,11 @@ class StandardRPNHead(nn.Module):
             # too small to fill the chip (p3..p6: 45 + 20 + 14 + 13 us next to 132 us for p2).  Same arithmetic per pixel.
             C = feats[0].shape[3]
             ms = [x.shape[0] * x.shape[1] * x.shape[2] for x in feats]
+            if MERGE_LEVELS_CONV and FUSE_PREDICTOR:
+                # inference needs the hidden maps for nothing but the predictor: it runs in the 3x3 launch's epilogue
+                out = K.conv3x3_levels_pred(list(feats), self.conv.packed(), pc, relu=True)
+                if out is not None:
+                    return out
             if sum(ms) * C * 4 < (1 << 31):
                 hid = torch.empty(sum(ms), C, device=feats[0].device, dtype=torch.float32)
                 views, off = [], 0

@@ -158,3 +158,34 @@ def test_grouped_launch_overflow_moves_its_layers():
             ref = K.conv2d_nhwc(x, plist[l] if isinstance(pcs, list) else pcs, relu=True)
             assert float((o - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
         assert K.conv_error_word(dev) == 0
+
+
+def test_hidden_overflow_of_the_fused_predictor_moves_the_predictor_only():
+    """kernels.conv3x3_levels_pred: a hidden value (act(conv), never written) beyond fp16 raises the POINTWISE layer's range word, not
+    the 3x3 layer's: the pointwise layer moves to the range-free kernels, the pair runs as two launches from then on (the fused launch
+    declines) and equals an fp64 evaluation."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(11)
+    dev = torch.device("cuda:0")
+    xs = [torch.randn(2, h, w, 256, generator=g).to(dev) * 40 for h, w in ((96, 128), (48, 64))]
+    wc = torch.randn(256, 256, 3, 3, generator=g).to(dev) * 20.0         # hidden values: sigma = 40 x 20 x sqrt(2304) = 38400, many beyond 65504
+    wp = torch.randn(16, 256, 1, 1, generator=g).to(dev) * 1e-4
+    wp[15] = 0
+    bp = torch.randn(16, generator=g).to(dev)
+    bp[15] = 0
+    pc, pred = K.pack_conv(wc, stride=1, pad=1), K.pack_conv(wp, bias=bp)
+    pc.two_acc = True
+    K.clear_conv_error_word(dev)
+    outs = K.conv3x3_levels_pred(xs, pc, pred, relu=True)
+    assert outs is not None
+    with pytest.raises(K.Fp16RangeError) as ei:
+        K.check_conv_error_word(dev)
+    assert ei.value.rerouted and pred.state["tier"] == 2 and pc.state["tier"] == 0
+    assert K.conv3x3_levels_pred(xs, pc, pred, relu=True) is None
+    for x in xs:
+        y = K.conv2d_nhwc(K.conv2d_nhwc(x, pc, relu=True), pred)
+        ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wc.double(), padding=1)),
+                                         wp.double(), bp.double()).permute(0, 2, 3, 1)
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert K.conv_error_word(dev) == 0

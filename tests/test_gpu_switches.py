@@ -78,6 +78,7 @@ def test_rpn_head_over_all_levels_in_two_launches(monkeypatch):
     g = torch.Generator().manual_seed(2)
     feats = [torch.randn(2, h, w, 256, generator=g).cuda() for h, w in ((104, 152), (52, 76), (26, 38), (13, 19), (7, 10))]
     res, n = {}, {}
+    monkeypatch.setattr(R, "FUSE_PREDICTOR", False)      # its own test below
     for merge, merge_conv in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(R, "MERGE_LEVELS", merge)
         monkeypatch.setattr(R, "MERGE_LEVELS_CONV", merge_conv)
@@ -93,6 +94,53 @@ def test_rpn_head_over_all_levels_in_two_launches(monkeypatch):
         scale = max(1.0, float(c.abs().max()))
         assert float((b - c).abs().max()) <= 1e-6 * scale
         assert float((a - c).abs().max()) <= 2e-5 * scale
+    assert K.conv_error_word(feats[0].device) == 0
+
+
+def test_rpn_predictor_in_the_epilogue_of_the_head_conv(monkeypatch):
+    """StandardRPNHead at inference as ONE launch (rpn.FUSE_PREDICTOR, kernels.conv3x3_levels_pred): every workgroup of the 3x3 kernel
+    contracts its 128 hidden channels with the predictor's weights and adds the slice to the zeroed output atomically.  Against the two
+    launches: one launch fewer, no hidden buffer, logits / deltas within the predictor's own summation-order tolerance (1e-6 of the
+    output scale); no further from an fp64 evaluation of the head than the two launches are (x 1.25); two addends per element: the
+    same bits on every run."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.proposal_generator import rpn as R
+    from test_gpu_e2e import _model
+
+    model = _model()
+    head = model.proposal_generator.rpn_head
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():     # weights of a trained head's size (the default init's 0.01 leaves the logits at 1e-2)
+        for l in (head.conv, head.objectness_logits, head.anchor_deltas):
+            l.weight.copy_(torch.randn(l.weight.shape, generator=g) * (2.0 / (l.weight[0].numel()) ** 0.5))
+            l.bias.copy_(torch.randn(l.bias.shape, generator=g) * 0.1)
+    feats = [torch.randn(2, h, w, 256, generator=g).cuda() * 3 for h, w in ((104, 152), (52, 76), (26, 38), (13, 19), (7, 10))]
+    res, n = {}, {}
+    for fuse in (True, False):
+        monkeypatch.setattr(R, "FUSE_PREDICTOR", fuse)
+        timer = K.LaunchTimer()
+        monkeypatch.setattr(K, "CONV_TIMER", timer)
+        with torch.no_grad():
+            res[fuse] = [t.clone() for t in head.forward_nhwc(feats)]
+        monkeypatch.setattr(K, "CONV_TIMER", None)
+        n[fuse] = len(timer.records)
+    assert n[True] == 1 and n[False] == 2
+    monkeypatch.setattr(R, "FUSE_PREDICTOR", True)
+    with torch.no_grad():
+        again = head.forward_nhwc(feats)
+    wc, bc = head.conv.weight.detach().double(), head.conv.bias.detach().double()
+    wp = torch.cat([head.objectness_logits.weight, head.anchor_deltas.weight], 0).detach().double()
+    bp = torch.cat([head.objectness_logits.bias, head.anchor_deltas.bias], 0).detach().double()
+    for a, b, a2, f in zip(res[True], res[False], again, feats):
+        assert a.shape == b.shape == (2, f.shape[1], f.shape[2], 16) and a.is_contiguous()
+        assert torch.equal(a, a2)
+        x64 = f.double().permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(x64, wc, bc, padding=1)), wp, bp).permute(0, 2, 3, 1)
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-6 * scale
+        ea, eb = float((a[..., :15].double() - ref).abs().max()), float((b[..., :15].double() - ref).abs().max())
+        assert ea <= 1.25 * eb + 1e-7 * scale, (ea, eb)
+        assert float(a[..., 15].abs().max()) == 0.0          # the padding output stays zero
     assert K.conv_error_word(feats[0].device) == 0
 
 
