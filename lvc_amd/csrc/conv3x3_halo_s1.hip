@@ -505,7 +505,12 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
 
     // ---- split tiles: a worker that does not own the tile's first chunk hands its partial sums to the one that does
     if (cc0 != 0) {
-      float* dst = p.partials + (size_t)lw * (NT * 32 * NI);
+      // The lane offset is made opaque HERE: left visible, the sixteen store addresses are loop invariants the compiler forms at the
+      // kernel's top and -- in the two-accumulator instances -- spills; every reload is a `vmcnt(0)` that waits for the store before it
+      // to be acknowledged (sixteen round trips in series on the hand-off the tile's owner is waiting for).
+      unsigned toff = (unsigned)tid * 16u;
+      asm volatile("" : "+v"(toff));
+      char* dst = reinterpret_cast<char*>(p.partials + (size_t)lw * (NT * 32 * NI)) + toff;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
 #pragma unroll
           for (int e4 = 0; e4 < 4; ++e4) {
             f32x4 v = {acc[mi][ni][e4 * 4 + 0], acc[mi][ni][e4 * 4 + 1], acc[mi][ni][e4 * 4 + 2], acc[mi][ni][e4 * 4 + 3]};
-            *reinterpret_cast<f32x4*>(dst + ((size_t)((mi * NI + ni) * 4 + e4) * NT + tid) * 4) = v;
+            *reinterpret_cast<f32x4*>(dst + (size_t)((mi * NI + ni) * 4 + e4) * NT * 16) = v;
           }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
