@@ -171,7 +171,10 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ 
       float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
       const float inter = w * h;
       const float ovr = inter / (aarea + jarea - inter);
-      const bool hit = (j_me < nend) && (j_me > row0 + ci * 64 + r) && (aid == jid) && ((double)ovr > thr);
+      // every pair but a box with itself: the diagonal block (wj == ci) is the SYMMETRIC overlap matrix of its 64 rows (IoU is symmetric
+      // in fp32 too: max / min / sum commute) -- row j's low bits are the earlier rows that suppress j (nms_reduce_lds_kernel); in the
+      // blocks right of it every column is later than every row anyway
+      const bool hit = (j_me < nend) && (j_me != row0 + ci * 64 + r) && (aid == jid) && ((double)ovr > thr);
       const u64 word = __ballot(hit);
       if (lane == r) my_word = word;
     }
@@ -302,6 +305,95 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const u64* __restrict__ 
       if (w < nwords) removed[w] |= acc;
     }
     __syncthreads();
+  }
+  if (lane == 0) num_keep[img] = nk < max_keep ? nk : max_keep;
+}
+
+// The same pass for lists of at most 1024 sorted rows (the RPN's per-level lists: 1000 candidates, 40 lists per batch), with the
+// bit matrix in LDS.  nms_reduce_kernel walks a list in chunks of 64 rows and pays, per chunk, the global-memory latency of the diagonal
+// block and of two batches of kept rows (6.4 us per chunk, 103 us for the RPN lists of a batch -- a third of the proposal stage).  Here
+// 256 threads copy the upper triangle (<= 128 KB) into LDS once, then ONE wave runs the chunks: diagonal word and kept rows come from
+// LDS, the removed words live in registers (lane w holds word w), the kept rows of a chunk are OR-ed by four lane groups of sixteen
+// words.  Same decisions, same output order.
+#define NMS_LDS_ROWS 1024
+#define NMS_LDS_PITCH 17      // u64 per row: 16 words + 1 (rows 136 B apart: the diagonal read, a row per lane, spreads over the banks)
+__global__ __launch_bounds__(256) void nms_reduce_lds_kernel(const u64* __restrict__ mask, const int* __restrict__ order,
+                                                             const int* __restrict__ counts, int Nmax, int nwords, int max_keep,
+                                                             int* __restrict__ keep, int* __restrict__ num_keep, int rows_cap) {
+  __shared__ u64 m[NMS_LDS_ROWS * NMS_LDS_PITCH];      // 139,264 B
+  __shared__ int sord[NMS_LDS_ROWS];                   // the rows' original indices: no global load on the serial chain below
+  const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  int n = counts ? counts[img] : Nmax;
+  if (n > Nmax) n = Nmax;
+  if (n > rows_cap) n = rows_cap;
+  const u64* mk = mask + (size_t)img * rows_cap * nwords;
+  const int* ord = order + (size_t)img * Nmax;
+  const int nchunks = (n + 63) >> 6;
+  for (int r = tid; r < n; r += 256) sord[r] = ord[r];
+  // eight loads in flight per thread; words left of the diagonal (never read) are skipped
+  const int total = n * nwords;
+  for (int base = tid; base < total; base += 256 * 8) {
+    u64 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = base + j * 256;
+      v[j] = idx < total ? mk[idx] : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int idx = base + j * 256;
+      const int r = idx / nwords, w = idx - r * nwords;
+      if (idx < total && w >= (r >> 6) && w < nchunks) m[r * NMS_LDS_PITCH + w] = v[j];
+    }
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  int* kp = keep + (size_t)img * Nmax;
+  u64 removed = 0;      // lane w: the removed word of chunk w
+  int nk = 0;
+  const int w16 = lane & 15, g4 = lane >> 4;
+  for (int c = 0; c < nchunks && nk < max_keep; ++c) {
+    const int row = c * 64 + lane;
+    const u64 diag = row < n ? m[row * NMS_LDS_PITCH + c] : 0ull;
+    const u64 rem_c = ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(removed >> 32), c) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)removed, c);
+    u64 alive = ~rem_c;
+    const int valid = n - c * 64;
+    if (valid < 64) alive &= ((1ull << valid) - 1ull);
+    // The greedy pass over the chunk in ROUNDS instead of row by row (64 dependent steps of ~70 cycles each when most rows survive, as
+    // on the RPN's lists).  col = the earlier rows of the chunk that overlap this lane's row (the diagonal block is symmetric).  A row
+    // still undecided is removed once a kept row is in col, and kept once col holds neither a kept nor an undecided row; the first
+    // undecided row is always decided, so the loop ends, and the decisions are the sequential ones.  Rounds = the longest chain of
+    // dependent decisions in the chunk (2 - 4 on scattered boxes), ~15 instructions each.
+    const u64 col = diag & ((1ull << lane) - 1ull);
+    u64 kept = 0;
+    while (alive) {      // `alive` (the undecided rows) and `kept` are wave-uniform
+      const bool und = (alive >> lane) & 1ull;
+      const bool rem = und && (col & kept) != 0ull;
+      const bool kp1 = und && !rem && (col & alive) == 0ull;
+      const u64 bk = __ballot(kp1), br = __ballot(rem);
+      kept |= bk;
+      alive &= ~(bk | br);
+    }
+    if ((kept >> lane) & 1ull) {
+      const int pos = nk + __popcll(kept & ((1ull << lane) - 1ull));
+      if (pos < max_keep) kp[pos] = sord[row];
+    }
+    nk += __popcll(kept);
+    if (c + 1 < nchunks) {
+      // lane = (row group g4, word w16): group g4 ORs the kept rows g4, g4 + 4, ... of this chunk; rows past n hold stale LDS, their
+      // bits are not in `kept`
+      u64 acc = 0;
+#pragma unroll
+      for (int i = 0; i < 64; i += 4) {
+        const int r = i + g4;
+        const u64 x = m[(c * 64 + r) * NMS_LDS_PITCH + w16];
+        acc |= ((kept >> r) & 1ull) ? x : 0ull;
+      }
+      acc |= (u64)__shfl_xor((long long)acc, 16);
+      acc |= (u64)__shfl_xor((long long)acc, 32);
+      if (lane < 16 && lane > c) removed |= acc;
+    }
   }
   if (lane == 0) num_keep[img] = nk < max_keep ? nk : max_keep;
 }
@@ -533,8 +625,12 @@ extern "C" int lvc_batched_nms(const float* boxes, const float* scores, const in
     hipLaunchKernelGGL(nms_mask_kernel, mask_grid, dim3(64), 0, st, sboxes, sidx, d_counts, Nmax, nwords, iou_threshold,
                        mask, 0, rows_cap, (const int*)nullptr, max_keep);
     LVC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, st, mask, order, d_counts, Nmax, nwords, max_keep, keep,
-                       d_num_keep, 0, rows_cap, (const u64*)nullptr, (int*)nullptr, 0);
+    if (rows_cap <= NMS_LDS_ROWS && !getenv("LVC_NMS_REDUCE_GLOBAL"))
+      hipLaunchKernelGGL(nms_reduce_lds_kernel, dim3(B), dim3(256), 0, st, mask, order, d_counts, Nmax, nwords, max_keep, keep, d_num_keep,
+                         rows_cap);
+    else
+      hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, st, mask, order, d_counts, Nmax, nwords, max_keep, keep,
+                         d_num_keep, 0, rows_cap, (const u64*)nullptr, (int*)nullptr, 0);
     LVC_CHECK_LAUNCH();
     return LVC_OK;
   }

@@ -597,6 +597,45 @@ def test_batched_nms_batch_with_counts_and_max_keep():
         assert keep[b, : len(ref)].tolist() == ref.tolist()
 
 
+@pytest.mark.parametrize("thr,max_keep", [(0.7, 0), (0.5, 100), (0.3, 37)])
+def test_nms_reduce_from_lds_equals_the_global_form_and_the_oracle(monkeypatch, thr, max_keep):
+    """Lists of <= 1024 rows (the RPN's per-level lists) run the ordered reduce with the bit matrix in LDS (nms_reduce_lds_kernel);
+    LVC_NMS_REDUCE_GLOBAL=1 keeps them on nms_reduce_kernel: same keep lists, equal to the oracle's, for ragged counts around the
+    64-row chunk edges, with and without a cap on the kept boxes."""
+    from lvc_amd import kernels as k
+    from oracle import ops as oops
+
+    g = torch.Generator().manual_seed(int(thr * 100) + max_keep)
+    counts = torch.tensor([1000, 999, 961, 960, 513, 129, 128, 65, 64, 63, 2, 1, 0], dtype=torch.int32)
+    B, Nmax = len(counts), 1000
+    boxes = torch.zeros(B, Nmax, 4)
+    scores = torch.zeros(B, Nmax)
+    idxs = torch.zeros(B, Nmax, dtype=torch.int32)
+    for b in range(B):
+        bb, ss, ii = _nms_case(g, Nmax, 1 + b % 3, 2.0 + b)
+        ss[::5] = ss[0]
+        boxes[b], scores[b], idxs[b] = bb, ss, ii.int()
+    d = _dev()
+    res = {}
+    for glob in (False, True):
+        if glob:
+            monkeypatch.setenv("LVC_NMS_REDUCE_GLOBAL", "1")
+        else:
+            monkeypatch.delenv("LVC_NMS_REDUCE_GLOBAL", raising=False)
+        keep, nk = k.batched_nms_batch(boxes.to(d), scores.to(d), idxs.to(d), counts.to(d), thr, max_keep=max_keep)
+        res[glob] = (keep.cpu(), nk.cpu())
+    monkeypatch.delenv("LVC_NMS_REDUCE_GLOBAL", raising=False)
+    assert res[False][1].tolist() == res[True][1].tolist()
+    for b in range(B):
+        n = int(counts[b])
+        ref = oops.batched_nms(boxes[b, :n], scores[b, :n], idxs[b, :n].long(), thr)
+        if max_keep:
+            ref = ref[:max_keep]
+        for keep, nk in res.values():
+            assert int(nk[b]) == len(ref)
+            assert keep[b, : len(ref)].tolist() == ref.tolist()
+
+
 def test_nms_empty():
     from lvc_amd import kernels as k
 
