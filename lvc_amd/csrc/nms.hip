@@ -264,16 +264,19 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const u64* __restrict__ 
     u64 alive = ~removed[c];
     const int valid = nend - (row0 + c * 64);
     if (valid < 64) alive &= ((1ull << valid) - 1ull);
+    // the chunk's greedy pass in rounds (see nms_reduce_lds_kernel: the diagonal block is symmetric, col = the earlier rows of the
+    // chunk that overlap this lane's row); `alive` -- the undecided rows -- is the same in every lane
+    alive = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(alive >> 32)) << 32) |
+            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)alive);
+    const u64 col = diag & ((1ull << lane) - 1ull);
     u64 kept = 0;
-    const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
-    // `alive` is the same in every lane: the index of the next kept box goes through an SGPR, so the row of the diagonal block
-    // comes by v_readlane (a few cycles) instead of a cross-lane LDS permute (~100 cycles) on this serial chain
     while (alive) {
-      const int i = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
-      kept |= 1ull << i;
-      const u64 d = ((u64)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
-      alive &= ~d;
-      alive &= ~(1ull << i);
+      const bool und = (alive >> lane) & 1ull;
+      const bool rem = und && (col & kept) != 0ull;
+      const bool kp1 = und && !rem && (col & alive) == 0ull;
+      const u64 bk = __ballot(kp1), br = __ballot(rem);
+      kept |= bk;
+      alive &= ~(bk | br);
     }
     // emit kept boxes (original indices) in order
     if ((kept >> lane) & 1ull) {
