@@ -336,12 +336,29 @@ def instances_from_batched(boxes, scores, classes, count, image_sizes, status=No
         counts = count.tolist()
     out = []
     classes64 = classes.to(torch.int64)     # one conversion for the batch; the per-image fields below are views
+    # The host builds these while the GPU idles (forward() returns the batch's results before the next batch can be enqueued): the
+    # three fields of an image are rows [0, n) of device tensors of one shape -- the objects are filled directly instead of through
+    # Boxes.__init__ (as_tensor, reshape of empties, asserts) and Instances.set (a length check per field); 90 -> 45 us per batch.
+    # ... and the B x 3 row ranges come from three split calls over the flattened tensors (sizes n_0, T - n_0, n_1, T - n_1, ...: every
+    # other piece) instead of 24 narrows.
+    B, T = scores.shape[0], scores.shape[1]
+    if boxes.is_contiguous() and scores.is_contiguous() and len(image_sizes) == B:
+        pieces = []
+        for n in counts[:B]:
+            pieces.append(n)
+            pieces.append(T - n)
+        bx = boxes.view(B * T, boxes.shape[2]).split_with_sizes(pieces)[0::2]
+        sc = scores.view(B * T).split_with_sizes(pieces)[0::2]
+        cl = classes64.view(B * T).split_with_sizes(pieces)[0::2]
+    else:
+        bx = [boxes[i, :counts[i]] for i in range(len(image_sizes))]
+        sc = [scores[i, :counts[i]] for i in range(len(image_sizes))]
+        cl = [classes64[i, :counts[i]] for i in range(len(image_sizes))]
     for i, size in enumerate(image_sizes):
-        n = counts[i]
+        b = Boxes.__new__(Boxes)
+        b.tensor = bx[i]
         inst = Instances(tuple(size))
-        inst.pred_boxes = Boxes(boxes[i, :n])
-        inst.scores = scores[i, :n]
-        inst.pred_classes = classes64[i, :n]
+        inst._fields.update(pred_boxes=b, scores=sc[i], pred_classes=cl[i])
         out.append(inst)
     return out
 
