@@ -871,7 +871,8 @@ static int halo_s1_levels(int oneacc, const float* const* xs, float* const* ys, 
   a.nlev = L;
   for (int l = 0; l < L; ++l) {
     LVC_CHECK_ARG(xs[l] && ys[l] && Hs[l] > 0 && Ws[l] > 0, "bad map");
-    LVC_CHECK_ARG(((uintptr_t)xs[l] & 15) == 0 && ((uintptr_t)ys[l] & 15) == 0, "pointers must be 16-byte aligned");
+    // outputs: float4 rows, or -- with a pointwise layer on top -- single floats added atomically
+    LVC_CHECK_ARG(((uintptr_t)xs[l] & 15) == 0 && ((uintptr_t)ys[l] & (pred ? 3 : 15)) == 0, "pointers must be 16-byte aligned");
     const long long xb = (long long)N * Hs[l] * Ws[l] * C * 4;
     LVC_CHECK_ARG(xb < (1ll << 31), "input tensor must be smaller than 2 GiB");
     a.lv_x[l] = xs[l]; a.lv_y[l] = ys[l]; a.lv_H[l] = Hs[l]; a.lv_W[l] = Ws[l]; a.lv_xbytes[l] = (int)xb;

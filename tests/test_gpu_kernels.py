@@ -890,3 +890,43 @@ def test_batched_nms_head_block_form_bit_exact(jitter, nidx, thr, max_keep):
         ref = oops.batched_nms(boxes[b, :n], scores[b, :n], idxs[b, :n].long(), thr)[:max_keep]
         assert int(nk[b]) == len(ref), (b, int(nk[b]), len(ref))
         assert keep[b, : len(ref)].tolist() == ref.tolist(), b
+
+
+@pytest.mark.parametrize("hidden,pred_k,shapes,n", [(256, 16, ((37, 53), (19, 27), (10, 14)), 2), (128, 32, ((64, 96),), 1),
+                                                   (256, 5, ((120, 168), (60, 84), (30, 42), (15, 21), (8, 11)), 3)])
+def test_conv3x3_levels_with_a_pointwise_layer_on_top_vs_fp64(hidden, pred_k, shapes, n):
+    """lvc_conv3x3_nhwc_f16_levels_pred at the edges of its contract: one or two 128-channel slices of the hidden layer, 5 .. 32
+    pointwise outputs, one to five maps with ragged sizes (partial patches, maps smaller than a patch), batch 1 .. 3 -- against an fp64
+    evaluation of relu(conv3x3) -> 1x1 (error of the order of the two launches': 2e-5 of the output scale), bit-identical run to run,
+    and equal to the two separate launches within the pointwise layer's summation-order tolerance."""
+    from lvc_amd import kernels as K
+
+    g = torch.Generator().manual_seed(hidden + pred_k)
+    d = _dev()
+    C = 64
+    xs = [(torch.randn(n, h, w, C, generator=g) * 2).to(d) for h, w in shapes]
+    wc = (torch.randn(hidden, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(d)
+    bc = (torch.randn(hidden, generator=g) * 0.1).to(d)
+    wp = (torch.randn(pred_k, hidden, 1, 1, generator=g) * (1.0 / hidden) ** 0.5).to(d)
+    bp = torch.randn(pred_k, generator=g).to(d)
+    pc = K.pack_conv(wc, bias=bc, stride=1, pad=1)
+    pc.two_acc = True
+    pred = K.pack_conv(wp, bias=bp)
+    K.clear_conv_error_word(d)
+    saved = K._HALO_H2_MIN_TILES
+    K._HALO_H2_MIN_TILES = 1          # the small cases too on the pipelined kernel
+    try:
+        outs = K.conv3x3_levels_pred(xs, pc, pred, relu=True)
+        again = K.conv3x3_levels_pred(xs, pc, pred, relu=True)
+    finally:
+        K._HALO_H2_MIN_TILES = saved
+    assert outs is not None and len(outs) == len(xs)
+    for x, o, o2 in zip(xs, outs, again):
+        assert o.shape == (n, x.shape[1], x.shape[2], pred_k) and torch.equal(o, o2)
+        ref = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), wc.double(), bc.double(), padding=1)),
+                                         wp.double(), bp.double()).permute(0, 2, 3, 1)
+        scale = float(ref.abs().max())
+        assert float((o.double() - ref).abs().max()) <= 2e-5 * scale
+        two = K.conv2d_nhwc(K.conv2d_nhwc(x, pc, relu=True), pred)
+        assert float((o - two).abs().max()) <= 2e-6 * scale
+    assert K.conv_error_word(d) == 0
