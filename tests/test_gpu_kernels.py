@@ -930,3 +930,18 @@ def test_conv3x3_levels_with_a_pointwise_layer_on_top_vs_fp64(hidden, pred_k, sh
         two = K.conv2d_nhwc(K.conv2d_nhwc(x, pc, relu=True), pred)
         assert float((o - two).abs().max()) <= 2e-6 * scale
     assert K.conv_error_word(d) == 0
+
+
+@pytest.mark.parametrize("h,w", [(25, 41), (50, 84), (1, 1), (2, 3)])
+def test_subsample2_into_a_wider_row_is_the_strided_slice(h, w):
+    """lvc_subsample2_nhwc (the input rows of a stride-2 projection shortcut next to conv2's output): out[n, i, j, :C] = x[n, 2i, 2j, :]
+    for odd and even extents, written into the tail channels of a wider concat row without touching the rest."""
+    from lvc_amd import kernels as K
+
+    d = _dev()
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn(2, h, w, 64, generator=g).to(d)
+    hs, ws = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    buf = torch.full((2, hs, ws, 96), 7.0, device=d)
+    K.subsample2_into(x, buf[..., 32:])
+    assert torch.equal(buf[..., 32:], x[:, ::2, ::2, :]) and bool((buf[..., :32] == 7.0).all())
