@@ -1,7 +1,7 @@
 """Every surviving LVC_* switch is exercised on the device: the ones without a test of their own elsewhere.
   LVC_CONV_ENGINE=f32  -> kernels.CONV_ENGINE  (every conv / GEMM on the exact fp32 MFMA kernel)
   LVC_CHAIN=0          -> kernels.CHAIN        (conv3 -> next conv1 as two launches)
-  resnet.FUSE_STRIDED_PROJECTION, fpn.MERGE_OUTPUT_CONVS, rpn.MERGE_LEVELS / MERGE_LEVELS_CONV (module constants)  (the RPN head's predictor / 3x3 conv over all levels as one launch each)
+  resnet.FUSE_STRIDED_PROJECTION, fpn.MERGE_OUTPUT_CONVS, rpn.MERGE_LEVELS / MERGE_LEVELS_CONV / FUSE_PREDICTOR (module constants)  (the RPN head's predictor / 3x3 conv over all levels as one launch each, then both as one)
 and the attention's range report (kernels.mha -> the shared error word)."""
 import pytest
 import torch
@@ -172,7 +172,8 @@ def test_fpn_output_convs_of_all_levels_in_one_launch(monkeypatch):
     assert K.conv_error_word(x.device) == 0
 
 
-def test_strided_projection_shortcut_fused_with_conv3(monkeypatch):
+@pytest.mark.parametrize("hw", [(416, 608), (394, 602)])      # the second: odd extents in front of res3.0 (99 x 151) and res5.0 (25 x 38)
+def test_strided_projection_shortcut_fused_with_conv3(monkeypatch, hw):
     """res4.0 / res5.0 (res3.0 keeps its chained launch): conv3 and the stride-2 projection shortcut as ONE pointwise GEMM over [conv2
     output | block input sampled at the even pixels] (resnet.FUSE_STRIDED_PROJECTION) against the two launches + residual: two conv launches fewer,
     features within the conv tolerance (the FrozenBN scales go into the fused weights: one more fp32 rounding per weight)."""
@@ -181,7 +182,7 @@ def test_strided_projection_shortcut_fused_with_conv3(monkeypatch):
     from test_gpu_e2e import _model
 
     model = _model()
-    x = torch.randn(2, 3, 416, 608, generator=torch.Generator().manual_seed(1)).cuda() * 40
+    x = torch.randn(2, 3, hw[0], hw[1], generator=torch.Generator().manual_seed(1)).cuda() * 40
     res, n = {}, {}
     for fuse in (True, False):
         monkeypatch.setattr(R, "FUSE_STRIDED_PROJECTION", fuse)
