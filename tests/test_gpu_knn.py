@@ -88,7 +88,9 @@ def test_topk_vote_ties_and_sizes(S):
 
 
 @pytest.mark.parametrize("Q,S,Dm,cosine", [(37, 300, 384, True), (2500, 600, 384, True), (5000, 1801, 96, True),
-                                            (1000, 330, 384, False), (40000, 2400, 384, True)])
+                                            (1000, 330, 384, False), (40000, 2400, 384, True),
+                                            # every row length of the 16-bit verification kernel (ceil(S / 512) = 3, 6, 7, 8; the others above)
+                                            (1500, 1300, 96, True), (1500, 2900, 96, True), (1500, 3500, 64, True), (1500, 4096, 64, True)])
 def test_knn_sweep_shapes(Q, S, Dm, cosine):
     """Descriptor widths and set sizes other than the benchmark's -- 384 is the ViT-S/8 width the reference's DINO
     descriptors have (tools/run_nearest_neighbours.py:292-293) -- including query counts below the 256-row GEMM tile, shot
