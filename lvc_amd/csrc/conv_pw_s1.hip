@@ -204,10 +204,12 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     };
     // one k16 step (see conv3x3_halo_s1.hip `step_body`): late reads of this step under G1, early reads of the next under G2
     auto step_body = [&](const unsigned char* A, int s2, const unsigned char* B, const unsigned char* An, int s2n, const unsigned char* Bn) {
+#ifndef PW_DIAG_SKIP_LATE_READS      // diagnostics build only (wrong results): half of the fragment reads gone -- is the chunk bound by the LDS port?
       alo[0] = rdA(A, 1, 0, s2);
       bhi[0] = rdB(B, 0, 0, s2);
       alo[1] = rdA(A, 1, 1, s2);
       if (NI == 2) bhi[NI - 1] = rdB(B, 0, NI - 1, s2);
+#endif
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -253,6 +255,12 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     for (int mi = 0; mi < 2; ++mi) ahi[mi] = rdA(sA, 0, mi, 0);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) blo[ni] = rdB(sB, 1, ni, 0);
+#ifdef PW_DIAG_SKIP_LATE_READS
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) alo[mi] = rdA(sA, 1, mi, 0);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) bhi[ni] = rdB(sB, 0, ni, 0);
+#endif
     // At the top of chunk i (i = cc - cc0) the VMEM queue holds, oldest first:  A(i+1), A(i+2) | B(i+1) issued at i-1  [i = 0: the
     // prologue's order, everything landed but nothing that matters is missing].  Steady state per chunk, program order:
     //   phase A: split + store A(i+1) -> needs A(i+1): everything issued after it may stay outstanding
