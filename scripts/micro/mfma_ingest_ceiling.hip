@@ -109,8 +109,8 @@ int main() {
   std::vector<unsigned short> h(n16);
   unsigned short* d; float* out; char* stream;
   hipMalloc(&d, n16 * 2); hipMalloc(&out, 4096);
-  const unsigned stream_bytes = 2u << 20;           // 2 MB: resident in every XCD's L2
-  hipMalloc(&stream, stream_bytes + 4096); hipMemset(stream, 0x3c, stream_bytes + 4096);
+  unsigned stream_bytes = 2u << 20;           // 2 MB: resident in every XCD's L2 (the last lines: 128 MB = Infinity Cache, 1 GB = HBM)
+  hipMalloc(&stream, (1u << 30) + 4096); hipMemset(stream, 0x3c, (1u << 30) + 4096);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   srand(1);
   for (size_t i = 0; i < n16; ++i) { const float a = gauss(); h[i] = f2h((i & 1) ? (a - (float)(_Float16)a) * 2048.f : a); }
@@ -135,5 +135,10 @@ int main() {
   run("64x64 wave tile, ONE acc, LDS reads,  8 KB DMA / step, barrier (= 3x3 kernel: weights only)", k<2, 2, false, 1, 8, 0, 1, 1>, 8, 2, 2, IT, 1);
   run("64x128 wave tile, ONE acc, LDS reads, 32 KB DMA / step, barrier (= 256 x 256 tile)", k<2, 4, false, 1, 8, 0, 4, 1>, 8, 2, 4, IT / 2, 4);
   run("64x128 wave tile, ONE acc, LDS reads, no DMA, barrier       ", k<2, 4, false, 1, 8, 0, 0, 1>, 8, 2, 4, IT / 2, 0);
+  stream_bytes = 128u << 20;
+  run("64x64 wave tile, two acc, LDS reads, 24 KB DMA / step, barrier, operands from a 128 MB region", k<2, 2, false, 1, 8, 1, 3, 1>, 8, 2, 2, IT, 3);
+  stream_bytes = 1u << 30;
+  run("64x64 wave tile, two acc, LDS reads, 24 KB DMA / step, barrier, operands from a 1 GB region", k<2, 2, false, 1, 8, 1, 3, 1>, 8, 2, 2, IT, 3);
+  run("64x128 wave tile, ONE acc, LDS reads, 32 KB DMA / step, barrier, operands from a 1 GB region", k<2, 4, false, 1, 8, 0, 4, 1>, 8, 2, 4, IT / 2, 4);
   return 0;
 }
