@@ -55,9 +55,15 @@ __global__ __launch_bounds__(NW * 64) void k(const u32x4* __restrict__ src, floa
                                          (lds_ptr_t)(ring + ((it % 3) * NW * DMA + wv * DMA + q) * 1024), 16, 0, 0);
         spos += 1024u * 61u;
       }
+#ifdef STRICT_WAIT      // everything issued ONE step ago has landed (the kernels' rule: the barrier publishes the buffer to all waves)
+      if (DMA == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (DMA == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+#else
       if (DMA == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if (DMA == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#endif
     }
     if (BAR && (it & 1)) __builtin_amdgcn_s_barrier();
     if (READS) {
