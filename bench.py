@@ -24,7 +24,7 @@ Rank 0 prints ONE JSON line carrying
   dp_legs             (N > 1) short RCCL legs: cfg-3 fine-tune steps with the gradient all-reduce, sharded kNN sweep
   train               (N = 1) cfg-3 fine-tune step (bs 8), cfg-5 R101 box-corrector step (bs 2) with ms forward / backward /
                       optimizer, and R101-FPN inference img/s
-  timed_batch_parity  the timed batch's detections against the CPU oracle's; bars = 3 x the oracle's own fp32-vs-fp64 noise on the
+  timed_batch_parity  the timed batch's detections against the CPU oracle's; bars = 2 x the oracle's own fp32-vs-fp64 noise on the
                       batch (oracle/noise.py); the run exits non-zero when a bar is missed
 `--workload train` / `--workload knn` time those two data-parallel legs as the main metric instead.
 """
@@ -460,7 +460,7 @@ def descriptor_leg(c, batch=64, steps=5, warmup=2):
     return out
 
 
-def r101_leg(c, steps=10, warmup=3):
+def r101_leg(c, steps=10, warmup=3, parity_images=2):
     """R101-FPN inference at the headline's batch (the depth BASELINE configs[4] names), same timing rules."""
     import torch
 
@@ -481,11 +481,88 @@ def r101_leg(c, steps=10, warmup=3):
         _barrier(c)
         dt, _ = _max_and_all(c, time.perf_counter() - t0)
     n_det = out[3].tolist()
+    parity = None
+    if c.rank == 0 and parity_images > 0:
+        # the LAST TIMED step's detections of the first images against the CPU oracle at depth 101 (pinned against the reference's own
+        # R101 run at this size: tests/test_oracle_golden.py::test_e2e_r101_800x1333), through the same noise gate as the headline
+        from oracle import noise as onoise
+        from oracle import rcnn as orc
+
+        torch.set_num_threads(min(os.cpu_count() or 1, 32))
+        ob, osc, ocl, cnt = (t.cpu() for t in out[:4])
+        idx = list(range(min(parity_images, BATCH_PER_GPU)))
+        hip = [(ob[i, : int(cnt[i])], osc[i, : int(cnt[i])], ocl[i, : int(cnt[i])].long()) for i in idx]
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        spec = orc.RCNNSpec(depth=101)
+        cpu_in = [{"image": batch[i]["image"].cpu(), "height": 800, "width": 1333} for i in idx]
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            ref = orc.generalized_rcnn_inference(sd, spec, cpu_in)
+            nz = onoise.fp32_vs_fp64(sd, spec, cpu_in, res32=ref)
+        dev = onoise.deviation(hip, [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in ref])
+        ok, bars, msg = onoise.gate(dev, nz)
+        parity = {"images_checked": idx, "deviation_among_matched": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev.items()},
+                  "cpu_path_fp32_vs_fp64_noise": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in nz.items()},
+                  "bars": {k: round(v, 6) for k, v in bars.items()}, "gate": msg, "gate_ok": bool(ok), "seconds": round(time.perf_counter() - t1, 1),
+                  "pass_bar": "as timed_batch_parity: equal counts, >= 90 % of the oracle's detections found within 0.1 px / 2e-3, median / p90 of "
+                              "the matched differences <= %g x the CPU path's own fp32-vs-fp64 noise on these images; else the run exits non-zero" % onoise.K_NOISE}
     del model
     torch.cuda.empty_cache()
     return {"workload": "R101-FPN GeneralizedRCNN inference, bs=%d synthetic 3x800x1333 per GPU" % BATCH_PER_GPU,
             "value": round(c.world * BATCH_PER_GPU * steps / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
-            "detections_per_image": n_det}
+            "detections_per_image": n_det, "parity": parity}
+
+
+def eval_loop_leg(c, model, steps, warm=4, distinct=3):
+    """The evaluation loop as the reference times it (lvc/evaluation/evaluator.py:85-157): batches arrive as HOST tensors from a
+    loader, `lvc_amd.evaluation.inference_on_dataset` (two batches in flight) moves them to the GPU on the stream the batch runs
+    on -- the copy of batch i+1 overlaps the trunk of batch i -- and every batch's Instances are collected (one D2H read each).
+    Two input forms: {"image": float32 CHW 3x800x1333} (what the reference's DatasetMapper hands over, dataset_mapper.py:148-158:
+    12.8 MB per image across PCIe) and {"raw": uint8 HWC 480x800x3} (the decoded file: ResizeShortestEdge on the device,
+    Pillow-exact, to 800x1333; 1.15 MB per image).  Host tensors are pinned, as a DataLoader(pin_memory=True) delivers them."""
+    import torch
+
+    from lvc_amd.evaluation import inference_on_dataset
+    from lvc_amd.utils import synthetic as syn
+
+    out = {}
+    for kind in ("image", "raw"):
+        batches = []
+        for b in range(distinct):
+            items = []
+            for i in range(BATCH_PER_GPU):
+                seed = 1 + (c.rank * BATCH_PER_GPU + b * BATCH_PER_GPU + i) % 16
+                if kind == "image":
+                    items.append({"image": syn.synthetic_image(seed).pin_memory(), "height": 800, "width": 1333})
+                else:
+                    raw = syn.synthetic_image(seed, 480, 800).permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
+                    items.append({"raw": raw.pin_memory(), "height": 480, "width": 800})
+            batches.append(items)
+        key = "image" if kind == "image" else "raw"
+        nbytes = sum(x[key].numel() * x[key].element_size() for x in batches[0])
+
+        def loader(n):
+            for i in range(n):
+                yield batches[i % distinct]
+
+        for _ in inference_on_dataset(model, loader(warm), depth=2):
+            pass
+        _barrier(c)
+        t0 = time.perf_counter()
+        n_img = n_det = 0
+        for _inputs, outputs in inference_on_dataset(model, loader(steps), depth=2):
+            n_img += len(outputs)
+            n_det += sum(len(o["instances"]) for o in outputs)
+        _barrier(c)
+        dt, _ = _max_and_all(c, time.perf_counter() - t0)
+        out[kind] = {"value": round(c.world * n_img / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
+                     "host_bytes_per_batch": nbytes, "pcie_GBps": round(nbytes * steps / dt / 1e9, 2), "detections_collected": n_det,
+                     "input": "float32 CHW 3x800x1333, pinned host memory" if kind == "image"
+                     else "uint8 HWC 480x800x3 (decoded file), pinned host memory; ResizeShortestEdge(800, 1333) on the device"}
+    out["note"] = ("inference_on_dataset(depth=2) over %d batches of %d HOST-resident images, every batch's Instances collected; H2D copies run on "
+                   "the batch's own stream and overlap the other stream's trunk.  `value` (the headline) starts with its inputs resident in HBM."
+                   % (steps, BATCH_PER_GPU))
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- HBM-side kernels
@@ -676,6 +753,17 @@ def infer_main(c, args):
         except Exception as e:
             graphed = {"error": repr(e)}
 
+    # The evaluation loop fed from host memory: not `value` -- the contract's value starts with inputs in HBM
+    eval_loop = None
+    if not args.no_extras and args.pipeline_depth > 1:
+        try:
+            eval_loop = eval_loop_leg(c, model, args.steps)
+            if pipelined is not None:
+                eval_loop["raw_over_pipelined"] = round(eval_loop["raw"]["value"] / pipelined["value"], 4)
+                eval_loop["image_over_pipelined"] = round(eval_loop["image"]["value"] / pipelined["value"], 4)
+        except Exception as e:
+            eval_loop = {"error": repr(e)}
+
     total_imgs = c.world * BATCH_PER_GPU * args.steps
     value = total_imgs / dt_max
 
@@ -761,7 +849,7 @@ def infer_main(c, args):
         # BASELINE configs[2] / [4] are training workloads and configs[4] names R101: their one-GPU rates, every run
         if c.world == 1:
             for key, fn in (("train_cfg3", lambda: train_leg(c, 5, 2, 8, "cfg3")), ("train_cfg5_r101", lambda: train_leg(c, 5, 2, 2, "cfg5")),
-                            ("r101_inference", lambda: r101_leg(c)), ("descriptors", lambda: descriptor_leg(c))):
+                            ("r101_inference", lambda: r101_leg(c, parity_images=0 if args.no_cpu_baseline else 2)), ("descriptors", lambda: descriptor_leg(c))):
                 try:
                     extras.setdefault("train", {})[key] = fn()
                 except Exception as e:
@@ -786,6 +874,7 @@ def infer_main(c, args):
             "rccl": c.rccl, "per_rank": {"img_per_s": [round(BATCH_PER_GPU * args.steps / t, 2) for t in dt_all],
                                          "seconds": [round(t, 4) for t in dt_all], "max_over_ranks_s": round(dt_max, 4)},
             "roofline": roofline, "value_inference_batched": through_forward, "pipelined": pipelined, "graphed": graphed,
+            "eval_loop_host_inputs": eval_loop, "value_inputs": "device-resident (the 8 fp32 images are in HBM before the timed region, as the bench contract asks; `eval_loop_host_inputs` is the PCIe-inclusive loop)",
             "cpu_baseline": cpu_baseline, "timed_batch_parity": parity,
         }
         line.update(extras)
@@ -793,6 +882,11 @@ def infer_main(c, args):
         if parity is not None and not (parity["matched_fraction_0.1px_2e-3"] >= 0.9 and parity["detection_counts_equal"] and parity["gate_ok"]):
             sys.stdout.flush()
             sys.stderr.write("bench.py: the timed batch's detections do not match the CPU oracle: %s\n" % json.dumps(parity))
+            os._exit(4)
+        r101p = (extras.get("train", {}).get("r101_inference") or {}).get("parity")
+        if r101p is not None and not r101p["gate_ok"]:
+            sys.stdout.flush()
+            sys.stderr.write("bench.py: the R101 leg's detections do not match the CPU oracle: %s\n" % json.dumps(r101p))
             os._exit(4)
 
 
@@ -1023,7 +1117,7 @@ def _cpu_baseline(model, imgs, gpu_dets):
             ref[i] = orc.generalized_rcnn_inference(sd, spec, cpu_in[i])[0]
             n += 1
         cdt = time.perf_counter() - t1
-    # the bars: 3 x the CPU path's OWN rounding noise (fp32 vs fp64 evaluation of the same weights) on two of the batch's images
+    # the bars: K_NOISE (= 2) x the CPU path's OWN rounding noise (fp32 vs fp64 evaluation of the same weights) on two of the batch's images
     from oracle import noise as onoise
 
     with torch.no_grad():
@@ -1052,7 +1146,7 @@ def _cpu_baseline(model, imgs, gpu_dets):
                                                   images=nz_imgs, seconds=round(nz_s, 1)),
               "bars": {k: round(v, 6) for k, v in bars.items()}, "gate": gate_msg, "gate_ok": bool(gate_ok),
               "pass_bar": "equal counts, matched_fraction_0.1px_2e-3 >= 0.9 (identity) AND median / p90 of the matched |box|, |score| differences "
-                          "<= 3 x the CPU path's own fp32-vs-fp64 noise on this batch (`bars`), else the run exits non-zero",
+                          "<= 2 x the CPU path's own fp32-vs-fp64 noise on this batch (`bars`), else the run exits non-zero",
               "note": "GPU detections of the LAST TIMED step vs oracle/rcnn.py (fp32 CPU) on the same images; both are fp32 evaluations "
                       "of a 53-layer trunk, each ~2e-3 px (median) from the fp64 answer (tests/test_gpu_chain.py), so the literal 1e-3 "
                       "fraction is what two valid fp32 paths share"}

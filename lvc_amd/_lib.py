@@ -44,6 +44,9 @@ def lib():
 def check(status, what=""):
     if status != 0:
         msg = lib().lvc_last_error().decode("utf-8", "replace")
+        # a failed launch must not leave the thread's range slot on the failing layer (it is reset on the success path only):
+        # later un-slotted launches would raise that layer's word instead of the shared one
+        lib().lvc_set_range_slot(0)
         raise LvcNativeError("{} failed (status {}): {}".format(what or "lvc_amd native call", status, msg))
 
 

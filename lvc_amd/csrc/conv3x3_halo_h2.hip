@@ -420,10 +420,12 @@ extern "C" int lvc_conv3x3_nhwc_f16x2(const float* x, const unsigned short* w_sp
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
   pick_patch_h(H, W, &a.PH, &a.PW);
+#ifdef LVC_HALO_PATCH_HOOK   // experiment build only (scripts/sweep_halo_patch.sh: make HOOKS=-DLVC_HALO_PATCH_HOOK): no getenv on the launch path otherwise
   if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
     int ph = 0, pw = 0;
     if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_MAX) { a.PH = ph; a.PW = pw; }
   }
+#endif
   a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
   a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
   const int ni = K <= 64 ? 1 : 2;   // 64-wide tiles for the 64-channel layers

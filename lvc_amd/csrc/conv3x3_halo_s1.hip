@@ -799,10 +799,12 @@ struct HaloPred {
 
 static void halo_s1_patch(HaloArgsS& a, int H, int W) {
   pick_patch_s(H, W, &a.PH, &a.PW);
+#ifdef LVC_HALO_PATCH_HOOK   // experiment build only (scripts/sweep_halo_patch.sh: make HOOKS=-DLVC_HALO_PATCH_HOOK): no getenv on the launch path otherwise
   if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
     int ph = 0, pw = 0;
     if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_S1) { a.PH = ph; a.PW = pw; }
   }
+#endif
   a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
   a.inv_pw = (65536 + a.PW - 1) / a.PW;
 }

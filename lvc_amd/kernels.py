@@ -34,7 +34,7 @@ class PackedConv:
     """
 
     __slots__ = ("w", "scale", "shift", "K", "C", "R", "S", "stride", "pad", "Kg", "mode", "_w3", "_w2h", "_w2s", "two_acc",
-                 "slot", "state", "last_one", "__weakref__")
+                 "slot", "state", "_last_one", "__weakref__")
 
     def __init__(self, w, scale, shift, K, C, R, S, stride, pad, Kg, mode):
         self.w, self.scale, self.shift = w, scale, shift
@@ -48,7 +48,22 @@ class PackedConv:
         # 2: the range-free bf16x3 kernels.  `state` may be a dict the owning module keeps across re-packs.
         self.slot = _new_range_slot(self)
         self.state = {"tier": 0}
-        self.last_one = False
+        self._last_one = False
+
+    @property
+    def last_one(self):
+        """True when the layer's most recent launch ran on the single-accumulator form (|a| <= 4094)."""
+        return self._last_one
+
+    @last_one.setter
+    def last_one(self, one):
+        # ... and, per (device, stream) workspace, the (tier, form) that launch ran on: a range word is read with the workspace of the
+        # stream it was raised on, possibly after another stream's pass already moved the layer (PipelinedInference) -- the reaction
+        # is chosen from the form the word was raised by, not from the layer's present one (ADVICE r4)
+        self._last_one = bool(one)
+        dev = self.w.device
+        if dev.type == "cuda":
+            self.state.setdefault("at", {})[(dev.index, torch.cuda.current_stream(dev).cuda_stream)] = (self.state["tier"], bool(one))
 
     def _split(self, planes):
         n = self.w.numel()
@@ -306,7 +321,8 @@ def check_conv_error_word(device):
     if any(w & 1 for w in words):
         raise LvcNativeError("conv/GEMM kernel: a stream-K worker timed out waiting for a partial tile")
     clear_conv_error_word(device)
-    moved = []
+    moved, stale = [], 0
+    ws_key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     # bit 1: a finite operand beyond the form's range -- that layer moves.  bit 2 alone: the layer saw inf (NaN is not tracked); when
     # another layer reports bit 1 in the same pass that is what the overflowing layer handed down, and the layer stays where it is
     # (the repeated pass will tell); with no bit 1 anywhere the non-finite values are the data's own and the layers move as before
@@ -323,11 +339,14 @@ def check_conv_error_word(device):
                         moved.append("chained pair %dx%d->%d->%d: two launches" % (o.K1, o.N1, o.N1, o.N2))
                     continue
                 tier = o.state["tier"]
-                new = 1 if (o.last_one and tier < 1) else 2
+                t_launch, one = o.state.get("at", {}).get(ws_key, (tier, o.last_one))
+                new = 1 if (one and t_launch < 1) else 2
                 if new > tier:
                     o.state["tier"] = new
-                    moved.append("%dx%d %d->%d: |a| > %s -> %s" % (o.R, o.S, o.C, o.K, "4094" if o.last_one else "65504",
+                    moved.append("%dx%d %d->%d: |a| > %s -> %s" % (o.R, o.S, o.C, o.K, "4094" if one else "65504",
                                                                    "two accumulators" if new == 1 else "bf16x3"))
+                elif tier > t_launch:
+                    stale += 1      # raised by a pass launched before the layer was moved: that pass is run again, nothing moves
     if moved:
         RANGE_EPOCH += 1
         import logging
@@ -337,7 +356,7 @@ def check_conv_error_word(device):
     e = Fp16RangeError("conv/GEMM kernel: an operand beyond the range of the fp16 split form it ran on (|a| > 4094 single-accumulator, "
                        "> 65504 two-accumulator, or NaN)" + ("; the layers concerned were moved to the next wider form" if moved else
                                                              "; set LVC_CONV_SPLIT=bf16x3 for range-free kernels"))
-    e.rerouted = bool(moved) and not (words[0] & 6)
+    e.rerouted = (bool(moved) or stale > 0) and not (words[0] & 6)
     raise e
 
 
@@ -627,7 +646,9 @@ def _group_slot(pcs):
         # the packed layers may have been rebuilt (new objects, same range state): keep the slot's owners current
         import weakref
 
-        _SLOT_OWNERS[ent[0]] = [weakref.ref(pc) for pc in pcs]
+        # (merged with the live owners: a slot handed out twice after the round-robin wrapped keeps its other layer)
+        live = [r for r in _SLOT_OWNERS.get(ent[0], []) if r() is not None and all(r() is not pc for pc in pcs)]
+        _SLOT_OWNERS[ent[0]] = live + [weakref.ref(pc) for pc in pcs]
     return ent[0]
 
 

@@ -218,7 +218,7 @@ class ResNet(Backbone):
         outputs = {}
         first = self.stages_and_names[0][0][0] if self.stages_and_names else None
         concat = []
-        if isinstance(first, BottleneckBlock) and first.can_fuse_projection():
+        if isinstance(first, BottleneckBlock) and first.shortcut is not None and first.shortcut.stride == 1 and first.can_fuse_projection():   # the stem writes into a concat buffer at ITS resolution: stride-1 projections only
             # the stem writes its output a second time, into the tail channels of res2.0's [conv2 output | x] buffer
             def second(shape):
                 n, h, w, c = shape

@@ -237,8 +237,25 @@ class GeneralizedRCNN(_RCNNBase):
         return {"input_ious": torch.cat(input_ious), "output_ious": torch.cat(output_ious), "gt_classes": torch.cat(gt_classes)}
 
     def _inference_modular(self, batched_inputs, do_postprocess):
+        from ..proposal_generator.rbg import RBG
+
         images = self.preprocess_image(batched_inputs)
         features = self.backbone(images.tensor)
+        if isinstance(self.proposal_generator, RBG):
+            # reference rcnn.py:277-299: the loaded proposals and the ground truth go through RBG (identity in eval,
+            # rbg.py:49-50) and the heads label / subsample them (roi_heads.py:561-562); the results are returned as the
+            # heads made them -- `do_postprocess` is forced off for every head but UBBRROIHeads (:286)
+            if "instances" not in batched_inputs[0] or "proposals" not in batched_inputs[0]:
+                raise KeyError("PROPOSAL_GENERATOR.NAME = 'RBG' evaluates loaded `proposals` against `instances` (reference "
+                               "rcnn.py:278-284); both keys are required in every input dict")
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+            proposals, _ = self.proposal_generator(proposals, gt_instances)
+            results, _ = self.roi_heads(images, features, proposals, gt_instances)
+            if getattr(self, "roi_heads_name", None) != "UBBRROIHeads":
+                return results
+            return [{"instances": detector_postprocess(r, inp.get("height", size[0]), inp.get("width", size[1]))}
+                    for r, inp, size in zip(results, batched_inputs, images.image_sizes)]
         if self.proposal_generator:
             proposals, _ = self.proposal_generator(images, features, None)
         else:

@@ -475,3 +475,14 @@ def test_standard_roi_heads_with_rbg_proposals_evaluates(monkeypatch):
         ref, _ = heads(images, feats, sampled, None)
     assert len(out) == 1 and len(out[0]) == len(ref[0])
     assert torch.equal(out[0].pred_boxes.tensor, ref[0].pred_boxes.tensor) and torch.equal(out[0].scores, ref[0].scores)
+    # the same through the model's own entry (reference rcnn.py:277-299: loaded proposals + GT -> RBG (identity in eval) ->
+    # heads; results returned un-postprocessed because the heads are not UBBRROIHeads)
+    heads.rbg = True
+    with torch.no_grad():
+        whole = model([{"image": img, "instances": tgt, "proposals": props, "height": 512, "width": 640}])
+    assert isinstance(whole, list) and len(whole) == 1 and isinstance(whole[0], Instances)
+    assert whole[0].image_size == (256, 320)          # not rescaled to height / width
+    assert torch.equal(whole[0].pred_boxes.tensor, ref[0].pred_boxes.tensor)
+    assert torch.equal(whole[0].scores, ref[0].scores) and torch.equal(whole[0].pred_classes, ref[0].pred_classes)
+    with pytest.raises(KeyError):
+        model([{"image": img, "proposals": props}])

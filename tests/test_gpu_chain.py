@@ -63,8 +63,9 @@ def _near_tie_pairs(sorted_scores, tie):
 
 
 # seeds 1..8 at 800x1333 = the batch bench.py times (`timed_batch_parity` re-checks it end to end in every bench run)
-@pytest.mark.parametrize("seeds,hw", [((1, 2, 3, 4, 5, 6, 7, 8), (800, 1333)), ((3, 4), (320, 480))])
-def test_post_trunk_chain_exact_decisions_and_1e3(seeds, hw):
+@pytest.mark.parametrize("seeds,hw,depth", [((1, 2, 3, 4, 5, 6, 7, 8), (800, 1333), 50), ((3, 4), (320, 480), 50),
+                                            ((1, 2), (800, 1333), 101)])
+def test_post_trunk_chain_exact_decisions_and_1e3(seeds, hw, depth):
     """No hand-set allowances: every budget below is measured, in this test, on the ORACLE itself -- the same chain evaluated
     in fp64 from the same features says how far a correct fp32 evaluation may sit from the exact answer, and therefore how
     far two correct fp32 evaluations may sit from each other:
@@ -77,14 +78,22 @@ def test_post_trunk_chain_exact_decisions_and_1e3(seeds, hw):
     from lvc_amd.utils import synthetic as syn
     from oracle import rcnn as orc
 
-    model = _r50()
-    sd = r50_state_dict()
+    if depth == 50:
+        model = _r50()
+        sd = r50_state_dict()
+    else:       # R101-FPN (BASELINE config 5's depth): the same post-trunk path on the deeper trunk's features and weights
+        from lvc_amd.config.presets import base_rcnn_fpn
+        from lvc_amd.modeling import build_model
+
+        model = build_model(base_rcnn_fpn(depth=depth)).eval()
+        syn.conditioned_r50_fpn_(model, depth=depth)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     sd64 = {k: v.double() for k, v in sd.items()}
-    spec = orc.RCNNSpec()
+    spec = orc.RCNNSpec(depth=depth)
     inputs = [{"image": syn.synthetic_image(s, *hw), "height": hw[0], "width": hw[1]} for s in seeds]
     with torch.no_grad():
         imgs, sizes = orc.preprocess([b["image"] for b in inputs], spec.pixel_mean, spec.pixel_std, 32)
-        feats = orc.fpn(sd, orc.resnet(sd, imgs, 50))
+        feats = orc.fpn(sd, orc.resnet(sd, imgs, depth))
         ref, mid = orc.generalized_rcnn_inference(sd, spec, inputs, return_intermediates=True, feats=feats)
         ref64, mid64 = orc.generalized_rcnn_inference(sd64, spec, inputs, return_intermediates=True,
                                                       feats={k: v.double() for k, v in feats.items()})
@@ -161,7 +170,14 @@ def test_post_trunk_chain_exact_decisions_and_1e3(seeds, hw):
         assert m2 == int(mr.sum())
         g_cl, g_src, g_sc, g_bx = ocl[i, :n][mg], src[mg], osc[i, :n][mg], ob[i, :n][mg]
         r_cl, r_rows, r_sc, r_bx = r["pred_classes"][mr], r["rows"][mr], r["scores"][mr], r["pred_boxes"][mr]
-        assert n - m2 <= 4 * n_edge + len(set_g ^ set_r), (n, m2, n_edge)       # only those proposals' detections were set aside
+        # what was set aside is EXACTLY the detections whose source proposal is an edge proposal plus the cut-off trades
+        # checked above ((class, row) pairs are unique in a detection list) -- no allowance
+        aside_g, aside_r = int((~kg).sum()), int((~kr).sum())
+        assert n - m2 == aside_g + len(set_g - set_r), (n, m2, aside_g, len(set_g - set_r))
+        assert len(r["scores"]) - m2 == aside_r + len(set_r - set_g), (len(r["scores"]), m2, aside_r, len(set_r - set_g))
+        # and the edge proposals' detections can only change places with detections at the cut-off or with each other: the two
+        # sides set aside the same number up to the entries that traded at the cut-off
+        assert abs(aside_g - aside_r) <= len(set_g ^ set_r), (aside_g, aside_r, len(set_g ^ set_r))
         key_g = torch.stack([g_cl.double(), g_src.double()], 1)
         key_r = torch.stack([r_cl.double(), r_rows.double()], 1)
         dperm, dmoved = _tie_aware_order(key_g, g_sc, key_r, r_sc, 0.0, 1e-3, tie_s)

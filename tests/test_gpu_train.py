@@ -273,7 +273,8 @@ def test_training_step_with_an_image_without_ground_truth():
     assert 0 < float(nfg) <= 64     # only image 0 has foreground (at most 25 % of 512, halved by the empty image)
 
 
-def test_three_sgd_steps_follow_the_reference_trajectory(monkeypatch):
+@pytest.mark.parametrize("numerics", ["two_accumulators_unchained", "default"])
+def test_three_sgd_steps_follow_the_reference_trajectory(monkeypatch, numerics):
     """Optimizer step + re-packing of every trainable weight (forward operand, split planes, data-gradient operand):
     four forward passes with three torch SGD steps in between against the reference's CPU trajectory
     (tests/golden/train_base_steps.npz).  A stale packed copy anywhere would freeze that layer; the classification
@@ -296,7 +297,19 @@ def test_three_sgd_steps_follow_the_reference_trajectory(monkeypatch):
     # gradients of res3 / res4 by 0.9 - 1.3 % through ReLU masks that flip (scripts/dbg_train2.py: identical losses to 1e-6, head
     # gradients to 1e-5, res3 weight gradients 1.3e-2 apart, run-to-run 9e-7) and the loss after one update by 0.1 - 5.4 % / 0.1 - 8.6 %.
     # What the test pins is the update path: a stale packed copy leaves loss_cls at 5.43 instead of 0.21 (2 400 %).
-    tol_roi = [2e-4, 0.15, 0.35, 2.0]    # third update: the sampled RoI set has drifted (seen 18 % .. 51 % run to run)
+    # the loose bar (2x the default kernels' measured drift) is kept for the default-kernel variant only; the variant
+    # that pins the trunk's arithmetic to the round-3 forms (main + cross accumulators everywhere, conv3 and conv1 as two launches)
+    # holds the first update to the 2 % those kernels give (0.4 % / 0.8 % measured), so a regression of a few percent in the update
+    # or re-packing path fails here.
+    from lvc_amd import kernels as K
+
+    if numerics == "two_accumulators_unchained":
+        monkeypatch.setattr(K, "CHAIN", False)
+        monkeypatch.setattr(K, "HALO_S1", 1)
+        monkeypatch.setattr(K, "PW_S1", 1)
+        tol_roi = [2e-4, 0.02, 0.25, 2.0]
+    else:
+        tol_roi = [2e-4, 0.15, 0.35, 2.0]    # third update: the sampled RoI set has drifted (seen 18 % .. 51 % run to run)
     tol_rpn = [2e-4, 0.005, 0.05, 0.10]
     with EventStorage(0):
         for step in range(4):

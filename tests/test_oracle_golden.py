@@ -5,7 +5,7 @@ import math
 import pytest
 import torch
 
-from helpers import gold, match_detections, r50_state_dict
+from helpers import gold, match_detections, r50_state_dict, r101_state_dict
 from oracle import ops as oops
 from oracle import rcnn as orc
 
@@ -96,11 +96,11 @@ def test_bottleneck_block():
     assert torch.allclose(y, g["y"], rtol=0, atol=1e-6)
 
 
-def _check_e2e(name, inputs):
+def _check_e2e(name, inputs, depth=50):
     g = gold(name)
-    sd = r50_state_dict()
+    sd = r50_state_dict() if depth == 50 else r101_state_dict()
     with torch.no_grad():
-        res, mid = orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), inputs, return_intermediates=True)
+        res, mid = orc.generalized_rcnn_inference(sd, orc.RCNNSpec(depth=depth), inputs, return_intermediates=True)
     for i in range(len(inputs)):
         pb, pl = mid["proposals"][i]
         assert pb.shape == g["prop_boxes%d" % i].shape
@@ -129,6 +129,18 @@ def test_e2e_800x1333():
     inputs = [{"image": syn.synthetic_image(1), "height": 800, "width": 1333},
               {"image": syn.synthetic_image(2), "height": 800, "width": 1333}]
     g, mid = _check_e2e("e2e_r50_fpn_800x1333", inputs)
+    for k in ("p2", "p3", "p4", "p5", "p6"):
+        assert torch.allclose(mid["feats"][k][:, ::16, ::8, ::8], g["feat_" + k], rtol=0, atol=2e-4)
+
+
+def test_e2e_r101_800x1333():
+    """The oracle at depth 101 against the reference's CPU run of R101-FPN at the headline's image size
+    (oracle/make_golden.py:gen_r101_full): what bench.py's r101 leg and the GPU tests are then held to."""
+    from lvc_amd.utils import synthetic as syn
+
+    inputs = [{"image": syn.synthetic_image(1), "height": 800, "width": 1333},
+              {"image": syn.synthetic_image(2), "height": 800, "width": 1333}]
+    g, mid = _check_e2e("e2e_r101_fpn_800x1333", inputs, depth=101)
     for k in ("p2", "p3", "p4", "p5", "p6"):
         assert torch.allclose(mid["feats"][k][:, ::16, ::8, ::8], g["feat_" + k], rtol=0, atol=2e-4)
 
