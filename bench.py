@@ -498,13 +498,14 @@ def r101_leg(c, steps=10, warmup=3, parity_images=2):
         t1 = time.perf_counter()
         with torch.no_grad():
             ref = orc.generalized_rcnn_inference(sd, spec, cpu_in)
-            nz = onoise.fp32_vs_fp64(sd, spec, cpu_in, res32=ref)
-        dev = onoise.deviation(hip, [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in ref])
+            nz = onoise.fp32_vs_fp64(sd, spec, cpu_in, res32=ref, box_tol=0.5, score_tol=1e-2)
+        dev = onoise.deviation(hip, [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in ref], 0.5, 1e-2)
         ok, bars, msg = onoise.gate(dev, nz)
         parity = {"images_checked": idx, "deviation_among_matched": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev.items()},
                   "cpu_path_fp32_vs_fp64_noise": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in nz.items()},
                   "bars": {k: round(v, 6) for k, v in bars.items()}, "gate": msg, "gate_ok": bool(ok), "seconds": round(time.perf_counter() - t1, 1),
-                  "pass_bar": "as timed_batch_parity: equal counts, >= 90 % of the oracle's detections found within 0.1 px / 2e-3, median / p90 of "
+                  "pass_bar": "as timed_batch_parity: equal counts, >= 90 %% of the oracle's detections found within the identity bars (0.5 px / 1e-2: R101's "
+                              "conditioned weights carry 6x R50's fp32 noise, tests/test_gpu_e2e.py), median / p90 of "
                               "the matched differences <= %g x the CPU path's own fp32-vs-fp64 noise on these images; else the run exits non-zero" % onoise.K_NOISE}
     del model
     torch.cuda.empty_cache()

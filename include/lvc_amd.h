@@ -146,6 +146,14 @@ int lvc_conv1x1_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, c
 int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                            const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* _f16s1_w2 (round 5, csrc/conv_pw_w2.hip): the single-accumulator form on a 256-row x 256-channel workgroup tile (wave tile 64 x
+ * 128, 16-deep stages) for layers with >= 256 input and output channels -- res4 / res5 conv1 and conv3, the FPN laterals
+ * (detectron2/modeling/backbone/fpn.py:128-140), box-head fc1 / fc2: 0.67 x the operand bytes per MFMA of the 256 x 128 tile.  Same
+ * operands and results as lvc_conv1x1_nhwc_f16s1 up to the fp32 summation order; C % 16 == 0; Kpad = rows of a weight plane
+ * (>= K rounded up to 256). */
+int lvc_conv1x1_nhwc_f16s1_w2(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
+                              const float* residual, float* y, int N, int H, int W, int C, int K, int Kpad, int stride, int relu,
+                              int res_mode, int ldy, int ldr, void* workspace, void* stream);
 /* Two chained pointwise layers in one launch, the second fed from the first one's accumulators (csrc/conv_pw_chain.hip):
  *   y1 = act1(x Wa^T * sa + ta (+ residual))   -- a bottleneck's conv3 + FrozenBN + shortcut add + ReLU,
  *   y2 = act2(y1 Wb^T * sb + tb)               -- the next bottleneck's conv1 + FrozenBN + ReLU,

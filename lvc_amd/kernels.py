@@ -432,6 +432,14 @@ PW_S1 = 2
 _PW_S1_MIN_C = 64
 _PW_S1_ONE_MIN_C = 256
 _PW_S1_RES = 1     # 1: layers with a residual / upsample-add operand qualify too
+# single-accumulator pointwise layers with >= 256 input channels and a multiple of 256 output channels on the 256 x 256 tile
+# (csrc/conv_pw_w2.hip); 0 = the 256 x 128 tile of conv_pw_s1.hip for all of them
+PW_W2 = _os.environ.get("LVC_PW_W2", "1") != "0"
+# ... from 4096 input channels on (box-head fc1: 0.609 -> 0.599 / 0.593 -> 0.566 ms on two boxes).  Measured per layer in
+# profiles/r05_pw_w2.txt: the stage loop is ~10 % faster per MFMA, but with 16 - 64 stages per tile (res4 / res5, the laterals) a tile's
+# fill, hand-off and epilogue outweigh it -- and half as many, twice as large tiles split worse over 256 CUs -- so those stay on the 256 x 128 tile
+_PW_W2_MIN_C = 4096
+_PW_W2_MIN_ROWS = 4096
 # inference: conv3 (+ shortcut add + ReLU) of a bottleneck and conv1 (+ ReLU) of the next one as ONE launch (csrc/conv_pw_chain.hip;
 # modeling/backbone/resnet.py `BottleneckBlock.chain_to`); 0 = the two launches
 CHAIN = _os.environ.get("LVC_CHAIN", "1") != "0"
@@ -540,7 +548,14 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
             if fused_act:
                 act = None
             code = c_int(2 if fused_act else 1 if relu else 0)
-            if one:
+            if one and PW_W2 and C >= _PW_W2_MIN_C and pc.K >= 256 and pc.K % 256 == 0 and N * Ho * Wo >= _PW_W2_MIN_ROWS:
+                # >= 256 input and output channels: the 256 x 256 tile (csrc/conv_pw_w2.hip; same operands, 0.67 x the bytes per MFMA)
+                planes, scale2 = pc.split2s()
+                st = _lib.lib().lvc_conv1x1_nhwc_f16s1_w2(
+                    ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(residual), ptr(out), c_int(N), c_int(H), c_int(W), c_int(C),
+                    c_int(pc.K), c_int(planes.shape[1]), c_int(pc.stride), code, c_int(res_mode), c_int(out.shape[-1]), c_int(ldr),
+                    ptr(conv_workspace(x.device)), _stream(x))
+            elif one:
                 planes, scale2 = pc.split2s()
                 st = _lib.lib().lvc_conv1x1_nhwc_f16s1(
                     ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(residual), ptr(out), c_int(N), c_int(H), c_int(W), c_int(C),

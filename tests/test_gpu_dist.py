@@ -78,6 +78,36 @@ def test_bench_gpus_2_end_to_end_on_this_box():
     assert legs["knn"]["top10_rows_identical_to_oracle"] if "top10_rows_identical_to_oracle" in legs["knn"] else legs["knn"]["queries_per_s"] > 0
 
 
+def test_bench_gpus_8_rehearsal_on_this_box():
+    """The real world size (BASELINE's whole-node configuration) rehearsed on whatever this box has: `python bench.py --gpus 8`
+    through the self-launcher -- eight processes, each with its own stream-K workspaces and persistent conv workers, sharing the
+    one GPU's CUs when the box has a single device (gloo instead of RCCL then) -- both data-parallel legs and ONE merged JSON line
+    with eight per-rank entries.  Exercises what a 1-GPU box can of the 8-rank path: launcher, rank-sharded inputs (InferenceSampler
+    blocks 0..7, reference detectron2/data/samplers/distributed_sampler.py:191-194), per-rank CPU slices, max-over-ranks timing,
+    the gradient exchange over eight ranks with identical parameters afterwards, the 8-way sharded kNN sweep, and spinning stream-K
+    workers of eight processes resident together (no time-out bit, equal detections on every rank)."""
+    import torch
+
+    env = _env()
+    env.pop("OMP_NUM_THREADS", None)
+    if torch.cuda.device_count() < 8:
+        env["LVC_BENCH_ALLOW_SHARED_GPU"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-live-pmc", "--pipeline-depth", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1700)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["global_batch"] == 64
+    assert line["rccl"]["world_size"] == 8 and line["rccl"]["allreduce_of_ones"] == 8.0
+    assert line["rccl"]["backend"] == ("nccl" if torch.cuda.device_count() >= 8 else "gloo")
+    assert len(line["per_rank"]["img_per_s"]) == 8 and len(line["per_rank"]["seconds"]) == 8 and line["value"] > 0
+    assert line["config"]["detections_per_image"] == [100] * 8
+    legs = line["dp_legs"]
+    assert legs["train_cfg3"]["parameters_identical_across_ranks"] is True and legs["train_cfg3"]["global_batch"] == 64
+    assert legs["knn"]["queries_per_s"] > 0
+
+
 def _worker(mode):
     out = _torchrun(2, os.path.join(ROOT, "tests", "_dp_worker.py"), mode)
     line = [l for l in out.splitlines() if l.startswith("DP_WORKER_RESULT ")][-1]

@@ -20,8 +20,12 @@ from helpers import ROOT, gold, match_fraction, r50_state_dict
 
 pytestmark = pytest.mark.gpu
 
-# identity bars (which detection is which) for R101 at 800x1333: set from the measurement printed by the test itself
-R101_FULL_BOX_TOL, R101_FULL_SCORE_TOL = 0.1, 2e-3
+# Identity bars (which detection is which) for R101 at 800x1333.  R50's are 0.1 px / 2e-3 = ~40 x its CPU path's own median
+# fp32-vs-fp64 noise (2.5e-3 px / 6e-5); the R101 conditioned weights carry 6 x that noise at this size (measured by the test itself:
+# 1.5e-2 px / 4.5e-4 median, 4.1e-2 / 1.6e-3 p90 -- with R50's bars only 68 % of the reference's detections are "found" although the
+# matched ones sit 1.3 x the noise from the reference), so the bars scale with it: 0.5 px / 1e-2.  The ACCURACY bars are not these:
+# median / p90 of the matched differences <= K_NOISE x the noise (oracle/noise.py).
+R101_FULL_BOX_TOL, R101_FULL_SCORE_TOL = 0.5, 1e-2
 
 
 def _model():

@@ -813,6 +813,63 @@ def test_pointwise_pipelined_forms_vs_fp64(N, H, W, C, K, stride, act, monkeypat
     assert rms[2] <= max(1.5 * rms_cpu, 2.0 * rms[0])
 
 
+@pytest.mark.parametrize("N,H,W,C,K,stride,act,res_mode", [(2, 50, 84, 256, 1024, 1, "relu", 1), (3, 26, 42, 512, 256, 1, None, 2), (9000, 1, 1, 4112, 512, 1, "relu", 0),
+                                                           (2, 57, 83, 512, 256, 2, "gelu", 0), (1, 64, 100, 1024, 256, 1, "relu", 0)])
+def test_pointwise_256x256_tile_vs_fp64_and_the_256x128_tile(N, H, W, C, K, stride, act, res_mode, monkeypatch):
+    """csrc/conv_pw_w2.hip (kernels.PW_W2: single-accumulator pointwise layers on the 256 x 256 workgroup tile) against fp64 and
+    against the 256 x 128 tile of conv_pw_s1.hip it replaces: same operands, another fp32 summation order across the stream-K
+    hand-offs.  Residual add, the nearest-x2 upsample-add of the FPN laterals, stride 2, row counts that are no multiple of 256, a
+    contraction with an odd number of 32-channel chunks, ReLU / GELU."""
+    from lvc_amd import kernels as k
+
+    monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
+    monkeypatch.setattr(k, "CONV_SPLIT", "f16x2")
+    monkeypatch.setattr(k, "PW_S1", 2)
+    monkeypatch.setattr(k, "_PW_W2_MIN_C", 256)
+    monkeypatch.setattr(k, "_PW_W2_MIN_ROWS", 1)
+    g = torch.Generator().manual_seed(C + K + H)
+    Cp = (C + 31) // 32 * 32          # packed layers carry C % 32 == 0; the tail channels beyond C are zero in x and w
+    x = torch.zeros(N, H, W, Cp)
+    x[..., :C] = torch.randn(N, H, W, C, generator=g)
+    w = torch.zeros(K, Cp, 1, 1)
+    w[:, :C] = torch.randn(K, C, 1, 1, generator=g) * (2.0 / C) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1
+    xs = x[:, ::stride, ::stride]
+    Ho, Wo = xs.shape[1], xs.shape[2]
+    z = xs.double() @ w[:, :, 0, 0].double().t() + b.double()
+    res = None
+    if res_mode == 1:
+        res = torch.randn(N, Ho, Wo, K, generator=g)
+        z = z + res.double()
+    elif res_mode == 2:
+        res = torch.randn(N, Ho // 2, Wo // 2, K, generator=g)
+        z = z + res.double().repeat_interleave(2, 1).repeat_interleave(2, 2)
+    fn = {"relu": torch.relu, "gelu": torch.nn.functional.gelu, None: lambda t: t}[act]
+    ref = fn(z)
+    sc = float(ref.abs().max())
+    d = _dev()
+    pc = k.pack_conv(w.to(d), bias=b.to(d), stride=stride)
+    out, tags = {}, {}
+    for w2 in (False, True):
+        monkeypatch.setattr(k, "PW_W2", w2)
+        y = k.conv2d_nhwc(x.to(d), pc, relu=act == "relu", act="gelu" if act == "gelu" else None, residual=res.to(d) if res is not None else None,
+                          res_mode=res_mode).cpu()
+        assert float((y.double() - ref).abs().max()) <= 2e-5 * sc, w2
+        out[w2] = y
+    assert k.conv_error_word(d) == 0
+    rms = {f: float((out[f].double() - ref).pow(2).mean().sqrt()) / sc for f in out}
+    print("pointwise %s C=%d K=%d: rms error / scale 256x128 tile %.2e, 256x256 tile %.2e" % ((N, H, W), C, K, rms[False], rms[True]))
+    assert not torch.equal(out[False], out[True]) or C <= 32      # the other kernel did run
+    assert rms[True] <= 1.5 * rms[False] + 1e-9
+    # range word: an activation beyond the single-accumulator form's 4094 raises the layer's word on this kernel too
+    monkeypatch.setattr(k, "PW_W2", True)
+    xb = x.clone()
+    xb[0, 0, 0, 0] = 5000.0
+    k.conv2d_nhwc(xb.to(d), pc)
+    assert k.conv_error_word(d) & 2
+    k.clear_conv_error_word(d)
+
+
 @pytest.mark.parametrize("shape", ["res2", "res2.0", "res3"])
 def test_chained_conv3_conv1_matches_two_launches_and_fp64(shape):
     """csrc/conv_pw_chain.hip (kernels.CHAIN / LVC_CHAIN): a bottleneck's conv3 + FrozenBN + shortcut add + ReLU and the next block's
