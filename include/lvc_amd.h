@@ -358,6 +358,34 @@ int lvc_decode_boxes(const float* deltas, int ld, const float* boxes, int M, int
 int lvc_match_boxes(const float* gt, int G, const float* boxes, int N, float t0, float t1, int nthr, int l0, int l1,
                     int l2, int allow_low_quality, long long* matches, signed char* labels, float* matched_vals,
                     unsigned int* d_gt_best, void* stream);
+/* The label-and-sample steps of a training forward for the whole batch (round 5, csrc/train_targets.hip; RPN.label_and_sample_anchors,
+ * detectron2/modeling/proposal_generator/rpn.py:269-325, and ROIHeads.label_and_sample_proposals, lvc/modeling/roi_heads/roi_heads.py:
+ * 173-278, without their per-image loops and device->host reads).
+ * lvc_match_boxes_batched: lvc_match_boxes for B images in two launches.  gt [Gtot,4] = the images' boxes one after the other, gt_off
+ *   [B+1] int32 DEVICE prefix of the per-image counts (0..512 each; an image without gt gets label l0, match 0 everywhere);
+ *   box_img_stride 0: boxes [N,4] shared (anchors), else [B][N][4] with nbox [B] rows in use (NULL: N; rows behind: label -1).
+ * lvc_subsample_batched: subsample_labels (sampling.py:10-54) per row of labels int8 [B,N] (1 positive, 0 negative, else ignored): the
+ *   min(#pos, cap_pos) positives and min(#neg, bs - num_pos) negatives with the smallest keys (int64 [B,N], distinct, < 2^nbits) ->
+ *   sel int32 [B,bs] (positives first, each group by increasing key, -1 padded), counts int32 [B,2].  bs <= 1024.
+ * lvc_rpn_gather_sampled: for sel / counts over the R = sum_l H_l W_l A anchors: logits [B bs], deltas / anchors / matched gt boxes
+ *   [B bs,4], labels int8 (1 / 0 / -1 padding) read from the head's per-level outputs fused[l] [B,H_l,W_l,ld_l] (channel a objectness,
+ *   A + 4a + c delta c); grid anchors = shift + cell anchor (anchor_generator.py:161-185).  Feeds lvc_rpn_losses.
+ * lvc_roi_build_table: add_ground_truth_to_proposals (proposal_utils.py:121-162) into a padded table boxes [B,Wt,4], logits [B,Wt],
+ *   nrow [B]; lvc_roi_gather_sampled: its sampled rows with classes (gt class of the match / K background / -1 padding). */
+int lvc_match_boxes_batched(const float* gt, const int* gt_off, int Gtot, int B, const float* boxes, long long box_img_stride,
+                            const int* nbox, int N, float t0, float t1, int nthr, int l0, int l1, int l2, int allow_low_quality,
+                            int* matches, signed char* labels, float* vals, unsigned int* gt_best, void* stream);
+int lvc_subsample_batched(const signed char* labels, const long long* keys, int B, int N, int nbits, int cap_pos, int bs, int* sel,
+                          int* counts, void* stream);
+int lvc_rpn_gather_sampled(const void* const* fused, const int* ld, const void* const* cell_anchors, const int* H, const int* W,
+                           const int* strides, int L, int A, int B, int bs, const int* sel, const int* counts, const int* matches,
+                           const float* gt, const int* gt_off, float* logits, float* deltas, float* anchors, float* gt_boxes,
+                           signed char* labels, void* stream);
+int lvc_roi_build_table(const float* pboxes, const float* plogits, const int* pcount, int B, int P, const float* gt, const int* gt_off,
+                        float gt_logit, int Wt, float* boxes, float* logits, int* nrow, void* stream);
+int lvc_roi_gather_sampled(const float* boxes, const float* logits, const int* matches, const int* sel, const int* counts,
+                           const long long* gt_classes, const int* gt_off, int B, int Wt, int bs, int K, float* s_boxes, float* s_logits,
+                           long long* s_cls, long long* s_match, void* stream);
 int lvc_fast_rcnn_losses(const float* logits, int ld_cls, const float* deltas, int ld_delta, int K, int cls_agnostic,
                          const float* proposals, const float* gt_boxes, const long long* gt_classes, int R, float wx,
                          float wy, float ww, float wh, float smooth_l1_beta, float* out_losses, float* dlogits,

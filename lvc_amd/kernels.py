@@ -1408,6 +1408,119 @@ def match_boxes(gt_boxes, boxes, thresholds, labels, allow_low_quality_matches):
     return matches, mlabels, vals
 
 
+def cat_ground_truth(gt_instances):
+    """The images' gt boxes one after the other + the prefix of their counts as a device int32 [B+1] (pinned staging, asynchronous copy:
+    a plain torch.tensor(..., device=) would wait for everything queued on the stream -- the trunk).  -> (gt [G,4], gt_off, counts list)."""
+    dev = gt_instances[0].gt_boxes.tensor.device
+    lens = [len(t) for t in gt_instances]
+    off = [0]
+    for n in lens:
+        off.append(off[-1] + n)
+    gt = torch.cat([t.gt_boxes.tensor for t in gt_instances], 0).float().contiguous() if off[-1] else torch.zeros(0, 4, device=dev)
+    gt_off = torch.tensor(off, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+    return gt, gt_off, lens
+
+
+def match_boxes_batched(gt, gt_off, B, boxes, nbox, thresholds, labels, allow_low_quality_matches):
+    """pairwise_iou + Matcher for B images in two launches (csrc/train_targets.hip).  gt [G,4] / gt_off int32 [B+1] from
+    `cat_ground_truth`; boxes [N,4] shared by the images (anchors) or [B,N,4] with nbox int32 [B] rows in use per image (None: all).
+    -> (matches int32 [B,N], labels int8 [B,N])."""
+    _req_cuda(gt_off, boxes)
+    shared = boxes.dim() == 2
+    N = boxes.shape[-2]
+    boxes = boxes.contiguous()
+    assert boxes.dtype == torch.float32 and gt.dtype == torch.float32 and gt_off.dtype == torch.int32
+    dev = boxes.device
+    matches = torch.empty(B, N, dtype=torch.int32, device=dev)
+    mlabels = torch.empty(B, N, dtype=torch.int8, device=dev)
+    vals = torch.empty(B, N, dtype=torch.float32, device=dev)
+    G = gt.shape[0]
+    scratch = torch.empty(max(G, 1), dtype=torch.int32, device=dev)
+    nthr = len(thresholds)
+    assert nthr in (1, 2) and len(labels) == nthr + 1
+    t = list(thresholds) + [0.0]
+    lab = list(labels) + [0]
+    rc = _lib.lib().lvc_match_boxes_batched(ptr(gt.contiguous()), ptr(gt_off), c_int(G), c_int(B), ptr(boxes), c_longlong(0 if shared else N * 4),
+                                            ptr(nbox), c_int(N), c_float(t[0]), c_float(t[1]), c_int(nthr), c_int(lab[0]), c_int(lab[1]),
+                                            c_int(lab[2]), c_int(1 if allow_low_quality_matches else 0), ptr(matches), ptr(mlabels), ptr(vals),
+                                            ptr(scratch), _stream(boxes))
+    check(rc, "lvc_match_boxes_batched")
+    return matches, mlabels
+
+
+def subsample_batched(labels, keys, cap_pos, bs):
+    """subsample_labels (reference sampling.py:10-54) for every row of labels int8 [B,N] (1 positive, 0 negative, else ignored) in one
+    launch: the min(#pos, cap_pos) positives and min(#neg, bs - num_pos) negatives with the smallest keys (int64 [B,N], distinct, e.g.
+    torch.randperm(B * N)).  -> (sel int32 [B,bs]: positives first, each group by increasing key, -1 padded; counts int32 [B,2])."""
+    _req_cuda(labels, keys)
+    B, N = labels.shape
+    assert labels.dtype == torch.int8 and keys.dtype == torch.int64 and keys.shape == labels.shape
+    sel = torch.empty(B, bs, dtype=torch.int32, device=labels.device)
+    counts = torch.empty(B, 2, dtype=torch.int32, device=labels.device)
+    nbits = max(1, int(B * N - 1).bit_length())
+    rc = _lib.lib().lvc_subsample_batched(ptr(labels.contiguous()), ptr(keys.contiguous()), c_int(B), c_int(N), c_int(nbits), c_int(cap_pos),
+                                          c_int(bs), ptr(sel), ptr(counts), _stream(labels))
+    check(rc, "lvc_subsample_batched")
+    return sel, counts
+
+
+def rpn_gather_sampled(fused, A, cell_anchors, strides, sel, counts, matches, gt, gt_off):
+    """Rows of the sampled anchors straight from the head's per-level outputs fused[l] [B,H,W,ld] (channel a = objectness, A + 4 a + c =
+    delta c).  -> (logits [S], deltas [S,4], anchors [S,4], matched gt boxes [S,4], labels int8 [S]) with S = B * bs; padding rows carry
+    label -1."""
+    L = len(fused)
+    B, bs = sel.shape
+    dev = sel.device
+    for t in fused:
+        assert t.dim() == 4 and t.dtype == torch.float32 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.shape[2] * t.stride(2)
+    VP, IP = c_void_p * L, c_int * L
+    S = B * bs
+    logits = torch.empty(S, device=dev)
+    deltas = torch.empty(S, 4, device=dev)
+    anchors = torch.empty(S, 4, device=dev)
+    gtb = torch.empty(S, 4, device=dev)
+    labels = torch.empty(S, dtype=torch.int8, device=dev)
+    cells = [c.contiguous() for c in cell_anchors]
+    rc = _lib.lib().lvc_rpn_gather_sampled(VP(*[t.data_ptr() for t in fused]), IP(*[t.stride(2) for t in fused]), VP(*[c.data_ptr() for c in cells]),
+                                           IP(*[t.shape[1] for t in fused]), IP(*[t.shape[2] for t in fused]), IP(*[int(s) for s in strides]),
+                                           c_int(L), c_int(A), c_int(B), c_int(bs), ptr(sel), ptr(counts), ptr(matches), ptr(gt), ptr(gt_off),
+                                           ptr(logits), ptr(deltas), ptr(anchors), ptr(gtb), ptr(labels), _stream(sel))
+    check(rc, "lvc_rpn_gather_sampled")
+    return logits, deltas, anchors, gtb, labels
+
+
+def roi_build_table(pboxes, plogits, pcount, gt, gt_off, gt_logit, Wt):
+    """proposals [B,P,4] / [B,P] / count int32 [B] + gt -> (boxes [B,Wt,4], logits [B,Wt], rows in use int32 [B]): every image's proposals
+    followed by its gt boxes (add_ground_truth_to_proposals)."""
+    _req_cuda(pboxes, plogits, pcount, gt_off)
+    B, P = plogits.shape
+    dev = pboxes.device
+    boxes = torch.empty(B, Wt, 4, device=dev)
+    logits = torch.empty(B, Wt, device=dev)
+    nrow = torch.empty(B, dtype=torch.int32, device=dev)
+    rc = _lib.lib().lvc_roi_build_table(ptr(pboxes.contiguous()), ptr(plogits.contiguous()), ptr(pcount), c_int(B), c_int(P), ptr(gt), ptr(gt_off),
+                                        c_float(gt_logit), c_int(Wt), ptr(boxes), ptr(logits), ptr(nrow), _stream(pboxes))
+    check(rc, "lvc_roi_build_table")
+    return boxes, logits, nrow
+
+
+def roi_gather_sampled(boxes, logits, matches, sel, counts, gt_classes, gt_off, num_classes):
+    """Sampled rows of the table -> (boxes [B,bs,4], logits [B,bs], classes int64 [B,bs] (K = background, -1 padding), matched gt index
+    int64 [B,bs])."""
+    B, Wt = logits.shape
+    bs = sel.shape[1]
+    dev = boxes.device
+    sb = torch.empty(B, bs, 4, device=dev)
+    sl = torch.empty(B, bs, device=dev)
+    sc = torch.empty(B, bs, dtype=torch.int64, device=dev)
+    sm = torch.empty(B, bs, dtype=torch.int64, device=dev)
+    assert gt_classes.dtype == torch.int64
+    rc = _lib.lib().lvc_roi_gather_sampled(ptr(boxes), ptr(logits), ptr(matches), ptr(sel), ptr(counts), ptr(gt_classes.contiguous()), ptr(gt_off),
+                                           c_int(B), c_int(Wt), c_int(bs), c_int(num_classes), ptr(sb), ptr(sl), ptr(sc), ptr(sm), _stream(boxes))
+    check(rc, "lvc_roi_gather_sampled")
+    return sb, sl, sc, sm
+
+
 def fast_rcnn_losses(logits, deltas, proposals, gt_boxes, gt_classes, num_classes, box_weights, smooth_l1_beta):
     """Returns (losses [2] = (loss_cls, loss_box_reg), dlogits [R,K+1], ddeltas [R,4K|4])."""
     _req_cuda(logits, deltas, proposals, gt_boxes, gt_classes)

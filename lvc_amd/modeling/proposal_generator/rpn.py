@@ -259,6 +259,57 @@ class RPN(nn.Module):
         return gt_labels, (_MatchedGT(matched) if lazy else torch.stack(matched_gt_boxes))
 
     batched_sampling = True     # class switch for A/B runs and tests (False: subsample_labels image by image)
+    batched_targets = True      # ... True: match + sample + gather for the whole batch in five launches (csrc/train_targets.hip)
+
+    def _anchors_cached(self, shapes, dev):
+        """The grid anchors of the pyramid, concatenated, computed once per set of map shapes (they depend on nothing else)."""
+        cache = self.__dict__.setdefault("_anchor_cache", {})
+        key = tuple(tuple(s) for s in shapes)
+        a = cache.get(key)
+        if a is None or a.device != dev:
+            if len(cache) > 16:
+                cache.clear()
+            a = cache[key] = torch.cat(self.anchor_generator._grid_anchors([tuple(s) for s in shapes]), 0).contiguous()
+        return a
+
+    def _losses_batched(self, fused, flist, gt_instances):
+        """label_and_sample_anchors + losses (reference rpn.py:269-400) for the whole batch without a device->host read: one batched
+        Matcher over the cached anchors, one sampling launch on the keys of ONE torch.randperm(B * R), and -- when the head does not train
+        -- the sampled rows gathered straight from the per-level outputs.  -> (losses, sampled counts int32 [B,2] on the device, (gt boxes,
+        gt offsets) for the ROI heads)."""
+        A = self.rpn_head.num_anchors
+        B = fused[0].shape[0]
+        dev = fused[0].device
+        anchors = self._anchors_cached([f.shape[1:3] for f in flist], dev)
+        R = anchors.shape[0]
+        with torch.no_grad():
+            gt, gt_off, _ = K.cat_ground_truth(gt_instances)
+            matches, labels = K.match_boxes_batched(gt, gt_off, B, anchors, None, self.anchor_matcher.thresholds[1:-1], self.anchor_matcher.labels, True)
+            keys = torch.randperm(B * R, device=dev).view(B, R)
+            bs = self.batch_size_per_image
+            sel, counts = K.subsample_batched(labels, keys, int(bs * self.positive_fraction), bs)
+        norm = float(bs * B)
+        trains = torch.is_grad_enabled() and any(f.requires_grad for f in fused)
+        if not trains:
+            lg, dl, an, gtb, lab = K.rpn_gather_sampled([f.detach() for f in fused], A, list(self.anchor_generator.cell_anchors),
+                                                        self.anchor_generator.strides, sel, counts, matches, gt, gt_off)
+            out = K.rpn_losses(lg, dl, an, gtb, lab, self.smooth_l1_beta, norm)
+        else:
+            # the head trains (base / ft_all yamls): rows through autograd's index path so that the gradients scatter back
+            flat_logits = torch.cat([f[..., :A].reshape(B, -1) for f in fused], 1)
+            flat_deltas = torch.cat([f[..., A:5 * A].reshape(B, -1, 4) for f in fused], 1)
+            j = torch.arange(bs, device=dev)[None, :]
+            npos, ntot = counts[:, :1].long(), counts.sum(1, keepdim=True).long()
+            lab = torch.where(j < npos, 1, torch.where(j < ntot, 0, -1)).to(torch.int8).view(-1)
+            idx = sel.clamp(min=0).long()
+            img = torch.arange(B, device=dev)[:, None].expand(B, bs)
+            midx = torch.gather(matches, 1, idx).long() + gt_off[:-1].long()[:, None]
+            gtb = gt[midx.clamp(max=max(gt.shape[0] - 1, 0)).view(-1)] if gt.shape[0] else torch.zeros(B * bs, 4, device=dev)
+            out = _RpnLossFn.apply(flat_logits[img, idx].view(-1), flat_deltas[img, idx].view(-1, 4), anchors[idx.view(-1)], gtb, lab,
+                                   self.smooth_l1_beta, norm)
+        losses = {"loss_rpn_cls": out[0] * self.loss_weight.get("loss_rpn_cls", 1.0),
+                  "loss_rpn_loc": out[1] * self.loss_weight.get("loss_rpn_loc", 1.0)}
+        return losses, counts, (gt, gt_off)
 
     def _subsample_batched(self, labels):
         """`subsample_labels` + the fill / scatter of the loop above for all images at once and without a device->host read
@@ -321,13 +372,39 @@ class RPN(nn.Module):
                 fused = self.rpn_head.forward_nhwc(flist)
             A = self.rpn_head.num_anchors
             N = fused[0].shape[0]
-            flat_logits = torch.cat([f[..., :A].reshape(N, -1) for f in fused], 1)
-            flat_deltas = torch.cat([f[..., A:5 * A].reshape(N, -1, 4) for f in fused], 1)
-            anchors = torch.cat(self.anchor_generator._grid_anchors([f.shape[1:3] for f in flist]), 0)
-            gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances, lazy=True)
-            losses = self.losses(anchors, flat_logits, gt_labels, flat_deltas, gt_boxes)
+            pending = None
+            if (self.batched_targets and self.batched_sampling and self.anchor_boundary_thresh < 0 and self.box_reg_loss_type == "smooth_l1"
+                    and all(len(t) <= 512 for t in gt_instances) and self.batch_size_per_image <= 1024):
+                losses, pending, gt_batch = self._losses_batched(fused, flist, gt_instances)
+            else:
+                gt_batch = None
+                flat_logits = torch.cat([f[..., :A].reshape(N, -1) for f in fused], 1)
+                flat_deltas = torch.cat([f[..., A:5 * A].reshape(N, -1, 4) for f in fused], 1)
+                anchors = torch.cat(self.anchor_generator._grid_anchors([f.shape[1:3] for f in flist]), 0)
+                gt_labels, gt_boxes = self.label_and_sample_anchors(anchors, gt_instances, lazy=True)
+                losses = self.losses(anchors, flat_logits, gt_labels, flat_deltas, gt_boxes)
             with torch.no_grad():
                 boxes, logits, count = self.predict_proposals_batched(feats, sizes, fused=fused)
+            if pending is not None:
+                # ONE device->host read for the entry point: the proposal counts and the sampled-anchor counts of the event scalars
+                meta = torch.cat([count, pending.view(-1)]).tolist()
+                counts = meta[:N]
+                storage = get_event_storage()
+                storage.put_scalar("rpn/num_pos_anchors", sum(meta[N::2]) / N)
+                storage.put_scalar("rpn/num_neg_anchors", sum(meta[N + 1::2]) / N)
+            else:
+                counts = count.tolist()
+            out = []
+            for i, size in enumerate(images.image_sizes):
+                inst = Instances(size)
+                inst.proposal_boxes = Boxes(boxes[i, : counts[i]])
+                inst.objectness_logits = logits[i, : counts[i]]
+                out.append(inst)
+            if gt_batch is not None and out:
+                # for ROIHeads.label_and_sample_proposals: the same proposals as ONE padded table + the concatenated ground truth (a plain
+                # python attribute of the first Instances, not a field: nothing else sees it)
+                out[0]._lvc_batch = (boxes, logits, count, counts) + gt_batch
+            return out, losses
         else:
             boxes, logits, count = self.predict_proposals_batched(feats, sizes)
         counts = count.tolist()  # the one host sync of this entry point

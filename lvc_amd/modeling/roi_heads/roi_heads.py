@@ -68,6 +68,8 @@ class ROIHeads(nn.Module):
 
     batched_sampling = True     # class switch for A/B runs and tests (False: the per-image loop in every case)
 
+    batched_targets = True      # class switch for A/B runs and tests (False: the padded table built image by image with torch ops)
+
     @torch.no_grad()
     def label_and_sample_proposals(self, proposals, targets, inference=False, log=None):
         """reference lvc roi_heads.py:173-278: append GT, match (IoU kernel), gt_ignores toggle, subsample.
@@ -92,6 +94,39 @@ class ROIHeads(nn.Module):
         B, dev = len(proposals), proposals[0].proposal_boxes.tensor.device
         K_, bs = self.num_classes, self.batch_size_per_image
         gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+        batch = getattr(proposals[0], "_lvc_batch", None)
+        if (batch is not None and self.batched_targets and bs <= 1024 and all(len(t) <= 512 for t in targets)
+                and len(self.proposal_matcher.user_thresholds) in (1, 2) and len(batch[3]) == B):
+            # the proposals as RPN.forward made them -- one padded [B,P] table on the device -- and the concatenated ground truth: table
+            # + Matcher + subsample_labels + gather for the whole batch in five launches (csrc/train_targets.hip), ONE device->host read
+            pboxes, plogits, pcount, pcounts_host, gt, gt_off = batch
+            Wt = pboxes.shape[1] + max(len(t) for t in targets)
+            with torch.no_grad():
+                tb, tl, nrow = K.roi_build_table(pboxes, plogits, pcount, gt, gt_off, gt_logit, Wt)
+                m, lab = K.match_boxes_batched(gt, gt_off, B, tb, nrow, self.proposal_matcher.user_thresholds, self.proposal_matcher.labels,
+                                               self.proposal_matcher.allow_low_quality_matches)
+                key = torch.randperm(B * Wt, device=dev).view(B, Wt)
+                sel, cnt = K.subsample_batched(lab, key, int(bs * self.positive_sample_fraction), bs)
+                gcls = torch.cat([t.gt_classes for t in targets]).to(torch.int64)
+                s_boxes, s_logits, s_cls, s_m = K.roi_gather_sampled(tb, tl, m, sel, cnt, gcls, gt_off, K_)
+            counts = cnt.tolist()      # the one device->host read
+            out = []
+            for i, (prop, tgt) in enumerate(zip(proposals, targets)):
+                c = counts[i][0] + counts[i][1]
+                inst = Instances(prop.image_size)
+                inst.proposal_boxes = Boxes(s_boxes[i, :c])
+                inst.objectness_logits = s_logits[i, :c]
+                inst.gt_classes = s_cls[i, :c]
+                st = s_m[i, :c]
+                for name, val in tgt.get_fields().items():
+                    if name.startswith("gt_") and not inst.has(name):
+                        inst.set(name, val[st])
+                out.append(inst)
+            if log:
+                storage = get_event_storage()
+                storage.put_scalar("roi_head/num_fg_samples", sum(c[0] for c in counts) / B)
+                storage.put_scalar("roi_head/num_bg_samples", sum(c[1] for c in counts) / B)
+            return out
         ns = [len(p) + len(t) for p, t in zip(proposals, targets)]
         W = max(max(ns), bs)
         boxes = torch.zeros(B, W, 4, device=dev)

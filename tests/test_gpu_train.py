@@ -531,3 +531,106 @@ def test_batched_anchor_sampling_equals_the_per_image_loop(monkeypatch):
     assert ((r >= 0).sum(1) == rpn.batch_size_per_image).all() and ((r == 1).sum(1) <= 128).all()
     assert bool(((r == 1) <= (raw == 1)).all()) and bool(((r == 0) <= (raw == 0)).all())
     assert int((r[2] == 1).sum()) == int((raw[2] == 1).sum())     # fewer positives than the cap: all of them are kept
+
+
+@pytest.mark.parametrize("B,N,bs,cap,p_pos,p_neg,ident", [(3, 50000, 256, 128, 0.004, 0.7, True), (3, 50000, 256, 128, 0.004, 0.7, False),
+                                                           (2, 2100, 512, 128, 0.2, 0.6, False), (4, 300, 512, 128, 0.1, 0.5, True),
+                                                           (2, 2200000, 256, 128, 0.0001, 0.9, False), (2, 5000, 256, 128, 0.0, 1.0, False),
+                                                           (2, 5000, 64, 64, 0.5, 0.0, False)])
+def test_subsample_kernel_equals_the_reference_selection(B, N, bs, cap, p_pos, p_neg, ident):
+    """csrc/train_targets.hip `lvc_subsample_batched` against subsample_labels restated with sorts (reference sampling.py:10-54 with
+    the permutation's keys as priorities): per row the min(#pos, cap) positives and min(#neg, bs - num_pos) negatives with the
+    smallest keys, by increasing key; identity keys (the parity tests' randperm) and random ones; fewer candidates than wanted, no
+    positives, no negatives, more than 2^22 keys (three radix passes)."""
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(N + bs)
+    lab = torch.full((B, N), -1, dtype=torch.int8)
+    u = torch.rand(B, N, generator=g)
+    lab[u < p_neg] = 0
+    lab[torch.rand(B, N, generator=g) < p_pos] = 1
+    keys = torch.arange(B * N).view(B, N) if ident else torch.randperm(B * N, generator=g).view(B, N)
+    d = torch.device("cuda:0")
+    sel, cnt = k.subsample_batched(lab.to(d), keys.to(d), cap, bs)
+    sel, cnt = sel.cpu(), cnt.cpu()
+    for b in range(B):
+        pos, neg = (lab[b] == 1).nonzero().view(-1), (lab[b] == 0).nonzero().view(-1)
+        npos = min(len(pos), cap)
+        nneg = min(len(neg), bs - npos)
+        want_p = pos[keys[b][pos].argsort()][:npos]
+        want_n = neg[keys[b][neg].argsort()][:nneg]
+        assert cnt[b].tolist() == [npos, nneg]
+        assert sel[b, :npos].tolist() == want_p.tolist()
+        assert sel[b, npos:npos + nneg].tolist() == want_n.tolist()
+        assert bool((sel[b, npos + nneg:] == -1).all())
+
+
+def test_match_boxes_batched_equals_the_per_image_matcher():
+    """`lvc_match_boxes_batched` against `lvc_match_boxes` image by image: shared boxes (the anchors) and per-image tables with ragged
+    row counts, an image without ground truth, both Matcher configurations of the detector (RPN: two thresholds + low-quality matches,
+    ROI heads: one threshold)."""
+    from lvc_amd import kernels as k
+    from lvc_amd.structures import Boxes, Instances
+
+    g = torch.Generator().manual_seed(5)
+    d = torch.device("cuda:0")
+    B, N = 4, 20000
+    xy = torch.rand(N, 2, generator=g) * 600
+    boxes = torch.cat([xy, xy + 8 + torch.rand(N, 2, generator=g) * 200], 1).to(d)
+    tg = []
+    for b, ng in enumerate((3, 0, 7, 1)):
+        t = Instances((800, 800))
+        q = torch.rand(ng, 2, generator=g) * 500
+        t.gt_boxes = Boxes(torch.cat([q, q + 20 + torch.rand(ng, 2, generator=g) * 250], 1).to(d))
+        tg.append(t)
+    gt, gt_off, _ = k.cat_ground_truth(tg)
+    for thr, labs, lq in (([0.3, 0.7], [0, -1, 1], True), ([0.5], [0, 1], False)):
+        m, l = k.match_boxes_batched(gt, gt_off, B, boxes, None, thr, labs, lq)
+        per = torch.stack([boxes + 3.0 * b for b in range(B)])
+        nbox = torch.tensor([N, N - 17, 5, N // 2], dtype=torch.int32, device=d)
+        m2, l2 = k.match_boxes_batched(gt, gt_off, B, per, nbox, thr, labs, lq)
+        for b, t in enumerate(tg):
+            G = len(t)
+            if G:
+                rm, rl, _ = k.match_boxes(t.gt_boxes.tensor, boxes, thr, labs, lq)
+                assert torch.equal(m[b].long(), rm) and torch.equal(l[b], rl)
+                nb = int(nbox[b])
+                rm2, rl2, _ = k.match_boxes(t.gt_boxes.tensor, per[b, :nb].contiguous(), thr, labs, lq)
+                assert torch.equal(m2[b, :nb].long(), rm2) and torch.equal(l2[b, :nb], rl2)
+                assert bool((l2[b, nb:] == -1).all()) and bool((m2[b, nb:] == 0).all())
+            else:
+                assert bool((l[b] == labs[0]).all()) and bool((m[b] == 0).all())
+
+
+@pytest.mark.parametrize("which", ["frozen_rpn", "trainable_rpn"])
+def test_batched_targets_equal_the_per_image_path(monkeypatch, which):
+    """The training forward with the batch-wide target kernels (RPN.batched_targets / ROIHeads.batched_targets: five launches each,
+    no device->host read before the counts) against the round-4 path (per-image Matcher calls, torch topk / argsort sampling): with
+    the identity permutation the same anchors and proposals are sampled, so the four losses agree to the fp32 summation order of
+    the loss kernels and the gradients of the trainable tensors to their scale."""
+    from lvc_amd.modeling.proposal_generator.rpn import RPN
+    from lvc_amd.modeling.roi_heads.roi_heads import ROIHeads
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_novel_ft" if which == "frozen_rpn" else "train_base")
+    model = _train_model() if which == "frozen_rpn" else _base_model()
+    params = [p for p in model.parameters() if p.requires_grad]
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    res = {}
+    for fast in (False, True):
+        monkeypatch.setattr(RPN, "batched_targets", fast)
+        monkeypatch.setattr(ROIHeads, "batched_targets", fast)
+        for p in params:
+            p.grad = None
+        with EventStorage(0) as st:
+            losses = model(_batch(g))
+            sum(losses.values()).backward()
+            scal = {k: (v[0] if isinstance(v, tuple) else v) for k, v in st.latest().items() if k.startswith(("rpn/", "roi_head/"))}
+        res[fast] = ({k: float(v.detach()) for k, v in losses.items()}, [p.grad.detach().clone() for p in params], scal)
+    print(res[False][0], res[True][0], res[True][2])
+    for k_ in res[False][0]:
+        assert abs(res[True][0][k_] - res[False][0][k_]) <= 2e-6 * max(1.0, abs(res[False][0][k_])), k_
+    for k_ in ("rpn/num_pos_anchors", "rpn/num_neg_anchors", "roi_head/num_fg_samples", "roi_head/num_bg_samples"):
+        assert float(res[True][2][k_]) == float(res[False][2][k_]), k_
+    for a, b in zip(res[True][1], res[False][1]):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-12) + 1e-9
