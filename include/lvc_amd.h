@@ -375,8 +375,9 @@ int lvc_match_boxes(const float* gt, int G, const float* boxes, int N, float t0,
 int lvc_match_boxes_batched(const float* gt, const int* gt_off, int Gtot, int B, const float* boxes, long long box_img_stride,
                             const int* nbox, int N, float t0, float t1, int nthr, int l0, int l1, int l2, int allow_low_quality,
                             int* matches, signed char* labels, float* vals, unsigned int* gt_best, void* stream);
+long long lvc_subsample_workspace_bytes(int B);   /* zeroed by the caller before the first use; the launches leave it zeroed */
 int lvc_subsample_batched(const signed char* labels, const long long* keys, int B, int N, int nbits, int cap_pos, int bs, int* sel,
-                          int* counts, void* stream);
+                          int* counts, void* workspace, void* stream);
 int lvc_rpn_gather_sampled(const void* const* fused, const int* ld, const void* const* cell_anchors, const int* H, const int* W,
                            const int* strides, int L, int A, int B, int bs, const int* sel, const int* counts, const int* matches,
                            const float* gt, const int* gt_off, float* logits, float* deltas, float* anchors, float* gt_boxes,

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void match_b_pass1_kernel(const float* __restr
     for (int g = 0; g < G; ++g) {
       const float v = iou_ref_b(sgt[g * 4], sgt[g * 4 + 1], sgt[g * 4 + 2], sgt[g * 4 + 3], bx.x, bx.y, bx.z, bx.w);
       if (v > best) { best = v; bi = g; }
-      atomicMax(&sbest[g], __float_as_uint(v));
+      if (v > 0.f) atomicMax(&sbest[g], __float_as_uint(v));      // the table starts at 0: only overlapping pairs can raise it
     }
     vals[(size_t)b * N + n] = best;
     matches[(size_t)b * N + n] = bi;
@@ -126,89 +126,149 @@ extern "C" int lvc_match_boxes_batched(const float* gt, const int* gt_off, int G
 #define SS_NT 1024
 #define SS_BINS 2048
 #define SS_CAP 1024      // most rows a class contributes to one image's sample
+#define SS_CHUNK 8192    // elements per workgroup of the streaming passes
 
-// One workgroup per row.  labels: 1 = positive, 0 = negative, anything else ignored.  keys: distinct non-negative integers below
-// 2^nbits (int64, as torch.randperm makes them).  Selected: the num_pos = min(#pos, cap_pos) positives with the smallest keys, then the
-// num_neg = min(#neg, bs - num_pos) negatives with the smallest keys, each group in increasing key order.
-__global__ __launch_bounds__(SS_NT) void subsample_kernel(const signed char* __restrict__ labels, const long long* __restrict__ keys, int N,
-                                                          int nbits, int cap_pos, int bs, int* __restrict__ sel, int* __restrict__ counts) {
+// Per (row, class) state of the radix select: {prefix, have, need, n}.  labels: 1 = positive, 0 = negative, anything else ignored.
+// keys: distinct non-negative integers below 2^nbits (int64, as torch.randperm makes them).  Selected: the num_pos = min(#pos, cap_pos)
+// positives with the smallest keys, then the num_neg = min(#neg, bs - num_pos) negatives with the smallest keys, each group in increasing
+// key order.  The 268 569-anchor rows are streamed by MANY workgroups per pass (one per 8192 elements: a single workgroup per row spent
+// 300 us on its three passes); the histograms and candidate lists of a row meet in global memory.
+struct SsState { unsigned prefix, have; int need, n; };
+
+// pass `pass` of the select: histogram of the 11-bit digit at `shift` over the elements whose leading digits equal the class's prefix
+__global__ __launch_bounds__(256) void ss_hist_kernel(const signed char* __restrict__ labels, const long long* __restrict__ keys, int N, int pass,
+                                                      int shift, const SsState* __restrict__ state, int* __restrict__ ghist) {
   __shared__ int hist[2][SS_BINS];
-  __shared__ unsigned long long list[2][SS_CAP];      // (key << 32) | index of the collected candidates
-  __shared__ int s_n[2], s_need[2], s_cnt[2];
-  __shared__ unsigned s_prefix[2], s_have[2];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < 2 * SS_BINS; i += 256) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  unsigned pre[2] = {0u, 0u};
+  bool live[2] = {true, true};
+  if (pass > 0) {
+    for (int c = 0; c < 2; ++c) {
+      const SsState st = state[b * 2 + c];
+      pre[c] = st.prefix;
+      live[c] = st.need > 0 && st.need < st.n;      // otherwise the class needs no threshold: nothing or everything is taken
+    }
+  }
   const signed char* lab = labels + (size_t)b * N;
   const long long* key = keys + (size_t)b * N;
-  if (tid < 2) { s_prefix[tid] = 0u; s_have[tid] = 0u; s_cnt[tid] = 0; }
-  int need[2] = {0, 0};
-  // radix select from the top: after pass p, s_prefix[c] holds the leading bits of the need[c]-th smallest key of class c
-  const int npass = (nbits + 10) / 11;
-  for (int pass = 0; pass < npass; ++pass) {
-    const int shift = (npass - 1 - pass) * 11;
-    for (int i = tid; i < 2 * SS_BINS; i += SS_NT) (&hist[0][0])[i] = 0;
-    __syncthreads();
-    const unsigned pre0 = s_prefix[0], pre1 = s_prefix[1];
-    for (int i = tid; i < N; i += SS_NT) {
-      const int l = lab[i];
-      if (l == 0 || l == 1) {
-        const unsigned k = (unsigned)key[i];
-        const unsigned pre = l ? pre1 : pre0;
-        if (pass == 0 || (k >> (shift + 11)) == pre) atomicAdd(&hist[l][(k >> shift) & (SS_BINS - 1)], 1);
-      }
+  const int i0 = blockIdx.x * SS_CHUNK, i1 = min(N, i0 + SS_CHUNK);
+  for (int i = i0 + tid; i < i1; i += 256) {
+    const int l = lab[i];
+    if ((l == 0 || l == 1) && live[l]) {
+      const unsigned k = (unsigned)key[i];
+      if (pass == 0 || (k >> (shift + 11)) == pre[l]) atomicAdd(&hist[l][(k >> shift) & (SS_BINS - 1)], 1);
     }
-    __syncthreads();
-    if (pass == 0) {
-      // class totals -> how many of each are wanted (subsample_labels: sampling.py:36-43)
-      if (tid < 2) {
-        int n = 0;
-        for (int i = 0; i < SS_BINS; ++i) n += hist[tid][i];
-        s_n[tid] = n;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        const int np = min(s_n[1], cap_pos);
-        s_need[1] = np;
-        s_need[0] = min(s_n[0], bs - np);
-      }
-      __syncthreads();
-    }
-    need[0] = s_need[0]; need[1] = s_need[1];
-    if (tid < 2) {
-      // the bin in which the need-th smallest key of the class falls (scan of 2048 bins by one thread: 2 x 2048 LDS reads per pass)
-      const int c = tid;
-      int want = need[c] - (int)s_have[c];       // rank inside the current prefix
-      int bin = 0;
-      if (need[c] > 0 && need[c] < s_n[c]) {
-        int acc = 0;
-        for (bin = 0; bin < SS_BINS; ++bin) {
-          if (acc + hist[c][bin] >= want) break;
-          acc += hist[c][bin];
-        }
-        s_have[c] += (unsigned)acc;
-        s_prefix[c] = (s_prefix[c] << 11) | (unsigned)bin;
-      }
-    }
-    __syncthreads();
   }
-  // threshold per class: need == #class -> everything; need == 0 -> nothing; else key <= the selected key
+  __syncthreads();
+  int* gh = ghist + (size_t)b * 2 * SS_BINS;
+  for (int i = tid; i < 2 * SS_BINS; i += 256) {
+    const int v = (&hist[0][0])[i];
+    if (v) atomicAdd(gh + i, v);
+  }
+}
+
+// one workgroup per row: class totals and wanted counts (pass 0), the bin of the need-th smallest key; clears the histogram
+__global__ __launch_bounds__(256) void ss_find_kernel(int pass, int cap_pos, int bs, SsState* __restrict__ state, int* __restrict__ ghist,
+                                                      int* __restrict__ cand_count) {
+  __shared__ int part[2][256];
+  __shared__ int s_bin[2], s_below[2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int* gh = ghist + (size_t)b * 2 * SS_BINS;
+  int h[2][8];
+  for (int c = 0; c < 2; ++c) {
+    int sum = 0;
+    for (int q = 0; q < 8; ++q) { h[c][q] = gh[c * SS_BINS + tid * 8 + q]; sum += h[c][q]; }
+    part[c][tid] = sum;
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * SS_BINS; i += 256) gh[i] = 0;
+  if (tid < 2) {
+    // exclusive prefix over the 256 partial sums by one thread per class (256 LDS reads), then the bin inside the group of eight
+    const int c = tid;
+    SsState st = state[b * 2 + c];
+    if (pass == 0) {
+      int n = 0;
+      for (int i = 0; i < 256; ++i) n += part[c][i];
+      st.n = n; st.prefix = 0u; st.have = 0u; st.need = 0;
+      state[b * 2 + c] = st;
+    }
+  }
+  __syncthreads();
+  if (pass == 0 && tid == 0) {
+    const int npos = min(state[b * 2 + 1].n, cap_pos);
+    state[b * 2 + 1].need = npos;
+    state[b * 2 + 0].need = min(state[b * 2 + 0].n, bs - npos);
+    cand_count[b * 2] = 0; cand_count[b * 2 + 1] = 0;
+  }
+  __syncthreads();
+  if (tid < 2) {
+    const int c = tid;
+    const SsState st = state[b * 2 + c];
+    s_bin[c] = -1;
+    if (st.need > 0 && st.need < st.n) {
+      const int want = st.need - (int)st.have;
+      int acc = 0, g = 0;
+      for (; g < 256; ++g) {
+        if (acc + part[c][g] >= want) break;
+        acc += part[c][g];
+      }
+      s_bin[c] = g; s_below[c] = acc;
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < 2; ++c) {
+    if (s_bin[c] == tid) {      // the thread that holds the group's eight bins
+      SsState st = state[b * 2 + c];
+      const int want = st.need - (int)st.have;
+      int acc = s_below[c], q = 0;
+      for (; q < 8; ++q) {
+        if (acc + h[c][q] >= want) break;
+        acc += h[c][q];
+      }
+      st.have += (unsigned)acc;
+      st.prefix = (st.prefix << 11) | (unsigned)(tid * 8 + q);
+      state[b * 2 + c] = st;
+    }
+  }
+}
+
+// elements at or below the class's threshold key -> the row's candidate list (exactly `need` of them: keys are distinct)
+__global__ __launch_bounds__(256) void ss_collect_kernel(const signed char* __restrict__ labels, const long long* __restrict__ keys, int N,
+                                                         const SsState* __restrict__ state, unsigned long long* __restrict__ cand,
+                                                         int* __restrict__ cand_count) {
+  const int b = blockIdx.y, tid = threadIdx.x;
   unsigned thr[2];
-  for (int c = 0; c < 2; ++c) thr[c] = need[c] <= 0 ? 0u : (need[c] >= s_n[c] ? 0xffffffffu : s_prefix[c]);
-  for (int i = tid; i < N; i += SS_NT) {
+  int need[2];
+  for (int c = 0; c < 2; ++c) {
+    const SsState st = state[b * 2 + c];
+    need[c] = st.need;
+    thr[c] = st.need <= 0 ? 0u : (st.need >= st.n ? 0xffffffffu : st.prefix);
+  }
+  const signed char* lab = labels + (size_t)b * N;
+  const long long* key = keys + (size_t)b * N;
+  const int i0 = blockIdx.x * SS_CHUNK, i1 = min(N, i0 + SS_CHUNK);
+  for (int i = i0 + tid; i < i1; i += 256) {
     const int l = lab[i];
     if (l == 0 || l == 1) {
       const unsigned k = (unsigned)key[i];
       if (need[l] > 0 && k <= thr[l]) {
-        const int pos = atomicAdd(&s_cnt[l], 1);
-        if (pos < SS_CAP) list[l][pos] = ((unsigned long long)k << 32) | (unsigned)i;
+        const int pos = atomicAdd(&cand_count[b * 2 + l], 1);
+        if (pos < SS_CAP) cand[((size_t)b * 2 + l) * SS_CAP + pos] = ((unsigned long long)k << 32) | (unsigned)i;
       }
     }
   }
-  __syncthreads();
-  // pad and sort each list by key (bitonic over SS_CAP entries, 1024 threads: one compare-exchange pair per thread and class step)
-  for (int c = 0; c < 2; ++c) {
-    const int n = min(s_cnt[c], SS_CAP);
-    if (tid >= n) list[c][tid] = ~0ull;
-  }
+}
+
+// one workgroup per row: both candidate lists sorted by key (bitonic over SS_CAP entries) and written positives first
+__global__ __launch_bounds__(SS_NT) void ss_emit_kernel(const SsState* __restrict__ state, const unsigned long long* __restrict__ cand, int bs,
+                                                        int* __restrict__ sel, int* __restrict__ counts) {
+  __shared__ unsigned long long list[2][SS_CAP];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int np = min(state[b * 2 + 1].need, SS_CAP), nn = min(state[b * 2 + 0].need, SS_CAP);
+  list[1][tid] = tid < np ? cand[((size_t)b * 2 + 1) * SS_CAP + tid] : ~0ull;
+  list[0][tid] = tid < nn ? cand[((size_t)b * 2 + 0) * SS_CAP + tid] : ~0ull;
   __syncthreads();
   for (int k = 2; k <= SS_CAP; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -222,7 +282,6 @@ __global__ __launch_bounds__(SS_NT) void subsample_kernel(const signed char* __r
       }
       __syncthreads();
     }
-  const int np = min(need[1], SS_CAP), nn = min(need[0], SS_CAP);
   for (int j = tid; j < bs; j += SS_NT) {
     int v = -1;
     if (j < np) v = (int)(unsigned)list[1][j];
@@ -232,12 +291,31 @@ __global__ __launch_bounds__(SS_NT) void subsample_kernel(const signed char* __r
   if (tid == 0) { counts[b * 2] = np; counts[b * 2 + 1] = nn; }
 }
 
-// labels int8 [B,N], keys int64 [B,N] distinct in [0, 2^nbits), -> sel int32 [B,bs] (positives first, -1 padded), counts int32 [B,2]
+extern "C" long long lvc_subsample_workspace_bytes(int B) {
+  return (long long)B * (2 * SS_BINS * 4 + 2 * sizeof(SsState) + 2 * 4 + 2 * SS_CAP * 8) + 256;
+}
+
+// labels int8 [B,N], keys int64 [B,N] distinct in [0, 2^nbits), -> sel int32 [B,bs] (positives first, -1 padded), counts int32 [B,2].
+// workspace: lvc_subsample_workspace_bytes(B) bytes, ZEROED by the caller before the first use (the launches leave it zeroed).
 extern "C" int lvc_subsample_batched(const signed char* labels, const long long* keys, int B, int N, int nbits, int cap_pos, int bs,
-                                     int* sel, int* counts, void* stream) {
-  LVC_CHECK_ARG(labels && keys && sel && counts, "null pointer");
+                                     int* sel, int* counts, void* workspace, void* stream) {
+  LVC_CHECK_ARG(labels && keys && sel && counts && workspace, "null pointer");
   LVC_CHECK_ARG(B > 0 && N > 0 && nbits > 0 && nbits <= 32 && cap_pos >= 0 && bs > 0 && bs <= SS_CAP && cap_pos <= bs, "bad arguments");
-  hipLaunchKernelGGL(subsample_kernel, dim3(B), dim3(SS_NT), 0, (hipStream_t)stream, labels, keys, N, nbits, cap_pos, bs, sel, counts);
+  char* w = (char*)workspace;
+  int* ghist = (int*)w;                         w += (size_t)B * 2 * SS_BINS * 4;
+  unsigned long long* cand = (unsigned long long*)w;  w += (size_t)B * 2 * SS_CAP * 8;
+  SsState* state = (SsState*)w;                 w += (size_t)B * 2 * sizeof(SsState);
+  int* cand_count = (int*)w;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(lvc_cdiv(N, SS_CHUNK), B);
+  const int npass = (nbits + 10) / 11;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int shift = (npass - 1 - pass) * 11;
+    hipLaunchKernelGGL(ss_hist_kernel, grid, dim3(256), 0, st, labels, keys, N, pass, shift, state, ghist);
+    hipLaunchKernelGGL(ss_find_kernel, dim3(B), dim3(256), 0, st, pass, cap_pos, bs, state, ghist, cand_count);
+  }
+  hipLaunchKernelGGL(ss_collect_kernel, grid, dim3(256), 0, st, labels, keys, N, state, cand, cand_count);
+  hipLaunchKernelGGL(ss_emit_kernel, dim3(B), dim3(SS_NT), 0, st, state, cand, bs, sel, counts);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -1448,6 +1448,9 @@ def match_boxes_batched(gt, gt_off, B, boxes, nbox, thresholds, labels, allow_lo
     return matches, mlabels
 
 
+_SUBSAMPLE_WS = {}
+
+
 def subsample_batched(labels, keys, cap_pos, bs):
     """subsample_labels (reference sampling.py:10-54) for every row of labels int8 [B,N] (1 positive, 0 negative, else ignored) in one
     launch: the min(#pos, cap_pos) positives and min(#neg, bs - num_pos) negatives with the smallest keys (int64 [B,N], distinct, e.g.
@@ -1458,8 +1461,16 @@ def subsample_batched(labels, keys, cap_pos, bs):
     sel = torch.empty(B, bs, dtype=torch.int32, device=labels.device)
     counts = torch.empty(B, 2, dtype=torch.int32, device=labels.device)
     nbits = max(1, int(B * N - 1).bit_length())
-    rc = _lib.lib().lvc_subsample_batched(ptr(labels.contiguous()), ptr(keys.contiguous()), c_int(B), c_int(N), c_int(nbits), c_int(cap_pos),
-                                          c_int(bs), ptr(sel), ptr(counts), _stream(labels))
+    lib = _lib.lib()
+    lib.lvc_subsample_workspace_bytes.restype = c_longlong
+    key = (labels.device.index, torch.cuda.current_stream(labels.device).cuda_stream, B)
+    ws = _SUBSAMPLE_WS.get(key)
+    if ws is None:      # zeroed once; the kernels leave it zeroed (per stream: two launches in flight must not share the histograms)
+        if len(_SUBSAMPLE_WS) > 16:
+            _SUBSAMPLE_WS.clear()
+        ws = _SUBSAMPLE_WS[key] = torch.zeros(lib.lvc_subsample_workspace_bytes(c_int(B)), dtype=torch.uint8, device=labels.device)
+    rc = lib.lvc_subsample_batched(ptr(labels.contiguous()), ptr(keys.contiguous()), c_int(B), c_int(N), c_int(nbits), c_int(cap_pos),
+                                   c_int(bs), ptr(sel), ptr(counts), ptr(ws), _stream(labels))
     check(rc, "lvc_subsample_batched")
     return sel, counts
 

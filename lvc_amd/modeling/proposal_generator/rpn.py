@@ -261,6 +261,18 @@ class RPN(nn.Module):
     batched_sampling = True     # class switch for A/B runs and tests (False: subsample_labels image by image)
     batched_targets = True      # ... True: match + sample + gather for the whole batch in five launches (csrc/train_targets.hip)
 
+    def _sizes_cached(self, image_sizes, dev):
+        """[B,2] int32 device tensor of the image sizes, cached by value: a fresh torch.tensor(..., device=) is a host->device copy
+        from pageable memory, which waits for the work queued on the stream -- here the whole trunk."""
+        cache = self.__dict__.setdefault("_sizes_cache", {})
+        key = (tuple(tuple(int(v) for v in s) for s in image_sizes), str(dev))
+        t = cache.get(key)
+        if t is None:
+            if len(cache) > 256:
+                cache.clear()
+            t = cache[key] = torch.tensor([list(s) for s in image_sizes], dtype=torch.int32, device=dev)
+        return t
+
     def _anchors_cached(self, shapes, dev):
         """The grid anchors of the pyramid, concatenated, computed once per set of map shapes (they depend on nothing else)."""
         cache = self.__dict__.setdefault("_anchor_cache", {})
@@ -362,7 +374,7 @@ class RPN(nn.Module):
         """Reference signature (rpn.py:402-451): -> (list[Instances], losses)."""
         feats = {f: to_nhwc(features[f]) for f in self.in_features}
         require_device(feats[self.in_features[0]], "RPN")
-        sizes = torch.tensor([list(s) for s in images.image_sizes], dtype=torch.int32, device=images.tensor.device)
+        sizes = self._sizes_cached(images.image_sizes, images.tensor.device)
         losses = {}
         if self.training:
             assert gt_instances is not None, "RPN requires gt_instances in training!"

@@ -109,6 +109,8 @@ class ROIHeads(nn.Module):
                 sel, cnt = K.subsample_batched(lab, key, int(bs * self.positive_sample_fraction), bs)
                 gcls = torch.cat([t.gt_classes for t in targets]).to(torch.int64)
                 s_boxes, s_logits, s_cls, s_m = K.roi_gather_sampled(tb, tl, m, sel, cnt, gcls, gt_off, K_)
+                # the matched gt box of every sampled row in ONE gather (two index launches per image otherwise)
+                s_gtb = gt[(gt_off[:-1].long()[:, None] + s_m).clamp(max=max(gt.shape[0] - 1, 0)).view(-1)].view(B, bs, 4)
             counts = cnt.tolist()      # the one device->host read
             out = []
             for i, (prop, tgt) in enumerate(zip(proposals, targets)):
@@ -117,11 +119,15 @@ class ROIHeads(nn.Module):
                 inst.proposal_boxes = Boxes(s_boxes[i, :c])
                 inst.objectness_logits = s_logits[i, :c]
                 inst.gt_classes = s_cls[i, :c]
-                st = s_m[i, :c]
+                inst.gt_boxes = Boxes(s_gtb[i, :c])
+                st = None
                 for name, val in tgt.get_fields().items():
                     if name.startswith("gt_") and not inst.has(name):
+                        st = s_m[i, :c] if st is None else st
                         inst.set(name, val[st])
                 out.append(inst)
+            # for _forward_train: the same rows as padded batch tensors (a python attribute, not a field)
+            out[0]._lvc_sampled = (s_boxes, s_cls, s_gtb, [c[0] + c[1] for c in counts])
             if log:
                 storage = get_event_storage()
                 storage.put_scalar("roi_head/num_fg_samples", sum(c[0] for c in counts) / B)
@@ -294,28 +300,41 @@ def _forward_train(self, features, proposals, targets):
     dev = feats[0].device
     counts = [len(p) for p in proposals]
     B, R = len(proposals), max(max(counts), 1)
-    boxes = torch.zeros(B, R, 4, device=dev)
-    for i, p in enumerate(proposals):
-        boxes[i, : counts[i]] = p.proposal_boxes.tensor
+    sampled = getattr(proposals[0], "_lvc_sampled", None) if proposals else None
+    if sampled is not None and sampled[3] == counts and sampled[0].shape[1] == R:
+        boxes = sampled[0]          # the sampler's own padded [B,R,4] table: no per-image copies
+    else:
+        sampled = None
+        boxes = torch.zeros(B, R, 4, device=dev)
+        for i, p in enumerate(proposals):
+            boxes[i, : counts[i]] = p.proposal_boxes.tensor
+    full = all(c == R for c in counts)
     # no graph when everything below the predictor is frozen (ft_novel yaml); otherwise ROIAlign backward into the
     # pyramid and the fused Linear autograd of the box head (base / ft_all yamls)
     below = any(f.requires_grad for f in feats) or any(p.requires_grad for p in self.box_head.parameters())
     with torch.set_grad_enabled(below and torch.is_grad_enabled()):
         pooled = self.box_pooler.pool_nhwc(feats, boxes)
-        keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
-        h = self.box_head.forward_nhwc(pooled[keep].contiguous())
-    pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
-    gb = torch.cat([p.gt_boxes.tensor for p in proposals], 0)
-    gc = torch.cat([p.gt_classes for p in proposals], 0)
+        if full:                    # every image filled its quota (the usual case): the pooled rows are the head's input as they lie
+            h = self.box_head.forward_nhwc(pooled)
+        else:
+            keep = torch.cat([torch.arange(c, device=dev) + i * R for i, c in enumerate(counts)])
+            h = self.box_head.forward_nhwc(pooled[keep].contiguous())
+    if sampled is not None and full:
+        pb, gc, gb = sampled[0].view(-1, 4), sampled[1].view(-1), sampled[2].view(-1, 4)
+    else:
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], 0)
+        gb = torch.cat([p.gt_boxes.tensor for p in proposals], 0)
+        gc = torch.cat([p.gt_classes for p in proposals], 0)
     losses, pred = fast_rcnn_losses(self.box_predictor, h, pb, gb, gc)
-    # accuracy scalars (reference fast_rcnn.py _log_accuracy)
+    # accuracy scalars (reference fast_rcnn.py _log_accuracy): the four counts in ONE device->host read
     storage = get_event_storage()
     fg = (gc >= 0) & (gc < self.num_classes)
-    nfg = int(fg.sum())
-    storage.put_scalar("fast_rcnn/cls_accuracy", float((pred == gc).sum()) / max(1, gc.numel()))
+    hit = pred == gc
+    nfg, ncorrect, nfg_correct, nfg_bg = torch.stack([fg.sum(), hit.sum(), (hit & fg).sum(), ((pred == self.num_classes) & fg).sum()]).tolist()
+    storage.put_scalar("fast_rcnn/cls_accuracy", float(ncorrect) / max(1, gc.numel()))
     if nfg > 0:
-        storage.put_scalar("fast_rcnn/fg_cls_accuracy", float((pred[fg] == gc[fg]).sum()) / nfg)
-        storage.put_scalar("fast_rcnn/false_negative", float((pred[fg] == self.num_classes).sum()) / nfg)
+        storage.put_scalar("fast_rcnn/fg_cls_accuracy", float(nfg_correct) / nfg)
+        storage.put_scalar("fast_rcnn/false_negative", float(nfg_bg) / nfg)
     return proposals, losses
 
 
