@@ -365,19 +365,20 @@ int lvc_match_boxes(const float* gt, int G, const float* boxes, int N, float t0,
  *   [B+1] int32 DEVICE prefix of the per-image counts (0..512 each; an image without gt gets label l0, match 0 everywhere);
  *   box_img_stride 0: boxes [N,4] shared (anchors), else [B][N][4] with nbox [B] rows in use (NULL: N; rows behind: label -1).
  * lvc_subsample_batched: subsample_labels (sampling.py:10-54) per row of labels int8 [B,N] (1 positive, 0 negative, else ignored): the
- *   min(#pos, cap_pos) positives and min(#neg, bs - num_pos) negatives with the smallest keys (int64 [B,N], distinct, < 2^nbits) ->
+ *   min(#pos, cap_pos) positives and min(#neg, bs - num_pos) negatives with the smallest keys (int64 [B,N], distinct, < 2^nbits; or NULL:
+ *   keys = a pseudo-random bijection of b N + i generated from `seed` by a 4-round Feistel network, nothing to sort or read) ->
  *   sel int32 [B,bs] (positives first, each group by increasing key, -1 padded), counts int32 [B,2].  bs <= 1024.
  * lvc_rpn_gather_sampled: for sel / counts over the R = sum_l H_l W_l A anchors: logits [B bs], deltas / anchors / matched gt boxes
  *   [B bs,4], labels int8 (1 / 0 / -1 padding) read from the head's per-level outputs fused[l] [B,H_l,W_l,ld_l] (channel a objectness,
  *   A + 4a + c delta c); grid anchors = shift + cell anchor (anchor_generator.py:161-185).  Feeds lvc_rpn_losses.
  * lvc_roi_build_table: add_ground_truth_to_proposals (proposal_utils.py:121-162) into a padded table boxes [B,Wt,4], logits [B,Wt],
- *   nrow [B]; lvc_roi_gather_sampled: its sampled rows with classes (gt class of the match / K background / -1 padding). */
+ *   nrow [B]; lvc_roi_gather_sampled: its sampled rows with classes (gt class of the match / K for background and padding rows). */
 int lvc_match_boxes_batched(const float* gt, const int* gt_off, int Gtot, int B, const float* boxes, long long box_img_stride,
                             const int* nbox, int N, float t0, float t1, int nthr, int l0, int l1, int l2, int allow_low_quality,
                             int* matches, signed char* labels, float* vals, unsigned int* gt_best, void* stream);
 long long lvc_subsample_workspace_bytes(int B);   /* zeroed by the caller before the first use; the launches leave it zeroed */
-int lvc_subsample_batched(const signed char* labels, const long long* keys, int B, int N, int nbits, int cap_pos, int bs, int* sel,
-                          int* counts, void* workspace, void* stream);
+int lvc_subsample_batched(const signed char* labels, const long long* keys /* NULL: generated from seed */, unsigned long long seed,
+                          int B, int N, int nbits, int cap_pos, int bs, int* sel, int* counts, void* workspace, void* stream);
 int lvc_rpn_gather_sampled(const void* const* fused, const int* ld, const void* const* cell_anchors, const int* H, const int* W,
                            const int* strides, int L, int A, int B, int bs, const int* sel, const int* counts, const int* matches,
                            const float* gt, const int* gt_off, float* logits, float* deltas, float* anchors, float* gt_boxes,

@@ -135,9 +135,28 @@ extern "C" int lvc_match_boxes_batched(const float* gt, const int* gt_off, int G
 // 300 us on its three passes); the histograms and candidate lists of a row meet in global memory.
 struct SsState { unsigned prefix, have; int need, n; };
 
+// The key of element i of row b: the caller's (torch.randperm) or, with keys == NULL, a pseudo-random BIJECTION of [0, 2^(2 hb)) applied
+// to b * N + i -- a four-round Feistel network whose round function is murmur3's finaliser keyed by the seed: distinct keys by
+// construction, no 17 MB key tensor to sort (torch.randperm of 2.1 M keys: 0.3 ms) or to read in the three passes.
+__device__ __forceinline__ unsigned ss_key(const long long* __restrict__ key, int i, unsigned base, unsigned long long seed, int hb) {
+  if (key) return (unsigned)key[i];
+  const unsigned mask = (1u << hb) - 1u;
+  const unsigned x = base + (unsigned)i;
+  unsigned L = x >> hb, R = x & mask;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    unsigned f = R ^ ((unsigned)(seed >> (16 * r)) * 0x9E3779B1u + (unsigned)r * 0x7F4A7C15u);
+    f ^= f >> 16; f *= 0x85EBCA6Bu; f ^= f >> 13; f *= 0xC2B2AE35u; f ^= f >> 16;
+    const unsigned t = L ^ (f & mask);
+    L = R; R = t;
+  }
+  return (L << hb) | R;
+}
+
 // pass `pass` of the select: histogram of the 11-bit digit at `shift` over the elements whose leading digits equal the class's prefix
 __global__ __launch_bounds__(256) void ss_hist_kernel(const signed char* __restrict__ labels, const long long* __restrict__ keys, int N, int pass,
-                                                      int shift, const SsState* __restrict__ state, int* __restrict__ ghist) {
+                                                      int shift, const SsState* __restrict__ state, int* __restrict__ ghist,
+                                                      unsigned long long seed, int hb) {
   __shared__ int hist[2][SS_BINS];
   const int b = blockIdx.y, tid = threadIdx.x;
   for (int i = tid; i < 2 * SS_BINS; i += 256) (&hist[0][0])[i] = 0;
@@ -152,12 +171,13 @@ __global__ __launch_bounds__(256) void ss_hist_kernel(const signed char* __restr
     }
   }
   const signed char* lab = labels + (size_t)b * N;
-  const long long* key = keys + (size_t)b * N;
+  const long long* key = keys ? keys + (size_t)b * N : nullptr;
+  const unsigned kbase = (unsigned)b * (unsigned)N;
   const int i0 = blockIdx.x * SS_CHUNK, i1 = min(N, i0 + SS_CHUNK);
   for (int i = i0 + tid; i < i1; i += 256) {
     const int l = lab[i];
     if ((l == 0 || l == 1) && live[l]) {
-      const unsigned k = (unsigned)key[i];
+      const unsigned k = ss_key(key, i, kbase, seed, hb);
       if (pass == 0 || (k >> (shift + 11)) == pre[l]) atomicAdd(&hist[l][(k >> shift) & (SS_BINS - 1)], 1);
     }
   }
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(256) void ss_find_kernel(int pass, int cap_pos, int
 // elements at or below the class's threshold key -> the row's candidate list (exactly `need` of them: keys are distinct)
 __global__ __launch_bounds__(256) void ss_collect_kernel(const signed char* __restrict__ labels, const long long* __restrict__ keys, int N,
                                                          const SsState* __restrict__ state, unsigned long long* __restrict__ cand,
-                                                         int* __restrict__ cand_count) {
+                                                         int* __restrict__ cand_count, unsigned long long seed, int hb) {
   const int b = blockIdx.y, tid = threadIdx.x;
   unsigned thr[2];
   int need[2];
@@ -247,12 +267,13 @@ __global__ __launch_bounds__(256) void ss_collect_kernel(const signed char* __re
     thr[c] = st.need <= 0 ? 0u : (st.need >= st.n ? 0xffffffffu : st.prefix);
   }
   const signed char* lab = labels + (size_t)b * N;
-  const long long* key = keys + (size_t)b * N;
+  const long long* key = keys ? keys + (size_t)b * N : nullptr;
+  const unsigned kbase = (unsigned)b * (unsigned)N;
   const int i0 = blockIdx.x * SS_CHUNK, i1 = min(N, i0 + SS_CHUNK);
   for (int i = i0 + tid; i < i1; i += 256) {
     const int l = lab[i];
     if (l == 0 || l == 1) {
-      const unsigned k = (unsigned)key[i];
+      const unsigned k = ss_key(key, i, kbase, seed, hb);
       if (need[l] > 0 && k <= thr[l]) {
         const int pos = atomicAdd(&cand_count[b * 2 + l], 1);
         if (pos < SS_CAP) cand[((size_t)b * 2 + l) * SS_CAP + pos] = ((unsigned long long)k << 32) | (unsigned)i;
@@ -295,12 +316,20 @@ extern "C" long long lvc_subsample_workspace_bytes(int B) {
   return (long long)B * (2 * SS_BINS * 4 + 2 * sizeof(SsState) + 2 * 4 + 2 * SS_CAP * 8) + 256;
 }
 
-// labels int8 [B,N], keys int64 [B,N] distinct in [0, 2^nbits), -> sel int32 [B,bs] (positives first, -1 padded), counts int32 [B,2].
+// labels int8 [B,N]; keys int64 [B,N] distinct in [0, 2^nbits), or NULL: keys generated from `seed` (a pseudo-random bijection of
+// b N + i; nbits is then rounded up to an even count) -> sel int32 [B,bs] (positives first, -1 padded), counts int32 [B,2].
 // workspace: lvc_subsample_workspace_bytes(B) bytes, ZEROED by the caller before the first use (the launches leave it zeroed).
-extern "C" int lvc_subsample_batched(const signed char* labels, const long long* keys, int B, int N, int nbits, int cap_pos, int bs,
-                                     int* sel, int* counts, void* workspace, void* stream) {
-  LVC_CHECK_ARG(labels && keys && sel && counts && workspace, "null pointer");
+extern "C" int lvc_subsample_batched(const signed char* labels, const long long* keys, unsigned long long seed, int B, int N, int nbits,
+                                     int cap_pos, int bs, int* sel, int* counts, void* workspace, void* stream) {
+  LVC_CHECK_ARG(labels && sel && counts && workspace, "null pointer");
   LVC_CHECK_ARG(B > 0 && N > 0 && nbits > 0 && nbits <= 32 && cap_pos >= 0 && bs > 0 && bs <= SS_CAP && cap_pos <= bs, "bad arguments");
+  LVC_CHECK_ARG((long long)B * N <= (1ll << 32), "more than 2^32 elements");
+  int hb = 0;
+  if (!keys) {
+    hb = (nbits + 1) / 2;
+    if (hb < 1) hb = 1;
+    nbits = 2 * hb;
+  }
   char* w = (char*)workspace;
   int* ghist = (int*)w;                         w += (size_t)B * 2 * SS_BINS * 4;
   unsigned long long* cand = (unsigned long long*)w;  w += (size_t)B * 2 * SS_CAP * 8;
@@ -311,10 +340,10 @@ extern "C" int lvc_subsample_batched(const signed char* labels, const long long*
   const int npass = (nbits + 10) / 11;
   for (int pass = 0; pass < npass; ++pass) {
     const int shift = (npass - 1 - pass) * 11;
-    hipLaunchKernelGGL(ss_hist_kernel, grid, dim3(256), 0, st, labels, keys, N, pass, shift, state, ghist);
+    hipLaunchKernelGGL(ss_hist_kernel, grid, dim3(256), 0, st, labels, keys, N, pass, shift, state, ghist, seed, hb);
     hipLaunchKernelGGL(ss_find_kernel, dim3(B), dim3(256), 0, st, pass, cap_pos, bs, state, ghist, cand_count);
   }
-  hipLaunchKernelGGL(ss_collect_kernel, grid, dim3(256), 0, st, labels, keys, N, state, cand, cand_count);
+  hipLaunchKernelGGL(ss_collect_kernel, grid, dim3(256), 0, st, labels, keys, N, state, cand, cand_count, seed, hb);
   hipLaunchKernelGGL(ss_emit_kernel, dim3(B), dim3(SS_NT), 0, st, state, cand, bs, sel, counts);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
@@ -439,7 +468,7 @@ __global__ __launch_bounds__(256) void roi_gather_kernel(const float* __restrict
   const int np = counts[b * 2], nn = counts[b * 2 + 1];
   float4 bx = {0.f, 0.f, 0.f, 0.f};
   float lg = 0.f;
-  long long cls = -1, m = 0;
+  long long cls = K, m = 0;      // padding rows: background (callers cut them off or check the counts)
   if (j < np + nn) {
     const int r = sel[t];
     bx = *reinterpret_cast<const float4*>(boxes + ((size_t)b * Wt + r) * 4);
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(256) void roi_gather_kernel(const float* __restrict
 }
 
 // rows sel [B,bs] of the table -> s_boxes [B,bs,4], s_logits [B,bs], s_cls int64 [B,bs] (the matched gt's class for the foreground rows,
-// K for background, -1 padding), s_match int64 [B,bs] (index of the matched gt inside the image)
+// K for background and for padding rows), s_match int64 [B,bs] (index of the matched gt inside the image)
 extern "C" int lvc_roi_gather_sampled(const float* boxes, const float* logits, const int* matches, const int* sel, const int* counts,
                                       const long long* gt_classes, const int* gt_off, int B, int Wt, int bs, int K, float* s_boxes,
                                       float* s_logits, long long* s_cls, long long* s_match, void* stream) {

@@ -1451,13 +1451,27 @@ def match_boxes_batched(gt, gt_off, B, boxes, nbox, thresholds, labels, allow_lo
 _SUBSAMPLE_WS = {}
 
 
-def subsample_batched(labels, keys, cap_pos, bs):
+def randperm_is_patched():
+    """True when torch.randperm has been replaced (the parity tests substitute arange to obtain the reference's deterministic choice):
+    the samplers then take their keys from it instead of generating them in the kernel."""
+    return getattr(torch.randperm, "__name__", "") != "randperm"
+
+
+def sampling_keys(B, N, device):
+    """(keys, seed) for `subsample_batched`: normally (None, a 62-bit seed from torch's CPU generator -- torch.manual_seed governs it, no
+    device work); with a patched torch.randperm its B * N values as int64 [B,N]."""
+    if randperm_is_patched():
+        return torch.randperm(B * N, device=device).view(B, N), 0
+    return None, int(torch.randint(0, 1 << 62, (1,)).item())
+
+
+def subsample_batched(labels, keys, cap_pos, bs, seed=0):
     """subsample_labels (reference sampling.py:10-54) for every row of labels int8 [B,N] (1 positive, 0 negative, else ignored) in one
     launch: the min(#pos, cap_pos) positives and min(#neg, bs - num_pos) negatives with the smallest keys (int64 [B,N], distinct, e.g.
-    torch.randperm(B * N)).  -> (sel int32 [B,bs]: positives first, each group by increasing key, -1 padded; counts int32 [B,2])."""
-    _req_cuda(labels, keys)
+    torch.randperm(B * N); None: generated in the kernel from `seed`, see `sampling_keys`).  -> (sel int32 [B,bs]: positives first, each group by increasing key, -1 padded; counts int32 [B,2])."""
+    _req_cuda(labels)
     B, N = labels.shape
-    assert labels.dtype == torch.int8 and keys.dtype == torch.int64 and keys.shape == labels.shape
+    assert labels.dtype == torch.int8 and (keys is None or (keys.is_cuda and keys.dtype == torch.int64 and keys.shape == labels.shape))
     sel = torch.empty(B, bs, dtype=torch.int32, device=labels.device)
     counts = torch.empty(B, 2, dtype=torch.int32, device=labels.device)
     nbits = max(1, int(B * N - 1).bit_length())
@@ -1469,8 +1483,10 @@ def subsample_batched(labels, keys, cap_pos, bs):
         if len(_SUBSAMPLE_WS) > 16:
             _SUBSAMPLE_WS.clear()
         ws = _SUBSAMPLE_WS[key] = torch.zeros(lib.lvc_subsample_workspace_bytes(c_int(B)), dtype=torch.uint8, device=labels.device)
-    rc = lib.lvc_subsample_batched(ptr(labels.contiguous()), ptr(keys.contiguous()), c_int(B), c_int(N), c_int(nbits), c_int(cap_pos),
-                                   c_int(bs), ptr(sel), ptr(counts), ptr(ws), _stream(labels))
+    from ctypes import c_ulonglong
+
+    rc = lib.lvc_subsample_batched(ptr(labels.contiguous()), ptr(keys.contiguous() if keys is not None else None), c_ulonglong(int(seed)),
+                                   c_int(B), c_int(N), c_int(nbits), c_int(cap_pos), c_int(bs), ptr(sel), ptr(counts), ptr(ws), _stream(labels))
     check(rc, "lvc_subsample_batched")
     return sel, counts
 

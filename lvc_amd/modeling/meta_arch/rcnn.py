@@ -129,8 +129,10 @@ class GeneralizedRCNN(_RCNNBase):
             return self.inference(batched_inputs)
 
         def once():
+            self.__dict__["_range_checked"] = False
             losses = self._forward_train(batched_inputs)
-            K.check_conv_error_word(self.device)   # fp16x2 range word of the forward kernels (the step syncs anyway)
+            if not self.__dict__["_range_checked"]:    # (the deferred-read path folds the range words into its one device->host read)
+                K.check_conv_error_word(self.device)   # fp16x2 range word of the forward kernels (the step syncs anyway)
             return losses
 
         return run_with_fallbacks(self, once)
@@ -153,6 +155,9 @@ class GeneralizedRCNN(_RCNNBase):
             proposals = [x["proposals"].to(self.device) for x in batched_inputs]
             proposal_losses = {}
             proposals, _ = self.proposal_generator(proposals, gt_instances)
+        elif (self.deferred_reads and isinstance(self.proposal_generator, RPN) and isinstance(self.roi_heads, StandardROIHeads)
+              and self.proposal_generator.can_batch_targets(gt_instances) and self.roi_heads.can_batch_train(gt_instances)):
+            return self._forward_train_deferred(images, features, gt_instances)
         elif self.proposal_generator:
             proposals, proposal_losses = self.proposal_generator(images, features, gt_instances)
         else:
@@ -160,6 +165,44 @@ class GeneralizedRCNN(_RCNNBase):
             proposals = [x["proposals"].to(self.device) for x in batched_inputs]
             proposal_losses = {}
         _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+    deferred_reads = True      # class switch for A/B runs and tests (False: RPN.forward / ROIHeads.forward with their own reads)
+
+    def _forward_train_deferred(self, images, features, gt_instances):
+        """RPN + StandardROIHeads training (reference rcnn.py:127-175) as ONE stream of launches with ONE device->host read at the end:
+        the proposal generator's batch tensors go straight to the heads (no per-image Instances in between), every count the step logs
+        -- proposals, sampled anchors, sampled rows, accuracy, the conv kernels' range words -- comes back together.  If an image fell
+        short of its ROI quota (the heads ran padded) the detector losses are recomputed by the per-image path: same values as the
+        reference's normalisation in every case."""
+        from ...utils.events import get_event_storage
+
+        rpn, heads = self.proposal_generator, self.roi_heads
+        boxes, logits, count, proposal_losses, rpn_counts, gt, gt_off = rpn.forward_train_batched(images, features, gt_instances)
+        detector_losses, cnt, stats = heads.forward_train_batched(features, boxes, logits, count, gt, gt_off, gt_instances)
+        B, bs = boxes.shape[0], heads.batch_size_per_image
+        meta = torch.cat([count.long(), rpn_counts.view(-1).long(), cnt.view(-1).long(), stats.long(), K.range_summary(self.device).long()]).tolist()
+        pc, rc, cc, st, flagged = meta[:B], meta[B:3 * B], meta[3 * B:5 * B], meta[5 * B:5 * B + 4], meta[-1]
+        if flagged:
+            K.check_conv_error_word(self.device)      # re-routes the layers concerned and raises: `run_with_fallbacks` repeats the pass
+        self.__dict__["_range_checked"] = True
+        storage = get_event_storage()
+        storage.put_scalar("rpn/num_pos_anchors", sum(rc[0::2]) / B)
+        storage.put_scalar("rpn/num_neg_anchors", sum(rc[1::2]) / B)
+        counts = [(cc[2 * i], cc[2 * i + 1]) for i in range(B)]
+        if all(a + b == bs for a, b in counts):
+            heads.log_train_scalars(counts, st, B * bs)
+        else:
+            proposals = []
+            for i, size in enumerate(images.image_sizes):
+                inst = Instances(size)
+                inst.proposal_boxes = Boxes(boxes[i, : pc[i]])
+                inst.objectness_logits = logits[i, : pc[i]]
+                proposals.append(inst)
+            _, detector_losses = heads(images, features, proposals, gt_instances)
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

@@ -261,6 +261,27 @@ class RPN(nn.Module):
     batched_sampling = True     # class switch for A/B runs and tests (False: subsample_labels image by image)
     batched_targets = True      # ... True: match + sample + gather for the whole batch in five launches (csrc/train_targets.hip)
 
+    def can_batch_targets(self, gt_instances):
+        return (self.batched_targets and self.batched_sampling and self.anchor_boundary_thresh < 0 and self.box_reg_loss_type == "smooth_l1"
+                and gt_instances is not None and all(len(t) <= 512 for t in gt_instances) and self.batch_size_per_image <= 1024)
+
+    def forward_train_batched(self, images, features, gt_instances):
+        """The training branch of `forward` WITHOUT its device->host read: -> (boxes [B,post,4], logits [B,post], count int32 [B], losses,
+        sampled-anchor counts int32 [B,2], gt boxes [G,4], gt offsets int32 [B+1]) -- everything on the device.  The caller
+        (GeneralizedRCNN._forward_train) hands the tensors to StandardROIHeads.forward_train_batched and reads all counts of the step at
+        once.  Requires `can_batch_targets`."""
+        feats = {f: to_nhwc(features[f]) for f in self.in_features}
+        require_device(feats[self.in_features[0]], "RPN")
+        sizes = self._sizes_cached(images.image_sizes, images.tensor.device)
+        flist = [feats[f] for f in self.in_features]
+        trains = any(p.requires_grad for p in self.parameters()) or any(f.requires_grad for f in flist)
+        with torch.set_grad_enabled(trains and torch.is_grad_enabled()):
+            fused = self.rpn_head.forward_nhwc(flist)
+        losses, pending, (gt, gt_off) = self._losses_batched(fused, flist, gt_instances)
+        with torch.no_grad():
+            boxes, logits, count = self.predict_proposals_batched(feats, sizes, fused=fused)
+        return boxes, logits, count, losses, pending, gt, gt_off
+
     def _sizes_cached(self, image_sizes, dev):
         """[B,2] int32 device tensor of the image sizes, cached by value: a fresh torch.tensor(..., device=) is a host->device copy
         from pageable memory, which waits for the work queued on the stream -- here the whole trunk."""
@@ -297,9 +318,9 @@ class RPN(nn.Module):
         with torch.no_grad():
             gt, gt_off, _ = K.cat_ground_truth(gt_instances)
             matches, labels = K.match_boxes_batched(gt, gt_off, B, anchors, None, self.anchor_matcher.thresholds[1:-1], self.anchor_matcher.labels, True)
-            keys = torch.randperm(B * R, device=dev).view(B, R)
+            keys, seed = K.sampling_keys(B, R, dev)
             bs = self.batch_size_per_image
-            sel, counts = K.subsample_batched(labels, keys, int(bs * self.positive_fraction), bs)
+            sel, counts = K.subsample_batched(labels, keys, int(bs * self.positive_fraction), bs, seed=seed)
         norm = float(bs * B)
         trains = torch.is_grad_enabled() and any(f.requires_grad for f in fused)
         if not trains:
@@ -385,8 +406,7 @@ class RPN(nn.Module):
             A = self.rpn_head.num_anchors
             N = fused[0].shape[0]
             pending = None
-            if (self.batched_targets and self.batched_sampling and self.anchor_boundary_thresh < 0 and self.box_reg_loss_type == "smooth_l1"
-                    and all(len(t) <= 512 for t in gt_instances) and self.batch_size_per_image <= 1024):
+            if self.can_batch_targets(gt_instances):
                 losses, pending, gt_batch = self._losses_batched(fused, flist, gt_instances)
             else:
                 gt_batch = None

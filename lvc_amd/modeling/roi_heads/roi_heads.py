@@ -100,17 +100,7 @@ class ROIHeads(nn.Module):
             # the proposals as RPN.forward made them -- one padded [B,P] table on the device -- and the concatenated ground truth: table
             # + Matcher + subsample_labels + gather for the whole batch in five launches (csrc/train_targets.hip), ONE device->host read
             pboxes, plogits, pcount, pcounts_host, gt, gt_off = batch
-            Wt = pboxes.shape[1] + max(len(t) for t in targets)
-            with torch.no_grad():
-                tb, tl, nrow = K.roi_build_table(pboxes, plogits, pcount, gt, gt_off, gt_logit, Wt)
-                m, lab = K.match_boxes_batched(gt, gt_off, B, tb, nrow, self.proposal_matcher.user_thresholds, self.proposal_matcher.labels,
-                                               self.proposal_matcher.allow_low_quality_matches)
-                key = torch.randperm(B * Wt, device=dev).view(B, Wt)
-                sel, cnt = K.subsample_batched(lab, key, int(bs * self.positive_sample_fraction), bs)
-                gcls = torch.cat([t.gt_classes for t in targets]).to(torch.int64)
-                s_boxes, s_logits, s_cls, s_m = K.roi_gather_sampled(tb, tl, m, sel, cnt, gcls, gt_off, K_)
-                # the matched gt box of every sampled row in ONE gather (two index launches per image otherwise)
-                s_gtb = gt[(gt_off[:-1].long()[:, None] + s_m).clamp(max=max(gt.shape[0] - 1, 0)).view(-1)].view(B, bs, 4)
+            s_boxes, s_logits, s_cls, s_m, s_gtb, cnt = _sample_batched(self, pboxes, plogits, pcount, gt, gt_off, targets)
             counts = cnt.tolist()      # the one device->host read
             out = []
             for i, (prop, tgt) in enumerate(zip(proposals, targets)):
@@ -291,6 +281,69 @@ class StandardROIHeads(ROIHeads):
         return instances_from_batched(ob, osc, ocl, cnt, [p.image_size for p in proposals], status), {}
 
 
+def _sample_batched(self, pboxes, plogits, pcount, gt, gt_off, targets):
+    """Table + Matcher + subsample_labels + gather for the whole batch (csrc/train_targets.hip), nothing read back:
+    -> (boxes [B,bs,4], logits [B,bs], classes int64 [B,bs], matched gt index int64 [B,bs], matched gt boxes [B,bs,4], counts int32 [B,2])."""
+    import math
+
+    B, dev = pboxes.shape[0], pboxes.device
+    K_, bs = self.num_classes, self.batch_size_per_image
+    gt_logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+    Wt = pboxes.shape[1] + max(len(t) for t in targets)
+    with torch.no_grad():
+        tb, tl, nrow = K.roi_build_table(pboxes, plogits, pcount, gt, gt_off, gt_logit, Wt)
+        m, lab = K.match_boxes_batched(gt, gt_off, B, tb, nrow, self.proposal_matcher.user_thresholds, self.proposal_matcher.labels,
+                                       self.proposal_matcher.allow_low_quality_matches)
+        key, seed = K.sampling_keys(B, Wt, dev)
+        sel, cnt = K.subsample_batched(lab, key, int(bs * self.positive_sample_fraction), bs, seed=seed)
+        gcls = torch.cat([t.gt_classes for t in targets]).to(torch.int64)
+        s_boxes, s_logits, s_cls, s_m = K.roi_gather_sampled(tb, tl, m, sel, cnt, gcls, gt_off, K_)
+        s_gtb = gt[(gt_off[:-1].long()[:, None] + s_m).clamp(max=max(gt.shape[0] - 1, 0)).view(-1)].view(B, bs, 4)
+    return s_boxes, s_logits, s_cls, s_m, s_gtb, cnt
+
+
+def can_batch_train(self, targets):
+    return (self.batched_sampling and self.batched_targets and self.proposal_append_gt and not self.rbg and self.batch_size_per_image <= 1024
+            and type(self)._forward_train is _forward_train and targets is not None and len(targets) > 0
+            and all(0 < len(t) <= 512 and not (self.relabel_ignored_gt and t.has("gt_ignores")) for t in targets)
+            and len(self.proposal_matcher.user_thresholds) in (1, 2))
+
+
+def forward_train_batched(self, features, pboxes, plogits, pcount, gt, gt_off, targets):
+    """StandardROIHeads' training branch on the proposal generator's batch tensors, without a device->host read: the sampled rows stay
+    one padded [B, bs] table, ROIAlign / box head / losses run on all B * bs rows as if every image had filled its quota (the usual case;
+    padding rows are zero boxes labelled background) and -> (losses, counts int32 [B,2], accuracy counts int64 [4]).  The CALLER reads the
+    counts with the step's other scalars and, if some image did fall short of bs rows, discards these losses and runs the per-image path
+    (`forward`) instead -- the reference's normalisation is by the true row count."""
+    from .fast_rcnn import fast_rcnn_losses
+
+    s_boxes, _s_logits, s_cls, _s_m, s_gtb, cnt = _sample_batched(self, pboxes, plogits, pcount, gt, gt_off, targets)
+    feats = [to_nhwc(features[f]) for f in self.in_features]
+    below = any(f.requires_grad for f in feats) or any(p.requires_grad for p in self.box_head.parameters())
+    with torch.set_grad_enabled(below and torch.is_grad_enabled()):
+        h = self.box_head.forward_nhwc(self.box_pooler.pool_nhwc(feats, s_boxes))
+    gc = s_cls.view(-1)
+    losses, pred = fast_rcnn_losses(self.box_predictor, h, s_boxes.view(-1, 4), s_gtb.view(-1, 4), gc)
+    with torch.no_grad():
+        fg = (gc >= 0) & (gc < self.num_classes)
+        hit = pred == gc
+        stats = torch.stack([fg.sum(), hit.sum(), (hit & fg).sum(), ((pred == self.num_classes) & fg).sum()])
+    return losses, cnt, stats
+
+
+def log_train_scalars(self, counts, stats, nrows):
+    """EventStorage scalars of label_and_sample_proposals and FastRCNNOutputs._log_accuracy from host values."""
+    storage = get_event_storage()
+    B = len(counts)
+    storage.put_scalar("roi_head/num_fg_samples", sum(c[0] for c in counts) / B)
+    storage.put_scalar("roi_head/num_bg_samples", sum(c[1] for c in counts) / B)
+    nfg, ncorrect, nfg_correct, nfg_bg = stats
+    storage.put_scalar("fast_rcnn/cls_accuracy", float(ncorrect) / max(1, nrows))
+    if nfg > 0:
+        storage.put_scalar("fast_rcnn/fg_cls_accuracy", float(nfg_correct) / nfg)
+        storage.put_scalar("fast_rcnn/false_negative", float(nfg_bg) / nfg)
+
+
 def _forward_train(self, features, proposals, targets):
     """StandardROIHeads training branch (reference roi_heads.py:554-629 + FastRCNNOutputs.losses)."""
     from .fast_rcnn import fast_rcnn_losses
@@ -339,6 +392,9 @@ def _forward_train(self, features, proposals, targets):
 
 
 StandardROIHeads._forward_train = _forward_train
+StandardROIHeads.can_batch_train = can_batch_train
+StandardROIHeads.forward_train_batched = forward_train_batched
+StandardROIHeads.log_train_scalars = log_train_scalars
 
 
 def widen_limits(model, exc):

@@ -634,3 +634,67 @@ def test_batched_targets_equal_the_per_image_path(monkeypatch, which):
         assert float(res[True][2][k_]) == float(res[False][2][k_]), k_
     for a, b in zip(res[True][1], res[False][1]):
         assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-12) + 1e-9
+
+
+def test_sampler_with_generated_keys_draws_valid_distinct_samples():
+    """`lvc_subsample_batched` with keys = NULL (the production path: a four-round Feistel bijection of b N + i keyed by a seed from torch's
+    CPU generator, nothing sorted or read): the counts are subsample_labels', every selected index carries the right label and appears
+    once, two seeds give different samples, one seed the same sample, and over many draws every candidate is taken about equally often."""
+    from lvc_amd import kernels as k
+
+    g = torch.Generator().manual_seed(3)
+    B, N, bs, cap = 3, 50000, 256, 128
+    lab = torch.full((B, N), -1, dtype=torch.int8)
+    lab[torch.rand(B, N, generator=g) < 0.6] = 0
+    lab[torch.rand(B, N, generator=g) < 0.01] = 1
+    lab[2][lab[2] == 1] = -1
+    lab[2, :40] = 1                       # fewer positives than the cap
+    d = torch.device("cuda:0")
+    labd = lab.to(d)
+    s1, c1 = k.subsample_batched(labd, None, cap, bs, seed=12345)
+    s1b, _ = k.subsample_batched(labd, None, cap, bs, seed=12345)
+    s2, _ = k.subsample_batched(labd, None, cap, bs, seed=99991)
+    assert torch.equal(s1, s1b) and not torch.equal(s1, s2)
+    s1, c1 = s1.cpu(), c1.cpu()
+    for b in range(B):
+        npos = min(int((lab[b] == 1).sum()), cap)
+        nneg = min(int((lab[b] == 0).sum()), bs - npos)
+        assert c1[b].tolist() == [npos, nneg]
+        idx = s1[b, :npos + nneg].long()
+        assert len(torch.unique(idx)) == npos + nneg
+        assert bool((lab[b][idx[:npos]] == 1).all()) and bool((lab[b][idx[npos:]] == 0).all())
+    # uniformity: 400 positives, 100 taken per draw, 600 draws -> each expected 150 times (binomial sd ~ 10.6)
+    lab2 = torch.full((1, 30000), 0, dtype=torch.int8)
+    pos = torch.randperm(30000, generator=g)[:400]
+    lab2[0, pos] = 1
+    hits = torch.zeros(30000)
+    lab2d = lab2.to(d)
+    for seed in range(600):
+        s, _ = k.subsample_batched(lab2d, None, 100, 256, seed=seed * 7919 + 13)
+        hits[s[0, :100].long().cpu()] += 1
+    h = hits[pos]
+    assert float(hits.sum()) == 600 * 100 and float(h.sum()) == 600 * 100
+    assert 100 <= float(h.min()) and float(h.max()) <= 200 and abs(float(h.std()) - 10.6) < 3.0, (float(h.min()), float(h.max()), float(h.std()))
+
+
+def test_deferred_read_training_forward_falls_back_when_an_image_misses_its_quota(monkeypatch):
+    """GeneralizedRCNN._forward_train_deferred runs the heads padded and checks the row counts in its one device->host read: with
+    fewer candidates than BATCH_SIZE_PER_IMAGE (here: 40 proposals kept per image by the RPN against a quota of 512) the per-image path
+    recomputes the detector losses, which must then equal the `deferred_reads = False` step."""
+    from lvc_amd.modeling.meta_arch.rcnn import GeneralizedRCNN
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("train_novel_ft")
+    model = _train_model()
+    model.proposal_generator.post_nms_topk = (model.proposal_generator.post_nms_topk[0], 40)
+    monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
+    res = {}
+    for fast in (False, True):
+        monkeypatch.setattr(GeneralizedRCNN, "deferred_reads", fast)
+        with EventStorage(0) as st:
+            losses = model(_batch(g))
+            res[fast] = ({k: float(v.detach()) for k, v in losses.items()}, {k: (v[0] if isinstance(v, tuple) else v) for k, v in st.latest().items()})
+    print(res)
+    for k_ in res[False][0]:
+        assert abs(res[True][0][k_] - res[False][0][k_]) <= 2e-6 * max(1.0, abs(res[False][0][k_])), k_
+    assert float(res[True][1]["roi_head/num_bg_samples"]) == float(res[False][1]["roi_head/num_bg_samples"]) < 512
