@@ -393,6 +393,36 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
         if phases:
             for _ in range(3):
                 step(sync=ph)
+    # Roofline of the backward's two kernel families: one more step with a HIP-event pair around every weight- and
+    # data-gradient launch (kernels.BWD_TIMER; the conv / GEMM launches of the backward, not the elementwise glue)
+    bwd_roof = None
+    if phases and which != "cfg3" and c.rank == 0:
+        from lvc_amd import kernels as K
+
+        K.BWD_TIMER = []
+        try:
+            with EventStorage(0):
+                step()
+            torch.cuda.synchronize()
+            rec, K.BWD_TIMER = K.BWD_TIMER, None
+        finally:
+            K.BWD_TIMER = None
+        bwd_roof = {}
+        for kind in ("wgrad", "dgrad"):
+            rs = [r for r in rec if r[0] == kind]
+            if not rs:
+                continue
+            ms = sum(r[4].elapsed_time(r[5]) for r in rs)
+            fl, nb = sum(r[2] for r in rs), sum(r[3] for r in rs)
+            eng = sorted({r[1] for r in rs})
+            peak = PEAK_F16X2_TFLOPS if eng == ["f16x2"] else PEAK_BF16X3_TFLOPS if "f32" not in eng else PEAK_F32_MFMA_TFLOPS
+            bwd_roof[kind] = {"launches": len(rs), "ms": round(ms, 3), "algorithmic_gflop": round(fl / 1e9, 1), "tflops": round(fl / ms / 1e9, 1),
+                              "engine": "+".join(eng), "peak_tflops": round(peak, 1), "frac_of_mfma_peak": round(fl / ms / 1e9 / peak, 4),
+                              "algorithmic_bytes": int(nb), "algorithmic_GBps": round(nb / ms / 1e6, 1),
+                              "frac_of_hbm_peak": round(nb / ms / 1e6 / PEAK_HBM_GBPS, 4)}
+        bwd_roof["note"] = ("HIP events around every lvc_conv_wgrad_* / data-gradient conv launch of ONE extra step (weight gradients: bf16 three-way "
+                            "split, 6 MFMAs per product -> peak 2500 / 6; data gradients run on the forward kernels with flipped weights); algorithmic "
+                            "bytes = operands + result once")
     chk = torch.cat([p.detach().reshape(-1) for p in params]).double().sum()
     same = None
     if c.use_dist:      # after averaged gradients + identical SGD steps every rank must hold the same parameters
@@ -411,6 +441,8 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
     if ph:
         out["ms_forward_backward_optimizer"] = [round(1e3 * sum(p[i] for p in ph) / len(ph), 2) for i in range(3)]
         out["phase_note"] = "3 extra steps with a synchronize after each phase (attribution; the timed steps have none)"
+    if bwd_roof:
+        out["roofline"] = bwd_roof
     if buckets is not None:
         buckets.remove()
     del model, opt

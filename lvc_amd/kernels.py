@@ -1616,8 +1616,31 @@ def colsum_rows(x2d):
     return out
 
 
+BWD_TIMER = None     # a list: every weight- / data-gradient launch appends (kind, engine, flops, algorithmic bytes, start, end events)
+
+
+def _bwd_timed(kind, engine, flops, nbytes, fn):
+    if BWD_TIMER is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    BWD_TIMER.append((kind, engine, flops, nbytes, e0, e1))
+    return out
+
+
 def conv_wgrad(x, dy, scale, R, S, stride, pad, split=None):
     """dW of y = conv(x, W) (* scale per output channel): x [N,H,W,C], dy [N,Ho,Wo,K] -> [K,R,S,C] fp32."""
+    if BWD_TIMER is not None:
+        eng = "f16x2" if (split or DGRAD_SPLIT) == "f16x2" else WGRAD_ENGINE
+        fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * x.shape[3] * R * S
+        nb = 4.0 * (x.numel() + dy.numel() + dy.shape[3] * R * S * x.shape[3])
+        return _bwd_timed("wgrad", eng, fl, nb, lambda: _conv_wgrad(x, dy, scale, R, S, stride, pad, split))
+    return _conv_wgrad(x, dy, scale, R, S, stride, pad, split)
+
+
+def _conv_wgrad(x, dy, scale, R, S, stride, pad, split=None):
     _req_cuda(x, dy, scale)
     assert x.dim() == 4 and dy.dim() == 4 and x.is_contiguous() and dy.is_contiguous()
     assert x.dtype == torch.float32 and dy.dtype == torch.float32
@@ -1693,7 +1716,12 @@ def conv_dgrad(dy, pcd, x_shape, stride):
     N, H, W, C = x_shape
     if dy.shape[3] != pcd.C:   # contraction padded to 32 channels
         dy = torch.nn.functional.pad(dy, (0, pcd.C - dy.shape[3]))
-    dxs = conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT)
+    if BWD_TIMER is not None:
+        fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * pcd.K * pcd.R * pcd.S
+        nb = 4.0 * (dy.numel() + dy.shape[0] * dy.shape[1] * dy.shape[2] * pcd.K + pcd.K * pcd.R * pcd.S * dy.shape[3])
+        dxs = _bwd_timed("dgrad", DGRAD_SPLIT, fl, nb, lambda: conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT))
+    else:
+        dxs = conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT)
     if stride == 1:
         assert tuple(dxs.shape) == (N, H, W, C), (dxs.shape, x_shape)
         return dxs
