@@ -689,6 +689,7 @@ def infer_main(c, args):
     # the per-kernel breakdown of every conv/GEMM launch comes from two more untimed steps after it.
     timer = full = None
     NAMES = {"f16x2_halo": "conv3x3_halo_s1_kernel (pipelined 3x3: one accumulator in the trunk, two in the RPN head)" if K.HALO_S1 else "conv3x3_halo_h2_kernel", "f16x2_pw": "conv_pw_dma_kernel (LDS-DMA pointwise: the layers with fewer than 64 input or output channels)",
+             "f16x2_wino": "conv3x3_wino_kernel (Winograd F(2,3) along x: the 3x3 layers on the large maps, 6 products per output instead of 9)",
              "f16x2_pws1": "conv_pw_s1_kernel (pipelined pointwise / FC: every layer with >= 64 input and output channels)", "bf16x3_halo": "conv3x3_halo_kernel",
              "f16s1_chain": "conv_pw_chain_kernel (conv3 + shortcut add + ReLU -> the next block's conv1 in one launch: res2 / res3)",
              "bf16x3": "conv_bf16x3_kernel (+ bf16 pointwise shapes)", "f32": "conv_igemm_f32_kernel"}

@@ -134,6 +134,13 @@ int lvc_conv3x3_nhwc_f16_levels_pred(int oneacc, const float* const* xs, float* 
 int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
                                 const unsigned short* const* ws, const float* const* scales, const float* const* shifts, int N, int C,
                                 int K, int Kg, int relu, void* workspace, void* stream);
+/* 3x3 / stride 1 / pad 1 as Winograd F(2,3) along x (round 5, csrc/conv3x3_wino.hip; the 256-channel layers of
+ * detectron2/modeling/backbone/fpn.py:141-144 and proposal_generator/rpn.py:92-94 on the large maps): two thirds of the MFMAs of
+ * lvc_conv3x3_nhwc_f16s1 at the same operand precision and the direct evaluation's fp32 error.  u = transformed row-scaled weight planes
+ * [3][C/16][4][2][Kpad][16] fp16 (Kpad % 128 == 0), scale [K] = their row factors x the layer's scale (lvc_amd.kernels.pack_wino);
+ * C % 16 == 0; |window value| <= 4094 or the layer's range word in `workspace` is raised. */
+int lvc_conv3x3_nhwc_wino(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H, int W,
+                          int C, int K, int Kpad, int relu, int ldy, void* workspace, void* stream);
 /* Pointwise (R = S = 1, pad 0) layers with a long contraction on the pipelined loop of the 3x3 kernel (csrc/conv_pw_s1.hip; the conv1
  * / FC layers of detectron2/modeling/backbone/resnet.py:195-211, roi_heads/box_head.py:80-93 and the ViT linears): y = act(conv(x,
  * w) * scale + shift (+ residual)), x [N,H,W,C] fp32 NHWC with C % 32 == 0, stride >= 1, relu: 0 none / 1 ReLU / 2 exact GELU,

@@ -1,0 +1,337 @@
+// conv3x3_wino.hip -- 3x3 / stride 1 / pad 1 layers as Winograd F(2,3) ALONG X (round 5): two output pixels of a row from four
+// transformed input positions, the three filter rows accumulated directly -- 6 products per output instead of 9, i.e. two thirds of the
+// MFMAs of csrc/conv3x3_halo_s1.hip at the same operand precision (single-accumulator two-way fp16 split: activations x 2^4, row-scaled
+// weight planes, fp32 accumulation).
+//
+//     d = x[.., 2t-1 .. 2t+2] (one filter row, one input channel)        g = that row's three taps
+//     V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3           U0 = g0   U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2
+//     M_p = sum over input channels and filter rows of V_p U_p            y[2t] = M0 + M1 + M2      y[2t+1] = M1 - M2 - M3
+//
+// Priced before it was built: scripts/winograd_error.py -- its fp32 error equals the direct evaluation's (rms x 0.99 on
+// a 256 -> 256 layer; the two-dimensional F(2x2,3x3) form: x 2.5, not built); scripts/micro/winograd_skeleton.hip -- a chunk loop with
+// this form's MFMA / fragment-read / weight-DMA mix runs the 3x3 work in 0.70 of the direct loop's time under the power cap
+// (profiles/r05_winograd_skeleton.txt).
+//
+// Tile: 128 pixel PAIRS (a PH x 2 PWP pixel patch, PH PWP = 128) x 128 output channels per workgroup, 8 waves = 2 position halves x 2
+// row blocks x 2 channel blocks: a wave owns 64 pairs x 64 channels for TWO of the four positions (128 accumulator registers) and reads
+// 16 fragments per 24 MFMAs -- the direct kernel's ratio; the other two positions are its partner wave's, and the output transform joins
+// them through LDS once per tile.  Per 16 input channels: the raw fp32 window is read to registers, transformed (V, fp32), split and
+// written as two fp16 planes x four positions [(PH+2) PWP rows x 32 B] into one of two V buffers (40 KB each) while the previous chunk
+// is multiplied; the transformed weight planes of a (filter row, chunk) -- 4 positions x 2 planes x 128 channels x 32 B = 32 KB, stored
+// in exactly that order by lvc_amd.kernels.pack_wino -- arrive by LDS-DMA one stage ahead into a ring of two.  A stage = (chunk, filter
+// row): 24 MFMAs per wave, one barrier.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define WN_NT 512
+#define WN_PAIRS 128
+#define WN_CH 128
+#define WN_VROWS 160                       // most (PH + 2) * PWP rows of a V buffer: PH x PWP = 8 x 16 (160) or 16 x 8 (144)
+#define WN_PP (WN_VROWS * 32)              // bytes of one (plane, position) image
+#define WN_VBUF (8 * WN_PP)                // 40,960 B: 2 planes x 4 positions
+#define WN_USLOT (8 * WN_CH * 32)          // 32,768 B: 4 positions x 2 planes x 128 channel rows x 32 B
+#define WN_SMEM (2 * WN_VBUF + 2 * WN_USLOT)
+#define ACT_SCALE 16.f
+#define ACT_MAX 4094.f
+#define LVC_MAX_WORKERS 1024
+
+struct WinoArgs {
+  const float* x;              // [N,H,W,C]
+  const unsigned short* u;     // [3][C/16][4][2][Kpad][16] fp16: transformed, row-scaled weight planes (kernels.pack_wino)
+  const float* scale;          // [K] row factor (x FrozenBN scale)
+  const float* shift;          // [K] or null
+  float* y;                    // [N,H,W,ldy]
+  int* flags;
+  int N, H, W, C, K, Kpad, ldy, relu;
+  int PH, PWP, lg_pwp, tiles_x, tiles_y, tiles_n, ntiles, nk, err_index;
+  unsigned x_bytes, y_bytes;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+__device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
+template <int N> __device__ __forceinline__ void wn_wait_vm_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
+  unsigned char* const sV = smem;
+  unsigned char* const sU = smem + 2 * WN_VBUF;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
+  const int fi = lane & 31, fh = lane >> 5;
+
+  // ---- tile: (image, patch row, patch column, channel tile); consecutive ids share the patch (channel tile fastest) and land on one XCD
+  const int t = lvc_xcd_remap(blockIdx.x, p.ntiles);
+  const int tn = t % p.tiles_n;
+  int r0 = t / p.tiles_n;
+  const int tx = r0 % p.tiles_x;
+  r0 /= p.tiles_x;
+  const int ty = r0 % p.tiles_y;
+  const int img = r0 / p.tiles_y;
+  const int y0 = ty * p.PH, x0 = tx * 2 * p.PWP, n0 = tn * WN_CH;
+  const int VR = (p.PH + 2) * p.PWP;                  // V rows of this patch shape
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+
+  // ---- transform items: (V row, 4-channel group).  Round 0: item tid (V rows 0..127), round 1: item 512 + tid (the rest, waves 0..).
+  // Per item the byte offset of its first pixel (x0 + 2 vx - 1) and a 4-bit mask of the pixels inside the image.
+  const int q = tid & 3;
+  unsigned it_off[2], it_mask[2];
+  int it_lds[2];
+  bool it_on[2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int vrow = (tid >> 2) + 128 * rd;
+    it_on[rd] = vrow < VR;
+    const int vy = vrow >> p.lg_pwp, vx = vrow & (p.PWP - 1);
+    const int iy = y0 - 1 + vy, ix = x0 + 2 * vx - 1;
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= (it_on[rd] && iy >= 0 && iy < p.H && ix + j >= 0 && ix + j < p.W) ? (1u << j) : 0u;
+    it_mask[rd] = m;
+    it_off[rd] = (unsigned)((((long long)img * p.H + iy) * p.W + ix) * p.C + q * 4) * 4u;      // wraps for masked pixels: never used
+    it_lds[rd] = vrow * 32 + (((q >> 1) ^ ((vrow >> 3) & 1)) << 4) + (q & 1) * 8;
+  }
+  const unsigned pix_b = (unsigned)p.C * 4u;
+  f32x4 raw[2][4];        // one register set per transform round: each round's loads are two stages in flight
+  float big = 0.f;
+  auto load_raw = [&](int rd, int kc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned off = ((it_mask[rd] >> j) & 1u) ? it_off[rd] + (unsigned)j * pix_b + (unsigned)kc * 64u : 0x80000000u;
+      raw[rd][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+    }
+  };
+  auto store_v = [&](int rd, unsigned char* vb) {
+    f32x4 v[4];
+    v[0] = raw[rd][0] - raw[rd][2];
+    v[1] = raw[rd][1] + raw[rd][2];
+    v[2] = raw[rd][2] - raw[rd][1];
+    v[3] = raw[rd][1] - raw[rd][3];
+#pragma unroll
+    for (int pz = 0; pz < 4; ++pz) {
+      f16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = v[pz][e] * ACT_SCALE;
+        const f16 hh = (f16)a;
+        h[e] = hh;
+        l[e] = (f16)(a - (float)hh);
+        big = fmaxf(big, fabsf(v[pz][e]));
+      }
+      *reinterpret_cast<f16x4*>(vb + pz * WN_PP + it_lds[rd]) = h;
+      *reinterpret_cast<f16x4*>(vb + (4 + pz) * WN_PP + it_lds[rd]) = l;
+    }
+  };
+
+  // ---- weight DMA: wave w brings (position, plane) image w of a stage (4 KB = four 1 KB pieces of 32 channel rows)
+  const int nk = p.nk;
+  const size_t u_img = (size_t)p.Kpad * 16;                        // halves per (row, chunk, position, plane) image
+  const int u_row = lane >> 1, u_g = (lane & 1) ^ ((u_row >> 3) & 1);
+  const unsigned short* const u_src = p.u + (size_t)wave * u_img + (size_t)(n0 + u_row) * 16 + u_g * 8;
+  auto dma_u = [&](int kc, int r, int slot) {
+    const unsigned short* s = u_src + (size_t)((r * nk + kc) * 8) * u_img;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wn_glds16(s + j * 32 * 16, sU + slot * WN_USLOT + wave * 4096 + j * 1024);
+  };
+
+  // ---- fragments.  A: V row m + r PWP of (plane, position); B: channel row of (position, plane)
+  const int m_lo = wm * 64 + fi;                                  // + 32 mi
+  const int b_off = (wn * 64 + fi) * 32 + ((fh ^ ((fi >> 3) & 1)) << 4);          // + 32 * 32 ni
+  f32x16 acc[2][2][2];                                           // [position of the half][mi][ni]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][c][e] = 0.f;
+
+  auto stage_mma = [&](const unsigned char* vb, const unsigned char* ub, int r) {
+    // V row of this lane's fragment rows for filter row r, and its swizzled granule
+    int arow[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const int vrow = m_lo + 32 * mi + r * p.PWP;
+      arow[mi] = vrow * 32 + ((fh ^ ((vrow >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      const int pz = 2 * ph + pp;
+      f16x8 ahi[2], alo[2], bhi[2], blo[2];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+        ahi[mi] = *reinterpret_cast<const f16x8*>(vb + pz * WN_PP + arow[mi]);
+        alo[mi] = *reinterpret_cast<const f16x8*>(vb + (4 + pz) * WN_PP + arow[mi]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        bhi[ni] = *reinterpret_cast<const f16x8*>(ub + (pz * 2 + 0) * 4096 + b_off + ni * 1024);
+        blo[ni] = *reinterpret_cast<const f16x8*>(ub + (pz * 2 + 1) * 4096 + b_off + ni * 1024);
+      }
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[pp][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo[ni], acc[pp][mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[pp][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi[ni], acc[pp][mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[pp][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], bhi[ni], acc[pp][mi][ni], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: chunk 0 transformed into V buffer 0, the weights of stage (0, 0) in slot 0
+  dma_u(0, 0, 0);
+  load_raw(0, 0);
+  store_v(0, sV);
+  if (it_on[1]) {
+    load_raw(1, 0);
+    store_v(1, sV);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- stages.  Vector-memory operations of a wave, program order (D = the next stage's weight DMA, 4 ops; L0 / L1 = the raw window
+  // loads of transform round 0 / 1 of the NEXT chunk, 4 ops each; round 1 exists in the waves that own V rows >= 128):
+  //     r = 0:  D L0 | MFMAs |                                  barrier behind D        (L0 may stay in flight: vmcnt(4))
+  //     r = 1:  D    | MFMAs | store round 0 (compiler waits L0) | L1 | barrier behind D (vmcnt(4) where L1 was issued, else 0)
+  //     r = 2:  D    | MFMAs | store round 1 (compiler waits L1)      | barrier behind D (vmcnt(0))
+  // The loads are compiler-tracked builtins: their uses carry the compiler's own counted waits; only the DMA's completion (other
+  // waves read that LDS) needs the explicit ones.
+  // No branch inside a stage (a branch ends the scheduling region: the transform's VALU work must share one with the MFMAs to issue in
+  // their shadow): the last chunk transforms ITSELF again into the idle buffer, and the stage loop exists once per kind of wave (with /
+  // without a second transform round).
+  // Transform schedule (chunk kc multiplies V(kc)):  round 0 of chunk kc+1 (V rows 0..127): loads at the top of r = 0, transform + store
+  // under the MFMAs of r = 2;  round 1 (V rows 128.., the waves that own them): loads at the top of r = 1, transform + store under
+  // the MFMAs of the NEXT chunk's r = 0 -- into the buffer that stage reads, but it reads rows < 128 only (pair row + filter row 0);
+  // rows >= 128 are first needed by r = 1, behind r = 0's barrier.  Every load is two stages in flight.
+  auto stages = [&](auto on1_tag) {
+    constexpr bool ON1 = decltype(on1_tag)::value;
+#pragma unroll 1
+    for (int kc = 0; kc < nk; ++kc) {
+      unsigned char* vb = sV + (kc & 1) * WN_VBUF;
+      unsigned char* vnext = sV + ((kc + 1) & 1) * WN_VBUF;
+      const int kn = min(kc + 1, nk - 1);
+      const int s0 = (kc * 3) & 1;
+      // r = 0
+      dma_u(kc, 1, 1 - s0);
+      load_raw(0, kn);
+      stage_mma(vb, sU + s0 * WN_USLOT, 0);
+      if (ON1) store_v(1, vb);              // (chunk 0: the prologue's values once more)
+      __builtin_amdgcn_sched_barrier(0);
+      wn_wait_vm_lds<4>();                  // the DMA; round 0's loads may stay in flight
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // r = 1
+      dma_u(kc, 2, s0);
+      if (ON1) load_raw(1, kn);
+      stage_mma(vb, sU + (1 - s0) * WN_USLOT, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ON1) wn_wait_vm_lds<4>(); else wn_wait_vm_lds<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // r = 2
+      dma_u(kn, 0, 1 - s0);
+      stage_mma(vb, sU + s0 * WN_USLOT, 2);
+      store_v(0, vnext);
+      __builtin_amdgcn_sched_barrier(0);
+      wn_wait_vm_lds<0>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if (__builtin_amdgcn_readfirstlane((int)it_on[1])) stages(std::true_type{}); else stages(std::false_type{});
+  if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
+
+  // ---- output transform.  This wave holds M_{2 ph}, M_{2 ph + 1}; its partner (same rows and channels, other half) the other two.
+  // Half 0 finishes the EVEN pixel y[2t] = (M0 + M1) + M2 and needs M2; half 1 the odd one y[2t+1] = (M1 - M2) - M3 and needs M1:
+  // each writes the block the other needs (lane-linear, 16 KB per wave) into the ring the stage loop has left.
+  float* xch = reinterpret_cast<float*>(smem);
+  const int pair_slot = wm * 2 + wn;
+  {
+    float* mine = xch + ((size_t)(ph * 4 + pair_slot) * 4) * 1024;
+    const int give = ph == 0 ? 1 : 0;                            // half 0 gives M1 (its second position), half 1 gives M2 (its first)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mine[((mi * 2 + ni) * 16 + e) * 64 + lane] = ph == 0 ? acc[1][mi][ni][e] : acc[0][mi][ni][e];
+    (void)give;
+  }
+  __syncthreads();
+  const float* theirs = xch + ((size_t)((1 - ph) * 4 + pair_slot) * 4) * 1024;
+  const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, p.y_bytes, 0x00020000);
+  float sc[2], sh[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int ch = n0 + wn * 64 + ni * 32 + fi;
+    sc[ni] = ch < p.K ? p.scale[ch] : 0.f;
+    sh[ni] = (p.shift && ch < p.K) ? p.shift[ch] : 0.f;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;       // pair of the tile
+      const int py = m >> p.lg_pwp, px = m & (p.PWP - 1);
+      const int oy = y0 + py, ox = x0 + 2 * px + ph;
+      const bool ok = oy < p.H && ox < p.W;
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const float o = theirs[((mi * 2 + ni) * 16 + e) * 64 + lane];
+        float v = ph == 0 ? (acc[0][mi][ni][e] + acc[1][mi][ni][e]) + o : (o - acc[0][mi][ni][e]) - acc[1][mi][ni][e];
+        v = v * sc[ni] + sh[ni];
+        if (p.relu) v = v > 0.f ? v : 0.f;
+        const int ch = n0 + wn * 64 + ni * 32 + fi;
+        const unsigned off = (ok && ch < p.K) ? (unsigned)((((long long)img * p.H + oy) * p.W + ox) * p.ldy + ch) * 4u : 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, off, 0, 0);
+      }
+    }
+}
+
+// y = act(conv3x3(x, w) * scale + shift), stride 1, pad 1, as Winograd F(2,3) along x.  x [N,H,W,C] fp32 NHWC (C % 16 == 0), u = the
+// transformed weight planes [3][C/16][4][2][Kpad][16] fp16 with Kpad % 128 == 0 and scale [K] = their row factors (x the layer's
+// per-channel scale) as lvc_amd.kernels.pack_wino makes them; y [N,H,W,ldy].  An activation window value |V| > 4094 (or NaN) raises the
+// layer's range word in `workspace` (the conv workspace of the other kernels; only its error words are used).
+extern "C" int lvc_conv3x3_nhwc_wino(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H,
+                                     int W, int C, int K, int Kpad, int relu, int ldy, void* workspace, void* stream) {
+  LVC_CHECK_ARG(x && u && scale && y && workspace, "null pointer");
+  LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
+  LVC_CHECK_ARG(C % 16 == 0 && Kpad % WN_CH == 0 && Kpad >= K, "needs C % 16 == 0 and weight planes padded to 128 rows");
+  WinoArgs a;
+  a.x = x; a.u = u; a.scale = scale; a.shift = shift; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.Kpad = Kpad; a.ldy = ldy > 0 ? ldy : K; a.relu = relu;
+  const long long xb = (long long)N * H * W * C * 4, yb = (long long)N * H * W * a.ldy * 4;
+  LVC_CHECK_ARG(xb < (1ll << 31) && yb < (1ll << 31), "tensors must be smaller than 2 GiB");
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+  // patch shape: 8 rows x 16 pairs (32 pixels), or 16 rows x 8 pairs for maps that waste less on it
+  auto waste = [&](int phh, int pwp) { return (long long)lvc_cdiv(H, phh) * phh * lvc_cdiv(W, 2 * pwp) * 2 * pwp; };
+  if (waste(16, 8) < waste(8, 16)) { a.PH = 16; a.PWP = 8; a.lg_pwp = 3; } else { a.PH = 8; a.PWP = 16; a.lg_pwp = 4; }
+  a.tiles_x = lvc_cdiv(W, 2 * a.PWP); a.tiles_y = lvc_cdiv(H, a.PH); a.tiles_n = lvc_cdiv(K, WN_CH);
+  const long long nt = (long long)N * a.tiles_x * a.tiles_y * a.tiles_n;
+  LVC_CHECK_ARG(nt < (1ll << 31), "too many tiles");
+  a.ntiles = (int)nt;
+  a.nk = C / 16;
+  a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
+  a.err_index = LVC_MAX_WORKERS + lvc_range_slot();
+  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}

@@ -511,7 +511,13 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not two_acc:
+        if (engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not two_acc and CONV_WINO and residual is None and pc.K >= 128
+                and out.is_contiguous() and out.shape[-1] == pc.K and wino_tiles(N, H, W, pc.K) >= _WINO_MIN_TILES):
+            # Winograd F(2,3) along x on the maps that fill the chip with its one-workgroup tiles (csrc/conv3x3_wino.hip)
+            pc.last_one = True
+            engine = "f16x2_wino"
+            conv3x3_wino(x, pc, relu=relu, out=out)
+        elif engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not two_acc:
             planes, scale2 = pc.split2s()
             pc.last_one = True
             st = _lib.lib().lvc_conv3x3_nhwc_f16s1(
@@ -641,6 +647,55 @@ def _chain_planes(pc):
     return planes, (fac * pc.scale if pc.scale is not None else fac).contiguous()
 
 
+# 3x3 / stride 1 single-accumulator layers as Winograd F(2,3) along x (csrc/conv3x3_wino.hip: two thirds of the MFMAs at the direct
+# evaluation's fp32 error, scripts/winograd_error.py) where the launch has at least _WINO_MIN_TILES 256-pixel x 128-channel tiles --
+# the kernel is one workgroup per tile, no stream-K: small maps keep the direct kernel
+CONV_WINO = _os.environ.get("LVC_CONV_WINO", "1") != "0"
+_WINO_MIN_TILES = 1024
+
+
+def pack_wino(pc):
+    """Transformed, row-scaled fp16 weight planes of a packed 3x3 layer for lvc_conv3x3_nhwc_wino, cached on the PackedConv:
+    U0 = g0, U1 = (g0 + g1 + g2) / 2, U2 = (g0 - g1 + g2) / 2, U3 = g2 per filter row (formed in fp64, one fp32 rounding), split by
+    lvc_split_weights_rowscaled (rows scaled by a power of two so that neither plane leaves fp16's normal range), stored
+    [3 rows][C/16][4 positions][2 planes][Kpad][16].  -> (planes uint16, scale [K] = row factor x the layer's scale)."""
+    cached = pc.state.get("_wino")
+    if cached is not None and cached[0] is pc.w:
+        return cached[1], cached[2]
+    assert pc.R == 3 and pc.S == 3 and pc.mode == 0 and pc.C % 32 == 0
+    K, C = pc.K, pc.C
+    w = pc.w[:K].view(K, C // 32, 3, 3, 32).permute(0, 1, 4, 2, 3).reshape(K, C, 3, 3).double()       # OIHW from the (c/32, r, s, c%32) packing
+    g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]
+    U = torch.stack([g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2], dim=-1).float()                 # [K, C, 3 rows, 4 positions]
+    Kpad = (K + 127) // 128 * 128
+    flat = torch.zeros(Kpad, C * 12, device=pc.w.device)
+    flat[:K] = U.reshape(K, C * 12)
+    planes = torch.empty(2, Kpad, C * 12, dtype=torch.int16, device=pc.w.device)
+    fac = torch.empty(Kpad, device=pc.w.device)
+    check(_lib.lib().lvc_split_weights_rowscaled(ptr(flat), c_int(Kpad), c_int(C * 12), ptr(planes), ptr(fac), _stream(flat)), "lvc_split_weights_rowscaled")
+    u = planes.view(2, Kpad, C // 16, 16, 3, 4).permute(4, 2, 5, 0, 1, 3).contiguous()                 # [r][kc][p][plane][Kpad][16]
+    scale = (fac[:K] * pc.scale if pc.scale is not None else fac[:K]).contiguous()
+    pc.state["_wino"] = (pc.w, u, scale)
+    return u, scale
+
+
+def conv3x3_wino(x, pc, relu=False, out=None):
+    """y = act(conv3x3(x) * scale + shift) on the Winograd F(2,3) kernel.  x [N,H,W,C] fp32 NHWC contiguous."""
+    _req_cuda(x)
+    N, H, W, C = x.shape
+    u, scale = pack_wino(pc)
+    if out is None:
+        out = torch.empty(N, H, W, pc.K, device=x.device, dtype=torch.float32)
+    check(_lib.lib().lvc_conv3x3_nhwc_wino(ptr(x), ptr(u), ptr(scale), ptr(pc.shift), ptr(out), c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc.K),
+                                           c_int(u.shape[4]), c_int(1 if relu else 0), c_int(out.stride(2)), ptr(conv_workspace(x.device)), _stream(x)),
+          "lvc_conv3x3_nhwc_wino")
+    return out
+
+
+def wino_tiles(N, H, W, K):
+    return N * ((H + 7) // 8) * ((W + 31) // 32) * ((K + 127) // 128)
+
+
 _GROUP_SLOTS = {}
 
 
@@ -694,8 +749,19 @@ def conv3x3_levels(xs, pc, relu=False, outs=None):
         for x, q, o in zip(xs, pcs, outs):
             conv2d_nhwc(x, q, relu=relu, out=o)
         return outs
+    one = HALO_S1 == 2 and not (True in forms)
+    if one and CONV_WINO:
+        # maps large enough to fill the chip with one-workgroup tiles run on the Winograd F(2,3) kernel (two thirds of the MFMAs), each
+        # alone; the small ones stay one grouped launch of the direct kernel
+        big = [i for i, (x, q) in enumerate(zip(xs, pcs)) if wino_tiles(x.shape[0], x.shape[1], x.shape[2], q.K) >= _WINO_MIN_TILES and q.K >= 128]
+        if big:
+            for i in big:
+                conv2d_nhwc(xs[i], pcs[i], relu=relu, out=outs[i])
+            rest = [i for i in range(len(xs)) if i not in big]
+            if rest:
+                conv3x3_levels([xs[i] for i in rest], pc if shared else [pcs[i] for i in rest], relu=relu, outs=[outs[i] for i in rest])
+            return outs
     L = len(xs)
-    one = HALO_S1 == 2 and not forms.pop()
     timer = CONV_TIMER
     if timer is not None and (not timer.active or (timer.only is not None and "f16x2_halo" not in timer.only)):
         timer = None

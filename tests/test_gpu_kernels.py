@@ -870,6 +870,59 @@ def test_pointwise_256x256_tile_vs_fp64_and_the_256x128_tile(N, H, W, C, K, stri
     k.clear_conv_error_word(d)
 
 
+@pytest.mark.parametrize("N,H,W,C,K,relu,bias", [(2, 100, 168, 256, 256, True, True), (1, 37, 53, 64, 192, False, True), (3, 16, 33, 128, 128, True, False),
+                                                 (1, 8, 32, 32, 320, True, True), (2, 21, 7, 96, 128, False, False)])
+def test_conv3x3_winograd_vs_fp64_and_the_direct_kernel(N, H, W, C, K, relu, bias, monkeypatch):
+    """csrc/conv3x3_wino.hip (kernels.CONV_WINO: Winograd F(2,3) along x, 6 products per output) against the fp64 convolution and the
+    direct single-accumulator kernel it replaces on large maps: map sizes that are no multiple of the 8 x 32 / 16 x 16 patch, odd
+    widths (the last pair's second pixel does not exist), channel counts off the 128-channel tile, with and without bias / ReLU.  Its
+    error must stay at the direct kernel's level (measured: 0.7 x; scripts/winograd_error.py has the fp32 argument)."""
+    from lvc_amd import kernels as k
+
+    monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
+    monkeypatch.setattr(k, "CONV_SPLIT", "f16x2")
+    monkeypatch.setattr(k, "_HALO_H2_MIN_TILES", 0)
+    g = torch.Generator().manual_seed(H * W + C)
+    x = torch.randn(N, H, W, C, generator=g).relu_()
+    w = torch.randn(K, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    b = torch.randn(K, generator=g) * 0.1 if bias else None
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double() if bias else None, padding=1).permute(0, 2, 3, 1)
+    if relu:
+        ref = ref.relu()
+    sc = float(ref.abs().max())
+    d = _dev()
+    pc = k.pack_conv(w.to(d), bias=b.to(d) if bias else None, pad=1)
+    monkeypatch.setattr(k, "CONV_WINO", False)
+    direct = k.conv2d_nhwc(x.to(d), pc, relu=relu).cpu()
+    got = k.conv3x3_wino(x.to(d), pc, relu=relu).cpu()
+    assert k.conv_error_word(d) == 0
+    e_w = (got.double() - ref).abs()
+    e_d = (direct.double() - ref).abs()
+    rms_w, rms_d = float(e_w.pow(2).mean().sqrt()) / sc, float(e_d.pow(2).mean().sqrt()) / sc
+    print("3x3 %s C=%d K=%d: rms error / scale Winograd %.2e, direct %.2e; max %.2e / %.2e" % ((N, H, W), C, K, rms_w, rms_d, float(e_w.max()) / sc, float(e_d.max()) / sc))
+    cpu = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, b, padding=1).permute(0, 2, 3, 1)
+    if relu:
+        cpu = cpu.relu()
+    rms_cpu = float((cpu.double() - ref).pow(2).mean().sqrt()) / sc
+    print("   the reference's own fp32 CPU convolution: %.2e" % rms_cpu)
+    assert float(e_w.max()) <= 2e-5 * sc
+    # at the level of the kernel it replaces, or of the reference's fp32 evaluation (small maps run the direct case on the bf16x3 kernels,
+    # which are closer to fp64 than either)
+    assert rms_w <= max(1.25 * rms_d, 1.5 * rms_cpu) + 1e-9
+    # routed automatically for launches with enough tiles (and only then), same result
+    monkeypatch.setattr(k, "CONV_WINO", True)
+    monkeypatch.setattr(k, "_WINO_MIN_TILES", 1)
+    auto = k.conv2d_nhwc(x.to(d), pc, relu=relu).cpu()
+    assert torch.equal(auto, got) if K >= 128 else True
+    # range word: a window value beyond the single-accumulator form's 4094 raises the layer's word
+    xb = x.clone()
+    xb[0, H // 2, W // 2, 0] = 3000.0
+    xb[0, H // 2, min(W - 1, W // 2 + 1), 0] = 3000.0        # V1 = d1 + d2 = 6000
+    k.conv3x3_wino(xb.to(d), pc)
+    assert k.conv_error_word(d) & 2
+    k.clear_conv_error_word(d)
+
+
 @pytest.mark.parametrize("shape", ["res2", "res2.0", "res3"])
 def test_chained_conv3_conv1_matches_two_launches_and_fp64(shape):
     """csrc/conv_pw_chain.hip (kernels.CHAIN / LVC_CHAIN): a bottleneck's conv3 + FrozenBN + shortcut add + ReLU and the next block's
