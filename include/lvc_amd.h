@@ -141,6 +141,12 @@ int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const
  * C % 16 == 0; |window value| <= 4094 or the layer's range word in `workspace` is raised. */
 int lvc_conv3x3_nhwc_wino(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H, int W,
                           int C, int K, int Kpad, int relu, int ldy, void* workspace, void* stream);
+/* ... with a pointwise layer (<= 32 outputs; the RPN predictor, rpn.py:95-106) on top of act(conv): y [N,H,W,ldy] = its outputs, ZEROED
+ * by the caller, the hidden map is never written; K in {128, 256} (at most two atomically added slices per element: order-free).  pred_*
+ * as for lvc_conv3x3_nhwc_f16_levels_pred. */
+int lvc_conv3x3_nhwc_wino_pred(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H,
+                               int W, int C, int K, int Kpad, int relu, int ldy, const unsigned short* pred_w, const float* pred_scale,
+                               const float* pred_shift, int pred_K, int pred_rows, int pred_slot, void* workspace, void* stream);
 /* Pointwise (R = S = 1, pad 0) layers with a long contraction on the pipelined loop of the 3x3 kernel (csrc/conv_pw_s1.hip; the conv1
  * / FC layers of detectron2/modeling/backbone/resnet.py:195-211, roi_heads/box_head.py:80-93 and the ViT linears): y = act(conv(x,
  * w) * scale + shift (+ residual)), x [N,H,W,C] fp32 NHWC with C % 32 == 0, stride >= 1, relu: 0 none / 1 ReLU / 2 exact GELU,

@@ -53,6 +53,12 @@ struct WinoArgs {
   int N, H, W, C, K, Kpad, ldy, relu;
   int PH, PWP, lg_pwp, tiles_x, tiles_y, tiles_n, ntiles, nk, err_index;
   unsigned x_bytes, y_bytes;
+  // PRED: a pointwise layer on top of act(conv) (the RPN predictor): y = ITS output rows (ldy floats, zeroed by the caller)
+  const unsigned short* pred_w;     // [2][pred_rows][K] fp16 planes of lvc_split_weights
+  const float* pred_scale;
+  const float* pred_shift;
+  long long pred_plane;
+  int pred_K, pred_err_index;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -60,6 +66,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
 template <int N> __device__ __forceinline__ void wn_wait_vm_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
+template <bool PRED>
 __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
   unsigned char* const sV = smem;
@@ -285,33 +292,114 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
     sc[ni] = ch < p.K ? p.scale[ch] : 0.f;
     sh[ni] = (p.shift && ch < p.K) ? p.shift[ch] : 0.f;
   }
+  if constexpr (!PRED) {
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int m = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;       // pair of the tile
-      const int py = m >> p.lg_pwp, px = m & (p.PWP - 1);
-      const int oy = y0 + py, ox = x0 + 2 * px + ph;
-      const bool ok = oy < p.H && ox < p.W;
+      for (int e = 0; e < 16; ++e) {
+        const int m = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;       // pair of the tile
+        const int py = m >> p.lg_pwp, px = m & (p.PWP - 1);
+        const int oy = y0 + py, ox = x0 + 2 * px + ph;
+        const bool ok = oy < p.H && ox < p.W;
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const float o = theirs[((mi * 2 + ni) * 16 + e) * 64 + lane];
-        float v = ph == 0 ? (acc[0][mi][ni][e] + acc[1][mi][ni][e]) + o : (o - acc[0][mi][ni][e]) - acc[1][mi][ni][e];
-        v = v * sc[ni] + sh[ni];
-        if (p.relu) v = v > 0.f ? v : 0.f;
-        const int ch = n0 + wn * 64 + ni * 32 + fi;
-        const unsigned off = (ok && ch < p.K) ? (unsigned)((((long long)img * p.H + oy) * p.W + ox) * p.ldy + ch) * 4u : 0xfffffff0u;
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, off, 0, 0);
+        for (int ni = 0; ni < 2; ++ni) {
+          const float o = theirs[((mi * 2 + ni) * 16 + e) * 64 + lane];
+          float v = ph == 0 ? (acc[0][mi][ni][e] + acc[1][mi][ni][e]) + o : (o - acc[0][mi][ni][e]) - acc[1][mi][ni][e];
+          v = v * sc[ni] + sh[ni];
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          const int ch = n0 + wn * 64 + ni * 32 + fi;
+          const unsigned off = (ok && ch < p.K) ? (unsigned)((((long long)img * p.H + oy) * p.W + ox) * p.ldy + ch) * 4u : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yres, off, 0, 0);
+        }
+      }
+  } else {
+    // ---- a pointwise layer on top (the RPN predictor; csrc/conv3x3_halo_s1.hip has the same epilogue): the workgroup holds act(conv)
+    // for 128 of the K hidden channels of its 256 pixels = a 128-deep slice of that layer's contraction.  The hidden tile goes to LDS
+    // ([pixel][channel] fp32; pixel row 2 m + parity), every wave multiplies 32 pixels x 128 channels by the layer's fp16 planes (read
+    // from L1 / L2; two-accumulator split: main a1 b1, cross (a2 b1 + a1 b2) x 2^-11) and adds its 32 x pred_K block to the ZEROED
+    // output atomically: K <= 256 -> at most two addends per element, the sum does not depend on their order.
+    constexpr int CSS = WN_CH + 4;
+    float bigp = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const float o = theirs[((mi * 2 + ni) * 16 + e) * 64 + lane];
+          float v = ph == 0 ? (acc[0][mi][ni][e] + acc[1][mi][ni][e]) + o : (o - acc[0][mi][ni][e]) - acc[1][mi][ni][e];
+          v = v * sc[ni] + sh[ni];
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          bigp = (fabsf(v) > bigp || v != v) ? fabsf(v) : bigp;
+          acc[0][mi][ni][e] = v;
+        }
+    __syncthreads();                      // every wave has read its partner's block: the ring may be overwritten
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) Cs[(2 * m + ph) * CSS + wn * 64 + ni * 32 + fi] = acc[0][mi][ni][e];
+      }
+    __syncthreads();
+    const unsigned short* bsrcp = p.pred_w + (size_t)fi * p.K + n0 + fh * 8;
+    f16x8 pbh = *reinterpret_cast<const f16x8*>(bsrcp), pbl = *reinterpret_cast<const f16x8*>(bsrcp + p.pred_plane);
+    f32x16 pm, px2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { pm[e] = 0.f; px2[e] = 0.f; }
+    const float* arow = Cs + (wave * 32 + fi) * CSS + fh * 8;
+#pragma unroll 1
+    for (int ks = 0; ks < WN_CH / 16; ++ks) {
+      const int kn = ks + 1 < WN_CH / 16 ? ks + 1 : ks;
+      const f16x8 nbh = *reinterpret_cast<const f16x8*>(bsrcp + kn * 16);
+      const f16x8 nbl = *reinterpret_cast<const f16x8*>(bsrcp + p.pred_plane + kn * 16);
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + ks * 16);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(arow + ks * 16 + 4);
+      f16x8 ah, al;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float a = j < 4 ? a0[j & 3] : a1[j & 3];
+        const f16 hh = (f16)a;
+        ah[j] = hh;
+        al[j] = (f16)((a - (float)hh) * 2048.f);
+      }
+      pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pbh, pm, 0, 0, 0);
+      px2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, pbh, px2, 0, 0, 0);
+      px2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pbl, px2, 0, 0, 0);
+      pbh = nbh; pbl = nbl;
+    }
+    // the 32 x 32 result block back through the wave's OWN rows of the tile (no other wave touches them), then out two pixels x pred_K
+    // outputs per instruction
+    float* rblk = Cs + wave * 32 * CSS;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rblk[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fi] = pm[e] + px2[e] * (1.f / 2048.f);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (fi < p.pred_K) {
+      const float psc = p.pred_scale ? p.pred_scale[fi] : 1.f;
+      const float psh = (n0 == 0 && p.pred_shift) ? p.pred_shift[fi] : 0.f;     // the bias once: with the first slice
+#pragma unroll 2
+      for (int rr = 0; rr < 32; rr += 2) {
+        const int r = wave * 32 + rr + fh;                                      // tile pixel row: pair r / 2, parity r & 1
+        const int m = r >> 1;
+        const int oy = y0 + (m >> p.lg_pwp), ox = x0 + 2 * (m & (p.PWP - 1)) + (r & 1);
+        const float v = rblk[(rr + fh) * 32 + fi];
+        if (oy < p.H && ox < p.W) unsafeAtomicAdd(p.y + ((size_t)((long long)img * p.H + oy) * p.W + ox) * p.ldy + fi, v * psc + psh);
       }
     }
+    if (!(bigp <= 65504.f)) atomicOr(p.flags + p.pred_err_index, bigp < INFINITY ? 2 : 4);      // the pointwise layer's own range word
+  }
 }
 
 // y = act(conv3x3(x, w) * scale + shift), stride 1, pad 1, as Winograd F(2,3) along x.  x [N,H,W,C] fp32 NHWC (C % 16 == 0), u = the
 // transformed weight planes [3][C/16][4][2][Kpad][16] fp16 with Kpad % 128 == 0 and scale [K] = their row factors (x the layer's
 // per-channel scale) as lvc_amd.kernels.pack_wino makes them; y [N,H,W,ldy].  An activation window value |V| > 4094 (or NaN) raises the
 // layer's range word in `workspace` (the conv workspace of the other kernels; only its error words are used).
-extern "C" int lvc_conv3x3_nhwc_wino(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H,
-                                     int W, int C, int K, int Kpad, int relu, int ldy, void* workspace, void* stream) {
+static int wino_launch(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H, int W, int C,
+                       int K, int Kpad, int relu, int ldy, const unsigned short* pred_w, const float* pred_scale, const float* pred_shift,
+                       int pred_K, int pred_rows, int pred_slot, void* workspace, void* stream) {
   LVC_CHECK_ARG(x && u && scale && y && workspace, "null pointer");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
   LVC_CHECK_ARG(C % 16 == 0 && Kpad % WN_CH == 0 && Kpad >= K, "needs C % 16 == 0 and weight planes padded to 128 rows");
@@ -331,7 +419,34 @@ extern "C" int lvc_conv3x3_nhwc_wino(const float* x, const unsigned short* u, co
   a.nk = C / 16;
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS + lvc_range_slot();
-  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+  a.pred_w = pred_w; a.pred_scale = pred_scale; a.pred_shift = pred_shift; a.pred_K = pred_K;
+  a.pred_plane = (long long)pred_rows * K;
+  a.pred_err_index = LVC_MAX_WORKERS + pred_slot;
+  if (pred_w) {
+    LVC_CHECK_ARG(K % WN_CH == 0 && K <= 2 * WN_CH, "the pointwise layer on top needs 128 or 256 hidden channels (at most two slices per output)");
+    LVC_CHECK_ARG(pred_K >= 1 && pred_K <= 32 && pred_rows >= 32 && pred_slot >= 0 && pred_slot < lvc_range_slots(), "bad pointwise layer");
+    hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+  }
   LVC_CHECK_LAUNCH();
   return LVC_OK;
+}
+
+extern "C" int lvc_conv3x3_nhwc_wino(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H,
+                                     int W, int C, int K, int Kpad, int relu, int ldy, void* workspace, void* stream) {
+  return wino_launch(x, u, scale, shift, y, N, H, W, C, K, Kpad, relu, ldy, nullptr, nullptr, nullptr, 0, 0, 0, workspace, stream);
+}
+
+// ... with a pointwise layer `pred` (<= 32 outputs) on top of act(conv): y [N,H,W,ldy] = ITS outputs, ZEROED by the caller; the hidden map is
+// never written (each workgroup adds its 128-channel slice of the contraction atomically: K in {128, 256}, at most two addends per
+// element).  pred_w: [2][pred_rows][K] fp16 planes of lvc_split_weights (pred_rows >= 32), pred_scale / pred_shift [pred_K] or NULL;
+// pred_slot: the pointwise layer's range word (a hidden value beyond fp16's range).  The arguments of lvc_conv3x3_nhwc_f16_levels_pred.
+extern "C" int lvc_conv3x3_nhwc_wino_pred(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N,
+                                          int H, int W, int C, int K, int Kpad, int relu, int ldy, const unsigned short* pred_w,
+                                          const float* pred_scale, const float* pred_shift, int pred_K, int pred_rows, int pred_slot,
+                                          void* workspace, void* stream) {
+  LVC_CHECK_ARG(pred_w, "null pointer");
+  return wino_launch(x, u, scale, shift, y, N, H, W, C, K, Kpad, relu, ldy, pred_w, pred_scale, pred_shift, pred_K, pred_rows, pred_slot, workspace,
+                     stream);
 }

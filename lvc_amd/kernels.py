@@ -651,6 +651,7 @@ def _chain_planes(pc):
 # evaluation's fp32 error, scripts/winograd_error.py) where the launch has at least _WINO_MIN_TILES 256-pixel x 128-channel tiles --
 # the kernel is one workgroup per tile, no stream-K: small maps keep the direct kernel
 CONV_WINO = _os.environ.get("LVC_CONV_WINO", "1") != "0"
+WINO_RPN = True        # the RPN head's large levels too (kernels.conv3x3_levels_pred); False: the two-accumulator direct kernel for all levels
 _WINO_MIN_TILES = 1024
 
 
@@ -795,7 +796,7 @@ def conv3x3_levels(xs, pc, relu=False, outs=None):
     return outs
 
 
-def conv3x3_levels_pred(xs, pc, pred, relu=True):
+def conv3x3_levels_pred(xs, pc, pred, relu=True, _outs=None):
     """act(conv3x3(xs[l])) through the pointwise layer `pred` (<= 32 outputs) in the ONE launch of `conv3x3_levels`: the hidden maps are
     never written -- every workgroup of the 3x3 kernel contracts its 128 hidden channels with the pointwise weights in its epilogue and
     adds the slice to the (zeroed) output atomically (two slices per element: order-free, csrc/conv3x3_halo_s1.hip).  The RPN head:
@@ -814,13 +815,51 @@ def conv3x3_levels_pred(xs, pc, pred, relu=True):
           and N * ((max(x.shape[1] * x.shape[2] for x in xs) + 255) // 256) * ((pc.K + 127) // 128) >= _HALO_H2_MIN_TILES)
     if not ok:
         return None
-    L = len(xs)
     ms = [x.shape[0] * x.shape[1] * x.shape[2] for x in xs]
-    y = torch.zeros(sum(ms), pred.K, device=xs[0].device, dtype=torch.float32)
-    outs, off = [], 0
-    for x, m in zip(xs, ms):
-        outs.append(y[off:off + m].view(x.shape[0], x.shape[1], x.shape[2], pred.K))
-        off += m
+    if _outs is None:
+        y = torch.zeros(sum(ms), pred.K, device=xs[0].device, dtype=torch.float32)
+        outs, off = [], 0
+        for x, m in zip(xs, ms):
+            outs.append(y[off:off + m].view(x.shape[0], x.shape[1], x.shape[2], pred.K))
+            off += m
+    else:
+        outs = _outs
+    if CONV_WINO and WINO_RPN and HALO_S1 == 2 and pc.state["tier"] == 0:
+        # The levels that fill the chip with one-workgroup tiles on the Winograd kernel, each alone, with the same epilogue; the small
+        # ones stay one grouped launch of the two-accumulator direct kernel.  (The head is packed `two_acc`: its logits decide top-k and
+        # NMS.  The Winograd form's measured error lies between the two direct forms' -- rms 4.8e-8 of the output scale against 6.7e-8
+        # one accumulator / ~4e-8 two -- and the post-trunk chain test holds it to the same logit bar: tests/test_gpu_chain.py.)
+        big = [i for i, x in enumerate(xs) if wino_tiles(x.shape[0], x.shape[1], x.shape[2], pc.K) >= _WINO_MIN_TILES]
+        if big:
+            u, scale = pack_wino(pc)
+            pplanes = pred.split2h()
+            pc.last_one = True
+            pred.last_one = False
+            wt = CONV_TIMER
+            if wt is not None and (not wt.active or (wt.only is not None and "f16x2_wino" not in wt.only)):
+                wt = None
+            for i in big:
+                x = xs[i]
+                if wt is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                _lib.lib().lvc_set_range_slot(c_int(pc.slot))
+                st = _lib.lib().lvc_conv3x3_nhwc_wino_pred(ptr(x), ptr(u), ptr(scale), ptr(pc.shift), ptr(outs[i]), c_int(N), c_int(x.shape[1]), c_int(x.shape[2]),
+                                                          c_int(C), c_int(pc.K), c_int(u.shape[4]), c_int(1 if relu else 0), c_int(pred.K), ptr(pplanes),
+                                                          ptr(pred.scale), ptr(pred.shift), c_int(pred.K), c_int(pred.w.shape[0]), c_int(pred.slot),
+                                                          ptr(conv_workspace(x.device)), _stream(x))
+                _lib.lib().lvc_set_range_slot(c_int(0))
+                check(st, "lvc_conv3x3_nhwc_wino_pred")
+                if wt is not None:
+                    e1.record()
+                    px = x.shape[0] * x.shape[1] * x.shape[2]
+                    wt.records.append((2.0 * px * pc.K * (C * 9 + pred.K), e0, e1, "f16x2_wino", 4.0 * (px * C + px * pred.K + pc.K * (C * 9 + pred.K))))
+            rest = [i for i in range(len(xs)) if i not in big]
+            if rest:
+                sub = conv3x3_levels_pred([xs[i] for i in rest], pc, pred, relu=relu, _outs=[outs[i] for i in rest])
+                assert sub is not None
+            return outs
+    L = len(xs)
     timer = CONV_TIMER
     if timer is not None and (not timer.active or (timer.only is not None and "f16x2_halo" not in timer.only)):
         timer = None
