@@ -827,7 +827,7 @@ def infer_main(c, args):
         roofline = {
             "kernel": "%s (%d launches/step; HIP-event brackets in %d of the %d timed steps)" % (NAMES[dom], nlaunch // max(1, timer.steps_timed()), timer.steps_timed(), args.steps),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split, a1 b1 + a1 b2 + a2 b1 in fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once; under the socket power cap a bare loop of these MFMAs on random data sustains 1.66 PFLOP/s = 552 TFLOP/s fp32-equivalent (profiles/r03_mfma_ceiling.txt)",
+            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split, a1 b1 + a1 b2 + a2 b1 in fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once (2 M K C 9 for a 3x3 layer -- also for the Winograd F(2,3) kernel, which issues two thirds of the direct form's MFMAs for them: its ceiling in this unit is 1.5 x 833); under the socket power cap a bare loop of these MFMAs on random data sustains 1.66 PFLOP/s = 552 TFLOP/s fp32-equivalent (profiles/r03_mfma_ceiling.txt)",
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic,
             "traffic_source": ("live rocprofv3 --pmc passes in this run" if live is not None else "profiles (not measured in this run)")
@@ -940,7 +940,7 @@ def _live_conv_pmc(timeout_s=90):
         return None
     tmp = tempfile.mkdtemp(prefix="lvc_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
-    agg, ms = {}, None
+    agg, ms, kname = {}, None, "?"
     try:
         passes = ["FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"]
         for i, ctr in enumerate(passes):
@@ -951,18 +951,19 @@ def _live_conv_pmc(timeout_s=90):
                 return None
             for f in glob.glob(os.path.join(tmp, "**", "t%d*counter_collection.csv" % i), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "halo" in row["Kernel_Name"]:
+                    if "conv3x3" in row["Kernel_Name"]:
                         agg[row["Counter_Name"]] = float(row["Counter_Value"])      # the last launch of the pass
+                        kname = row["Kernel_Name"].split("(")[0]
             if i == 2:
                 for f in glob.glob(os.path.join(tmp, "**", "t2*kernel_trace.csv"), recursive=True):
-                    d = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in csv.DictReader(open(f)) if "halo" in x["Kernel_Name"]]
+                    d = [(int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e6 for x in csv.DictReader(open(f)) if "conv3x3" in x["Kernel_Name"]]
                     ms = d[-1] if d else None
         if "FETCH_SIZE" not in agg or "WRITE_SIZE" not in agg:
             return None
         cyc = agg.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         alg = 8 * 200 * 336 * 256 * 4 * 2 + 256 * 2304 * 4      # the p2 activation tensor read once and written once + the weights
         out = {"source": "live: rocprofv3 --pmc passes of scripts/probe_one.py 8 256 200 336 256 3 1 1 on this box, inside this bench run",
-               "launch": "the 3x3 fp16-split kernel (conv3x3_halo_s1_kernel), 3x3 256 -> 256 on [8,200,336,256]: the largest 3x3 launch, 2 per step",
+               "launch": "the 3x3 layer 256 -> 256 on [8,200,336,256] (fpn_output2; the RPN head on p2 is the same shape) on the kernel the detector runs it on: " + kname,
                "hbm_bytes_per_launch": int(2 * agg["FETCH_SIZE"] * 1024 + agg["WRITE_SIZE"] * 1024),
                "correction": "FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide coalesced reads at 64 B: MI355X_MICROARCH.md, HBM), WRITE_SIZE as is",
                "algorithmic_bytes_per_launch": alg,

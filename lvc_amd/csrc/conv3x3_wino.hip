@@ -64,6 +64,24 @@ struct WinoArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
+// The stage loop's vector-memory operations are issued as inline asm the compiler does not track: left to it, every LDS read behind an
+// LDS-DMA of the same scheduling region is preceded by s_waitcnt vmcnt(0) (the DMA's destination may alias the read) -- the weight DMA
+// just issued for the NEXT stage then has to land before the CURRENT stage's first MFMA can start, 0.4 us per stage.  Completion is the
+// counted waits before the barriers (wn_wait_*), which also tie the destination registers.
+__device__ __forceinline__ void wn_dma16(const void* g, unsigned lds_byte) {
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte) : "memory", "m0");
+}
+__device__ __forceinline__ f32x4 wn_load_untracked(u32x4 rsrc, unsigned voff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
+  return v;
+}
+template <int N> __device__ __forceinline__ void wn_wait_tied2(f32x4& a, f32x4& b) {
+  asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+template <int N> __device__ __forceinline__ void wn_wait_tied(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
+}
 template <int N> __device__ __forceinline__ void wn_wait_vm_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 
 template <bool PRED>
@@ -90,56 +108,86 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   const int VR = (p.PH + 2) * p.PWP;                  // V rows of this patch shape
 
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const unsigned long long xbase = (unsigned long long)p.x;
+  const u32x4 xres_u = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)xbase), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(xbase >> 32) & 0xffffu),
+                        p.x_bytes, 0x00020000u};
 
-  // ---- transform items: (V row, 4-channel group).  Round 0: item tid (V rows 0..127), round 1: item 512 + tid (the rest, waves 0..).
-  // Per item the byte offset of its first pixel (x0 + 2 vx - 1) and a 4-bit mask of the pixels inside the image.
+  // ---- transform work of a thread per 16-channel chunk.  Round 0: ONE item = (V row tid / 4 < 128, 4-channel group tid % 4): four
+  // pixels in, four positions out.  Round 1 (the V rows >= 128: the last two window rows): ONE (item, position) = (V row 128 + tid / 16,
+  // position (tid / 4) % 4, group tid % 4): two pixels in, one position out -- every wave carries the same load (with whole items the
+  // two waves that owned the extra rows kept the other six waiting at every barrier).  Per item the byte offset of its first pixel
+  // (x0 + 2 vx - 1) and which of its pixels lie inside the image.
   const int q = tid & 3;
-  unsigned it_off[2], it_mask[2];
-  int it_lds[2];
-  bool it_on[2];
-#pragma unroll
-  for (int rd = 0; rd < 2; ++rd) {
-    const int vrow = (tid >> 2) + 128 * rd;
-    it_on[rd] = vrow < VR;
+  const unsigned pix_b = (unsigned)p.C * 4u;
+  unsigned off0, mask0, off1[2];
+  int lds0, lds1;
+  bool on1;
+  float sgn1;
+  {
+    const int vrow = tid >> 2;
     const int vy = vrow >> p.lg_pwp, vx = vrow & (p.PWP - 1);
     const int iy = y0 - 1 + vy, ix = x0 + 2 * vx - 1;
     unsigned m = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m |= (it_on[rd] && iy >= 0 && iy < p.H && ix + j >= 0 && ix + j < p.W) ? (1u << j) : 0u;
-    it_mask[rd] = m;
-    it_off[rd] = (unsigned)((((long long)img * p.H + iy) * p.W + ix) * p.C + q * 4) * 4u;      // wraps for masked pixels: never used
-    it_lds[rd] = vrow * 32 + (((q >> 1) ^ ((vrow >> 3) & 1)) << 4) + (q & 1) * 8;
+    for (int j = 0; j < 4; ++j) m |= (iy >= 0 && iy < p.H && ix + j >= 0 && ix + j < p.W) ? (1u << j) : 0u;
+    mask0 = m;
+    off0 = (unsigned)((((long long)img * p.H + iy) * p.W + ix) * p.C + q * 4) * 4u;      // wraps for masked pixels: never used
+    lds0 = vrow * 32 + (((q >> 1) ^ ((vrow >> 3) & 1)) << 4) + (q & 1) * 8;
   }
-  const unsigned pix_b = (unsigned)p.C * 4u;
-  f32x4 raw[2][4];        // one register set per transform round: each round's loads are two stages in flight
+  {
+    const int vrow = 128 + (tid >> 4), pz = (tid >> 2) & 3;
+    on1 = vrow < VR;
+    const int vy = vrow >> p.lg_pwp, vx = vrow & (p.PWP - 1);
+    const int iy = y0 - 1 + vy, ix = x0 + 2 * vx - 1;
+    // position -> (first pixel, second pixel, sign):  V0 = d0 - d2, V1 = d1 + d2, V2 = d2 - d1, V3 = d1 - d3
+    const int ja = pz == 0 ? 0 : pz == 2 ? 2 : 1, jb = pz == 3 ? 3 : pz == 2 ? 1 : 2;
+    sgn1 = pz == 1 ? 1.f : -1.f;
+    const unsigned base = (unsigned)((((long long)img * p.H + iy) * p.W + ix) * p.C + q * 4) * 4u;
+    const bool rowok = on1 && iy >= 0 && iy < p.H;
+    off1[0] = (rowok && ix + ja >= 0 && ix + ja < p.W) ? base + (unsigned)ja * pix_b : 0x80000000u;
+    off1[1] = (rowok && ix + jb >= 0 && ix + jb < p.W) ? base + (unsigned)jb * pix_b : 0x80000000u;
+    lds1 = pz * WN_PP + vrow * 32 + (((q >> 1) ^ ((vrow >> 3) & 1)) << 4) + (q & 1) * 8;
+  }
+  f32x4 raw0[4], raw1[2];
   float big = 0.f;
-  auto load_raw = [&](int rd, int kc) {
+  // `untracked`: the stage loop's loads (inline asm, completion by the counted waits); the prologue uses the compiler's
+  auto load0 = [&](int kc, auto untracked) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const unsigned off = ((it_mask[rd] >> j) & 1u) ? it_off[rd] + (unsigned)j * pix_b + (unsigned)kc * 64u : 0x80000000u;
-      raw[rd][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+      const unsigned off = ((mask0 >> j) & 1u) ? off0 + (unsigned)j * pix_b + (unsigned)kc * 64u : 0x80000000u;
+      if constexpr (decltype(untracked)::value) raw0[j] = wn_load_untracked(xres_u, off);
+      else raw0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
     }
   };
-  auto store_v = [&](int rd, unsigned char* vb) {
-    f32x4 v[4];
-    v[0] = raw[rd][0] - raw[rd][2];
-    v[1] = raw[rd][1] + raw[rd][2];
-    v[2] = raw[rd][2] - raw[rd][1];
-    v[3] = raw[rd][1] - raw[rd][3];
+  auto load1 = [&](int kc, auto untracked) {
 #pragma unroll
-    for (int pz = 0; pz < 4; ++pz) {
-      f16x4 h, l;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float a = v[pz][e] * ACT_SCALE;
-        const f16 hh = (f16)a;
-        h[e] = hh;
-        l[e] = (f16)(a - (float)hh);
-        big = fmaxf(big, fabsf(v[pz][e]));
-      }
-      *reinterpret_cast<f16x4*>(vb + pz * WN_PP + it_lds[rd]) = h;
-      *reinterpret_cast<f16x4*>(vb + (4 + pz) * WN_PP + it_lds[rd]) = l;
+    for (int j = 0; j < 2; ++j) {
+      const unsigned off = off1[j] == 0x80000000u ? 0x80000000u : off1[j] + (unsigned)kc * 64u;
+      if constexpr (decltype(untracked)::value) raw1[j] = wn_load_untracked(xres_u, off);
+      else raw1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
     }
+  };
+  auto split_store = [&](f32x4 v, unsigned char* hi_dst) {       // hi plane at hi_dst, lo plane 4 position images further
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = v[e] * ACT_SCALE;
+      const f16 hh = (f16)a;
+      h[e] = hh;
+      l[e] = (f16)(a - (float)hh);
+      big = fmaxf(big, fabsf(v[e]));
+    }
+    *reinterpret_cast<f16x4*>(hi_dst) = h;
+    *reinterpret_cast<f16x4*>(hi_dst + 4 * WN_PP) = l;
+  };
+  auto store0 = [&](unsigned char* vb) {
+    split_store(raw0[0] - raw0[2], vb + 0 * WN_PP + lds0);
+    split_store(raw0[1] + raw0[2], vb + 1 * WN_PP + lds0);
+    split_store(raw0[2] - raw0[1], vb + 2 * WN_PP + lds0);
+    split_store(raw0[1] - raw0[3], vb + 3 * WN_PP + lds0);
+  };
+  auto store1 = [&](unsigned char* vb) {      // no branch: V rows VR .. 159 of the smaller patch shape exist in the buffer and are never read
+    split_store(raw1[0] + sgn1 * raw1[1], vb + lds1);
   };
 
   // ---- weight DMA: wave w brings (position, plane) image w of a stage (4 KB = four 1 KB pieces of 32 channel rows)
@@ -151,6 +199,12 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
     const unsigned short* s = u_src + (size_t)((r * nk + kc) * 8) * u_img;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wn_glds16(s + j * 32 * 16, sU + slot * WN_USLOT + wave * 4096 + j * 1024);
+  };
+  const unsigned su_byte = (unsigned)(size_t)(sU - smem) + (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto dma_u_u = [&](int kc, int r, int slot) {      // the stage loop's form: untracked
+    const unsigned short* s = u_src + (size_t)((r * nk + kc) * 8) * u_img;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wn_dma16(s + j * 32 * 16, su_byte + (unsigned)(slot * WN_USLOT + wave * 4096 + j * 1024));
   };
 
   // ---- fragments.  A: V row m + r PWP of (plane, position); B: channel row of (position, plane)
@@ -205,65 +259,52 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
 
   // ---- prologue: chunk 0 transformed into V buffer 0, the weights of stage (0, 0) in slot 0
   dma_u(0, 0, 0);
-  load_raw(0, 0);
-  store_v(0, sV);
-  if (it_on[1]) {
-    load_raw(1, 0);
-    store_v(1, sV);
-  }
+  load0(0, std::false_type{});
+  load1(0, std::false_type{});
+  store0(sV);
+  store1(sV);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- stages.  Vector-memory operations of a wave, program order (D = the next stage's weight DMA, 4 ops; L0 / L1 = the raw window
-  // loads of transform round 0 / 1 of the NEXT chunk, 4 ops each; round 1 exists in the waves that own V rows >= 128):
-  //     r = 0:  D L0 | MFMAs |                                  barrier behind D        (L0 may stay in flight: vmcnt(4))
-  //     r = 1:  D    | MFMAs | store round 0 (compiler waits L0) | L1 | barrier behind D (vmcnt(4) where L1 was issued, else 0)
-  //     r = 2:  D    | MFMAs | store round 1 (compiler waits L1)      | barrier behind D (vmcnt(0))
-  // The loads are compiler-tracked builtins: their uses carry the compiler's own counted waits; only the DMA's completion (other
-  // waves read that LDS) needs the explicit ones.
-  // No branch inside a stage (a branch ends the scheduling region: the transform's VALU work must share one with the MFMAs to issue in
-  // their shadow): the last chunk transforms ITSELF again into the idle buffer, and the stage loop exists once per kind of wave (with /
-  // without a second transform round).
+  // ---- stages.  No branch inside a stage (a branch ends the scheduling region: the transform's VALU work must share one with the MFMAs
+  // to issue in their shadow): the last chunk transforms ITSELF again into the idle buffer.
   // Transform schedule (chunk kc multiplies V(kc)):  round 0 of chunk kc+1 (V rows 0..127): loads at the top of r = 0, transform + store
-  // under the MFMAs of r = 2;  round 1 (V rows 128.., the waves that own them): loads at the top of r = 1, transform + store under
-  // the MFMAs of the NEXT chunk's r = 0 -- into the buffer that stage reads, but it reads rows < 128 only (pair row + filter row 0);
-  // rows >= 128 are first needed by r = 1, behind r = 0's barrier.  Every load is two stages in flight.
-  auto stages = [&](auto on1_tag) {
-    constexpr bool ON1 = decltype(on1_tag)::value;
+  // under the MFMAs of r = 2;  round 1 (V rows 128..): loads at the top of r = 1, transform + store under the MFMAs of the NEXT chunk's
+  // r = 0 -- into the buffer that stage reads, but it reads rows < 128 only (pair row + filter row 0); rows >= 128 are first needed by
+  // r = 1, behind r = 0's barrier.  In-order queue of a wave (D = 4 DMA ops, L0 = 4 loads, L1 = 2):  r0: D L0 | r1: D L1 | r2: D.
+  // A wait for a stage's D also completes everything older: L0 is complete behind r1's barrier wait, L1 behind r2's.
 #pragma unroll 1
-    for (int kc = 0; kc < nk; ++kc) {
-      unsigned char* vb = sV + (kc & 1) * WN_VBUF;
-      unsigned char* vnext = sV + ((kc + 1) & 1) * WN_VBUF;
-      const int kn = min(kc + 1, nk - 1);
-      const int s0 = (kc * 3) & 1;
-      // r = 0
-      dma_u(kc, 1, 1 - s0);
-      load_raw(0, kn);
-      stage_mma(vb, sU + s0 * WN_USLOT, 0);
-      if (ON1) store_v(1, vb);              // (chunk 0: the prologue's values once more)
-      __builtin_amdgcn_sched_barrier(0);
-      wn_wait_vm_lds<4>();                  // the DMA; round 0's loads may stay in flight
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // r = 1
-      dma_u(kc, 2, s0);
-      if (ON1) load_raw(1, kn);
-      stage_mma(vb, sU + (1 - s0) * WN_USLOT, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (ON1) wn_wait_vm_lds<4>(); else wn_wait_vm_lds<0>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // r = 2
-      dma_u(kn, 0, 1 - s0);
-      stage_mma(vb, sU + s0 * WN_USLOT, 2);
-      store_v(0, vnext);
-      __builtin_amdgcn_sched_barrier(0);
-      wn_wait_vm_lds<0>();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  if (__builtin_amdgcn_readfirstlane((int)it_on[1])) stages(std::true_type{}); else stages(std::false_type{});
+  for (int kc = 0; kc < nk; ++kc) {
+    unsigned char* vb = sV + (kc & 1) * WN_VBUF;
+    unsigned char* vnext = sV + ((kc + 1) & 1) * WN_VBUF;
+    const int kn = min(kc + 1, nk - 1);
+    const int s0 = (kc * 3) & 1;
+    // r = 0
+    dma_u_u(kc, 1, 1 - s0);
+    load0(kn, std::true_type{});
+    stage_mma(vb, sU + s0 * WN_USLOT, 0);
+    store1(vb);                           // (chunk 0: the prologue's values once more)
+    __builtin_amdgcn_sched_barrier(0);
+    wn_wait_vm_lds<4>();                  // the DMA; round 0's loads stay in flight
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // r = 1
+    dma_u_u(kc, 2, s0);
+    load1(kn, std::true_type{});
+    stage_mma(vb, sU + (1 - s0) * WN_USLOT, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    wn_wait_tied<2>(raw0[0], raw0[1], raw0[2], raw0[3]);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // r = 2
+    dma_u_u(kn, 0, 1 - s0);
+    stage_mma(vb, sU + s0 * WN_USLOT, 2);
+    store0(vnext);
+    __builtin_amdgcn_sched_barrier(0);
+    wn_wait_tied2<0>(raw1[0], raw1[1]);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
   if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
 
   // ---- output transform.  This wave holds M_{2 ph}, M_{2 ph + 1}; its partner (same rows and channels, other half) the other two.

@@ -652,7 +652,7 @@ def _chain_planes(pc):
 # the kernel is one workgroup per tile, no stream-K: small maps keep the direct kernel
 CONV_WINO = _os.environ.get("LVC_CONV_WINO", "1") != "0"
 WINO_RPN = True        # the RPN head's large levels too (kernels.conv3x3_levels_pred); False: the two-accumulator direct kernel for all levels
-_WINO_MIN_TILES = 1024
+_WINO_MIN_TILES = 512
 
 
 def pack_wino(pc):

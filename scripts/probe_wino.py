@@ -25,6 +25,7 @@ for name, N, H, W, C, K in LAYERS:
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         outs[mode] = f(0).clone()
+        line += " (word %d)" % k.conv_error_word(d)
         line += " | %s %.4f ms %6.1f TF/s" % (mode, ms, 2.0 * N * H * W * C * K * 9 / ms / 1e9)
     n = min(N, 2)
     ref = torch.nn.functional.conv2d(xs[0][:n].permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1).relu().permute(0, 2, 3, 1)
@@ -33,3 +34,4 @@ for name, N, H, W, C, K in LAYERS:
         e = (outs[mode][:n].double() - ref).abs()
         line += " | %s err max %.1e rms %.1e" % (mode, float(e.max()) / sc, float(e.pow(2).mean().sqrt()) / sc)
     print(line, "| word", k.conv_error_word(d), flush=True)
+    k.clear_conv_error_word(d)

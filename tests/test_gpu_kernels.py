@@ -916,8 +916,9 @@ def test_conv3x3_winograd_vs_fp64_and_the_direct_kernel(N, H, W, C, K, relu, bia
     assert torch.equal(auto, got) if K >= 128 else True
     # range word: a window value beyond the single-accumulator form's 4094 raises the layer's word
     xb = x.clone()
-    xb[0, H // 2, W // 2, 0] = 3000.0
-    xb[0, H // 2, min(W - 1, W // 2 + 1), 0] = 3000.0        # V1 = d1 + d2 = 6000
+    xe = (W // 2) & ~1                                         # the two pixels of ONE pair: V1 = d1 + d2 = 6000
+    xb[0, H // 2, xe, 0] = 3000.0
+    xb[0, H // 2, xe + 1, 0] = 3000.0
     k.conv3x3_wino(xb.to(d), pc)
     assert k.conv_error_word(d) & 2
     k.clear_conv_error_word(d)
