@@ -64,26 +64,8 @@ struct WinoArgs {
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
-// The stage loop's vector-memory operations are issued as inline asm the compiler does not track: left to it, every LDS read behind an
-// LDS-DMA of the same scheduling region is preceded by s_waitcnt vmcnt(0) (the DMA's destination may alias the read) -- the weight DMA
-// just issued for the NEXT stage then has to land before the CURRENT stage's first MFMA can start, 0.4 us per stage.  Completion is the
-// counted waits before the barriers (wn_wait_*), which also tie the destination registers.
-__device__ __forceinline__ void wn_dma16(const void* g, unsigned lds_byte) {
-  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte) : "memory", "m0");
-}
-__device__ __forceinline__ f32x4 wn_load_untracked(u32x4 rsrc, unsigned voff) {
-  f32x4 v;
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rsrc) : "memory");
-  return v;
-}
-template <int N> __device__ __forceinline__ void wn_wait_tied2(f32x4& a, f32x4& b) {
-  asm volatile("s_waitcnt vmcnt(%2) lgkmcnt(0)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
-template <int N> __device__ __forceinline__ void wn_wait_tied(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
-  asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N) : "memory");
-}
+// behind it: at most N vector-memory operations outstanding and every LDS operation of this wave complete
 template <int N> __device__ __forceinline__ void wn_wait_vm_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
-
 template <bool PRED>
 __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
@@ -108,9 +90,6 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   const int VR = (p.PH + 2) * p.PWP;                  // V rows of this patch shape
 
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const unsigned long long xbase = (unsigned long long)p.x;
-  const u32x4 xres_u = {(unsigned)__builtin_amdgcn_readfirstlane((unsigned)xbase), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(xbase >> 32) & 0xffffu),
-                        p.x_bytes, 0x00020000u};
 
   // ---- transform work of a thread per 16-channel chunk.  Round 0: ONE item = (V row tid / 4 < 128, 4-channel group tid % 4): four
   // pixels in, four positions out.  Round 1 (the V rows >= 128: the last two window rows): ONE (item, position) = (V row 128 + tid / 16,
@@ -150,25 +129,26 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   }
   f32x4 raw0[4], raw1[2];
   float big = 0.f;
-  // `untracked`: the stage loop's loads (inline asm, completion by the counted waits); the prologue uses the compiler's
-  auto load0 = [&](int kc, auto untracked) {
+  auto load0 = [&](int kc) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const unsigned off = ((mask0 >> j) & 1u) ? off0 + (unsigned)j * pix_b + (unsigned)kc * 64u : 0x80000000u;
-      if constexpr (decltype(untracked)::value) raw0[j] = wn_load_untracked(xres_u, off);
-      else raw0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+      raw0[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
     }
   };
-  auto load1 = [&](int kc, auto untracked) {
+  auto load1 = [&](int kc) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const unsigned off = off1[j] == 0x80000000u ? 0x80000000u : off1[j] + (unsigned)kc * 64u;
-      if constexpr (decltype(untracked)::value) raw1[j] = wn_load_untracked(xres_u, off);
-      else raw1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+      raw1[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
     }
   };
-  auto split_store = [&](f32x4 v, unsigned char* hi_dst) {       // hi plane at hi_dst, lo plane 4 position images further
-    f16x4 h, l;
+  // Transform = conversion (VALU) + LDS writes, both under the MFMAs of a stage.  Diagnostics builds (scripts/build_variant.sh; p2 layer
+  // 1.42 ms): without the LDS writes 1.25, without conversion and writes 1.15 (the window loads themselves cost nothing), with half of
+  // the fragment reads 1.39; writes issued a stage later at its top instead (conversion results parked in registers): slower (1.40 vs
+  // 1.37 at equal direct-kernel time) -- kept as below.
+  f16x4 pk0[4][2], pk1[2];           // round 0: [position][hi, lo]; round 1: hi, lo
+  auto split = [&](f32x4 v, f16x4& h, f16x4& l) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float a = v[e] * ACT_SCALE;
@@ -177,17 +157,28 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
       l[e] = (f16)(a - (float)hh);
       big = fmaxf(big, fabsf(v[e]));
     }
-    *reinterpret_cast<f16x4*>(hi_dst) = h;
-    *reinterpret_cast<f16x4*>(hi_dst + 4 * WN_PP) = l;
   };
-  auto store0 = [&](unsigned char* vb) {
-    split_store(raw0[0] - raw0[2], vb + 0 * WN_PP + lds0);
-    split_store(raw0[1] + raw0[2], vb + 1 * WN_PP + lds0);
-    split_store(raw0[2] - raw0[1], vb + 2 * WN_PP + lds0);
-    split_store(raw0[1] - raw0[3], vb + 3 * WN_PP + lds0);
+  auto prep0 = [&]() {
+    split(raw0[0] - raw0[2], pk0[0][0], pk0[0][1]);
+    split(raw0[1] + raw0[2], pk0[1][0], pk0[1][1]);
+    split(raw0[2] - raw0[1], pk0[2][0], pk0[2][1]);
+    split(raw0[1] - raw0[3], pk0[3][0], pk0[3][1]);
   };
-  auto store1 = [&](unsigned char* vb) {      // no branch: V rows VR .. 159 of the smaller patch shape exist in the buffer and are never read
-    split_store(raw1[0] + sgn1 * raw1[1], vb + lds1);
+  auto write0 = [&](unsigned char* vb) {
+#ifndef WN_DIAG_NO_LDSWRITE
+#pragma unroll
+    for (int pz = 0; pz < 4; ++pz) {
+      *reinterpret_cast<f16x4*>(vb + pz * WN_PP + lds0) = pk0[pz][0];
+      *reinterpret_cast<f16x4*>(vb + (4 + pz) * WN_PP + lds0) = pk0[pz][1];
+    }
+#endif
+  };
+  auto prep1 = [&]() { split(raw1[0] + sgn1 * raw1[1], pk1[0], pk1[1]); };
+  auto write1 = [&](unsigned char* vb) {      // no branch: V rows VR .. 159 of the smaller patch shape exist in the buffer and are never read
+#ifndef WN_DIAG_NO_LDSWRITE
+    *reinterpret_cast<f16x4*>(vb + lds1) = pk1[0];
+    *reinterpret_cast<f16x4*>(vb + 4 * WN_PP + lds1) = pk1[1];
+#endif
   };
 
   // ---- weight DMA: wave w brings (position, plane) image w of a stage (4 KB = four 1 KB pieces of 32 channel rows)
@@ -199,12 +190,6 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
     const unsigned short* s = u_src + (size_t)((r * nk + kc) * 8) * u_img;
 #pragma unroll
     for (int j = 0; j < 4; ++j) wn_glds16(s + j * 32 * 16, sU + slot * WN_USLOT + wave * 4096 + j * 1024);
-  };
-  const unsigned su_byte = (unsigned)(size_t)(sU - smem) + (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto dma_u_u = [&](int kc, int r, int slot) {      // the stage loop's form: untracked
-    const unsigned short* s = u_src + (size_t)((r * nk + kc) * 8) * u_img;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) wn_dma16(s + j * 32 * 16, su_byte + (unsigned)(slot * WN_USLOT + wave * 4096 + j * 1024));
   };
 
   // ---- fragments.  A: V row m + r PWP of (plane, position); B: channel row of (position, plane)
@@ -235,12 +220,20 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
         ahi[mi] = *reinterpret_cast<const f16x8*>(vb + pz * WN_PP + arow[mi]);
+#ifdef WN_DIAG_HALF_READS      // diagnostics build only (wrong results): is the stage bound by the LDS port?
+        alo[mi] = ahi[mi];
+#else
         alo[mi] = *reinterpret_cast<const f16x8*>(vb + (4 + pz) * WN_PP + arow[mi]);
+#endif
       }
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         bhi[ni] = *reinterpret_cast<const f16x8*>(ub + (pz * 2 + 0) * 4096 + b_off + ni * 1024);
+#ifdef WN_DIAG_HALF_READS
+        blo[ni] = bhi[ni];
+#else
         blo[ni] = *reinterpret_cast<const f16x8*>(ub + (pz * 2 + 1) * 4096 + b_off + ni * 1024);
+#endif
       }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -259,10 +252,12 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
 
   // ---- prologue: chunk 0 transformed into V buffer 0, the weights of stage (0, 0) in slot 0
   dma_u(0, 0, 0);
-  load0(0, std::false_type{});
-  load1(0, std::false_type{});
-  store0(sV);
-  store1(sV);
+  load0(0);
+  load1(0);
+  prep0();
+  prep1();
+  write0(sV);
+  write1(sV);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -271,37 +266,40 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   // Transform schedule (chunk kc multiplies V(kc)):  round 0 of chunk kc+1 (V rows 0..127): loads at the top of r = 0, transform + store
   // under the MFMAs of r = 2;  round 1 (V rows 128..): loads at the top of r = 1, transform + store under the MFMAs of the NEXT chunk's
   // r = 0 -- into the buffer that stage reads, but it reads rows < 128 only (pair row + filter row 0); rows >= 128 are first needed by
-  // r = 1, behind r = 0's barrier.  In-order queue of a wave (D = 4 DMA ops, L0 = 4 loads, L1 = 2):  r0: D L0 | r1: D L1 | r2: D.
-  // A wait for a stage's D also completes everything older: L0 is complete behind r1's barrier wait, L1 behind r2's.
+  // r = 1, behind r = 0's barrier.  In-order queue of a wave (D = 4 DMA ops, L0 = 4 loads, L1 = 2):  r0: D L0 | r1: D L1 | r2: D: the
+  // explicit waits before the barriers cover the DMA (other waves read that LDS); the loads' uses carry the compiler's own waits.
+  // (Issuing DMA and loads as untracked inline asm -- no compiler wait before LDS reads behind a DMA -- was measured: no difference.)
 #pragma unroll 1
   for (int kc = 0; kc < nk; ++kc) {
     unsigned char* vb = sV + (kc & 1) * WN_VBUF;
     unsigned char* vnext = sV + ((kc + 1) & 1) * WN_VBUF;
     const int kn = min(kc + 1, nk - 1);
     const int s0 = (kc * 3) & 1;
-    // r = 0
-    dma_u_u(kc, 1, 1 - s0);
-    load0(kn, std::true_type{});
+    // r = 0: round 0 of the next chunk is requested; round 1 of THIS chunk (rows >= 128: not read before r = 1) is converted and written
+    dma_u(kc, 1, 1 - s0);
+    load0(kn);
     stage_mma(vb, sU + s0 * WN_USLOT, 0);
-    store1(vb);                           // (chunk 0: the prologue's values once more)
+    prep1();                              // (chunk 0: the prologue's values once more)
+    write1(vb);
     __builtin_amdgcn_sched_barrier(0);
     wn_wait_vm_lds<4>();                  // the DMA; round 0's loads stay in flight
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // r = 1
-    dma_u_u(kc, 2, s0);
-    load1(kn, std::true_type{});
+    // r = 1: round 1 of the next chunk is requested
+    dma_u(kc, 2, s0);
+    load1(kn);
     stage_mma(vb, sU + (1 - s0) * WN_USLOT, 1);
     __builtin_amdgcn_sched_barrier(0);
-    wn_wait_tied<2>(raw0[0], raw0[1], raw0[2], raw0[3]);
+    wn_wait_vm_lds<2>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    // r = 2
-    dma_u_u(kn, 0, 1 - s0);
+    // r = 2: round 0 of the next chunk is converted and written
+    dma_u(kn, 0, 1 - s0);
     stage_mma(vb, sU + s0 * WN_USLOT, 2);
-    store0(vnext);
+    prep0();
+    write0(vnext);
     __builtin_amdgcn_sched_barrier(0);
-    wn_wait_tied2<0>(raw1[0], raw1[1]);
+    wn_wait_vm_lds<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   }
