@@ -558,6 +558,9 @@ int lvc_layernorm(const float* x, int ldx, const float* w, const float* b, float
                   void* stream);
 int lvc_gelu(const float* x, float* y, long long n, void* stream);
 int lvc_mha(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, void* stream);
+/* The attention output of token 0 (the class token) of every image only: qkv [B*N, 3*H*64] -> out [B, H*64] (N <= 1024).  The last block
+ * of the descriptor network: its output is read at the class rows (tools/run_nearest_neighbours.py:102-128). */
+int lvc_mha_cls(const float* qkv, float* out, int B, int N, int H, float scale, void* stream);
 long long lvc_mha_workspace_bytes(int B, int N, int H);
 int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, int* d_error_word, void* stream);
 

@@ -468,6 +468,59 @@ extern "C" int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B
   return LVC_OK;
 }
 
+// Attention of ONE query per image -- token 0, the class token -- against all N keys / values: what the LAST block of the descriptor network
+// needs (its output is read at the class rows only, run_nearest_neighbours.py:102-128 -> `x[:, 0]` of the DINO forward).  One wave
+// per (image, head): the lanes split the keys (scores, two-pass softmax with wave-wide max / sum), then the 64 output dimensions.
+__global__ __launch_bounds__(64) void mha_cls_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int H, float scale) {
+  __shared__ float sp[1024];           // probabilities of up to 1024 keys
+  const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+  const int ld = 3 * H * MHA_DH;
+  const float* base = qkv + (size_t)b * N * ld + h * MHA_DH;
+  float q[MHA_DH];
+#pragma unroll
+  for (int d4 = 0; d4 < MHA_DH / 4; ++d4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(base + d4 * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) q[d4 * 4 + e] = t[e] * scale;
+  }
+  float mx = -INFINITY;
+  for (int k = lane; k < N; k += 64) {
+    const float* kr = base + (size_t)k * ld + H * MHA_DH;
+    float acc = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < MHA_DH / 4; ++d4) {
+      const f32x4 kv = *reinterpret_cast<const f32x4*>(kr + d4 * 4);
+      acc += q[d4 * 4] * kv[0] + q[d4 * 4 + 1] * kv[1] + q[d4 * 4 + 2] * kv[2] + q[d4 * 4 + 3] * kv[3];
+    }
+    sp[k] = acc;
+    mx = fmaxf(mx, acc);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int k = lane; k < N; k += 64) {
+    const float pk = expf(sp[k] - mx);
+    sp[k] = pk;
+    sum += pk;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  __syncthreads();
+  // lane = output dimension: sum over the keys of p_k v[k][lane] (a row of V is 64 consecutive floats: coalesced)
+  float acc = 0.f;
+  const float* vb = base + 2 * H * MHA_DH + lane;
+  for (int k = 0; k < N; ++k) acc += sp[k] * vb[(size_t)k * ld];
+  out[(size_t)b * H * MHA_DH + h * MHA_DH + lane] = acc / sum;
+}
+
+// qkv [B*N, 3*H*64] -> out [B, H*64]: the attention output of token 0 of every image (fp32 arithmetic throughout).  N <= 1024.
+extern "C" int lvc_mha_cls(const float* qkv, float* out, int B, int N, int H, float scale, void* stream) {
+  LVC_CHECK_ARG(B >= 0 && N > 0 && N <= 1024 && H > 0 && H <= 65535 && B <= 65535, "bad sizes");
+  if (B == 0) return LVC_OK;
+  LVC_CHECK_ARG(qkv && out && ((uintptr_t)qkv & 15) == 0, "null or unaligned pointer");
+  hipLaunchKernelGGL(mha_cls_kernel, dim3(H, B), dim3(64), 0, (hipStream_t)stream, qkv, out, N, H, scale);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
 extern "C" int lvc_mha(const float* qkv, float* out, int B, int N, int H, int head_dim, float scale, void* stream) {
   LVC_CHECK_ARG(B >= 0 && N > 0 && H > 0, "bad sizes");
   LVC_CHECK_ARG(head_dim == MHA_DH, "head dimension must be 64");

@@ -511,7 +511,7 @@ def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=No
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     if engine != "f32":
-        if (engine == "f16x2_halo" and HALO_S1 == 2 and split is None and not two_acc and CONV_WINO and residual is None and pc.K >= 128
+        if (engine == "f16x2_halo" and HALO_S1 == 2 and split is None and tier == 0 and (not pc.two_acc or WINO_RPN) and CONV_WINO and residual is None and pc.K >= 128
                 and out.is_contiguous() and out.shape[-1] == pc.K and wino_tiles(N, H, W, pc.K) >= _WINO_MIN_TILES):
             # Winograd F(2,3) along x on the maps that fill the chip with its one-workgroup tiles (csrc/conv3x3_wino.hip)
             pc.last_one = True
@@ -751,7 +751,9 @@ def conv3x3_levels(xs, pc, relu=False, outs=None):
             conv2d_nhwc(x, q, relu=relu, out=o)
         return outs
     one = HALO_S1 == 2 and not (True in forms)
-    if one and CONV_WINO:
+    # (`two_acc` layers -- the RPN head outside its fused-predictor launch, e.g. in a training forward -- qualify under WINO_RPN: the
+    # Winograd form's error is below the one-accumulator direct form's and passes the head's chain test, see conv3x3_levels_pred)
+    if CONV_WINO and HALO_S1 == 2 and all(q.state["tier"] == 0 and (not q.two_acc or WINO_RPN) for q in pcs):
         # maps large enough to fill the chip with one-workgroup tiles run on the Winograd F(2,3) kernel (two thirds of the MFMAs), each
         # alone; the small ones stay one grouped launch of the direct kernel
         big = [i for i, (x, q) in enumerate(zip(xs, pcs)) if wino_tiles(x.shape[0], x.shape[1], x.shape[2], q.K) >= _WINO_MIN_TILES and q.K >= 128]
@@ -1971,6 +1973,16 @@ def gelu(x):
 
 
 MHA_MFMA = True   # 0: the one-thread-per-query fp32 VALU kernel of round 2 (lvc_mha)
+
+
+def mha_cls(qkv, B, N, num_heads, head_dim, scale):
+    """qkv [B*N, 3*H*64] -> [B, H*64]: softmax(q_0 k^T scale) v for the class token of every image (the descriptor network's last block)."""
+    _req_cuda(qkv)
+    assert head_dim == 64 and N <= 1024
+    qkv = qkv.contiguous()
+    out = torch.empty(B, num_heads * head_dim, device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().lvc_mha_cls(ptr(qkv), ptr(out), c_int(B), c_int(N), c_int(num_heads), c_float(scale), _stream(qkv)), "lvc_mha_cls")
+    return out
 
 
 def mha(qkv, B, N, num_heads, head_dim, scale, mfma=None):

@@ -19,6 +19,9 @@ from torch import nn
 from .. import kernels as K
 
 
+CLASS_ROWS_ONLY = True     # the last block evaluated at the class rows only (False: every token, then the class rows are read)
+
+
 class _Cache:
     """Packed GEMM operands of a Linear, rebuilt when a parameter changes (as layers/wrappers.py does)."""
 
@@ -94,6 +97,18 @@ class _Block(nn.Module):
         y = self.mlp.fc1(self.norm2(t), act="gelu")      # GELU in fc1's epilogue: the [M, 4 dim] hidden map makes one trip less
         return self.mlp.fc2(y, residual=t)
 
+    def forward_class_rows(self, t, B, N):
+        """The block's output at the class rows only, [B, dim] -- all the network reads of its LAST block: keys and values of every
+        token still come from the full qkv GEMM, but attention runs for one query per image and the projection / MLP on B rows instead of
+        B * N (785 x fewer)."""
+        a = self.attn
+        D = t.shape[1]
+        qkv = a.qkv(self.norm1(t))
+        y = K.mha_cls(qkv, B, N, a.num_heads, D // a.num_heads, a.scale)
+        c = a.proj(y, residual=t.view(B, N, D)[:, 0].contiguous())
+        y = self.mlp.fc1(self.norm2(c), act="gelu")
+        return self.mlp.fc2(y, residual=c)
+
 
 class _PatchEmbed(nn.Module):
     def __init__(self, img_size, patch_size, in_chans, embed_dim):
@@ -140,8 +155,11 @@ class VisionTransformer(nn.Module):
         emb = K.conv2d_nhwc(patches.view(M, 1, 1, kpad), pc).view(M, self.embed_dim)
         N = pe.num_patches + 1
         t = K.vit_tokens(emb, self.cls_token.view(-1), self.pos_embed.view(N, self.embed_dim), B)
-        for blk in self.blocks:
+        for blk in self.blocks[:-1]:
             t = blk(t, B, N)
+        if CLASS_ROWS_ONLY and N <= 1024 and self.embed_dim // self.blocks[-1].attn.num_heads == 64:
+            return self.norm(self.blocks[-1].forward_class_rows(t, B, N))
+        t = self.blocks[-1](t, B, N)
         cls_rows = t.view(B, N, self.embed_dim)[:, 0].contiguous()
         return self.norm(cls_rows)
 

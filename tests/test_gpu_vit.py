@@ -74,6 +74,19 @@ def test_vit_s8_descriptors_match_oracle():
     rel1 = float((one - ref[:1]).abs().max() / ref.abs().max())
     print("ViT-S/8 class-token descriptors: max error relative to the descriptor scale %.2e (batch 9), %.2e (batch 1)" % (rel, rel1))
     assert got.shape == (9, 384) and rel <= 1e-4 and rel1 <= 1e-4
+    # the last block at the class rows only (modeling/vit.py CLASS_ROWS_ONLY, csrc/vit.hip mha_cls_kernel) against every token + read
+    from lvc_amd.modeling import vit as V
+
+    V.CLASS_ROWS_ONLY = False
+    try:
+        with torch.no_grad():
+            full = model(x.cuda()).cpu()
+    finally:
+        V.CLASS_ROWS_ONLY = True
+    d = float((got - full).abs().max() / ref.abs().max())
+    relf = float((full - ref).abs().max() / ref.abs().max())
+    print("   class rows only vs every token: %.2e apart; every-token form vs the oracle %.2e" % (d, relf))
+    assert d <= 2e-5 and relf <= 1e-4
 
 
 def test_verification_chain_crops_descriptors_knn_keep():
