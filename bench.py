@@ -366,7 +366,7 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
         losses = model(batch)
         if sync is not None:
             torch.cuda.synchronize(); t.append(time.perf_counter())
-        opt.zero_grad(set_to_none=buckets is None)
+        opt.zero_grad()      # set_to_none: the deferred weight gradients are written straight into the bucket slices
         sum(losses.values()).backward()
         if buckets is not None:
             nbytes = buckets.finish()

@@ -467,6 +467,17 @@ int lvc_conv_wgrad_nhwc_bf16x3(const float* x, const float* dy, const float* sca
  * 65504 raises bit 1 (value 2) of *err_word (the conv error word of lvc_conv_workspace; may be NULL). */
 int lvc_conv_wgrad_nhwc_f16x2(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                               int K, int R, int S, int stride, int pad, int lddy, int* err_word, void* stream);
+/* The weight gradients of `njobs` layers in one launch of the bf16x3 kernel (round 5): ATen's conv2d backward runs one wgrad per
+ * layer (resnet.py:195-211, fpn.py:109-144 under autograd); at 2 images per GPU (cascade_ubbr_R_101_FPN_base.yaml) a res4 layer's
+ * 16-36 tiles cannot fill the chip, and the weight gradient is off the backward's critical path, so the host queues the (x, dy)
+ * pairs (lvc_amd.kernels.defer_wgrad) and launches them together.  x / dy / scale / dw: host arrays of njobs device pointers
+ * (scale[j] may be NULL); shapes: host array, 10 ints per job = N, H, W, C, K, R, S, stride, pad, lddy (as lvc_conv_wgrad_nhwc).
+ * dw[j] ([K][R][S][C]) must be ZERO on entry: partial sums over pixel slices are added with fp32 atomics. */
+int lvc_conv_wgrad_group_bf16x3(int njobs, const float* const* x, const float* const* dy, const float* const* scale,
+                                float* const* dw, const int* shapes, void* stream);
+/* dst[j] (the parameter's OIHW layout [K][C][R*S]) = (beta ? dst[j] : 0) + src[j] ([K][R*S][C], what the wgrad kernels write), all
+ * jobs in one launch; shapes: 4 ints per job = K, C, R*S, beta.  (AccumulateGrad's `grad += dw` / first assignment.) */
+int lvc_wgrad_finalize_group(int njobs, const float* const* src, float* const* dst, const int* shapes, void* stream);
 int lvc_scatter_stride2_nhwc(const float* x, float* y, int N, int H, int W, int C, void* stream);
 /* y[n, i, j, 0..C) = x[n, 2i, 2j, :], rows of ldy floats in y (0 = C): the sampling of a stride-2 1x1 convolution as a copy (the
  * block input of res3.0 / res4.0 / res5.0 next to conv2's output: conv3 + projection shortcut as one GEMM, resnet.py:117-160). */

@@ -592,11 +592,9 @@ __device__ __forceinline__ void wg_split3(float a, wg_bf16& h, wg_bf16& m, wg_bf
 }
 
 template <bool BUF>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(const WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
-  __shared__ __attribute__((aligned(16))) wg_bf16 lds[2 * 6 * WB_PLANE];   // [buffer][dY hi,mid,lo, X hi,mid,lo][16][WG_PITCH]
+__device__ __forceinline__ void wgrad_bf16x3_body(const WgradParams& p, const int lid, unsigned x_bytes, unsigned dy_bytes, wg_bf16* lds) {
   const wg_lds_char* lds3 = (const wg_lds_char*)lds;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lid = lvc_xcd_remap(blockIdx.x, gridDim.x);
   int t = lid % p.tiles;
   const int split = lid / p.tiles;
   const int ct = t % p.c_tiles; t /= p.c_tiles;
@@ -753,6 +751,142 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(const WgradPa
         if (c < p.C) unsafeAtomicAdd(row + c, acc[mi][ni][e] * sc);
       }
     }
+}
+
+template <bool BUF>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16x3_kernel(const WgradParams p, unsigned x_bytes, unsigned dy_bytes) {
+  __shared__ __attribute__((aligned(16))) wg_bf16 lds[2 * 6 * WB_PLANE];   // [buffer][dY hi,mid,lo, X hi,mid,lo][16][WG_PITCH]
+  wgrad_bf16x3_body<BUF>(p, lvc_xcd_remap(blockIdx.x, gridDim.x), x_bytes, dy_bytes, lds);
+}
+
+// ---- the weight gradients of SEVERAL layers in one launch (round 5).  At the training batch of the shipped box-corrector configs
+// (2 images per GPU) a res4 layer has 8 400 output pixels: its 16-36 tiles cannot fill 256 CUs, the pixel range had to be cut
+// into 512-pixel slices whose workgroups spend their time in prologue, atomics and a zeroing launch (65-95 us per layer for
+// 10-25 us of MFMA work).  The weight gradient is not on the backward's critical path -- only the data gradients chain -- so
+// the host queues the (x, dy) pairs and launches them together (lvc_amd.kernels.defer_wgrad): the tiles of ~24 layers fill the
+// chip with long pixel loops (a few slices per tile instead of 17).  Jobs travel as kernel arguments (no table in memory).
+#define WG_GROUP_MAX 24
+struct WgradJob {
+  WgradParams p;
+  int wg_begin;                  // first logical workgroup of this job
+  unsigned x_bytes, dy_bytes;
+  int pad_;
+};
+struct WgradGroup {
+  WgradJob job[WG_GROUP_MAX];
+  int njobs, total_wgs;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_group_bf16x3_kernel(const WgradGroup g) {
+  __shared__ __attribute__((aligned(16))) wg_bf16 lds[2 * 6 * WB_PLANE];
+  const int lid = lvc_xcd_remap(blockIdx.x, gridDim.x);
+  int j = 0;
+#pragma unroll 1
+  for (int i = 1; i < g.njobs; ++i)
+    if (lid >= g.job[i].wg_begin) j = i;
+  j = __builtin_amdgcn_readfirstlane(j);
+  const WgradJob& job = g.job[j];
+  wgrad_bf16x3_body<true>(job.p, lid - job.wg_begin, job.x_bytes, job.dy_bytes, lds);
+}
+
+// dst (OIHW, the parameter's layout) = (beta ? dst : 0) + src ([K][R*S][C], what the weight-gradient kernels write): the
+// transposition ATen's conv backward never needs because it writes the parameter's layout directly.  One launch per group.
+struct WgradFinJob { const float* src; float* dst; int K, C, RS, beta; long long begin; };   // begin: first (k, c) pair of this job in the launch
+struct WgradFinGroup { WgradFinJob job[WG_GROUP_MAX]; int njobs; long long total; };
+__global__ __launch_bounds__(256) void wgrad_finalize_group_kernel(const WgradFinGroup g) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= g.total) return;
+  int j = 0;
+  for (int q = 1; q < g.njobs; ++q)
+    if (i >= g.job[q].begin) j = q;
+  const WgradFinJob& f = g.job[j];
+  const long long e = i - f.begin;
+  const int c = (int)(e % f.C);
+  const long long k = e / f.C;
+  const float* s = f.src + k * f.RS * f.C + c;
+  float* d = f.dst + (k * f.C + c) * f.RS;
+  for (int t = 0; t < f.RS; ++t) {
+    const float v = s[(long long)t * f.C];
+    d[t] = f.beta ? d[t] + v : v;
+  }
+}
+
+static int wgrad_bf16x3_params(WgradParams& p, const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W,
+                               int C, int K, int R, int S, int stride, int pad, int lddy) {
+  const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+  p.x = x; p.dy = dy; p.scale = scale; p.dw = dw;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.K = K; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.lddy = lddy; p.M = N * Ho * Wo;
+  p.k_tiles = lvc_cdiv(K, 128); p.c_tiles = lvc_cdiv(C, 128);
+  p.tiles = p.k_tiles * p.c_tiles * R * S;
+  return lvc_cdiv(p.M, 16);
+}
+
+extern "C" int lvc_conv_wgrad_group_bf16x3(int njobs, const float* const* x, const float* const* dy, const float* const* scale,
+                                           float* const* dw, const int* shapes, void* stream) {
+  LVC_CHECK_ARG(njobs > 0 && x && dy && scale && dw && shapes, "null pointer / no jobs");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += WG_GROUP_MAX) {
+    const int nj = njobs - j0 < WG_GROUP_MAX ? njobs - j0 : WG_GROUP_MAX;
+    WgradGroup g;
+    long long total_chunks = 0;
+    int nchunks[WG_GROUP_MAX];
+    for (int j = 0; j < nj; ++j) {
+      const int* sh = shapes + (size_t)(j0 + j) * 10;
+      const int N = sh[0], H = sh[1], W = sh[2], C = sh[3], K = sh[4], R = sh[5], S = sh[6], stride = sh[7], pad = sh[8], lddy = sh[9];
+      LVC_CHECK_ARG(x[j0 + j] && dy[j0 + j] && dw[j0 + j], "null pointer");
+      LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, "bad shape");
+      LVC_CHECK_ARG(C % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && lddy >= K, "C, K and lddy must be multiples of 4");
+      LVC_CHECK_ARG((((uintptr_t)x[j0 + j] | (uintptr_t)dy[j0 + j] | (uintptr_t)dw[j0 + j]) & 15) == 0, "pointers must be 16-byte aligned");
+      const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+      LVC_CHECK_ARG(Ho > 0 && Wo > 0, "empty output map");
+      const long long xb = (long long)N * H * W * C * 4, dyb = (long long)N * Ho * Wo * lddy * 4;
+      LVC_CHECK_ARG(xb < (1ll << 31) && dyb < (1ll << 31), "a grouped job's tensors must be smaller than 2 GiB (launch it alone)");
+      nchunks[j] = wgrad_bf16x3_params(g.job[j].p, x[j0 + j], dy[j0 + j], scale[j0 + j], dw[j0 + j], N, H, W, C, K, R, S, stride, pad, lddy);
+      g.job[j].x_bytes = (unsigned)xb; g.job[j].dy_bytes = (unsigned)dyb; g.job[j].pad_ = 0;
+      total_chunks += (long long)g.job[j].p.tiles * nchunks[j];
+    }
+    // equal slices of the pixel range over the whole group: about three rounds of the 768 resident workgroups, never shorter than 32 chunks
+    constexpr int target_wgs = 2304, min_chunks = 32;
+    long long per_wg = (total_chunks + target_wgs - 1) / target_wgs;
+    if (per_wg < min_chunks) per_wg = min_chunks;
+    int wgs = 0;
+    for (int j = 0; j < nj; ++j) {
+      WgradParams& p = g.job[j].p;
+      int splits = (int)((nchunks[j] + per_wg / 2) / per_wg);
+      if (splits < 1) splits = 1;
+      p.chunks_per_split = lvc_cdiv(nchunks[j], splits);
+      splits = lvc_cdiv(nchunks[j], p.chunks_per_split);
+      g.job[j].wg_begin = wgs;
+      wgs += p.tiles * splits;
+    }
+    g.njobs = nj; g.total_wgs = wgs;
+    hipLaunchKernelGGL(conv_wgrad_group_bf16x3_kernel, dim3(wgs), dim3(256), 0, st, g);
+    LVC_CHECK_LAUNCH();
+  }
+  return LVC_OK;
+}
+
+extern "C" int lvc_wgrad_finalize_group(int njobs, const float* const* src, float* const* dst, const int* shapes, void* stream) {
+  LVC_CHECK_ARG(njobs > 0 && src && dst && shapes, "null pointer / no jobs");
+  hipStream_t st = (hipStream_t)stream;
+  for (int j0 = 0; j0 < njobs; j0 += WG_GROUP_MAX) {
+    const int nj = njobs - j0 < WG_GROUP_MAX ? njobs - j0 : WG_GROUP_MAX;
+    WgradFinGroup g;
+    long long total = 0;
+    for (int j = 0; j < nj; ++j) {
+      const int* sh = shapes + (size_t)(j0 + j) * 4;
+      LVC_CHECK_ARG(src[j0 + j] && dst[j0 + j] && sh[0] > 0 && sh[1] > 0 && sh[2] > 0, "bad job");
+      g.job[j].src = src[j0 + j]; g.job[j].dst = dst[j0 + j];
+      g.job[j].K = sh[0]; g.job[j].C = sh[1]; g.job[j].RS = sh[2]; g.job[j].beta = sh[3];
+      g.job[j].begin = total;
+      total += (long long)sh[0] * sh[1];
+    }
+    g.njobs = nj; g.total = total;
+    hipLaunchKernelGGL(wgrad_finalize_group_kernel, dim3((unsigned)lvc_cdiv64(total, 256)), dim3(256), 0, st, g);
+    LVC_CHECK_LAUNCH();
+  }
+  return LVC_OK;
 }
 
 // lvc_conv_wgrad_nhwc on the three-way bf16 split kernel: same arguments, same semantics, no range restriction.

@@ -159,8 +159,18 @@ class GradientBuckets:
         if cur:
             self._close(cur)
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        # deferred weight gradients (kernels.defer_wgrad) bypass AccumulateGrad: they are written straight into the bucket slice
+        # (when the parameter has no .grad yet) and reported through the same hook
+        from . import kernels as K
+
+        for p in self.params:
+            K.register_wgrad_sink(p, self._slot, self._hook)
         self._next = 0
         self.bytes_reduced = 0
+
+    def _slot(self, p):
+        bi, off = self._where[id(p)]
+        return self.buckets[bi]["flat"][off: off + p.numel()].view_as(p)
 
     def _close(self, plist):
         total = sum(p.numel() for p in plist)
@@ -175,6 +185,8 @@ class GradientBuckets:
         self.buckets.append(b)
 
     def _hook(self, p):
+        if p.grad is None:      # AccumulateGrad ran on an undefined gradient (a deferred weight gradient: it arrives through the sink)
+            return
         bi, off = self._where[id(p)]
         b = self.buckets[bi]
         view = b["flat"][off: off + p.numel()].view_as(p)
@@ -230,5 +242,9 @@ class GradientBuckets:
         return n
 
     def remove(self):
+        from . import kernels as K
+
         for h in self._handles:
             h.remove()
+        for p in self.params:
+            K.unregister_wgrad_sink(p)

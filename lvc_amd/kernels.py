@@ -1726,14 +1726,14 @@ def colsum_rows(x2d):
 BWD_TIMER = None     # a list: every weight- / data-gradient launch appends (kind, engine, flops, algorithmic bytes, start, end events)
 
 
-def _bwd_timed(kind, engine, flops, nbytes, fn):
+def _bwd_timed(kind, engine, flops, nbytes, fn, tag=""):
     if BWD_TIMER is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     out = fn()
     e1.record()
-    BWD_TIMER.append((kind, engine, flops, nbytes, e0, e1))
+    BWD_TIMER.append((kind, engine, flops, nbytes, e0, e1, tag))
     return out
 
 
@@ -1743,7 +1743,8 @@ def conv_wgrad(x, dy, scale, R, S, stride, pad, split=None):
         eng = "f16x2" if (split or DGRAD_SPLIT) == "f16x2" else WGRAD_ENGINE
         fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * x.shape[3] * R * S
         nb = 4.0 * (x.numel() + dy.numel() + dy.shape[3] * R * S * x.shape[3])
-        return _bwd_timed("wgrad", eng, fl, nb, lambda: _conv_wgrad(x, dy, scale, R, S, stride, pad, split))
+        tag = "%dx%dx%d %d>%d %dx%d s%d" % (dy.shape[0], dy.shape[1], dy.shape[2], x.shape[3], dy.shape[3], R, S, stride)
+        return _bwd_timed("wgrad", eng, fl, nb, lambda: _conv_wgrad(x, dy, scale, R, S, stride, pad, split), tag)
     return _conv_wgrad(x, dy, scale, R, S, stride, pad, split)
 
 
@@ -1765,6 +1766,116 @@ def _conv_wgrad(x, dy, scale, R, S, stride, pad, split=None):
     check(getattr(_lib.lib(), fn)(ptr(x), ptr(dy), ptr(scale), ptr(dw), c_int(N), c_int(H), c_int(W), c_int(C), c_int(K),
                                   c_int(R), c_int(S), c_int(stride), c_int(pad), c_int(K), _stream(x)), fn)
     return dw
+
+
+# ---- deferred, grouped weight gradients (csrc/conv_wgrad.hip: conv_wgrad_group_bf16x3_kernel) --------------------------------------
+DEFER_WGRAD = _os.environ.get("LVC_DEFER_WGRAD", "1") != "0"
+_WGRAD_GROUP = 24            # jobs per launch (kernel-argument table)
+_WGRAD_Q = []                # (param, x, g, scale, R, stride, pad)
+_WGRAD_ARMED = [False]
+_WGRAD_SINKS = {}            # id(param) -> (destination(param) -> tensor the gradient is written into, ready(param))
+
+
+def register_wgrad_sink(param, destination, ready):
+    """A gradient exchange that owns flat buckets hands out the bucket slice as the place the deferred weight gradient is written
+    to (no copy into the bucket afterwards) and is told when it is there (`lvc_amd.distributed.GradientBuckets`)."""
+    _WGRAD_SINKS[id(param)] = (destination, ready)
+
+
+def unregister_wgrad_sink(param):
+    _WGRAD_SINKS.pop(id(param), None)
+
+
+def reset_wgrad_queue():
+    del _WGRAD_Q[:]
+    _WGRAD_ARMED[0] = False
+
+
+def can_defer_wgrad(x, g):
+    """Deferred grouped launch: the default unscaled bf16x3 path inside a `backward()` (not torch.autograd.grad: the gradient is
+    written to `param.grad` by a callback at the end of the pass, as AccumulateGrad would)."""
+    return (DEFER_WGRAD and WGRAD_ENGINE == "bf16x3" and DGRAD_SPLIT != "f16x2" and x.numel() * 4 < (1 << 31) and g.numel() * 4 < (1 << 31)
+            and x.is_contiguous() and g.is_contiguous())
+
+
+def defer_wgrad(param, x, g, scale, R, stride, pad):
+    """Queue dW of y = conv(x, param) (* scale) for the grouped launch; `param.grad` holds it when `backward()` returns."""
+    _WGRAD_Q.append((param, x, g, scale, R, stride, pad))
+    if not _WGRAD_ARMED[0]:
+        _WGRAD_ARMED[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_end)
+    if len(_WGRAD_Q) >= _WGRAD_GROUP:
+        flush_wgrad()
+
+
+def _flush_wgrad_end():
+    _WGRAD_ARMED[0] = False
+    flush_wgrad()
+
+
+def flush_wgrad():
+    """Launch the queued weight gradients: one zeroing, one grouped wgrad launch, one grouped layout / accumulate launch."""
+    q = list(_WGRAD_Q)
+    del _WGRAD_Q[:]
+    if not q:
+        return
+    import ctypes
+
+    dev = q[0][1].device
+    n = len(q)
+    first = {}               # a parameter used several times in the pass (the RPN head over the pyramid levels): ONE accumulation buffer
+    offs, total = [], 0
+    for j, (p, *_r) in enumerate(q):
+        if id(p) in first:
+            offs.append(offs[first[id(p)]])
+        else:
+            first[id(p)] = j
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+    flat = torch.zeros(total, device=dev, dtype=torch.float32)
+    PA = ctypes.c_void_p * n
+    xs, dys, scs, dws = PA(), PA(), PA(), PA()
+    nf = len(first)
+    PF = ctypes.c_void_p * nf
+    srcs, dsts = PF(), PF()
+    shapes = (c_int * (10 * n))()
+    fshapes = (c_int * (4 * nf))()
+    outs = []
+    flops = nbytes = 0.0
+    f = 0
+    for j, (p, x, g, scale, R, stride, pad) in enumerate(q):
+        N, H, W, C = x.shape
+        Kc = g.shape[3]
+        xs[j], dys[j], scs[j] = x.data_ptr(), g.data_ptr(), (scale.data_ptr() if scale is not None else None)
+        dws[j] = flat.data_ptr() + 4 * offs[j]
+        shapes[10 * j: 10 * j + 10] = [N, H, W, C, Kc, R, R, stride, pad, Kc]
+        flops += 2.0 * g.shape[0] * g.shape[1] * g.shape[2] * Kc * C * R * R
+        nbytes += 4.0 * (x.numel() + g.numel() + p.numel())
+        if first[id(p)] != j:
+            continue
+        sink = _WGRAD_SINKS.get(id(p))
+        if p.grad is not None:
+            dst, beta = p.grad, 1
+            assert dst.is_contiguous() and dst.dtype == torch.float32
+        else:
+            dst = sink[0](p) if sink is not None else torch.empty_like(p, memory_format=torch.contiguous_format)
+            beta = 0
+        outs.append((p, dst, beta, sink))
+        srcs[f], dsts[f] = dws[j], dst.data_ptr()
+        fshapes[4 * f: 4 * f + 4] = [Kc, C, R * R, beta]
+        f += 1
+    st = _stream(flat)
+
+    def launch():
+        check(_lib.lib().lvc_conv_wgrad_group_bf16x3(c_int(n), xs, dys, scs, dws, shapes, st), "lvc_conv_wgrad_group_bf16x3")
+
+    _bwd_timed("wgrad", "bf16x3", flops, nbytes, launch, "group of %d" % n)
+    check(_lib.lib().lvc_wgrad_finalize_group(c_int(nf), srcs, dsts, fshapes, st), "lvc_wgrad_finalize_group")
+    for p, dst, beta, sink in outs:
+        if not beta:
+            p.grad = dst
+        if sink is not None:
+            sink[1](p)
 
 
 def scatter_stride2(x, H, W):
@@ -1826,7 +1937,8 @@ def conv_dgrad(dy, pcd, x_shape, stride):
     if BWD_TIMER is not None:
         fl = 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * pcd.K * pcd.R * pcd.S
         nb = 4.0 * (dy.numel() + dy.shape[0] * dy.shape[1] * dy.shape[2] * pcd.K + pcd.K * pcd.R * pcd.S * dy.shape[3])
-        dxs = _bwd_timed("dgrad", DGRAD_SPLIT, fl, nb, lambda: conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT))
+        tag = "%dx%dx%d %d>%d %dx%d" % (dy.shape[0], dy.shape[1], dy.shape[2], dy.shape[3], pcd.K, pcd.R, pcd.S)
+        dxs = _bwd_timed("dgrad", DGRAD_SPLIT, fl, nb, lambda: conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT), tag)
     else:
         dxs = conv2d_nhwc(dy.contiguous(), pcd, split=DGRAD_SPLIT)
     if stride == 1:

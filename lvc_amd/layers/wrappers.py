@@ -126,6 +126,8 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual, conv, res_mode, relu):
         if conv.in_channels == 3:
             raise NotImplementedError("training the 7x7 stem is not implemented (every shipped config has FREEZE_AT >= 1)")
+        if K._WGRAD_ARMED[0]:
+            K.reset_wgrad_queue()     # a backward() that raised left queued weight gradients behind
         y = K.conv2d_nhwc(x, conv.packed(), relu=relu, residual=residual, res_mode=res_mode)
         ctx.save_for_backward(x, y if relu else None)
         ctx.conv, ctx.res_mode, ctx.relu = conv, res_mode, relu
@@ -143,8 +145,14 @@ class _ConvFn(torch.autograd.Function):
             dres = g if ctx.res_mode == 1 else K.downsum2x2(g)
         if need_w:
             R = conv.kernel_size[0]
-            dw = K.conv_wgrad(x, g, conv.packed().scale if conv.norm is not None else None, R, R, conv.stride, conv.padding)
-            dw = dw.permute(0, 3, 1, 2).contiguous()   # [K,R,S,C] -> the parameter's OIHW
+            scale = conv.packed().scale if conv.norm is not None else None
+            if K.can_defer_wgrad(x, g):
+                # off the critical path: queued, launched with the other layers' (kernels.flush_wgrad) and written to weight.grad
+                # before backward() returns -- this node hands autograd no gradient for the weight
+                K.defer_wgrad(conv.weight, x, g, scale, R, conv.stride, conv.padding)
+            else:
+                dw = K.conv_wgrad(x, g, scale, R, R, conv.stride, conv.padding)
+                dw = dw.permute(0, 3, 1, 2).contiguous()   # [K,R,S,C] -> the parameter's OIHW
         if need_b:
             db = K.colsum_rows(g.view(-1, g.shape[-1]))
         if need_x:

@@ -198,3 +198,91 @@ def test_linear_backward_keeps_tiny_gradients():
         ew = float((dw.cpu().double() - rw).norm() / rw.norm())
         print("gradient scale %.0e: dx rel %.2e, dw rel %.2e" % (mag, ex, ew))
         assert ex <= 5e-6 and ew <= 5e-6, mag
+
+
+def test_grouped_wgrad_matches_single_launches():
+    """lvc_conv_wgrad_group_bf16x3 + lvc_wgrad_finalize_group (round 5: the queued weight gradients of many layers in one launch,
+    `kernels.flush_wgrad`) against one lvc_conv_wgrad_nhwc_bf16x3 launch per layer and against fp64: 30 jobs (more than one
+    kernel-argument table), mixed 1x1 / 3x3 / strided / scaled shapes, ragged channel counts, a parameter used twice."""
+    import ctypes
+
+    from lvc_amd import _lib, kernels as K
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    shapes = [(2, 13, 17, 64, 128, 3, 1, 1, True), (2, 25, 42, 256, 256, 3, 1, 1, False), (1, 9, 11, 36, 20, 1, 1, 0, False),
+              (2, 50, 84, 256, 64, 1, 1, 0, True), (2, 20, 30, 128, 256, 1, 2, 0, True), (3, 7, 9, 32, 160, 3, 1, 1, False)]
+    jobs = []
+    for i in range(30):
+        N, H, W, C, Kc, R, stride, pad, scaled = shapes[i % len(shapes)]
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+        x = torch.randn(N, H, W, C, generator=g).to(dev)
+        dy = (torch.randn(N, Ho, Wo, Kc, generator=g) * 10.0 ** -(i % 7)).to(dev)       # gradients over many binades
+        sc = (torch.rand(Kc, generator=g) + 0.5).to(dev) if scaled else None
+        jobs.append((x, dy, sc, R, stride, pad))
+    n = len(jobs)
+    sizes = [j[1].shape[3] * j[3] * j[3] * j[0].shape[3] for j in jobs]
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + (s + 3) // 4 * 4)
+    flat = torch.zeros(offs[-1], device=dev)
+    PA = ctypes.c_void_p * n
+    xs, dys, scs, dws, dsts = PA(), PA(), PA(), PA(), PA()
+    sh = (ctypes.c_int * (10 * n))()
+    fsh = (ctypes.c_int * (4 * n))()
+    outs = []
+    for j, (x, dy, sc, R, stride, pad) in enumerate(jobs):
+        N, H, W, C = x.shape
+        Kc = dy.shape[3]
+        xs[j], dys[j], scs[j], dws[j] = x.data_ptr(), dy.data_ptr(), (sc.data_ptr() if sc is not None else None), flat.data_ptr() + 4 * offs[j]
+        sh[10 * j: 10 * j + 10] = [N, H, W, C, Kc, R, R, stride, pad, Kc]
+        beta = j % 2
+        out = torch.full((Kc, C, R, R), 0.25 if beta else float("nan"), device=dev)
+        outs.append(out)
+        dsts[j] = out.data_ptr()
+        fsh[4 * j: 4 * j + 4] = [Kc, C, R * R, beta]
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.lib().lvc_conv_wgrad_group_bf16x3(ctypes.c_int(n), xs, dys, scs, dws, sh, st), "group")
+    _lib.check(_lib.lib().lvc_wgrad_finalize_group(ctypes.c_int(n), dws, dsts, fsh, st), "finalize")
+    for j, (x, dy, sc, R, stride, pad) in enumerate(jobs):
+        single = K._conv_wgrad(x, dy, sc, R, R, stride, pad).permute(0, 3, 1, 2)
+        got = outs[j] - (0.25 if j % 2 else 0.0)
+        xr = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(False)
+        wr = torch.zeros(dy.shape[3], x.shape[3], R, R, dtype=torch.float64, requires_grad=True)
+        yr = F.conv2d(xr, wr, stride=stride, padding=pad)
+        gr = dy.double().cpu().permute(0, 3, 1, 2)
+        if sc is not None:
+            gr = gr * sc.double().cpu()[None, :, None, None]
+        (yr * gr).sum().backward()
+        scale = float(wr.grad.abs().max())
+        tol = 2e-5 if j % 2 == 0 else 2e-5 + 1e-7 * 0.25 / max(scale, 1e-30)     # the accumulate form rounds (0.25 + dw) once
+        assert float((got.cpu().double() - wr.grad).abs().max()) <= tol * scale, (j, jobs[j][0].shape)
+        assert float((got - single).abs().max()) <= 1e-5 * scale + (1e-7 * 0.25 if j % 2 else 0.0), j
+
+
+def test_deferred_wgrad_equals_the_immediate_path_shared_parameter_and_accumulation(monkeypatch):
+    """`kernels.defer_wgrad`: a conv applied to two maps in one graph (the RPN head over pyramid levels: one accumulation buffer),
+    `weight.grad` present when backward() returns, a second backward() accumulates into it -- against LVC_DEFER_WGRAD=0 (autograd's
+    own AccumulateGrad)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.layers import Conv2d
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(9)
+    conv = Conv2d(64, 128, 3, padding=1, bias=True).to(dev)
+    xa = torch.randn(2, 24, 40, 64, generator=g).to(dev)
+    xb = torch.randn(2, 12, 20, 64, generator=g).to(dev)
+
+    def run():
+        conv.weight.grad = conv.bias.grad = None
+        for _ in range(2):
+            (conv.forward_nhwc(xa).square().sum() * 1e-3 + conv.forward_nhwc(xb).sum() * 1e-2).backward()
+            assert conv.weight.grad is not None and not K._WGRAD_Q
+        return conv.weight.grad.clone(), conv.bias.grad.clone()
+
+    monkeypatch.setattr(K, "DEFER_WGRAD", True)
+    w1, b1 = run()
+    monkeypatch.setattr(K, "DEFER_WGRAD", False)
+    w0, b0 = run()
+    assert _rel(w1, w0) < 1e-5 and _rel(b1, b0) < 1e-6
+    assert w1.is_contiguous() and w1.shape == conv.weight.shape
