@@ -456,6 +456,13 @@ int lvc_split_weights(const float* wp, long long n, int planes, void* out, int* 
  * (fp16) or 3 (bf16); err_word as lvc_split_weights. */
 int lvc_pack_split_conv_weights(const float* w, const float* scale, float* wp, void* planes_out, int planes, int* err_word,
                                 int K, int C, int R, int S, int rows_pad, int cin_pad, int mode, void* stream);
+/* lvc_pack_split_conv_weights (+ lvc_split_weights_rowscaled) for `njobs` layers in one launch per 24 jobs (round 5: an optimizer
+ * step invalidates the packed operands of every trainable layer -- the reference has no such step, ATen reads OIHW directly).
+ * ptrs: host array, 6 device pointers per job = w (OIHW), scale (mode 1: folded into the operand, or NULL), fac_scale (fmt 4:
+ * multiplied into the row factors, or NULL), wp ([rows_pad][R*S*cin_pad] fp32), planes, fac ([rows_pad] fp32, fmt 4);
+ * shapes: 8 ints per job = K, C, R, S, rows_pad, cin_pad, mode (as lvc_pack_conv_weights), fmt -- 0: wp only, 2: fp16 planes
+ * (lvc_split_weights), 3: bf16 planes, 4: row-scaled fp16 planes + fac[row] = 2^-e / 16 (* fac_scale[row]) (lvc_split_weights_rowscaled). */
+int lvc_pack_group(int njobs, const void* const* ptrs, const int* shapes, int* err_word, void* stream);
 int lvc_conv_wgrad_nhwc(const float* x, const float* dy, const float* scale, float* dw, int N, int H, int W, int C,
                         int K, int R, int S, int stride, int pad, int lddy, void* stream);
 /* lvc_conv_wgrad_nhwc on the three-way bf16 split MFMA path (six bf16 MFMAs per fp32-accurate product, one fp32

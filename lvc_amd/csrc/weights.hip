@@ -109,3 +109,125 @@ extern "C" int lvc_split_weights(const float* wp, long long n, int planes, void*
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }
+
+
+// ---- every stale layer of a training step in a few launches (round 5) --------------------------------------------------------------
+// One optimizer step invalidates the packed operands of every trainable layer: the forward one (mode 0; fp16 planes plain or
+// row-scaled, or bf16 planes) and the data-gradient one (mode 1).  Per layer that was a pack launch, a split launch and a
+// torch multiply for the row factors: ~330 launches of 5-7 us in the box-corrector step (R101, 110 trainable convolutions).
+// Here one workgroup owns one packed row of one job; jobs travel as kernel arguments.
+//   fmt 0: wp only; 2: + fp16 planes (w1, (w - w1) * 2048); 3: + bf16 planes (hi, mid, lo); 4: + ROW-SCALED fp16 planes (the
+//   one-accumulator kernels' operand, see split_rowscaled_kernel in conv3x3_halo_s1.hip: e = 13 - floor(log2 max|row|), w1 =
+//   fp16(w 2^e), w2 = fp16(w 2^e - w1)) and fac[row] = 2^-e / 16 * (fac_scale ? fac_scale[row] : 1) for rows < K.
+#define PK_GROUP_MAX 24
+struct PackJob {
+  const float* w;
+  const float* scale;        // mode 1: the FrozenBN scale folded into the data-gradient operand (or NULL)
+  const float* fac_scale;    // fmt 4: the layer's epilogue scale multiplied into the row factors (or NULL)
+  float* wp;
+  unsigned short* planes;
+  float* fac;
+  int K, C, R, S, rows_pad, cin_pad, mode, fmt;
+  int row_begin, pad_;
+};
+struct PackGroup { PackJob job[PK_GROUP_MAX]; int njobs, total_rows; int* err_word; };
+
+__device__ __forceinline__ float pk_gather(const PackJob& f, int row, int k) {
+  const int ci = k & 31; k >>= 5;
+  const int s = k % f.S; k /= f.S;
+  const int r = k % f.R; k /= f.R;
+  const int cin = k * 32 + ci;
+  float v = 0.f;
+  if (f.mode == 0) {
+    if (row < f.K && cin < f.C) v = f.w[(((size_t)row * f.C + cin) * f.R + r) * f.S + s];
+  } else if (row < f.C && cin < f.K) {
+    v = f.w[(((size_t)cin * f.C + row) * f.R + (f.R - 1 - r)) * f.S + (f.S - 1 - s)];
+    if (f.scale) v *= f.scale[cin];
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void pack_group_kernel(const PackGroup g) {
+  __shared__ float red[256];
+  int j = 0;
+  for (int q = 1; q < g.njobs; ++q)
+    if ((int)blockIdx.x >= g.job[q].row_begin) j = q;
+  const PackJob& f = g.job[j];
+  const int row = blockIdx.x - f.row_begin;
+  const int Kg = f.R * f.S * f.cin_pad;
+  const long long plane = (long long)f.rows_pad * Kg;
+  float s2 = 1.f;
+  if (f.fmt == 4) {
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < Kg; i += 256) {
+      const float v = fabsf(pk_gather(f, row, i));
+      mx = (v > mx || v != v) ? v : mx;
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        const float o = red[threadIdx.x + s];
+        if (o > red[threadIdx.x] || o != o) red[threadIdx.x] = o;
+      }
+      __syncthreads();
+    }
+    mx = red[0];
+    int e = 0;
+    if (mx > 0.f && mx < INFINITY) {
+      int ex;
+      frexpf(mx, &ex);
+      e = 13 - (ex - 1);
+      e = e > 100 ? 100 : e < -100 ? -100 : e;
+    }
+    s2 = ldexpf(1.f, e);
+    if (threadIdx.x == 0) {
+      float fa = ldexpf(1.f, -e) * (1.f / 16.f);
+      const int nrow = f.mode == 0 ? f.K : f.C;
+      if (f.fac_scale && row < nrow) fa *= f.fac_scale[row];
+      f.fac[row] = fa;
+    }
+  }
+  for (int i = threadIdx.x; i < Kg; i += 256) {
+    const float v = pk_gather(f, row, i);
+    const long long o = (long long)row * Kg + i;
+    f.wp[o] = v;
+    if (f.fmt == 2 || f.fmt == 3) {
+      emit_planes(v, o, plane, f.fmt, f.planes, g.err_word);
+    } else if (f.fmt == 4) {
+      const float vs = v * s2;
+      const _Float16 h = (_Float16)vs;
+      const _Float16 l = (_Float16)(vs - (float)h);
+      f.planes[o] = __builtin_bit_cast(unsigned short, h);
+      f.planes[plane + o] = __builtin_bit_cast(unsigned short, l);
+    }
+  }
+}
+
+// ptrs: 6 pointers per job (w, scale, fac_scale, wp, planes, fac); shapes: 8 ints per job (K, C, R, S, rows_pad, cin_pad, mode, fmt)
+extern "C" int lvc_pack_group(int njobs, const void* const* ptrs, const int* shapes, int* err_word, void* stream) {
+  LVC_CHECK_ARG(njobs > 0 && ptrs && shapes, "null pointer / no jobs");
+  for (int j0 = 0; j0 < njobs; j0 += PK_GROUP_MAX) {
+    const int nj = njobs - j0 < PK_GROUP_MAX ? njobs - j0 : PK_GROUP_MAX;
+    PackGroup g;
+    int rows = 0;
+    for (int j = 0; j < nj; ++j) {
+      const void* const* pp = ptrs + (size_t)(j0 + j) * 6;
+      const int* sh = shapes + (size_t)(j0 + j) * 8;
+      PackJob& f = g.job[j];
+      f.w = (const float*)pp[0]; f.scale = (const float*)pp[1]; f.fac_scale = (const float*)pp[2];
+      f.wp = (float*)pp[3]; f.planes = (unsigned short*)pp[4]; f.fac = (float*)pp[5];
+      f.K = sh[0]; f.C = sh[1]; f.R = sh[2]; f.S = sh[3]; f.rows_pad = sh[4]; f.cin_pad = sh[5]; f.mode = sh[6]; f.fmt = sh[7];
+      LVC_CHECK_ARG(f.w && f.wp && f.K > 0 && f.C > 0 && f.R > 0 && f.S > 0 && (f.mode == 0 || f.mode == 1), "bad job");
+      LVC_CHECK_ARG(f.fmt == 0 || ((f.fmt == 2 || f.fmt == 3 || f.fmt == 4) && f.planes), "bad plane format / null planes");
+      LVC_CHECK_ARG(f.fmt != 4 || f.fac, "fmt 4 needs the row-factor output");
+      LVC_CHECK_ARG(f.cin_pad % 32 == 0 && f.cin_pad >= (f.mode == 0 ? f.C : f.K) && f.rows_pad >= (f.mode == 0 ? f.K : f.C), "bad padding");
+      f.row_begin = rows; f.pad_ = 0;
+      rows += f.rows_pad;
+    }
+    g.njobs = nj; g.total_rows = rows; g.err_word = err_word;
+    hipLaunchKernelGGL(pack_group_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g);
+    LVC_CHECK_LAUNCH();
+  }
+  return LVC_OK;
+}

@@ -212,6 +212,86 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False,
     return PackedConv(wp, scale, shift, K, Cphys, R, S, stride, pad, Kg, mode)
 
 
+PREPACK = __import__("os").environ.get("LVC_PREPACK", "1") != "0"
+
+
+def prepack_group(jobs):
+    """The packed operands of many layers in a few launches (csrc/weights.hip pack_group_kernel) instead of two or three launches
+    per layer: what `pack_conv` (+ `PackedConv.split2s`) and `pack_conv_dgrad` produce, for the layers whose parameters an
+    optimizer step just changed.  jobs: list of dicts {"weight", "kind": "fwd" | "dgrad", "stride", "pad", "affine": (scale, shift),
+    "two_acc", "tier", "scale"}; returns the list of PackedConv objects (same fields as the per-layer functions fill)."""
+    import ctypes
+
+    if not jobs:
+        return []
+    dev = jobs[0]["weight"].device
+    metas, total = [], 0
+
+    def take(nbytes):
+        nonlocal total
+        o = total
+        total += (nbytes + 255) // 256 * 256
+        return o
+
+    for jb in jobs:
+        w = jb["weight"]
+        Kc, C, R, S = w.shape
+        if jb["kind"] == "fwd":
+            assert C % BK == 0
+            rows_pad, cin_pad, mode = (Kc + BN - 1) // BN * BN, C, 0
+            hint = _planes_hint(R, S, C, None)
+            one = (hint == 2 and not jb.get("two_acc") and jb.get("tier", 0) == 0
+                   and ((R == 3 and HALO_S1 == 2) or (R == 1 and PW_S1 == 2 and C >= _PW_S1_ONE_MIN_C)))
+            fmt = 4 if one else hint
+        else:
+            cin_pad = (Kc + 31) // 32 * 32
+            rows_pad, mode = (C + BN - 1) // BN * BN, 1
+            fmt = _planes_hint(R, S, cin_pad, DGRAD_SPLIT)
+        Kg = R * S * cin_pad
+        nplanes = 3 if fmt == 3 else 2 if fmt in (2, 4) else 0
+        metas.append((rows_pad, cin_pad, mode, fmt, Kg, take(rows_pad * Kg * 4), take(nplanes * rows_pad * Kg * 2) if nplanes else -1,
+                      take(rows_pad * 4) if fmt == 4 else -1))
+    buf = torch.empty(total, dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    n = len(jobs)
+    ptrs = (ctypes.c_void_p * (6 * n))()
+    shapes = (c_int * (8 * n))()
+    out = []
+    for j, (jb, (rows_pad, cin_pad, mode, fmt, Kg, o_wp, o_pl, o_fac)) in enumerate(zip(jobs, metas)):
+        w = jb["weight"].detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        jb["_w"] = w           # alive until the launch is queued
+        Kc, C, R, S = w.shape
+        aff = jb.get("affine") or (None, None)
+        wp = buf[o_wp: o_wp + rows_pad * Kg * 4].view(torch.float32).view(rows_pad, Kg)
+        pl = fac = None
+        if fmt in (2, 4):
+            pl = buf[o_pl: o_pl + 2 * rows_pad * Kg * 2].view(torch.float16).view(2, rows_pad, Kg)
+        elif fmt == 3:
+            pl = buf[o_pl: o_pl + 3 * rows_pad * Kg * 2].view(torch.bfloat16).view(3, rows_pad, Kg)
+        if fmt == 4:
+            fac = buf[o_fac: o_fac + rows_pad * 4].view(torch.float32)
+        dg_scale = jb.get("scale") if mode == 1 else None
+        ptrs[6 * j: 6 * j + 6] = [w.data_ptr(), dg_scale.data_ptr() if dg_scale is not None else None,
+                                  aff[0].data_ptr() if (fmt == 4 and aff[0] is not None) else None, base + o_wp,
+                                  (base + o_pl) if pl is not None else None, (base + o_fac) if fac is not None else None]
+        shapes[8 * j: 8 * j + 8] = [Kc, C, R, S, rows_pad, cin_pad, mode, fmt]
+        if mode == 0:
+            pc = PackedConv(wp, aff[0], aff[1], Kc, C, R, S, jb["stride"], jb["pad"], Kg, 0)
+        else:
+            pc = PackedConv(wp, None, None, C, cin_pad, R, S, 1, R - 1 - jb["pad"], Kg, 0)
+        if fmt == 2:
+            pc._w2h = pl
+        elif fmt == 3:
+            pc._w3 = pl
+        elif fmt == 4:
+            pc._w2s = (pl, fac[:Kc])
+        out.append(pc)
+    check(_lib.lib().lvc_pack_group(c_int(n), ptrs, shapes, ptr(_conv_error_view(dev)), _stream(buf)), "lvc_pack_group")
+    return out
+
+
 def pack_linear(weight, bias=None, split=None, two_acc=True):
     """weight [K_out, K_in] -> a 1x1 'conv' over M x 1 x 1 x K_in rows.  split: the operand split the GEMM will be
     asked for (None = LVC_CONV_SPLIT), so that the matching planes are produced by the packing launch.

@@ -87,6 +87,34 @@ class Conv2d(nn.Module):
         pc.state = self._range_state
         return pc
 
+    def _stale(self, cache, tensors):
+        return cache.key != tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+    @staticmethod
+    def prepack(convs, dgrad=None):
+        """Re-pack the stale operands of `convs` (trainable layers after an optimizer step) in grouped launches
+        (`kernels.prepack_group`): what `packed()` / `packed_dgrad()` would build one layer at a time.  dgrad: the layers whose
+        data-gradient operand is needed too (default: all of them)."""
+        jobs, targets = [], []
+        for conv in convs:
+            if conv.in_channels == 3 or conv.in_channels % 32:
+                continue
+            aff = conv._affine()
+            srcs = [conv.weight, aff[0], aff[1]]
+            if conv._stale(conv._cache, srcs):
+                jobs.append({"weight": conv.weight, "kind": "fwd", "stride": conv.stride, "pad": conv.padding, "affine": aff,
+                             "two_acc": bool(getattr(conv, "two_acc", False)), "tier": conv._range_state.get("tier", 0)})
+                targets.append((conv._cache, srcs))
+            if dgrad is None or conv in dgrad:
+                scale = aff[0] if conv.norm is not None else None
+                srcs = [conv.weight, scale]
+                if conv._stale(conv._cache_dgrad, srcs):
+                    jobs.append({"weight": conv.weight, "kind": "dgrad", "stride": conv.stride, "pad": conv.padding, "scale": scale})
+                    targets.append((conv._cache_dgrad, srcs))
+        for (cache, srcs), pc in zip(targets, K.prepack_group(jobs)):
+            cache.value = pc
+            cache.key = tuple((t.data_ptr(), t._version) for t in srcs if t is not None)
+
     def packed_dgrad(self):
         """Packed weights of the data gradient (flipped, transposed, times the FrozenBN scale)."""
         scale = self._affine()[0] if self.norm is not None else None

@@ -130,12 +130,29 @@ class GeneralizedRCNN(_RCNNBase):
 
         def once():
             self.__dict__["_range_checked"] = False
+            self._prepack_trainable()
             losses = self._forward_train(batched_inputs)
             if not self.__dict__["_range_checked"]:    # (the deferred-read path folds the range words into its one device->host read)
                 K.check_conv_error_word(self.device)   # fp16x2 range word of the forward kernels (the step syncs anyway)
             return losses
 
         return run_with_fallbacks(self, once)
+
+    def _prepack_trainable(self):
+        """The kernel-layout operands of every convolution whose weight trains, rebuilt after an optimizer step in a few grouped
+        launches (forward operand, and the data-gradient operand where a gradient flows further down) instead of 2-3 per layer."""
+        if not K.PREPACK or not torch.is_grad_enabled():
+            return
+        lst = self.__dict__.get("_trainable_convs")
+        if lst is None or lst[0] != sum(1 for p in self.parameters() if p.requires_grad):
+            from ...layers import Conv2d
+
+            convs = [m for m in self.modules() if isinstance(m, Conv2d) and m.weight.requires_grad]
+            lst = self.__dict__["_trainable_convs"] = (sum(1 for p in self.parameters() if p.requires_grad), convs)
+        if lst[1]:
+            from ...layers import Conv2d
+
+            Conv2d.prepack(lst[1])
 
     def _forward_train(self, batched_inputs):
         # training forward (reference rcnn.py:127-175): losses of the RPN (logged; frozen) and of the box predictor

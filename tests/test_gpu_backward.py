@@ -286,3 +286,52 @@ def test_deferred_wgrad_equals_the_immediate_path_shared_parameter_and_accumulat
     w0, b0 = run()
     assert _rel(w1, w0) < 1e-5 and _rel(b1, b0) < 1e-6
     assert w1.is_contiguous() and w1.shape == conv.weight.shape
+
+
+def test_prepack_group_equals_the_per_layer_packing():
+    """`Conv2d.prepack` (one grouped launch: csrc/weights.hip pack_group_kernel) fills the same operands, bit for bit, as `packed()` /
+    `packed_dgrad()` + the lazy splits do one layer at a time: fp32 operand, plain fp16 planes (two-accumulator layers), row-scaled
+    fp16 planes + row factors (one-accumulator layers), bf16 planes (short contractions, data gradients)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.layers import Conv2d, FrozenBatchNorm2d
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    specs = [(256, 256, 3, 1, True, False), (256, 128, 3, 1, False, True), (512, 128, 1, 0, True, False), (64, 256, 1, 0, True, False),
+             (32, 40, 1, 0, False, False), (128, 512, 1, 0, True, True), (1024, 2048, 1, 0, True, False)] * 5     # 35 layers: two tables
+    convs = []
+    for C, Kc, R, pad, bn, two in specs:
+        norm = FrozenBatchNorm2d(Kc) if bn else None
+        conv = Conv2d(C, Kc, R, padding=pad, bias=not bn, norm=norm)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(Kc, C, R, R, generator=g) * 10.0 ** float(torch.randint(-3, 2, (1,), generator=g)))
+            if bn:
+                norm.weight.copy_(torch.rand(Kc, generator=g) + 0.5)
+                norm.running_var.copy_(torch.rand(Kc, generator=g) + 0.5)
+        conv.two_acc = two
+        convs.append(conv.to(dev))
+    Conv2d.prepack(convs)
+    got = [(c._cache.value, c._cache_dgrad.value) for c in convs]
+    for c in convs:
+        c._cache.key = c._cache_dgrad.key = None
+    for c, (pf, pd) in zip(convs, got):
+        rf, rd = c.packed(), c.packed_dgrad()
+        assert rf is not pf and rd is not pd
+        assert torch.equal(pf.w, rf.w) and torch.equal(pd.w, rd.w) and (pf.K, pf.C, pf.R, pf.stride, pf.pad, pf.Kg) == (rf.K, rf.C, rf.R, rf.stride, rf.pad, rf.Kg)
+        assert (pd.K, pd.C, pd.R, pd.stride, pd.pad, pd.Kg) == (rd.K, rd.C, rd.R, rd.stride, rd.pad, rd.Kg)
+        if pf._w2s is not None:
+            planes, fac = rf.split2s()
+            assert torch.equal(pf._w2s[0].view(torch.int16), planes.view(torch.int16)) and torch.equal(pf._w2s[1], fac)
+        if pf._w2h is not None:
+            assert torch.equal(pf._w2h.view(torch.int16), rf.split2h().view(torch.int16))
+        if pf._w3 is not None:
+            assert torch.equal(pf._w3.view(torch.int16), rf.split3().view(torch.int16))
+        assert pd._w3 is not None and torch.equal(pd._w3.view(torch.int16), rd.split3().view(torch.int16))
+    kinds = {("s" if p._w2s is not None else "h" if p._w2h is not None else "3") for p, _ in got}
+    assert kinds == {"s", "h", "3"}
+    # and the forward through a pre-packed layer equals the forward through a per-layer-packed one
+    x = torch.randn(2, 20, 28, 256, generator=g).to(dev)
+    y_ref = convs[0].forward_nhwc(x)
+    convs[0]._cache.key = None
+    Conv2d.prepack(convs[:1])
+    assert torch.equal(convs[0].forward_nhwc(x), y_ref)
