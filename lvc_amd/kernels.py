@@ -215,81 +215,93 @@ def pack_conv(weight, bias=None, bn=None, stride=1, pad=0, eps=1e-5, stem=False,
 PREPACK = __import__("os").environ.get("LVC_PREPACK", "1") != "0"
 
 
-def prepack_group(jobs):
+class PrepackPlan:
     """The packed operands of many layers in a few launches (csrc/weights.hip pack_group_kernel) instead of two or three launches
     per layer: what `pack_conv` (+ `PackedConv.split2s`) and `pack_conv_dgrad` produce, for the layers whose parameters an
     optimizer step just changed.  jobs: list of dicts {"weight", "kind": "fwd" | "dgrad", "stride", "pad", "affine": (scale, shift),
-    "two_acc", "tier", "scale"}; returns the list of PackedConv objects (same fields as the per-layer functions fill)."""
-    import ctypes
+    "two_acc", "tier", "scale"}; `.packed`: the PackedConv objects (same fields as the per-layer functions fill).
+    The plan owns its buffers: `relaunch()` packs the (changed) parameters into the SAME operands again -- the host side of a
+    training step's re-packing is then one kernel-argument table per 24 layers, not ~10 tensor views per layer."""
 
-    if not jobs:
-        return []
-    dev = jobs[0]["weight"].device
-    metas, total = [], 0
+    def __init__(self, jobs):
+        import ctypes
 
-    def take(nbytes):
-        nonlocal total
-        o = total
-        total += (nbytes + 255) // 256 * 256
-        return o
+        dev = jobs[0]["weight"].device
+        metas, total = [], 0
 
-    for jb in jobs:
-        w = jb["weight"]
-        Kc, C, R, S = w.shape
-        if jb["kind"] == "fwd":
-            assert C % BK == 0
-            rows_pad, cin_pad, mode = (Kc + BN - 1) // BN * BN, C, 0
-            hint = _planes_hint(R, S, C, None)
-            one = (hint == 2 and not jb.get("two_acc") and jb.get("tier", 0) == 0
-                   and ((R == 3 and HALO_S1 == 2) or (R == 1 and PW_S1 == 2 and C >= _PW_S1_ONE_MIN_C)))
-            fmt = 4 if one else hint
-        else:
-            cin_pad = (Kc + 31) // 32 * 32
-            rows_pad, mode = (C + BN - 1) // BN * BN, 1
-            fmt = _planes_hint(R, S, cin_pad, DGRAD_SPLIT)
-        Kg = R * S * cin_pad
-        nplanes = 3 if fmt == 3 else 2 if fmt in (2, 4) else 0
-        metas.append((rows_pad, cin_pad, mode, fmt, Kg, take(rows_pad * Kg * 4), take(nplanes * rows_pad * Kg * 2) if nplanes else -1,
-                      take(rows_pad * 4) if fmt == 4 else -1))
-    buf = torch.empty(total, dtype=torch.uint8, device=dev)
-    base = buf.data_ptr()
-    n = len(jobs)
-    ptrs = (ctypes.c_void_p * (6 * n))()
-    shapes = (c_int * (8 * n))()
-    out = []
-    for j, (jb, (rows_pad, cin_pad, mode, fmt, Kg, o_wp, o_pl, o_fac)) in enumerate(zip(jobs, metas)):
-        w = jb["weight"].detach()
-        if w.dtype != torch.float32 or not w.is_contiguous():
-            w = w.float().contiguous()
-        jb["_w"] = w           # alive until the launch is queued
-        Kc, C, R, S = w.shape
-        aff = jb.get("affine") or (None, None)
-        wp = buf[o_wp: o_wp + rows_pad * Kg * 4].view(torch.float32).view(rows_pad, Kg)
-        pl = fac = None
-        if fmt in (2, 4):
-            pl = buf[o_pl: o_pl + 2 * rows_pad * Kg * 2].view(torch.float16).view(2, rows_pad, Kg)
-        elif fmt == 3:
-            pl = buf[o_pl: o_pl + 3 * rows_pad * Kg * 2].view(torch.bfloat16).view(3, rows_pad, Kg)
-        if fmt == 4:
-            fac = buf[o_fac: o_fac + rows_pad * 4].view(torch.float32)
-        dg_scale = jb.get("scale") if mode == 1 else None
-        ptrs[6 * j: 6 * j + 6] = [w.data_ptr(), dg_scale.data_ptr() if dg_scale is not None else None,
-                                  aff[0].data_ptr() if (fmt == 4 and aff[0] is not None) else None, base + o_wp,
-                                  (base + o_pl) if pl is not None else None, (base + o_fac) if fac is not None else None]
-        shapes[8 * j: 8 * j + 8] = [Kc, C, R, S, rows_pad, cin_pad, mode, fmt]
-        if mode == 0:
-            pc = PackedConv(wp, aff[0], aff[1], Kc, C, R, S, jb["stride"], jb["pad"], Kg, 0)
-        else:
-            pc = PackedConv(wp, None, None, C, cin_pad, R, S, 1, R - 1 - jb["pad"], Kg, 0)
-        if fmt == 2:
-            pc._w2h = pl
-        elif fmt == 3:
-            pc._w3 = pl
-        elif fmt == 4:
-            pc._w2s = (pl, fac[:Kc])
-        out.append(pc)
-    check(_lib.lib().lvc_pack_group(c_int(n), ptrs, shapes, ptr(_conv_error_view(dev)), _stream(buf)), "lvc_pack_group")
-    return out
+        def take(nbytes):
+            nonlocal total
+            o = total
+            total += (nbytes + 255) // 256 * 256
+            return o
+
+        for jb in jobs:
+            w = jb["weight"]
+            Kc, C, R, S = w.shape
+            if jb["kind"] == "fwd":
+                assert C % BK == 0
+                rows_pad, cin_pad, mode = (Kc + BN - 1) // BN * BN, C, 0
+                hint = _planes_hint(R, S, C, None)
+                one = (hint == 2 and not jb.get("two_acc") and jb.get("tier", 0) == 0
+                       and ((R == 3 and HALO_S1 == 2) or (R == 1 and PW_S1 == 2 and C >= _PW_S1_ONE_MIN_C)))
+                fmt = 4 if one else hint
+            else:
+                cin_pad = (Kc + 31) // 32 * 32
+                rows_pad, mode = (C + BN - 1) // BN * BN, 1
+                fmt = _planes_hint(R, S, cin_pad, DGRAD_SPLIT)
+            Kg = R * S * cin_pad
+            nplanes = 3 if fmt == 3 else 2 if fmt in (2, 4) else 0
+            metas.append((rows_pad, cin_pad, mode, fmt, Kg, take(rows_pad * Kg * 4), take(nplanes * rows_pad * Kg * 2) if nplanes else -1,
+                          take(rows_pad * 4) if fmt == 4 else -1))
+        self.buf = buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = buf.data_ptr()
+        self.n = n = len(jobs)
+        self.ptrs = ptrs = (ctypes.c_void_p * (6 * n))()
+        self.shapes = shapes = (c_int * (8 * n))()
+        self.packed, self.planes, self.keep = [], [], []
+        self.reusable = True
+        for j, (jb, (rows_pad, cin_pad, mode, fmt, Kg, o_wp, o_pl, o_fac)) in enumerate(zip(jobs, metas)):
+            w = jb["weight"].detach()
+            if w.dtype != torch.float32 or not w.is_contiguous():
+                w = w.float().contiguous()
+                self.reusable = False          # a converted copy: its address is not the parameter's
+            self.keep.append(w)
+            Kc, C, R, S = w.shape
+            aff = jb.get("affine") or (None, None)
+            wp = buf[o_wp: o_wp + rows_pad * Kg * 4].view(torch.float32).view(rows_pad, Kg)
+            pl = fac = None
+            if fmt in (2, 4):
+                pl = buf[o_pl: o_pl + 2 * rows_pad * Kg * 2].view(torch.float16).view(2, rows_pad, Kg)
+            elif fmt == 3:
+                pl = buf[o_pl: o_pl + 3 * rows_pad * Kg * 2].view(torch.bfloat16).view(3, rows_pad, Kg)
+            if fmt == 4:
+                fac = buf[o_fac: o_fac + rows_pad * 4].view(torch.float32)
+            dg_scale = jb.get("scale") if mode == 1 else None
+            self.keep.append((dg_scale, aff))
+            ptrs[6 * j: 6 * j + 6] = [w.data_ptr(), dg_scale.data_ptr() if dg_scale is not None else None,
+                                      aff[0].data_ptr() if (fmt == 4 and aff[0] is not None) else None, base + o_wp,
+                                      (base + o_pl) if pl is not None else None, (base + o_fac) if fac is not None else None]
+            shapes[8 * j: 8 * j + 8] = [Kc, C, R, S, rows_pad, cin_pad, mode, fmt]
+            if mode == 0:
+                pc = PackedConv(wp, aff[0], aff[1], Kc, C, R, S, jb["stride"], jb["pad"], Kg, 0)
+            else:
+                pc = PackedConv(wp, None, None, C, cin_pad, R, S, 1, R - 1 - jb["pad"], Kg, 0)
+            self.packed.append(pc)
+            self.planes.append((fmt, pl, fac[:Kc] if fac is not None else None))
+        self._err = _conv_error_view(dev)
+        self.relaunch()
+
+    def relaunch(self):
+        for pc, (fmt, pl, fac) in zip(self.packed, self.planes):
+            pc._w2h = pl if fmt == 2 else None          # lazily made planes of the previous parameters go too
+            pc._w3 = pl if fmt == 3 else None
+            pc._w2s = (pl, fac) if fmt == 4 else None
+            pc.state.pop("_wino", None)
+        check(_lib.lib().lvc_pack_group(c_int(self.n), self.ptrs, self.shapes, ptr(self._err), _stream(self.buf)), "lvc_pack_group")
+
+
+def prepack_group(jobs):
+    return PrepackPlan(jobs).packed if jobs else []
 
 
 def pack_linear(weight, bias=None, split=None, two_acc=True):
@@ -1854,6 +1866,11 @@ _WGRAD_GROUP = 24            # jobs per launch (kernel-argument table)
 _WGRAD_Q = []                # (param, x, g, scale, R, stride, pad)
 _WGRAD_ARMED = [False]
 _WGRAD_SINKS = {}            # id(param) -> (destination(param) -> tensor the gradient is written into, ready(param))
+# "1": the grouped launches on a second stream.  Measured on the box-corrector step (2 images per GPU): 28.41 / 28.46 / 28.49 ms against
+# 28.28 / 28.68 / 29.24 on the pass's own stream -- the step is bound by the host's launch rate there, not by the chip; off by default
+WGRAD_SIDE_STREAM = _os.environ.get("LVC_WGRAD_SIDE_STREAM", "0") != "0"
+_WGRAD_SIDE = {}             # device index -> the stream the grouped launches run on
+_WGRAD_PENDING = []          # (event, deliveries, operands kept alive) of groups in flight on the side stream
 
 
 def register_wgrad_sink(param, destination, ready):
@@ -1868,6 +1885,7 @@ def unregister_wgrad_sink(param):
 
 def reset_wgrad_queue():
     del _WGRAD_Q[:]
+    del _WGRAD_PENDING[:]
     _WGRAD_ARMED[0] = False
 
 
@@ -1890,14 +1908,16 @@ def defer_wgrad(param, x, g, scale, R, stride, pad):
 
 def _flush_wgrad_end():
     _WGRAD_ARMED[0] = False
-    flush_wgrad()
+    flush_wgrad(final=True)
 
 
-def flush_wgrad():
+def flush_wgrad(final=False):
     """Launch the queued weight gradients: one zeroing, one grouped wgrad launch, one grouped layout / accumulate launch."""
     q = list(_WGRAD_Q)
     del _WGRAD_Q[:]
     if not q:
+        if final:
+            _retire_wgrad()
         return
     import ctypes
 
@@ -1944,18 +1964,45 @@ def flush_wgrad():
         srcs[f], dsts[f] = dws[j], dst.data_ptr()
         fshapes[4 * f: 4 * f + 4] = [Kc, C, R * R, beta]
         f += 1
-    st = _stream(flat)
+    main = torch.cuda.current_stream(dev)
+    side = main
+    if WGRAD_SIDE_STREAM and BWD_TIMER is None:
+        # off the critical path in time as well: the group runs on a second stream next to the data-gradient chain, whose launches
+        # (8 400-pixel maps at 2 images per GPU) leave most of the chip idle
+        side = _WGRAD_SIDE.get(dev.index)
+        if side is None:
+            side = _WGRAD_SIDE[dev.index] = torch.cuda.Stream(dev)
+        side.wait_stream(main)              # x, dy, the zeroed buffer and the destinations are complete on the main stream
+    st = c_void_p(side.cuda_stream)
 
     def launch():
         check(_lib.lib().lvc_conv_wgrad_group_bf16x3(c_int(n), xs, dys, scs, dws, shapes, st), "lvc_conv_wgrad_group_bf16x3")
 
     _bwd_timed("wgrad", "bf16x3", flops, nbytes, launch, "group of %d" % n)
     check(_lib.lib().lvc_wgrad_finalize_group(c_int(nf), srcs, dsts, fshapes, st), "lvc_wgrad_finalize_group")
+    if side is main:
+        _deliver_wgrad(outs)
+        return
+    ev = torch.cuda.Event()
+    ev.record(side)
+    _WGRAD_PENDING.append((ev, outs, (q, flat)))     # operands stay alive until the main stream has passed the group's event
+    _retire_wgrad(keep=0 if final else 1)
+
+
+def _deliver_wgrad(outs):
     for p, dst, beta, sink in outs:
         if not beta:
             p.grad = dst
         if sink is not None:
             sink[1](p)
+
+
+def _retire_wgrad(keep=0):
+    """Hand the finished groups' gradients over (main stream ordered behind them); the newest `keep` groups stay in flight."""
+    while len(_WGRAD_PENDING) > keep:
+        ev, outs, _alive = _WGRAD_PENDING.pop(0)
+        torch.cuda.current_stream().wait_event(ev)
+        _deliver_wgrad(outs)
 
 
 def scatter_stride2(x, H, W):

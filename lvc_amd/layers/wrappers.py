@@ -91,11 +91,12 @@ class Conv2d(nn.Module):
         return cache.key != tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
     @staticmethod
-    def prepack(convs, dgrad=None):
+    def prepack(convs, dgrad=None, holder=None):
         """Re-pack the stale operands of `convs` (trainable layers after an optimizer step) in grouped launches
-        (`kernels.prepack_group`): what `packed()` / `packed_dgrad()` would build one layer at a time.  dgrad: the layers whose
-        data-gradient operand is needed too (default: all of them)."""
-        jobs, targets = [], []
+        (`kernels.PrepackPlan`): what `packed()` / `packed_dgrad()` would build one layer at a time.  dgrad: the layers whose
+        data-gradient operand is needed too (default: all of them).  holder: a dict that keeps the plan between steps -- the same
+        set of stale layers is then re-packed into the same buffers (no per-layer host work)."""
+        jobs, targets, sig = [], [], []
         for conv in convs:
             if conv.in_channels == 3 or conv.in_channels % 32:
                 continue
@@ -105,13 +106,25 @@ class Conv2d(nn.Module):
                 jobs.append({"weight": conv.weight, "kind": "fwd", "stride": conv.stride, "pad": conv.padding, "affine": aff,
                              "two_acc": bool(getattr(conv, "two_acc", False)), "tier": conv._range_state.get("tier", 0)})
                 targets.append((conv._cache, srcs))
+                sig.append((id(conv), 0, conv.weight.data_ptr(), id(aff[0]), jobs[-1]["two_acc"], jobs[-1]["tier"]))
             if dgrad is None or conv in dgrad:
                 scale = aff[0] if conv.norm is not None else None
                 srcs = [conv.weight, scale]
                 if conv._stale(conv._cache_dgrad, srcs):
                     jobs.append({"weight": conv.weight, "kind": "dgrad", "stride": conv.stride, "pad": conv.padding, "scale": scale})
                     targets.append((conv._cache_dgrad, srcs))
-        for (cache, srcs), pc in zip(targets, K.prepack_group(jobs)):
+                    sig.append((id(conv), 1, conv.weight.data_ptr(), id(scale)))
+        if not jobs:
+            return
+        sig = (tuple(sig), K.DGRAD_SPLIT, K.HALO_S1, K.PW_S1, K.CONV_ENGINE, K.CONV_SPLIT)
+        plan = holder.get("plan") if holder is not None else None
+        if plan is not None and holder.get("sig") == sig and plan.reusable:
+            plan.relaunch()
+        else:
+            plan = K.PrepackPlan(jobs)
+            if holder is not None:
+                holder["plan"], holder["sig"] = plan, sig
+        for (cache, srcs), pc in zip(targets, plan.packed):
             cache.value = pc
             cache.key = tuple((t.data_ptr(), t._version) for t in srcs if t is not None)
 

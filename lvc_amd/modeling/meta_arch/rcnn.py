@@ -152,7 +152,7 @@ class GeneralizedRCNN(_RCNNBase):
         if lst[1]:
             from ...layers import Conv2d
 
-            Conv2d.prepack(lst[1])
+            Conv2d.prepack(lst[1], holder=self.__dict__.setdefault("_prepack_plan", {}))
 
     def _forward_train(self, batched_inputs):
         # training forward (reference rcnn.py:127-175): losses of the RPN (logged; frozen) and of the box predictor

@@ -280,12 +280,16 @@ def test_deferred_wgrad_equals_the_immediate_path_shared_parameter_and_accumulat
             assert conv.weight.grad is not None and not K._WGRAD_Q
         return conv.weight.grad.clone(), conv.bias.grad.clone()
 
-    monkeypatch.setattr(K, "DEFER_WGRAD", True)
-    w1, b1 = run()
     monkeypatch.setattr(K, "DEFER_WGRAD", False)
     w0, b0 = run()
-    assert _rel(w1, w0) < 1e-5 and _rel(b1, b0) < 1e-6
-    assert w1.is_contiguous() and w1.shape == conv.weight.shape
+    monkeypatch.setattr(K, "DEFER_WGRAD", True)
+    for side in (False, True):       # the grouped launches on the pass's own stream / on a second stream next to the data-gradient chain
+        monkeypatch.setattr(K, "WGRAD_SIDE_STREAM", side)
+        w1, b1 = run()
+        torch.cuda.synchronize()
+        assert not K._WGRAD_PENDING
+        assert _rel(w1, w0) < 1e-5 and _rel(b1, b0) < 1e-6
+        assert w1.is_contiguous() and w1.shape == conv.weight.shape
 
 
 def test_prepack_group_equals_the_per_layer_packing():
@@ -335,3 +339,38 @@ def test_prepack_group_equals_the_per_layer_packing():
     convs[0]._cache.key = None
     Conv2d.prepack(convs[:1])
     assert torch.equal(convs[0].forward_nhwc(x), y_ref)
+
+
+def test_prepack_plan_is_reused_after_an_optimizer_step(monkeypatch):
+    """The plan kept between steps (`Conv2d.prepack(..., holder=)`): after an in-place parameter update the SAME buffers are filled
+    again (no new PackedConv objects), lazily made planes of the old parameters are dropped, the Winograd operand is rebuilt, and
+    the operands equal a fresh per-layer packing of the new parameters."""
+    from lvc_amd import kernels as K
+    from lvc_amd.layers import Conv2d, FrozenBatchNorm2d
+
+    dev = torch.device("cuda", 0)
+    monkeypatch.setattr(K, "_WINO_MIN_TILES", 1)
+    g = torch.Generator().manual_seed(12)
+    convs = [Conv2d(256, 256, 3, padding=1, bias=False, norm=FrozenBatchNorm2d(256)).to(dev), Conv2d(256, 64, 1, bias=True).to(dev)]
+    holder = {}
+    Conv2d.prepack(convs, holder=holder)
+    plan = holder["plan"]
+    first = [c.packed() for c in convs]
+    first[0].split2h()                                    # a lazily made plane set of the OLD parameters
+    x = torch.randn(1, 128, 160, 256, generator=g).to(dev)   # enough tiles for the Winograd route
+    y_old = convs[0].forward_nhwc(x)
+    assert "_wino" in first[0].state
+    with torch.no_grad():
+        for c in convs:
+            c.weight.add_(torch.randn(c.weight.shape, generator=g).to(dev) * 0.05)
+    Conv2d.prepack(convs, holder=holder)
+    assert holder["plan"] is plan and [c.packed() for c in convs] == first and first[0]._w2h is None and "_wino" not in first[0].state
+    y_new = convs[0].forward_nhwc(x)
+    assert not torch.equal(y_new, y_old)
+    got = [(c._cache.value.w.clone(), c._cache.value._w2s[0].clone(), c._cache_dgrad.value._w3.clone()) for c in convs]
+    for c in convs:
+        c._cache.key = c._cache_dgrad.key = None
+    for c, (w, pl, d3) in zip(convs, got):
+        rf, rd = c.packed(), c.packed_dgrad()
+        assert torch.equal(w, rf.w) and torch.equal(pl.view(torch.int16), rf.split2s()[0].view(torch.int16)) and torch.equal(d3.view(torch.int16), rd.split3().view(torch.int16))
+    assert torch.equal(convs[0].forward_nhwc(x), y_new)
