@@ -1620,7 +1620,7 @@ def cat_ground_truth(gt_instances):
     return gt, gt_off, lens
 
 
-def match_boxes_batched(gt, gt_off, B, boxes, nbox, thresholds, labels, allow_low_quality_matches):
+def match_boxes_batched(gt, gt_off, B, boxes, nbox, thresholds, labels, allow_low_quality_matches, return_vals=False):
     """pairwise_iou + Matcher for B images in two launches (csrc/train_targets.hip).  gt [G,4] / gt_off int32 [B+1] from
     `cat_ground_truth`; boxes [N,4] shared by the images (anchors) or [B,N,4] with nbox int32 [B] rows in use per image (None: all).
     -> (matches int32 [B,N], labels int8 [B,N])."""
@@ -1644,6 +1644,8 @@ def match_boxes_batched(gt, gt_off, B, boxes, nbox, thresholds, labels, allow_lo
                                             c_int(lab[2]), c_int(1 if allow_low_quality_matches else 0), ptr(matches), ptr(mlabels), ptr(vals),
                                             ptr(scratch), _stream(boxes))
     check(rc, "lvc_match_boxes_batched")
+    if return_vals:
+        return matches, mlabels, vals       # vals: the best IoU of each box (Matcher's matched_vals)
     return matches, mlabels
 
 

@@ -171,6 +171,15 @@ class GeneralizedRCNN(_RCNNBase):
         if isinstance(self.proposal_generator, RBG):  # reference rcnn.py:150-155: loaded proposals -> jittered GT boxes
             proposals = [x["proposals"].to(self.device) for x in batched_inputs]
             proposal_losses = {}
+            from ..roi_heads.cascade_rcnn import CascadeROIHeads
+
+            if (isinstance(self.roi_heads, CascadeROIHeads) and self.roi_heads.can_batch_train(gt_instances)
+                    and self.proposal_generator.can_batch(proposals, gt_instances)):
+                # the box corrector's training rows as padded batch tensors: no per-image lists, one read for the logged counts
+                gt, gt_off, _n = K.cat_ground_truth(gt_instances)
+                table, keep = self.proposal_generator.forward_batched(proposals, gt_instances, gt, gt_off)
+                return self.roi_heads.forward_train_batched(features, table, keep, gt, gt_off, gt_instances,
+                                                            [x.image_size for x in gt_instances])
             proposals, _ = self.proposal_generator(proposals, gt_instances)
         elif (self.deferred_reads and isinstance(self.proposal_generator, RPN) and isinstance(self.roi_heads, StandardROIHeads)
               and self.proposal_generator.can_batch_targets(gt_instances) and self.roi_heads.can_batch_train(gt_instances)):

@@ -91,7 +91,30 @@ def _train_model(num_classes=80, freeze_backbone=True, depth=50):
     return model.train()
 
 
-def test_box_corrector_training_step_matches_reference(monkeypatch):
+def _rbg_rows(monkeypatch, model, g, dev, rows):
+    """rows = "lists": CascadeROIHeads.forward on per-image Instances (the reference's structure); "batched": the padded-table path
+    (RBG.forward_batched -> CascadeROIHeads.forward_train_batched) fed the same recorded boxes, with a dropped junk row after every
+    recorded one so that the keep mask has gaps."""
+    if rows == "lists":
+        monkeypatch.setattr(model.roi_heads, "batched_training", False)
+        return
+
+    def recorded_table(proposals, targets, gt, gt_off):
+        per = [g["rbg_boxes%d" % i].to(dev) for i in range(len(targets))]
+        P = 2 * max(len(p) for p in per) + 3
+        table = torch.zeros(len(per), P, 4, device=dev)
+        keep = torch.zeros(len(per), P, dtype=torch.bool, device=dev)
+        for i, p in enumerate(per):
+            table[i, 0: 2 * len(p): 2] = p
+            table[i, 1: 2 * len(p): 2] = p.flip(0) + 7.0        # plausible boxes that RBG "dropped"
+            keep[i, 0: 2 * len(p): 2] = True
+        return table, keep
+
+    monkeypatch.setattr(model.proposal_generator, "forward_batched", recorded_table)
+
+
+@pytest.mark.parametrize("rows", ["lists", "batched"])
+def test_box_corrector_training_step_matches_reference(monkeypatch, rows):
     """SURVEY row 20 with a frozen trunk: GeneralizedRCNN.forward (RBG branch) -> CascadeROIHeads training
     (label_and_sample_proposals, 3 x [pool -> 3 FC -> Linear(1024,4) -> decode -> clip/filter -> match]) ->
     BoxOnlyLayersCascade GIoU losses -> backward through the heads, vs the reference's CPU step
@@ -126,6 +149,7 @@ def test_box_corrector_training_step_matches_reference(monkeypatch):
         return out, {}
 
     monkeypatch.setattr(model.proposal_generator, "forward", recorded_rbg)
+    _rbg_rows(monkeypatch, model, g, dev, rows)
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0) as storage:
         losses = model(batch)
@@ -175,7 +199,8 @@ def test_box_corrector_training_step_matches_reference(monkeypatch):
                 assert ok >= 0.85, (name, ok)
 
 
-def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch):
+@pytest.mark.parametrize("rows", ["lists", "batched"])
+def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch, rows):
     """BASELINE config 5 proper (cascade_ubbr_R_50_FPN_base.yaml, FREEZE_AT 2): the same step with the trunk training
     from res3 up -- ROIAlign backward into p2..p5 (x 1/3, `_ScaleGradient`), FPN (3x3 output convs, laterals with the
     fused nearest-x2 add -> 2x2 down-sum), res5..res3 (wgrad kernel, dgrad on the forward kernels, stride-2 scatter,
@@ -211,6 +236,7 @@ def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch):
         return out, {}
 
     monkeypatch.setattr(model.proposal_generator, "forward", recorded_rbg)
+    _rbg_rows(monkeypatch, model, g, dev, rows)
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0):
         losses = model(batch)
@@ -246,7 +272,8 @@ def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch):
     assert not bad, bad
 
 
-def test_box_corrector_training_step_r101_matches_reference(monkeypatch):
+@pytest.mark.parametrize("rows", ["lists", "batched"])
+def test_box_corrector_training_step_r101_matches_reference(monkeypatch, rows):
     """BASELINE config 5 as named: box-corrector training on R101-FPN (cascade_ubbr base yaml with RESNETS.DEPTH 101):
     133 trainable tensors (res4 has 23 blocks) against the reference's CPU step
     (tests/golden/box_corrector_train_r101.npz); same robust metrics as the R50 step."""
@@ -278,6 +305,7 @@ def test_box_corrector_training_step_r101_matches_reference(monkeypatch):
         return out, {}
 
     monkeypatch.setattr(model.proposal_generator, "forward", recorded_rbg)
+    _rbg_rows(monkeypatch, model, g, dev, rows)
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0):
         losses = model(batch)
@@ -486,3 +514,35 @@ def test_standard_roi_heads_with_rbg_proposals_evaluates(monkeypatch):
     assert torch.equal(whole[0].scores, ref[0].scores) and torch.equal(whole[0].pred_classes, ref[0].pred_classes)
     with pytest.raises(KeyError):
         model([{"image": img, "proposals": props}])
+
+
+def test_rbg_batched_table_equals_the_per_image_lists():
+    """RBG.forward_batched (one padded table + a keep mask, no device->host read) holds, at the kept rows and in order, exactly the
+    boxes RBG.forward returns per image for the same generator state (reference lvc/modeling/proposal_generator/rbg.py)."""
+    from lvc_amd import kernels as K
+    from lvc_amd.structures import Boxes, Instances
+
+    g = gold("box_corrector_train")
+    model = _train_model()
+    dev = torch.device("cuda:0")
+    targets, props = [], []
+    for i, (h, w) in enumerate([(240, 320), (200, 352)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(g["gt_boxes%d" % i].to(dev))
+        inst.gt_classes = g["gt_classes%d" % i].to(dev)
+        targets.append(inst)
+        p = Instances((h, w))
+        p.proposal_boxes = Boxes(g["loaded_boxes%d" % i].to(dev))
+        p.objectness_logits = g["loaded_logits%d" % i].to(dev)
+        props.append(p)
+    rbg = model.proposal_generator
+    rbg.train()
+    assert rbg.can_batch(props, targets)
+    torch.manual_seed(123)
+    lists, _ = rbg(props, targets)
+    gt, gt_off, _n = K.cat_ground_truth(targets)
+    torch.manual_seed(123)
+    table, keep = rbg.forward_batched(props, targets, gt, gt_off)
+    assert 0 < int(keep.sum()) < keep.numel()
+    for i, inst in enumerate(lists):
+        assert torch.equal(table[i][keep[i]], inst.proposal_boxes.tensor), i
