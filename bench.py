@@ -550,28 +550,32 @@ def eval_loop_leg(c, model, steps, warm=4, distinct=3):
     """The evaluation loop as the reference times it (lvc/evaluation/evaluator.py:85-157): batches arrive as HOST tensors from a
     loader, `lvc_amd.evaluation.inference_on_dataset` (two batches in flight) moves them to the GPU on the stream the batch runs
     on -- the copy of batch i+1 overlaps the trunk of batch i -- and every batch's Instances are collected (one D2H read each).
-    Two input forms: {"image": float32 CHW 3x800x1333} (what the reference's DatasetMapper hands over, dataset_mapper.py:148-158:
-    12.8 MB per image across PCIe) and {"raw": uint8 HWC 480x800x3} (the decoded file: ResizeShortestEdge on the device,
-    Pillow-exact, to 800x1333; 1.15 MB per image).  Host tensors are pinned, as a DataLoader(pin_memory=True) delivers them."""
+    Three input forms: {"image": uint8 CHW 3x800x1333} -- what the reference's DatasetMapper hands over (lvc/data/dataset_mapper.py:164:
+    `torch.as_tensor(image.transpose(2, 0, 1))` of the uint8 array its ResizeShortestEdge produced; 3.2 MB per image across PCIe) --,
+    {"image": float32 CHW 3x800x1333} (a mapper that converts on the host: 12.8 MB per image) and {"raw": uint8 HWC 480x800x3} (the
+    decoded file: ResizeShortestEdge on the device, Pillow-exact, to 800x1333; 1.15 MB per image).  Host tensors are pinned, as a
+    DataLoader(pin_memory=True) delivers them."""
     import torch
 
     from lvc_amd.evaluation import inference_on_dataset
     from lvc_amd.utils import synthetic as syn
 
     out = {}
-    for kind in ("image", "raw"):
+    for kind in ("image_u8", "image", "raw"):
         batches = []
         for b in range(distinct):
             items = []
             for i in range(BATCH_PER_GPU):
                 seed = 1 + (c.rank * BATCH_PER_GPU + b * BATCH_PER_GPU + i) % 16
-                if kind == "image":
+                if kind == "image_u8":
+                    items.append({"image": syn.synthetic_image(seed).round().clamp(0, 255).to(torch.uint8).pin_memory(), "height": 800, "width": 1333})
+                elif kind == "image":
                     items.append({"image": syn.synthetic_image(seed).pin_memory(), "height": 800, "width": 1333})
                 else:
                     raw = syn.synthetic_image(seed, 480, 800).permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
                     items.append({"raw": raw.pin_memory(), "height": 480, "width": 800})
             batches.append(items)
-        key = "image" if kind == "image" else "raw"
+        key = "raw" if kind == "raw" else "image"
         nbytes = sum(x[key].numel() * x[key].element_size() for x in batches[0])
 
         def loader(n):
@@ -590,7 +594,8 @@ def eval_loop_leg(c, model, steps, warm=4, distinct=3):
         dt, _ = _max_and_all(c, time.perf_counter() - t0)
         out[kind] = {"value": round(c.world * n_img / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
                      "host_bytes_per_batch": nbytes, "pcie_GBps": round(nbytes * steps / dt / 1e9, 2), "detections_collected": n_det,
-                     "input": "float32 CHW 3x800x1333, pinned host memory" if kind == "image"
+                     "input": "uint8 CHW 3x800x1333 (the reference DatasetMapper's output, dataset_mapper.py:164), pinned host memory" if kind == "image_u8"
+                     else "float32 CHW 3x800x1333, pinned host memory" if kind == "image"
                      else "uint8 HWC 480x800x3 (decoded file), pinned host memory; ResizeShortestEdge(800, 1333) on the device"}
     out["note"] = ("inference_on_dataset(depth=2) over %d batches of %d HOST-resident images, every batch's Instances collected; H2D copies run on "
                    "the batch's own stream and overlap the other stream's trunk.  `value` (the headline) starts with its inputs resident in HBM."
@@ -795,6 +800,7 @@ def infer_main(c, args):
             if pipelined is not None:
                 eval_loop["raw_over_pipelined"] = round(eval_loop["raw"]["value"] / pipelined["value"], 4)
                 eval_loop["image_over_pipelined"] = round(eval_loop["image"]["value"] / pipelined["value"], 4)
+                eval_loop["image_u8_over_pipelined"] = round(eval_loop["image_u8"]["value"] / pipelined["value"], 4)
         except Exception as e:
             eval_loop = {"error": repr(e)}
 

@@ -33,11 +33,11 @@ def test_pipelined_inference_equals_sequential():
                 assert torch.equal(a.scores, b.scores) and torch.equal(a.pred_classes, b.pred_classes)
 
 
-@pytest.mark.parametrize("kind", ["image", "raw"])
+@pytest.mark.parametrize("kind", ["image_u8", "image", "raw"])
 def test_evaluation_loop_from_host_memory_equals_device_resident_inputs(kind):
     """The loop as the reference runs it (lvc/evaluation/evaluator.py:85-157: the loader hands over HOST tensors): pinned host
-    inputs -- float32 CHW `image` as the reference's DatasetMapper makes them, or the decoded uint8 HWC file under `raw`
-    (dataset_mapper.py:148-158 done on the device) -- copied on the batch's own stream while the other stream computes, give the
+    inputs -- uint8 CHW `image` as the reference's DatasetMapper makes them (dataset_mapper.py:164), the same as float32, or the
+    decoded uint8 HWC file under `raw` (the mapper's resize done on the device) -- copied on the batch's own stream while the other stream computes, give the
     detections of the same tensors already resident in HBM, bit for bit, batch after batch."""
     from lvc_amd.config.presets import base_rcnn_fpn
     from lvc_amd.evaluation import inference_on_dataset
@@ -51,24 +51,32 @@ def test_evaluation_loop_from_host_memory_equals_device_resident_inputs(kind):
     for b in range(5):
         hb, db = [], []
         for i in range(2):
-            if kind == "image":
+            if kind in ("image", "image_u8"):
                 h, w = (416, 608) if b % 2 else (384, 640)
                 t = syn.synthetic_image(20 + 2 * b + i, h, w)
+                if kind == "image_u8":
+                    t = t.round().clamp(0, 255).to(torch.uint8)
                 extra = {"height": 2 * h, "width": 2 * w}
             else:
                 h, w = (150, 200) if b % 2 else (180, 160)
                 t = syn.synthetic_image(20 + 2 * b + i, h, w).permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
                 extra = {"height": h, "width": w}
-            hb.append(dict({kind: t.pin_memory()}, **extra))
-            db.append(dict({kind: t.to(dev)}, **extra))
+            key = "raw" if kind == "raw" else "image"
+            hb.append(dict({key: t.pin_memory()}, **extra))
+            db.append(dict({key: t.to(dev)}, **extra))
         host.append(hb)
         resident.append(db)
     with torch.no_grad():
         ref = [model(batch) for batch in resident]
+    if kind == "image_u8":      # uint8 pixels are the float32 pixels of the same values: same detections as the fp32 tensors of those values
+        with torch.no_grad():
+            same = model([dict(d, image=d["image"].float()) for d in resident[0]])
+        for o, r in zip(same, ref[0]):
+            assert torch.equal(o["instances"].pred_boxes.tensor, r["instances"].pred_boxes.tensor)
     got = list(inference_on_dataset(model, host, depth=2))
     assert len(got) == len(host)
     for (inputs, outs), want, batch in zip(got, ref, host):
-        assert inputs is batch and not inputs[0][kind].is_cuda
+        assert inputs is batch and not inputs[0]["raw" if kind == "raw" else "image"].is_cuda
         for o, r in zip(outs, want):
             a, b = o["instances"], r["instances"]
             assert a.image_size == b.image_size and len(a) == len(b) > 0
