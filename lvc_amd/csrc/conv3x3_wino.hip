@@ -239,10 +239,12 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[pp][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[mi], blo[ni], acc[pp][mi][ni], 0, 0, 0);
+#ifndef WN_DIAG_DROP_CROSS      // gate check (scripts/perturbed_build_check.sh): without this term the layer is a 2^-11 product, and smoke / bench / e2e must fail
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) acc[pp][mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi[ni], acc[pp][mi][ni], 0, 0, 0);
+#endif
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
           f32x16& c = ONEACC ? acc[mi][ni] : accx[ONEACC ? 0 : mi][ONEACC ? 0 : ni];
+#ifndef PW_DIAG_DROP_CROSS       // gate check (scripts/perturbed_build_check.sh): without this term every pointwise layer is a 2^-11 product
           c = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[mi], bhi[ni], c, 0, 0, 0);
+#endif
         }
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) ahi_n[mi] = rdA(An, 0, mi, s2n);
