@@ -67,8 +67,7 @@ __device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_am
 // behind it: at most N vector-memory operations outstanding and every LDS operation of this wave complete
 template <int N> __device__ __forceinline__ void wn_wait_vm_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 template <bool PRED>
-__global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
+__device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, unsigned char* const smem) {
   unsigned char* const sV = smem;
   unsigned char* const sU = smem + 2 * WN_VBUF;
 
@@ -79,7 +78,6 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   const int fi = lane & 31, fh = lane >> 5;
 
   // ---- tile: (image, patch row, patch column, channel tile); consecutive ids share the patch (channel tile fastest) and land on one XCD
-  const int t = lvc_xcd_remap(blockIdx.x, p.ntiles);
   const int tn = t % p.tiles_n;
   int r0 = t / p.tiles_n;
   const int tx = r0 % p.tiles_x;
@@ -434,10 +432,43 @@ __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   }
 }
 
+template <bool PRED>
+__global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
+#ifdef WN_PERSISTENT
+  // one resident workgroup per CU walks its share of the tiles: XCD x (blockIdx % 8) owns the x-th eighth of the tile list, its workgroups
+  // take neighbouring tiles side by side (the same patch's channel tiles, adjacent patches: shared rows come from that XCD's L2)
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = gridDim.x >> 3;
+  const int lo = (int)((long long)p.ntiles * xcd / 8), hi = (int)((long long)p.ntiles * (xcd + 1) / 8);
+#pragma unroll 1
+  for (int t = lo + local; t < hi; t += per) {
+    wino_tile<PRED>(p, t, smem);
+    __syncthreads();
+  }
+#else
+  wino_tile<PRED>(p, lvc_xcd_remap(blockIdx.x, p.ntiles), smem);
+#endif
+}
+
 // y = act(conv3x3(x, w) * scale + shift), stride 1, pad 1, as Winograd F(2,3) along x.  x [N,H,W,C] fp32 NHWC (C % 16 == 0), u = the
 // transformed weight planes [3][C/16][4][2][Kpad][16] fp16 with Kpad % 128 == 0 and scale [K] = their row factors (x the layer's
 // per-channel scale) as lvc_amd.kernels.pack_wino makes them; y [N,H,W,ldy].  An activation window value |V| > 4094 (or NaN) raises the
 // layer's range word in `workspace` (the conv workspace of the other kernels; only its error words are used).
+static int wn_grid(int ntiles) {
+#ifdef WN_PERSISTENT
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n / 8 * 8;
+    if (cus < 8) cus = 8;
+  }
+  return ntiles < cus ? (ntiles + 7) / 8 * 8 : cus;
+#else
+  return ntiles;
+#endif
+}
+
 static int wino_launch(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H, int W, int C,
                        int K, int Kpad, int relu, int ldy, const unsigned short* pred_w, const float* pred_scale, const float* pred_shift,
                        int pred_K, int pred_rows, int pred_slot, void* workspace, void* stream) {
@@ -466,9 +497,9 @@ static int wino_launch(const float* x, const unsigned short* u, const float* sca
   if (pred_w) {
     LVC_CHECK_ARG(K % WN_CH == 0 && K <= 2 * WN_CH, "the pointwise layer on top needs 128 or 256 hidden channels (at most two slices per output)");
     LVC_CHECK_ARG(pred_K >= 1 && pred_K <= 32 && pred_rows >= 32 && pred_slot >= 0 && pred_slot < lvc_range_slots(), "bad pointwise layer");
-    hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(wn_grid(a.ntiles)), dim3(WN_NT), 0, (hipStream_t)stream, a);
   } else {
-    hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(wn_grid(a.ntiles)), dim3(WN_NT), 0, (hipStream_t)stream, a);
   }
   LVC_CHECK_LAUNCH();
   return LVC_OK;
