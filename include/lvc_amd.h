@@ -134,6 +134,10 @@ int lvc_conv3x3_nhwc_f16_levels_pred(int oneacc, const float* const* xs, float* 
 int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const* ys, const int* Hs, const int* Ws, int L,
                                 const unsigned short* const* ws, const float* const* scales, const float* const* shifts, int N, int C,
                                 int K, int Kg, int relu, void* workspace, void* stream);
+/* Work distribution of the two entries below: 0 (default) = one workgroup per tile; 1 = stream-K (one resident workgroup per CU takes an
+ * equal share of the (tile, 16-channel chunk) list; split tiles are completed through `workspace` as in the other conv kernels, in worker
+ * order: deterministic); 2 = persistent workgroups on whole tiles.  Measured: neither beats 0 on the detector's layers (conv3x3_wino.hip). */
+void lvc_set_wino_streamk(int mode);
 /* 3x3 / stride 1 / pad 1 as Winograd F(2,3) along x (round 5, csrc/conv3x3_wino.hip; the 256-channel layers of
  * detectron2/modeling/backbone/fpn.py:141-144 and proposal_generator/rpn.py:92-94 on the large maps): two thirds of the MFMAs of
  * lvc_conv3x3_nhwc_f16s1 at the same operand precision and the direct evaluation's fp32 error.  u = transformed row-scaled weight planes

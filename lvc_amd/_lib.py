@@ -37,6 +37,9 @@ def lib():
         L.lvc_last_error.restype = ctypes.c_char_p
         L.lvc_batched_nms_workspace_bytes.restype = c_longlong
         L.lvc_abi_version.restype = c_int
+        L.lvc_set_wino_streamk.restype = None
+        if os.environ.get("LVC_WINO_STREAMK", "0") != "0":
+            L.lvc_set_wino_streamk(c_int(int(os.environ["LVC_WINO_STREAMK"])))
         _lib = L
     return _lib
 

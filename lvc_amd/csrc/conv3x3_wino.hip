@@ -50,8 +50,10 @@ struct WinoArgs {
   const float* shift;          // [K] or null
   float* y;                    // [N,H,W,ldy]
   int* flags;
+  float* partials;             // stream-K: 256 KB per worker (the conv workspace of the other kernels)
   int N, H, W, C, K, Kpad, ldy, relu;
   int PH, PWP, lg_pwp, tiles_x, tiles_y, tiles_n, ntiles, nk, err_index;
+  int units_per_worker, nworkers;   // stream-K: a unit = one 16-channel chunk of one tile
   unsigned x_bytes, y_bytes;
   // PRED: a pointwise layer on top of act(conv) (the RPN predictor): y = ITS output rows (ldy floats, zeroed by the caller)
   const unsigned short* pred_w;     // [2][pred_rows][K] fp16 planes of lvc_split_weights
@@ -66,12 +68,18 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 __device__ __forceinline__ void wn_glds16(const void* g, void* l) { __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)l, 16, 0, 0); }
 // behind it: at most N vector-memory operations outstanding and every LDS operation of this wave complete
 template <int N> __device__ __forceinline__ void wn_wait_vm_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
-template <bool PRED>
-__device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, unsigned char* const smem) {
+// One tile segment: chunks [cc0, cc1) of tile t.  Whole tiles (cc0 = 0, cc1 = nk) go straight to the epilogue.  Stream-K (SK): a worker
+// whose segment does not hold the tile's first chunk hands its partial sums (still in the transformed domain: the output transform is
+// linear) to the worker that does -- the protocol of conv3x3_halo_s1.hip: partials [worker][128 values][512 threads], a flag per
+// worker, the owner adds the later workers' parts in worker order (deterministic) and runs the epilogue.  lw = this worker.
+template <bool PRED, bool SK>
+__device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, const int cc0, const int cc1, const int lw, unsigned char* const smem) {
   unsigned char* const sV = smem;
   unsigned char* const sU = smem + 2 * WN_VBUF;
 
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  if constexpr (SK) asm volatile("" : "+v"(tid_));      // opaque per segment: what derives from it is not hoisted out of the worker's loop (and spilled)
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ph = wave & 1, wn = (wave >> 1) & 1, wm = wave >> 2;
@@ -250,10 +258,10 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, unsign
     }
   };
 
-  // ---- prologue: chunk 0 transformed into V buffer 0, the weights of stage (0, 0) in slot 0
-  dma_u(0, 0, 0);
-  load0(0);
-  load1(0);
+  // ---- prologue: the segment's first chunk transformed into V buffer 0, the weights of its stage 0 in slot 0
+  dma_u(cc0, 0, 0);
+  load0(cc0);
+  load1(cc0);
   prep0();
   prep1();
   write0(sV);
@@ -269,12 +277,14 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, unsign
   // r = 1, behind r = 0's barrier.  In-order queue of a wave (D = 4 DMA ops, L0 = 4 loads, L1 = 2):  r0: D L0 | r1: D L1 | r2: D: the
   // explicit waits before the barriers cover the DMA (other waves read that LDS); the loads' uses carry the compiler's own waits.
   // (Issuing DMA and loads as untracked inline asm -- no compiler wait before LDS reads behind a DMA -- was measured: no difference.)
+  __builtin_assume(cc1 > cc0);       // at least one chunk: the zero accumulators never reach the code behind the loop
 #pragma unroll 1
-  for (int kc = 0; kc < nk; ++kc) {
-    unsigned char* vb = sV + (kc & 1) * WN_VBUF;
-    unsigned char* vnext = sV + ((kc + 1) & 1) * WN_VBUF;
-    const int kn = min(kc + 1, nk - 1);
-    const int s0 = (kc * 3) & 1;
+  for (int kc = cc0; kc < cc1; ++kc) {
+    const int kr = kc - cc0;
+    unsigned char* vb = sV + (kr & 1) * WN_VBUF;
+    unsigned char* vnext = sV + ((kr + 1) & 1) * WN_VBUF;
+    const int kn = min(kc + 1, cc1 - 1);
+    const int s0 = (kr * 3) & 1;
     // r = 0: round 0 of the next chunk is requested; round 1 of THIS chunk (rows >= 128: not read before r = 1) is converted and written
     dma_u(kc, 1, 1 - s0);
     load0(kn);
@@ -304,6 +314,69 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, unsign
     __builtin_amdgcn_sched_barrier(0);
   }
   if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
+
+  if constexpr (SK) {
+    if (cc0 != 0) {          // not the tile's owner: publish the partial sums, done
+      // one descriptor + scalar offsets: 32 flat stores 8 KB apart would each carry their own 64-bit address (64 registers: spills)
+      const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.partials + (size_t)lw * (WN_NT * 128)), 0, WN_NT * 128 * 4, 0x00020000);
+      const unsigned toff = (unsigned)tid * 16u;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+              const f32x4 v = {acc[a][b][c][e4 * 4 + 0], acc[a][b][c][e4 * 4 + 1], acc[a][b][c][e4 * 4 + 2], acc[a][b][c][e4 * 4 + 3]};
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), pres, toff, ((((a * 2 + b) * 2 + c) * 4 + e4)) * WN_NT * 16, 0);
+            }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.flags + lw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+    if (cc1 < nk) {          // the owner of a split tile: add the later workers' parts in worker order
+      const int last_worker = (t * nk + nk - 1) / p.units_per_worker;
+#pragma unroll 1
+      for (int pw = lw + 1; pw <= last_worker; ++pw) {
+        if (tid == 0) {
+          int spins = 0;
+          while (__hip_atomic_load(p.flags + pw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 24)) { atomicOr(p.flags + p.err_index, 1); break; }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t pres = __builtin_amdgcn_make_buffer_rsrc((void*)(p.partials + (size_t)pw * (WN_NT * 128)), 0, WN_NT * 128 * 4, 0x00020000);
+        const unsigned toff = (unsigned)tid * 16u;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              f32x4 v[4];      // one accumulator block at a time: 16 registers in flight, not 128
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4)
+                v[e4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pres, toff, ((((a * 2 + b) * 2 + c) * 4 + e4)) * WN_NT * 16, 0));
+#pragma unroll
+              for (int e4 = 0; e4 < 4; ++e4) {
+                acc[a][b][c][e4 * 4 + 0] += v[e4][0]; acc[a][b][c][e4 * 4 + 1] += v[e4][1];
+                acc[a][b][c][e4 * 4 + 2] += v[e4][2]; acc[a][b][c][e4 * 4 + 3] += v[e4][3];
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.flags + pw, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 
   // ---- output transform.  This wave holds M_{2 ph}, M_{2 ph + 1}; its partner (same rows and channels, other half) the other two.
   // Half 0 finishes the EVEN pixel y[2t] = (M0 + M1) + M2 and needs M2; half 1 the odd one y[2t+1] = (M1 - M2) - M3 and needs M1:
@@ -435,27 +508,42 @@ __device__ __forceinline__ void wino_tile(const WinoArgs& p, const int t, unsign
 template <bool PRED>
 __global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_kernel(WinoArgs p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
-#ifdef WN_PERSISTENT
-  // one resident workgroup per CU walks its share of the tiles: XCD x (blockIdx % 8) owns the x-th eighth of the tile list, its workgroups
-  // take neighbouring tiles side by side (the same patch's channel tiles, adjacent patches: shared rows come from that XCD's L2)
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, per = gridDim.x >> 3;
-  const int lo = (int)((long long)p.ntiles * xcd / 8), hi = (int)((long long)p.ntiles * (xcd + 1) / 8);
+  wino_tile<PRED, false>(p, lvc_xcd_remap(blockIdx.x, p.ntiles), 0, p.nk, 0, smem);
+}
+
+// Stream-K form: one resident workgroup per CU, worker w takes the units [w upw, (w + 1) upw) of the (tile, chunk) list -- consecutive
+// workers sit on one XCD (lvc_xcd_remap) and walk neighbouring tiles.  For the maps whose tile count does not fill whole rounds of the
+// 256 CUs (p3 / res3: 2.4 - 4.8 rounds, res4 / p4: 1.03): every CU gets the same number of stages.
+template <bool PRED, bool SPLIT>     // SPLIT = false: units_per_worker is a multiple of nk (whole tiles per worker: no hand-off code)
+__global__ __launch_bounds__(WN_NT, 2) void conv3x3_wino_sk_kernel(WinoArgs p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[WN_SMEM];
+  const int lw = lvc_xcd_remap(blockIdx.x, p.nworkers);
+  int u = lw * p.units_per_worker;
+  const int u_end = min(u + p.units_per_worker, p.ntiles * p.nk);
 #pragma unroll 1
-  for (int t = lo + local; t < hi; t += per) {
-    wino_tile<PRED>(p, t, smem);
+  while (u < u_end) {
+    const int t = u / p.nk, cc0 = u - t * p.nk;
+    const int cc1 = min(p.nk, cc0 + (u_end - u));
+    if constexpr (SPLIT) wino_tile<PRED, true>(p, t, cc0, cc1, lw, smem);
+    else wino_tile<PRED, false>(p, t, 0, p.nk, lw, smem);
     __syncthreads();
+    u += cc1 - cc0;
   }
-#else
-  wino_tile<PRED>(p, lvc_xcd_remap(blockIdx.x, p.ntiles), smem);
-#endif
 }
 
 // y = act(conv3x3(x, w) * scale + shift), stride 1, pad 1, as Winograd F(2,3) along x.  x [N,H,W,C] fp32 NHWC (C % 16 == 0), u = the
 // transformed weight planes [3][C/16][4][2][Kpad][16] fp16 with Kpad % 128 == 0 and scale [K] = their row factors (x the layer's
 // per-channel scale) as lvc_amd.kernels.pack_wino makes them; y [N,H,W,ldy].  An activation window value |V| > 4094 (or NaN) raises the
 // layer's range word in `workspace` (the conv workspace of the other kernels; only its error words are used).
-static int wn_grid(int ntiles) {
-#ifdef WN_PERSISTENT
+// Work distribution of lvc_conv3x3_nhwc_wino*: 0 (default) one workgroup per tile; 1 stream-K (the (tile, chunk) list split evenly over one
+// resident workgroup per CU, split tiles completed through the workspace); 2 persistent workgroups on whole tiles.  Measured on the layers
+// the detector routes here (scripts/probe_wino_modes.py, alternated): p2 1.33-1.44 / 1.38-1.39 / 1.34-1.36 ms, p3 0.361-0.374 / 0.397-0.406 /
+// 0.370-0.380, res3 0.116-0.119 / 0.118-0.120 / 0.115-0.118, res4 0.131-0.133 / 0.117-0.120 / 0.135-0.143 (direct kernel there: 0.109-0.115):
+// a hand-off moves 128 accumulator values per thread (256 KB per worker each way) and costs more than the partial last round it removes.
+static int g_wino_streamk = 0;
+extern "C" void lvc_set_wino_streamk(int mode) { g_wino_streamk = mode; }
+
+static int wn_cus() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -463,10 +551,7 @@ static int wn_grid(int ntiles) {
     cus = n / 8 * 8;
     if (cus < 8) cus = 8;
   }
-  return ntiles < cus ? (ntiles + 7) / 8 * 8 : cus;
-#else
-  return ntiles;
-#endif
+  return cus;
 }
 
 static int wino_launch(const float* x, const unsigned short* u, const float* scale, const float* shift, float* y, int N, int H, int W, int C,
@@ -497,9 +582,31 @@ static int wino_launch(const float* x, const unsigned short* u, const float* sca
   if (pred_w) {
     LVC_CHECK_ARG(K % WN_CH == 0 && K <= 2 * WN_CH, "the pointwise layer on top needs 128 or 256 hidden channels (at most two slices per output)");
     LVC_CHECK_ARG(pred_K >= 1 && pred_K <= 32 && pred_rows >= 32 && pred_slot >= 0 && pred_slot < lvc_range_slots(), "bad pointwise layer");
-    hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(wn_grid(a.ntiles)), dim3(WN_NT), 0, (hipStream_t)stream, a);
+  }
+  // stream-K / persistent forms only on request (see g_wino_streamk)
+  a.partials = (float*)workspace;
+  const long long nunits = (long long)a.ntiles * a.nk;
+  const int cus = wn_cus() < LVC_MAX_WORKERS / 2 ? wn_cus() : LVC_MAX_WORKERS / 2;      // 256 KB of partial sums per worker in a 128 MB region
+  bool sk = g_wino_streamk != 0 && nunits < (1ll << 31) && a.ntiles % cus != 0;
+  if (sk) {
+    constexpr int min_units = 4;        // a segment restarts the pipeline: at least four chunks (12 stages) per worker
+    long long workers = (nunits + min_units - 1) / min_units;
+    if (workers > cus) workers = cus;
+    a.units_per_worker = (int)((nunits + workers - 1) / workers);
+    const bool whole = g_wino_streamk == 2;
+    if (whole) a.units_per_worker = (a.units_per_worker + a.nk - 1) / a.nk * a.nk;      // whole tiles per worker: persistent workgroups, no hand-off
+    a.nworkers = (int)((nunits + a.units_per_worker - 1) / a.units_per_worker);
+    if (pred_w) {
+      if (whole) hipLaunchKernelGGL((conv3x3_wino_sk_kernel<true, false>), dim3(a.nworkers), dim3(WN_NT), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv3x3_wino_sk_kernel<true, true>), dim3(a.nworkers), dim3(WN_NT), 0, (hipStream_t)stream, a);
+    } else {
+      if (whole) hipLaunchKernelGGL((conv3x3_wino_sk_kernel<false, false>), dim3(a.nworkers), dim3(WN_NT), 0, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((conv3x3_wino_sk_kernel<false, true>), dim3(a.nworkers), dim3(WN_NT), 0, (hipStream_t)stream, a);
+    }
   } else {
-    hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(wn_grid(a.ntiles)), dim3(WN_NT), 0, (hipStream_t)stream, a);
+    a.units_per_worker = a.nk; a.nworkers = a.ntiles;
+    if (pred_w) hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3(a.ntiles), dim3(WN_NT), 0, (hipStream_t)stream, a);
   }
   LVC_CHECK_LAUNCH();
   return LVC_OK;

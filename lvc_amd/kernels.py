@@ -743,6 +743,15 @@ def _chain_planes(pc):
 # evaluation's fp32 error, scripts/winograd_error.py) where the launch has at least _WINO_MIN_TILES 256-pixel x 128-channel tiles --
 # the kernel is one workgroup per tile, no stream-K: small maps keep the direct kernel
 CONV_WINO = _os.environ.get("LVC_CONV_WINO", "1") != "0"
+# the Winograd kernel's work distribution: 0 = one workgroup per tile (default: fastest on every routed layer, csrc/conv3x3_wino.hip),
+# 1 = stream-K, 2 = persistent workgroups on whole tiles
+WINO_STREAMK = int(_os.environ.get("LVC_WINO_STREAMK", "0"))
+
+
+def set_wino_streamk(mode):
+    global WINO_STREAMK
+    WINO_STREAMK = int(mode)
+    _lib.lib().lvc_set_wino_streamk(c_int(int(mode)))
 WINO_RPN = True        # the RPN head's large levels too (kernels.conv3x3_levels_pred); False: the two-accumulator direct kernel for all levels
 _WINO_MIN_TILES = 512
 

@@ -872,12 +872,25 @@ def test_pointwise_256x256_tile_vs_fp64_and_the_256x128_tile(N, H, W, C, K, stri
 
 @pytest.mark.parametrize("N,H,W,C,K,relu,bias", [(2, 100, 168, 256, 256, True, True), (1, 37, 53, 64, 192, False, True), (3, 16, 33, 128, 128, True, False),
                                                  (1, 8, 32, 32, 320, True, True), (2, 21, 7, 96, 128, False, False)])
-def test_conv3x3_winograd_vs_fp64_and_the_direct_kernel(N, H, W, C, K, relu, bias, monkeypatch):
+@pytest.mark.parametrize("streamk", [0, 1, 2])
+def test_conv3x3_winograd_vs_fp64_and_the_direct_kernel(N, H, W, C, K, relu, bias, streamk, monkeypatch):
     """csrc/conv3x3_wino.hip (kernels.CONV_WINO: Winograd F(2,3) along x, 6 products per output) against the fp64 convolution and the
     direct single-accumulator kernel it replaces on large maps: map sizes that are no multiple of the 8 x 32 / 16 x 16 patch, odd
     widths (the last pair's second pixel does not exist), channel counts off the 128-channel tile, with and without bias / ReLU.  Its
-    error must stay at the direct kernel's level (measured: 0.7 x; scripts/winograd_error.py has the fp32 argument)."""
+    error must stay at the direct kernel's level (measured: 0.7 x; scripts/winograd_error.py has the fp32 argument).  streamk: one
+    workgroup per tile (0, the default), the (tile, chunk) list split evenly over the CUs (1: split tiles completed through the
+    workspace, run-to-run identical) or persistent workgroups on whole tiles (2)."""
     from lvc_amd import kernels as k
+
+    prev = k.WINO_STREAMK
+    k.set_wino_streamk(streamk)
+    try:
+        _winograd_case(k, N, H, W, C, K, relu, bias, monkeypatch)
+    finally:
+        k.set_wino_streamk(prev)
+
+
+def _winograd_case(k, N, H, W, C, K, relu, bias, monkeypatch):
 
     monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
     monkeypatch.setattr(k, "CONV_SPLIT", "f16x2")
@@ -896,6 +909,7 @@ def test_conv3x3_winograd_vs_fp64_and_the_direct_kernel(N, H, W, C, K, relu, bia
     direct = k.conv2d_nhwc(x.to(d), pc, relu=relu).cpu()
     got = k.conv3x3_wino(x.to(d), pc, relu=relu).cpu()
     assert k.conv_error_word(d) == 0
+    assert torch.equal(k.conv3x3_wino(x.to(d), pc, relu=relu).cpu(), got)       # split tiles are summed in worker order: deterministic
     e_w = (got.double() - ref).abs()
     e_d = (direct.double() - ref).abs()
     rms_w, rms_d = float(e_w.pow(2).mean().sqrt()) / sc, float(e_d.pow(2).mean().sqrt()) / sc
