@@ -585,6 +585,14 @@ int lvc_mha(const float* qkv, float* out, int B, int N, int H, int head_dim, flo
 int lvc_mha_cls(const float* qkv, float* out, int B, int N, int H, float scale, void* stream);
 long long lvc_mha_workspace_bytes(int B, int N, int H);
 int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B, int N, int H, float scale, int* d_error_word, void* stream);
+/* The qkv layer of a ViT block written straight into lvc_mha_mfma's operand planes (round 5; the DINO ViT's `attention.qkv` + the first
+ * pass of the attention, tools/run_nearest_neighbours.py:102-128): lvc_conv1x1_nhwc_f16s1 on x [B*N][C] (w_split / scale / shift as there,
+ * K = 3 * H * 64 columns = (q | k | v, head, d)); planes [6][B*H][Npad][64] fp16 (lvc_mha_workspace_bytes), q multiplied by softmax_scale *
+ * log2(e) (as lvc_mha_mfma does); rows N..Npad-1 are not written (the caller keeps them zero).  Bit-identical to the two launches it replaces.
+ * An operand beyond fp16's range raises bit 1 (value 2) of *err_word.  lvc_mha_mfma_planes: the attention on such planes. */
+int lvc_conv1x1_qkv_planes_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift, void* planes,
+                                 int B, int N, int C, int H, float softmax_scale, int* err_word, void* workspace, void* stream);
+int lvc_mha_mfma_planes(const void* planes, float* out, int B, int N, int H, void* stream);
 
 #ifdef __cplusplus
 }

@@ -48,6 +48,12 @@ struct PwArgsS {
   int tiles_n, nk, total_units, units_per_worker, nworkers, err_index, ngroup;
   int x_bytes;
   long long w_plane_elems;
+  // PLANES instance only (lvc_conv1x1_qkv_planes_f16s1): the output goes to the attention kernel's fp16 operand planes instead of y
+  unsigned short* planes;    // [6][B*H][Npad][64]: q hi, q lo, k hi, k lo, v hi, v lo
+  int* pl_err;               // bit 1 (value 2) when an operand leaves fp16's range
+  long long pl_PS;           // elements per plane
+  int pl_N, pl_Npad, pl_H;
+  float pl_qscale;           // multiplied into q (softmax scale x log2 e)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -68,7 +74,7 @@ template <int N> __device__ __forceinline__ void wait_tied(f32x4& a, f32x4& b, f
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NI, bool ONEACC>
+template <int NI, bool ONEACC, bool PLANES = false>
 __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
   constexpr int HN = 64 * NI;
   constexpr int PLANE_A = PM * AROW;               // bytes
@@ -503,7 +509,40 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
           }
         };
         using A0 = std::integral_constant<int, 0>; using A1 = std::integral_constant<int, 1>; using A2 = std::integral_constant<int, 2>;
-        if (has_res) {
+        if constexpr (PLANES) {
+          // y = qkv of a ViT block (row m = image b, token n; column = (q | k | v, head, d)): what lvc_mha_mfma's first pass (mha_split_kernel)
+          // makes of the fp32 tensor -- q * qscale, k, v as fp16 (hi, lo) pairs in [B*H][Npad][64] planes -- written here, the fp32 tensor never
+          // exists.  Same arithmetic in the same order (affine, one fp32 rounding, x qscale, split): the planes are bit-identical.
+          const int hd = p.pl_H * 64;
+          const int which = col / hd, hh = (col - which * hd) >> 6, d = col & 63;
+          const float f = which == 0 ? p.pl_qscale : 1.f;
+          unsigned short* const ph = p.planes + (size_t)(2 * which) * p.pl_PS + d;
+          float bigp = 0.f;
+#pragma unroll 1
+          for (int g = 0; g < NIT; ++g) {
+            const int m = m0 + g * RPI + rsub;
+            if (m < p.M) {
+              const f32x4 v = *reinterpret_cast<const f32x4*>(cs + g * RPI * CS_STRIDE);
+              f32x4 o = v * sc + sh;
+              o *= f;
+              const int b = m / p.pl_N, n = m - b * p.pl_N;
+              f16x4 hi, lo;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float a = o[e];
+                asm volatile("" : "+v"(a));      // the rounded value, as mha_split_kernel (vit.hip) splits it
+                bigp = fmaxf(bigp, fabsf(a));
+                if (a != a) bigp = INFINITY;
+                hi[e] = (f16)a;
+                lo[e] = (f16)(a - (float)hi[e]);
+              }
+              unsigned short* dst = ph + ((size_t)(b * p.pl_H + hh) * p.pl_Npad + n) * 64;
+              *reinterpret_cast<f16x4*>(dst) = hi;
+              *reinterpret_cast<f16x4*>(dst + p.pl_PS) = lo;
+            }
+          }
+          if (p.pl_err && !(bigp <= 65504.f)) atomicOr(p.pl_err, 2);
+        } else if (has_res) {
           if (p.relu == 1) rows(std::true_type{}, A1{}); else if (p.relu == 2) rows(std::true_type{}, A2{}); else rows(std::true_type{}, A0{});
         } else {
           if (p.relu == 1) rows(std::false_type{}, A1{}); else if (p.relu == 2) rows(std::false_type{}, A2{}); else rows(std::false_type{}, A0{});
@@ -631,9 +670,11 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
 #define LVC_MAX_WORKERS 1024
 static int g_cus_pw_s = 0;
 
+struct PwPlanes { unsigned short* planes; int* err; long long PS; int N, Npad, H; float qscale; };
+
 static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                         const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu, int res_mode,
-                        int ldy, int ldr, void* workspace, void* stream) {
+                        int ldy, int ldr, void* workspace, void* stream, const PwPlanes* pl = nullptr) {
   LVC_CHECK_ARG(x && w_split && y && workspace, "null pointer");
   LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && stride >= 1, "non-positive dimension");
@@ -689,6 +730,14 @@ static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_spl
   a.flags = (int*)((char*)workspace + (size_t)LVC_MAX_WORKERS * 256 * 128 * 4);
   a.err_index = LVC_MAX_WORKERS + lvc_range_slot();   // the layer's own range word (common.cpp)
   hipStream_t st = (hipStream_t)stream;
+  a.planes = nullptr; a.pl_err = nullptr; a.pl_PS = 0; a.pl_N = a.pl_Npad = a.pl_H = 0; a.pl_qscale = 1.f;
+  if (pl) {
+    LVC_CHECK_ARG(oneacc && ni == 2 && res_mode == 0 && relu == 0, "the planes epilogue exists for the single-accumulator 128-column tile");
+    a.planes = pl->planes; a.pl_err = pl->err; a.pl_PS = pl->PS; a.pl_N = pl->N; a.pl_Npad = pl->Npad; a.pl_H = pl->H; a.pl_qscale = pl->qscale;
+    hipLaunchKernelGGL((conv_pw_s1_kernel<2, true, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+    LVC_CHECK_LAUNCH();
+    return LVC_OK;
+  }
   if (oneacc) {
     if (ni == 1) hipLaunchKernelGGL((conv_pw_s1_kernel<1, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((conv_pw_s1_kernel<2, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
@@ -714,4 +763,21 @@ extern "C" int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_sp
                                        const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
                                        int res_mode, int ldy, int ldr, void* workspace, void* stream) {
   return pw_s1_launch(true, x, w_split, scale, shift, residual, y, N, H, W, C, K, stride, relu, res_mode, ldy, ldr, workspace, stream);
+}
+
+
+// The qkv layer of a ViT block straight into the attention kernel's operand planes (round 5): lvc_conv1x1_nhwc_f16s1 on x [B*N][C] with
+// K = 3 * H * 64 output columns (q | k | v, head, d) whose epilogue writes what lvc_mha_mfma's first pass would make of the fp32 result --
+// q * qscale, k, v as fp16 (hi, lo) pairs, planes [6][B*H][Npad][64] (Npad = N rounded up to 128; rows N..Npad-1 are NOT written: the
+// caller keeps them zero) -- bit-identical to lvc_conv1x1_nhwc_f16s1 + the split.  scale = the softmax scale (q is multiplied by scale * log2(e)).  An operand beyond
+// fp16's range (or NaN) raises bit 1 of *err_word.  Reference: tools/run_nearest_neighbours.py:102-128 (the DINO ViT's attention.qkv).
+extern "C" int lvc_conv1x1_qkv_planes_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift, void* planes,
+                                            int B, int N, int C, int H, float softmax_scale, int* err_word, void* workspace, void* stream) {
+  LVC_CHECK_ARG(planes && B > 0 && N > 0 && H > 0, "bad arguments");
+  const int Npad = (N + 127) / 128 * 128;
+  PwPlanes pl;
+  pl.planes = (unsigned short*)planes; pl.err = err_word; pl.N = N; pl.Npad = Npad; pl.H = H; pl.qscale = softmax_scale * 1.44269504088896340736f;      // the product lvc_mha_mfma forms (in float)
+  pl.PS = (long long)B * H * Npad * 64;
+  // y is only a non-null placeholder for the shared argument checks (never written)
+  return pw_s1_launch(true, x, w_split, scale, shift, nullptr, (float*)planes, B * N, 1, 1, C, 3 * H * 64, 1, 0, 0, 0, 0, workspace, stream, &pl);
 }

@@ -278,8 +278,10 @@ __global__ __launch_bounds__(256) void mha_split_kernel(const float* __restrict_
     h16x4 hi, lo;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      hi[e] = (h16)v[e];
-      lo[e] = (h16)(v[e] - (float)hi[e]);
+      float a = v[e];
+      asm volatile("" : "+v"(a));      // a VALUE (the rounded q * qscale), not a product the compiler may fuse into the subtraction below:
+      hi[e] = (h16)a;                  // the qkv GEMM's planes epilogue (conv_pw_s1.hip) forms the same two numbers
+      lo[e] = (h16)(a - (float)hi[e]);
     }
     const size_t o = ((size_t)(b * H + h) * Npad + n) * 64 + d4 * 4;
     *reinterpret_cast<h16x4*>(ws + (size_t)(2 * which) * PS + o) = hi;
@@ -464,6 +466,19 @@ extern "C" int lvc_mha_mfma(const float* qkv, float* out, void* workspace, int B
   LVC_CHECK_LAUNCH();
   hipLaunchKernelGGL(mha_mfma_kernel, dim3(Npad / AT_TQ, H, B), dim3(256), 0, (hipStream_t)stream, (const h16*)workspace, out, B, N, H,
                      Npad);
+  LVC_CHECK_LAUNCH();
+  return LVC_OK;
+}
+
+// lvc_mha_mfma's second pass alone, on operand planes that already exist (lvc_conv1x1_qkv_planes_f16s1 wrote them from the qkv GEMM's epilogue):
+// planes [6][B*H][Npad][64] fp16 with q pre-multiplied by scale * log2(e) and rows N..Npad-1 zero.
+extern "C" int lvc_mha_mfma_planes(const void* planes, float* out, int B, int N, int H, void* stream) {
+  LVC_CHECK_ARG(B >= 0 && N > 0 && H > 0, "bad sizes");
+  if (B == 0) return LVC_OK;
+  LVC_CHECK_ARG(planes && out && ((uintptr_t)planes & 15) == 0 && ((uintptr_t)out & 15) == 0, "null or unaligned pointer");
+  LVC_CHECK_ARG(H <= 65535 && B <= 65535, "too many heads / images for one launch");
+  const int Npad = (N + AT_TQ - 1) / AT_TQ * AT_TQ;
+  hipLaunchKernelGGL(mha_mfma_kernel, dim3(Npad / AT_TQ, H, B), dim3(256), 0, (hipStream_t)stream, (const h16*)planes, out, B, N, H, Npad);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

@@ -2225,6 +2225,49 @@ def gelu(x):
 MHA_MFMA = True   # 0: the one-thread-per-query fp32 VALU kernel of round 2 (lvc_mha)
 
 
+QKV_PLANES = _os.environ.get("LVC_QKV_PLANES", "1") != "0"
+_MHA_PLANES_WS = {}
+
+
+def can_qkv_planes(x, pc, num_heads, head_dim):
+    """The qkv GEMM may write the attention's fp16 operand planes from its epilogue (csrc/conv_pw_s1.hip PLANES instance): the layer
+    runs on the single-accumulator pointwise kernel and the attention on the matrix-core kernel."""
+    return (QKV_PLANES and MHA_MFMA and CONV_ENGINE == "bf16x3" and CONV_SPLIT == "f16x2" and PW_S1 == 2 and head_dim == 64
+            and not pc.two_acc and pc.state.get("tier", 0) == 0 and pc.R == 1 and pc.stride == 1 and pc.C >= _PW_S1_ONE_MIN_C and pc.C % 32 == 0
+            and pc.K == 3 * num_heads * 64 and x.numel() * 4 < (1 << 31)
+            and x.shape[0] >= 2048 and x.shape[0] * pc.K < (1 << 29))      # the rows for which `conv2d_nhwc` takes that kernel too
+
+
+def qkv_attention(x, pc, B, N, num_heads, scale):
+    """softmax(q k^T scale) v of a ViT block from the block's normalised input x [B*N, C] and its packed qkv layer: the qkv GEMM writes
+    q * scale * log2(e), k, v as fp16 (hi, lo) planes from its epilogue (lvc_conv1x1_qkv_planes_f16s1: the fp32 qkv tensor and the
+    split pass of lvc_mha_mfma do not exist), lvc_mha_mfma_planes consumes them.  Bit-identical to `mha(linear(x, pc), ...)`.
+    -> [B*N, H*64]."""
+    _req_cuda(x)
+    x = x.contiguous()
+    dev = x.device
+    lib = _lib.lib()
+    lib.lvc_mha_workspace_bytes.restype = c_longlong
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, N, num_heads)
+    ws = _MHA_PLANES_WS.get(key)
+    if ws is None:      # zeroed ONCE: the epilogue never writes the padding rows N..Npad-1, which must stay zero
+        if len(_MHA_PLANES_WS) > 8:
+            _MHA_PLANES_WS.clear()
+        ws = _MHA_PLANES_WS[key] = torch.zeros(max(16, lib.lvc_mha_workspace_bytes(c_int(B), c_int(N), c_int(num_heads))), dtype=torch.uint8, device=dev)
+    planes, scale2 = pc.split2s()
+    pc.last_one = True
+    lib.lvc_set_range_slot(c_int(pc.slot))
+    try:
+        check(lib.lvc_conv1x1_qkv_planes_f16s1(ptr(x), ptr(planes), ptr(scale2), ptr(pc.shift), ptr(ws), c_int(B), c_int(N), c_int(pc.C),
+                                               c_int(num_heads), c_float(scale), ptr(_conv_error_view(dev)),
+                                               ptr(conv_workspace(dev)), _stream(x)), "lvc_conv1x1_qkv_planes_f16s1")
+    finally:
+        lib.lvc_set_range_slot(c_int(0))
+    out = torch.empty(B * N, num_heads * 64, device=dev, dtype=torch.float32)
+    check(lib.lvc_mha_mfma_planes(ptr(ws), ptr(out), c_int(B), c_int(N), c_int(num_heads), _stream(x)), "lvc_mha_mfma_planes")
+    return out
+
+
 def mha_cls(qkv, B, N, num_heads, head_dim, scale):
     """qkv [B*N, 3*H*64] -> [B, H*64]: softmax(q_0 k^T scale) v for the class token of every image (the descriptor network's last block)."""
     _req_cuda(qkv)

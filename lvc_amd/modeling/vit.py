@@ -43,11 +43,14 @@ class _Linear(nn.Module):
         nn.init.trunc_normal_(self.weight, std=0.02)
         self._packed = _Cache()
 
+    def packed(self):
+        return self._packed.get([self.weight] + ([self.bias] if self.bias is not None else []),
+                                lambda: K.pack_linear(self.weight, self.bias, two_acc=False))
+
     def forward(self, x, residual=None, act=None):
         """x [M, din] device rows -> [M, dout]; `residual` [M, dout] is added in the GEMM epilogue; act="gelu": the exact
         GELU in the same epilogue."""
-        pc = self._packed.get([self.weight] + ([self.bias] if self.bias is not None else []),
-                              lambda: K.pack_linear(self.weight, self.bias, two_acc=False))
+        pc = self.packed()
         M = x.shape[0]
         y = K.conv2d_nhwc(x.view(M, 1, 1, x.shape[1]), pc,
                           residual=residual.view(M, 1, 1, residual.shape[1]) if residual is not None else None, act=act)
@@ -91,8 +94,13 @@ class _Block(nn.Module):
 
     def forward(self, t, B, N):
         a = self.attn
-        qkv = a.qkv(self.norm1(t))
-        y = K.mha(qkv, B, N, a.num_heads, t.shape[1] // a.num_heads, a.scale)
+        x = self.norm1(t)
+        pc = a.qkv.packed()
+        if K.can_qkv_planes(x, pc, a.num_heads, t.shape[1] // a.num_heads):
+            # the qkv GEMM writes the attention's fp16 operand planes from its epilogue: no fp32 qkv tensor, no split pass (bit-identical)
+            y = K.qkv_attention(x, pc, B, N, a.num_heads, a.scale)
+        else:
+            y = K.mha(a.qkv(x), B, N, a.num_heads, t.shape[1] // a.num_heads, a.scale)
         t = a.proj(y, residual=t)
         y = self.mlp.fc1(self.norm2(t), act="gelu")      # GELU in fc1's epilogue: the [M, 4 dim] hidden map makes one trip less
         return self.mlp.fc2(y, residual=t)

@@ -144,3 +144,45 @@ def test_verification_chain_crops_descriptors_knn_keep():
         total += len(rq)
     print("verification chain: %d / %d query rows with identical top-10 class lists, %d / %d identical keep flags" % (same_top, total, same_keep, total))
     assert same_keep == total and same_top >= total - 1
+
+
+@pytest.mark.parametrize("B,N", [(3, 785), (11, 197), (17, 128), (2, 197)])
+def test_qkv_planes_from_the_gemm_epilogue_are_bit_identical(B, N, monkeypatch):
+    """`kernels.qkv_attention` (the qkv GEMM writes the attention's fp16 operand planes from its epilogue, csrc/conv_pw_s1.hip PLANES instance;
+    no fp32 qkv tensor, no mha_split pass) against the two-launch form `mha(linear(x))`: same arithmetic in the same order, so the attention
+    output is bit-identical; a ViT block gives the same result with the fused path on and off; an operand beyond fp16's range raises the
+    shared error word."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.vit import _Block
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    blk = _Block(384, 6, 4.0, True).to(dev).eval()
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.05 if p.dim() > 1 else 0.2))
+    x = torch.randn(B * N, 384, generator=g).to(dev)
+    a = blk.attn
+    pc = a.qkv.packed()
+    if B * N < 2048:      # fewer rows than the pointwise kernel takes: the block keeps the two-launch form
+        assert not K.can_qkv_planes(x, pc, 6, 64)
+        return
+    assert K.can_qkv_planes(x, pc, 6, 64)
+    with torch.no_grad():
+        ref = K.mha(a.qkv(x), B, N, 6, 64, a.scale)
+        for _ in range(2):       # the second call reuses the cached planes workspace (padding rows still zero)
+            got = K.qkv_attention(x, pc, B, N, 6, a.scale)
+            assert torch.equal(got, ref)
+        y1 = blk(x, B, N)
+        monkeypatch.setattr(K, "QKV_PLANES", False)
+        y0 = blk(x, B, N)
+        assert torch.equal(y1, y0)
+        monkeypatch.setattr(K, "QKV_PLANES", True)
+        K.clear_conv_error_word(dev)
+        xb = x.clone()
+        xb[0] = 3000.0           # inside the GEMM's own operand range (4094), far outside fp16 after the projection
+        with torch.no_grad():
+            a.qkv.weight.mul_(40.0)
+        K.qkv_attention(xb, a.qkv.packed(), B, N, 6, a.scale)
+        assert K.conv_error_word(dev) & 2
+        K.clear_conv_error_word(dev)
