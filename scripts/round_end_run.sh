@@ -1,6 +1,6 @@
 # One gpurun call at the end of a round: the GPU test suite, smoke(), the full default bench line, and the rocprofv3 kernel trace of the
 # same command (summaries are copied into profiles/ by hand afterwards).  usage: gpurun --timeout 2400 -- 'bash scripts/round_end_run.sh r4x'
-tag=${1:-r4x}
+tag=${1:-r5x}
 mkdir -p gpurun_out/$tag
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/$tag/pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$tag/smoke.txt 2>&1
