@@ -86,32 +86,9 @@ __global__ __launch_bounds__(1024) void nms_prep_kernel(const float* __restrict_
   for (int i = tid; i < npad; i += 1024)
     keys[i] = i < n ? (((u64)ordered_desc_key(sc[i]) << 32) | (unsigned)i) : ~0ull;
   __syncthreads();
-  // Bitonic sort ascending on 64-bit keys.  Compare distances below 64 stay inside one 64-element block: a wave keeps such a block in
-  // registers (lane = element) and runs those passes with lane exchanges -- all passes of the stages k <= 64 in one visit, the last six
-  // of every later stage in one visit -- so only the passes with distance >= 64 go through LDS with a barrier each: 35 barriers instead
-  // of 91 for 8 192 keys (the detection stage's lists: 100 -> ~45 us for the one workgroup per image this kernel is).
-  const int lane = tid & 63, wv = tid >> 6;
-  auto in_wave = [&](int k_first, int k_last) {      // stages k_first .. k_last (each k <= 64: all its passes; k > 64: the passes j = 32 .. 1)
-    for (int blk = wv; blk < (npad >> 6); blk += 16) {
-      const int i = (blk << 6) | lane;
-      u64 v = keys[i];
-      for (int k = k_first; k <= k_last; k <<= 1) {
-        const bool up = (i & k) == 0;
-        for (int j = (k > 64 ? 32 : k >> 1); j > 0; j >>= 1) {
-          const unsigned olo = __shfl_xor((unsigned)v, j), ohi = __shfl_xor((unsigned)(v >> 32), j);
-          const u64 o = ((u64)ohi << 32) | olo;
-          const bool lower = (lane & j) == 0;                 // this lane holds the pair's lower position
-          const bool take_min = lower == up;
-          v = ((o < v) == take_min) ? o : v;
-        }
-      }
-      keys[i] = v;
-    }
-    __syncthreads();
-  };
-  in_wave(2, 64);
-  for (int k = 128; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j >= 64; j >>= 1) {
+  // bitonic sort ascending on 64-bit keys
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < npad / 2; t += 1024) {
         int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         int hi = lo | j;
@@ -121,7 +98,6 @@ __global__ __launch_bounds__(1024) void nms_prep_kernel(const float* __restrict_
       }
       __syncthreads();
     }
-    in_wave(k, k);
   }
   int* ord = order + (size_t)img * Nmax;
   float* sb = sboxes + (size_t)img * Nmax * 4;
