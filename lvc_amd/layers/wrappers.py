@@ -87,6 +87,19 @@ class Conv2d(nn.Module):
         pc.state = self._range_state
         return pc
 
+    def _grad_lands_in_weight(self):
+        """True inside a pass that will run the weight's AccumulateGrad node -- `loss.backward()` -- i.e. when the deferred weight gradient
+        may be written to `weight.grad` in its place; False under `torch.autograd.grad(...)` / `backward(inputs=...)`, where the node must
+        hand its gradient back to the engine."""
+        node = self.__dict__.get("_acc_node")
+        if node is None or node[0] is not self.weight:
+            with torch.enable_grad():
+                node = self.__dict__["_acc_node"] = (self.weight, self.weight.view_as(self.weight).grad_fn.next_functions[0][0])
+        try:
+            return bool(torch._C._will_engine_execute_node(node[1]))
+        except RuntimeError:       # "a leaf node was passed ... running autograd.grad()": the weight is one of its inputs
+            return False
+
     def _stale(self, cache, tensors):
         return cache.key != tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
@@ -187,7 +200,7 @@ class _ConvFn(torch.autograd.Function):
         if need_w:
             R = conv.kernel_size[0]
             scale = conv.packed().scale if conv.norm is not None else None
-            if K.can_defer_wgrad(x, g):
+            if K.can_defer_wgrad(x, g) and conv._grad_lands_in_weight():
                 # off the critical path: queued, launched with the other layers' (kernels.flush_wgrad) and written to weight.grad
                 # before backward() returns -- this node hands autograd no gradient for the weight
                 K.defer_wgrad(conv.weight, x, g, scale, R, conv.stride, conv.padding)

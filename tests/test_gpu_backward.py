@@ -374,3 +374,27 @@ def test_prepack_plan_is_reused_after_an_optimizer_step(monkeypatch):
         rf, rd = c.packed(), c.packed_dgrad()
         assert torch.equal(w, rf.w) and torch.equal(pl.view(torch.int16), rf.split2s()[0].view(torch.int16)) and torch.equal(d3.view(torch.int16), rd.split3().view(torch.int16))
     assert torch.equal(convs[0].forward_nhwc(x), y_new)
+
+
+def test_weight_gradient_is_not_deferred_under_autograd_grad():
+    """`torch.autograd.grad` must get the weight gradient back from the node (nothing may be written to `.grad`), and `backward(inputs=[x])`
+    must leave `weight.grad` alone: the deferred path (`kernels.defer_wgrad`) is taken only when the engine will run the weight's
+    AccumulateGrad node."""
+    from lvc_amd import kernels as K
+    from lvc_amd.layers import Conv2d
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(21)
+    conv = Conv2d(64, 128, 3, padding=1, bias=False).to(dev)
+    x = torch.randn(2, 24, 40, 64, generator=g).to(dev).requires_grad_(True)
+    conv.forward_nhwc(x).square().sum().backward()
+    ref_w, ref_x = conv.weight.grad.clone(), x.grad.clone()
+    conv.weight.grad = None
+    x.grad = None
+    gx, gw = torch.autograd.grad(conv.forward_nhwc(x).square().sum(), [x, conv.weight])
+    assert conv.weight.grad is None and not K._WGRAD_Q and not K._WGRAD_ARMED[0]
+    assert _rel(gw, ref_w) < 1e-5 and _rel(gx, ref_x) < 1e-6
+    (gx2,) = torch.autograd.grad(conv.forward_nhwc(x).square().sum(), [x])
+    assert conv.weight.grad is None and not K._WGRAD_Q and _rel(gx2, ref_x) < 1e-6
+    conv.forward_nhwc(x).square().sum().backward(inputs=[x])
+    assert conv.weight.grad is None and not K._WGRAD_Q and _rel(x.grad, ref_x) < 1e-6
