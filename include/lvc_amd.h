@@ -138,6 +138,10 @@ int lvc_conv3x3_nhwc_f16_layers(int oneacc, const float* const* xs, float* const
  * equal share of the (tile, 16-channel chunk) list; split tiles are completed through `workspace` as in the other conv kernels, in worker
  * order: deterministic); 2 = persistent workgroups on whole tiles.  Measured: neither beats 0 on the detector's layers (conv3x3_wino.hip). */
 void lvc_set_wino_streamk(int mode);
+/* Process-wide A/B and test switches (no environment lookups inside the library): the NMS ordered reduce of short lists from global
+ * memory instead of LDS (same keep lists); the bf16x3 3x3 halo kernel with a fixed patch shape / without its small-map fallback. */
+void lvc_set_nms_reduce_global(int on);
+void lvc_set_halo_test_hooks(int ph, int pw, int force);
 /* 3x3 / stride 1 / pad 1 as Winograd F(2,3) along x (round 5, csrc/conv3x3_wino.hip; the 256-channel layers of
  * detectron2/modeling/backbone/fpn.py:141-144 and proposal_generator/rpn.py:92-94 on the large maps): two thirds of the MFMAs of
  * lvc_conv3x3_nhwc_f16s1 at the same operand precision and the direct evaluation's fp32 error.  u = transformed row-scaled weight planes

@@ -40,6 +40,10 @@ def lib():
         L.lvc_set_wino_streamk.restype = None
         if os.environ.get("LVC_WINO_STREAMK", "0") != "0":
             L.lvc_set_wino_streamk(c_int(int(os.environ["LVC_WINO_STREAMK"])))
+        L.lvc_set_nms_reduce_global.restype = None
+        L.lvc_set_halo_test_hooks.restype = None
+        if os.environ.get("LVC_NMS_REDUCE_GLOBAL", "0") != "0":      # read once, here: the library itself never looks at the environment
+            L.lvc_set_nms_reduce_global(c_int(1))
         _lib = L
     return _lib
 

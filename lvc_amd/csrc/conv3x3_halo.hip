@@ -394,6 +394,11 @@ static void pick_patch(int H, int W, int* PH, int* PW) {
 
 // 3x3 / stride 1 / pad 1 specialisation of lvc_conv2d_nhwc_bf16x3: same arguments minus (R, S, stride, pad), same
 // packed weights, same workspace, same result contract.
+// Test hooks of this kernel (tests/test_gpu_kernels.py::test_conv3x3_halo_matches_cpu; no environment lookups on the launch path):
+// a fixed patch shape ph x pw (0 = the kernel's choice) and `force` = no fallback to the generic kernel on small maps.
+static int g_halo_test_ph = 0, g_halo_test_pw = 0, g_halo_test_force = 0;
+extern "C" void lvc_set_halo_test_hooks(int ph, int pw, int force) { g_halo_test_ph = ph; g_halo_test_pw = pw; g_halo_test_force = force; }
+
 extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_split, const float* scale,
                                        const float* shift, const float* residual, float* y, int N, int H, int W, int C,
                                        int K, int Kg, int relu, int res_mode, int ldy, int ldr, void* workspace,
@@ -411,9 +416,8 @@ extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_s
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0, "pointers must be 16-byte aligned");
   pick_patch(H, W, &a.PH, &a.PW);
-  if (const char* e = getenv("LVC_HALO_PATCH")) {   // experiments: "PH,PW"
-    int ph = 0, pw = 0;
-    if (sscanf(e, "%d,%d", &ph, &pw) == 2 && ph > 0 && pw > 0 && ph * pw <= HM && (ph + 2) * (pw + 2) <= HALO_MAX) { a.PH = ph; a.PW = pw; }
+  if (g_halo_test_ph > 0 && g_halo_test_pw > 0 && g_halo_test_ph * g_halo_test_pw <= HM && (g_halo_test_ph + 2) * (g_halo_test_pw + 2) <= HALO_MAX) {
+    a.PH = g_halo_test_ph; a.PW = g_halo_test_pw;      // test hook (lvc_set_halo_test_hooks): a fixed patch shape
   }
   a.HW = a.PW + 2; a.HP = (a.PH + 2) * a.HW; a.MP = a.PH * a.PW;
   a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
@@ -423,7 +427,7 @@ extern "C" int lvc_conv3x3_nhwc_bf16x3(const float* x, const unsigned short* w_s
   a.nk = C / 32;
   // small feature maps (p5 / p6 / a single image's res5): too few 256-pixel patches to fill 256 CUs before stream-K
   // splits every tile eight ways -- the generic 128-row kernel measures faster there (scripts/probe_halo.py)
-  if ((long long)N * a.tiles_x * a.tiles_y * a.tiles_n < 128 && !getenv("LVC_HALO_FORCE"))
+  if ((long long)N * a.tiles_x * a.tiles_y * a.tiles_n < 128 && !g_halo_test_force)
     return lvc_conv2d_nhwc_bf16x3(x, w_split, scale, shift, residual, y, N, H, W, C, K, 3, 3, 1, 1, Kg, relu, res_mode,
                                   ldy, ldr, workspace, stream);
   long long units = (long long)N * a.tiles_x * a.tiles_y * a.tiles_n * a.nk;

@@ -545,6 +545,11 @@ extern "C" long long lvc_batched_nms_workspace_bytes(int B, int Nmax) {
 // reference switches to a per-class loop at 40 000 boxes, detectron2/layers/nms.py:22-29, with the same result): global
 // bitonic sort, then the greedy pass in blocks of 16 384 sorted rows -- suppression by boxes kept in earlier blocks
 // (nms_cross_kernel), mask + reduce inside the block; images whose count fits the first block skip the rest.
+// 1: lists of <= NMS_LDS_ROWS rows on nms_reduce_kernel (bit matrix read from global memory) instead of nms_reduce_lds_kernel -- the A/B
+// form of tests/test_gpu_kernels.py::test_nms_reduce_from_lds_equals_the_global_form_and_the_oracle (no environment lookup per launch)
+static int g_nms_reduce_global = 0;
+extern "C" void lvc_set_nms_reduce_global(int on) { g_nms_reduce_global = on; }
+
 extern "C" int lvc_batched_nms(const float* boxes, const float* scores, const int* idxs,
                                const int* d_counts, int B, int Nmax, double iou_threshold,
                                int max_keep, int* keep, int* d_num_keep, void* workspace,
@@ -628,7 +633,7 @@ extern "C" int lvc_batched_nms(const float* boxes, const float* scores, const in
     hipLaunchKernelGGL(nms_mask_kernel, mask_grid, dim3(64), 0, st, sboxes, sidx, d_counts, Nmax, nwords, iou_threshold,
                        mask, 0, rows_cap, (const int*)nullptr, max_keep);
     LVC_CHECK_LAUNCH();
-    if (rows_cap <= NMS_LDS_ROWS && !getenv("LVC_NMS_REDUCE_GLOBAL"))
+    if (rows_cap <= NMS_LDS_ROWS && !g_nms_reduce_global)
       hipLaunchKernelGGL(nms_reduce_lds_kernel, dim3(B), dim3(256), 0, st, mask, order, d_counts, Nmax, nwords, max_keep, keep, d_num_keep,
                          rows_cap);
     else

@@ -92,9 +92,17 @@ def test_conv3x3_halo_matches_cpu(N, C, H, W, K, patch, split, monkeypatch):
     CPU, with bias, FrozenBN scale/shift, ReLU, residual add and FPN upsample-add epilogues."""
     from lvc_amd import kernels as k
 
-    monkeypatch.setenv("LVC_HALO_FORCE", "1")
-    if patch:
-        monkeypatch.setenv("LVC_HALO_PATCH", patch)
+    from lvc_amd import _lib
+
+    ph, pw = [int(v) for v in patch.split(",")] if patch else (0, 0)
+    _lib.lib().lvc_set_halo_test_hooks(ph, pw, 1)      # fixed patch shape, no small-map fallback
+    try:
+        _halo_case(k, N, C, H, W, K, split, monkeypatch)
+    finally:
+        _lib.lib().lvc_set_halo_test_hooks(0, 0, 0)
+
+
+def _halo_case(k, N, C, H, W, K, split, monkeypatch):
     monkeypatch.setattr(k, "CONV_ENGINE", "bf16x3")
     monkeypatch.setattr(k, "CONV_HALO", True)
     monkeypatch.setattr(k, "CONV_SPLIT", split)
@@ -600,7 +608,7 @@ def test_batched_nms_batch_with_counts_and_max_keep():
 @pytest.mark.parametrize("thr,max_keep", [(0.7, 0), (0.5, 100), (0.3, 37)])
 def test_nms_reduce_from_lds_equals_the_global_form_and_the_oracle(monkeypatch, thr, max_keep):
     """Lists of <= 1024 rows (the RPN's per-level lists) run the ordered reduce with the bit matrix in LDS (nms_reduce_lds_kernel);
-    LVC_NMS_REDUCE_GLOBAL=1 keeps them on nms_reduce_kernel: same keep lists, equal to the oracle's, for ragged counts around the
+    `lvc_set_nms_reduce_global(1)` (LVC_NMS_REDUCE_GLOBAL=1 at import) keeps them on nms_reduce_kernel: same keep lists, equal to the oracle's, for ragged counts around the
     64-row chunk edges, with and without a cap on the kept boxes."""
     from lvc_amd import kernels as k
     from oracle import ops as oops
@@ -618,13 +626,14 @@ def test_nms_reduce_from_lds_equals_the_global_form_and_the_oracle(monkeypatch, 
     d = _dev()
     res = {}
     for glob in (False, True):
-        if glob:
-            monkeypatch.setenv("LVC_NMS_REDUCE_GLOBAL", "1")
-        else:
-            monkeypatch.delenv("LVC_NMS_REDUCE_GLOBAL", raising=False)
-        keep, nk = k.batched_nms_batch(boxes.to(d), scores.to(d), idxs.to(d), counts.to(d), thr, max_keep=max_keep)
+        from lvc_amd import _lib
+
+        _lib.lib().lvc_set_nms_reduce_global(1 if glob else 0)
+        try:
+            keep, nk = k.batched_nms_batch(boxes.to(d), scores.to(d), idxs.to(d), counts.to(d), thr, max_keep=max_keep)
+        finally:
+            _lib.lib().lvc_set_nms_reduce_global(0)
         res[glob] = (keep.cpu(), nk.cpu())
-    monkeypatch.delenv("LVC_NMS_REDUCE_GLOBAL", raising=False)
     assert res[False][1].tolist() == res[True][1].tolist()
     for b in range(B):
         n = int(counts[b])
