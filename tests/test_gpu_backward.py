@@ -398,3 +398,58 @@ def test_weight_gradient_is_not_deferred_under_autograd_grad():
     assert conv.weight.grad is None and not K._WGRAD_Q and _rel(gx2, ref_x) < 1e-6
     conv.forward_nhwc(x).square().sum().backward(inputs=[x])
     assert conv.weight.grad is None and not K._WGRAD_Q and _rel(x.grad, ref_x) < 1e-6
+
+
+def test_deferred_wgrad_queue_survives_a_failed_backward_and_buckets_take_the_gradients_in_place():
+    """(1) A backward() that raises after weight gradients were queued leaves them behind; the next forward drops the stale queue
+    (`kernels.reset_wgrad_queue`) and the next backward() delivers exactly its own gradients.  (2) With `GradientBuckets` and
+    `zero_grad(set_to_none=True)` the deferred gradients are written straight into the bucket slices, step after step."""
+    from lvc_amd import distributed as D, kernels as K
+    from lvc_amd.layers import Conv2d
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(31)
+    conv = Conv2d(64, 64, 3, padding=1, bias=True).to(dev)
+    x = torch.randn(1, 16, 24, 64, generator=g).to(dev)
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            raise RuntimeError("boom")
+
+    xin = x.clone().requires_grad_(True)
+    y = conv.forward_nhwc(Boom.apply(conv.forward_nhwc(xin)))       # the outer conv's gradient is queued, then the inner node raises
+    with pytest.raises(RuntimeError, match="boom"):
+        y.sum().backward()
+    assert K._WGRAD_Q and K._WGRAD_ARMED[0] and conv.weight.grad is None
+    conv.forward_nhwc(x).sum().backward()
+    assert not K._WGRAD_Q and not K._WGRAD_ARMED[0]
+    got = conv.weight.grad.clone()
+    conv.weight.grad = None
+    K.DEFER_WGRAD, prev = False, K.DEFER_WGRAD
+    try:
+        conv.forward_nhwc(x).sum().backward()
+    finally:
+        K.DEFER_WGRAD = prev
+    assert _rel(got, conv.weight.grad) < 1e-5
+    # (2)
+    params = list(conv.parameters())
+    for p in params:
+        p.grad = None
+    buckets = D.GradientBuckets(params, bucket_bytes=1 << 20)
+    opt = torch.optim.SGD(params, lr=0.1)
+    try:
+        for step in range(2):
+            opt.zero_grad(set_to_none=True)
+            conv.forward_nhwc(x).square().sum().backward()
+            buckets.finish()
+            flat = buckets.buckets[0]["flat"]
+            for p in params:
+                assert p.grad is not None and flat.data_ptr() <= p.grad.data_ptr() < flat.data_ptr() + flat.numel() * 4
+            opt.step()
+    finally:
+        buckets.remove()

@@ -546,3 +546,55 @@ def test_rbg_batched_table_equals_the_per_image_lists():
     assert 0 < int(keep.sum()) < keep.numel()
     for i, inst in enumerate(lists):
         assert torch.equal(table[i][keep[i]], inst.proposal_boxes.tensor), i
+
+
+def test_box_corrector_training_with_live_rbg_both_row_structures_and_an_image_without_ground_truth():
+    """The box-corrector step with RBG's own random jitter (no recorded boxes): (1) the padded-table path and the per-image lists give
+    finite losses of the same size for the same generator state (their proposals are the same boxes; the samplers draw differently,
+    so only the magnitude is compared), two steps in a row (the second re-packs through the kept plan); (2) a batch in which one image
+    has no ground truth cannot be batched (`can_batch` / `can_batch_train` are False) and still trains through the lists."""
+    from lvc_amd.structures import Boxes, Instances
+    from lvc_amd.utils import synthetic as syn
+    from lvc_amd.utils.events import EventStorage
+
+    g = gold("box_corrector_train")
+    model = _train_model()
+    batch = []
+    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(g["gt_boxes%d" % i])
+        inst.gt_classes = g["gt_classes%d" % i]
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(g["loaded_boxes%d" % i])
+        props.objectness_logits = g["loaded_logits%d" % i]
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+    opt = torch.optim.SGD([p for p in model.parameters() if p.requires_grad], lr=1e-4)
+    out = {}
+    for rows in (True, False):
+        model.roi_heads.batched_training = rows
+        vals = []
+        for step in range(2):
+            torch.manual_seed(77 + step)
+            with EventStorage(0):
+                losses = model(batch)
+            assert set(losses) == {"loss_box_reg_stage0", "loss_box_reg_stage1", "loss_box_reg_stage2"}
+            total = sum(losses.values())
+            assert bool(torch.isfinite(total))
+            opt.zero_grad()
+            total.backward()
+            assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters() if p.requires_grad)
+            vals.append(float(total))
+        out[rows] = vals
+    model.roi_heads.batched_training = True
+    for a, b in zip(out[True], out[False]):
+        assert 0.5 < a / b < 2.0, (out[True], out[False])
+    # one image without ground truth: per-image lists (the reference's structure handles it, roi_heads.py:236-262)
+    empty = Instances((200, 352))
+    empty.gt_boxes = Boxes(torch.zeros(0, 4))
+    empty.gt_classes = torch.zeros(0, dtype=torch.int64)
+    batch[1] = dict(batch[1], instances=empty)
+    gts = [b["instances"].to(model.device) for b in batch]
+    assert not model.roi_heads.can_batch_train(gts) and not model.proposal_generator.can_batch([b["proposals"] for b in batch], gts)
+    with EventStorage(0):
+        losses = model(batch)
+    assert bool(torch.isfinite(sum(losses.values())))
