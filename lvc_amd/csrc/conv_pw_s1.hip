@@ -715,7 +715,7 @@ static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_spl
   int cap = g_cus_pw_s;
   if (cap > LVC_MAX_WORKERS) cap = LVC_MAX_WORKERS;
   a.ngroup = 1;
-  if ((a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8) && cap % a.tiles_n == 0 && units / a.tiles_n >= (long long)(cap / a.tiles_n) * 4) {
+  if ((a.tiles_n == 2 || a.tiles_n == 4 || a.tiles_n == 8 || a.tiles_n == 16) && cap % a.tiles_n == 0 && units / a.tiles_n >= (long long)(cap / a.tiles_n) * 4) {
     a.ngroup = a.tiles_n;       // the workers of one row tile's channel tiles are neighbours on one XCD: the rows come from L2
     units /= a.tiles_n;
     cap /= a.tiles_n;
