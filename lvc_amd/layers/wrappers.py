@@ -91,6 +91,15 @@ class Conv2d(nn.Module):
         """True inside a pass that will run the weight's AccumulateGrad node -- `loss.backward()` -- i.e. when the deferred weight gradient
         may be written to `weight.grad` in its place; False under `torch.autograd.grad(...)` / `backward(inputs=...)`, where the node must
         hand its gradient back to the engine."""
+        w = self.weight
+        if id(w) not in K._WGRAD_SINKS:
+            # no registered taker for the deferred gradient (GradientBuckets registers one per parameter): anything that listens to the
+            # autograd path of this parameter -- tensor hooks, or a data-parallel wrapper's hooks on the AccumulateGrad node
+            # (torch DistributedDataParallel, which the reference's DefaultTrainer uses) -- must see the gradient arrive there
+            if w._backward_hooks or getattr(w, "_post_accumulate_grad_hooks", None):
+                return False
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                return False
         node = self.__dict__.get("_acc_node")
         if node is None or node[0] is not self.weight:
             with torch.enable_grad():

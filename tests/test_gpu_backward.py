@@ -453,3 +453,25 @@ def test_deferred_wgrad_queue_survives_a_failed_backward_and_buckets_take_the_gr
             opt.step()
     finally:
         buckets.remove()
+
+
+def test_weight_gradient_takes_the_autograd_path_when_a_hook_listens():
+    """A tensor hook or a post-accumulate hook on the weight (what a data-parallel wrapper other than GradientBuckets relies on) must see the
+    gradient: such a parameter is not deferred."""
+    from lvc_amd import kernels as K
+    from lvc_amd.layers import Conv2d
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(41)
+    conv = Conv2d(64, 64, 3, padding=1, bias=False).to(dev)
+    x = torch.randn(1, 16, 24, 64, generator=g).to(dev)
+    seen = []
+    h = conv.weight.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.detach().clone()))
+    conv.forward_nhwc(x).sum().backward()
+    assert len(seen) == 1 and not K._WGRAD_Q and torch.equal(seen[0], conv.weight.grad)
+    h.remove()
+    conv.weight.grad = None
+    h2 = conv.weight.register_hook(lambda gr: seen.append(gr.detach().clone()))
+    conv.forward_nhwc(x).sum().backward()
+    assert len(seen) == 2 and _rel(seen[1], seen[0]) < 1e-5
+    h2.remove()
