@@ -450,6 +450,25 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
     return out
 
 
+def vendor_trunk_leg(timeout_s=240):
+    """Context, not a product path and not `vs_baseline`: the same R50-FPN trunk (stem, res2-5, FPN) on PyTorch-ROCm's own convolutions
+    (F.conv2d = MIOpen, what the reference's modules would call on this GPU) in fp32, against this repo's backbone on the same batch
+    (scripts/probe_torch_trunk.py in a subprocess: the library's first call searches its kernels for ~20 s)."""
+    import re
+
+    env = dict(os.environ, LVC_TRUNK_YARDSTICK_FP32_ONLY="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "probe_torch_trunk.py")], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
+    mine = re.search(r"lvc_amd backbone \+ FPN.*?: ([0-9.]+) ms", r.stdout)
+    lib = re.search(r"F\.conv2d fp32, channels_last: ([0-9.]+) ms per batch  \(([0-9.]+) x lvc_amd; max \|diff\| / scale vs lvc_amd ([0-9.e+-]+)\)", r.stdout)
+    if not (mine and lib):
+        return {"error": "no result (rc %d)" % r.returncode}
+    return {"workload": "R50-FPN trunk (stem, res2-5, FPN + p6), 8 x 800x1333, FrozenBN folded", "lvc_amd_ms": float(mine.group(1)),
+            "pytorch_rocm_miopen_fp32_ms": float(lib.group(1)), "ratio": float(lib.group(2)), "max_abs_diff_over_scale": float(lib.group(3)),
+            "note": "yardstick only: F.conv2d (MIOpen as shipped in the image, channels_last, default find mode) on the same GPU in the same run; "
+                    "fp16 through the same library: profiles/r05_torch_trunk.txt"}
+
+
 def descriptor_leg(c, batch=64, steps=5, warmup=2):
     """the descriptor network in front of the kNN sweep (tools/run_nearest_neighbours.py:102-128 get_descriptors,
     :292-293 DINO ViT-S/8): crops/s on 224x224 crops at batch 64, random-init weights of that architecture.  Algorithmic work per
@@ -889,7 +908,8 @@ def infer_main(c, args):
         # BASELINE configs[2] / [4] are training workloads and configs[4] names R101: their one-GPU rates, every run
         if c.world == 1:
             for key, fn in (("train_cfg3", lambda: train_leg(c, 5, 2, 8, "cfg3")), ("train_cfg5_r101", lambda: train_leg(c, 5, 2, 2, "cfg5")),
-                            ("r101_inference", lambda: r101_leg(c, parity_images=0 if args.no_cpu_baseline else 2)), ("descriptors", lambda: descriptor_leg(c))):
+                            ("r101_inference", lambda: r101_leg(c, parity_images=0 if args.no_cpu_baseline else 2)), ("descriptors", lambda: descriptor_leg(c)),
+                            ("vendor_trunk_yardstick", vendor_trunk_leg)):
                 try:
                     extras.setdefault("train", {})[key] = fn()
                 except Exception as e:

@@ -85,7 +85,10 @@ with torch.no_grad():
     mine = model.backbone(x)
     t_mine = timeit(lambda: model.backbone(x), 10)
     print("lvc_amd backbone + FPN (fp32-accurate fp16-split kernels): %.2f ms per batch of %d" % (t_mine, B), flush=True)
-    for dtype, name in ((torch.float32, "fp32"), (torch.float16, "fp16 (not the reference's precision)")):
+    kinds = ((torch.float32, "fp32"), (torch.float16, "fp16 (not the reference's precision)"))
+    if os.environ.get("LVC_TRUNK_YARDSTICK_FP32_ONLY") == "1":
+        kinds = kinds[:1]
+    for dtype, name in kinds:
         P = build(dtype)
         xin = x[:, :3].to(dtype).contiguous(memory_format=torch.channels_last)
         t0 = time.perf_counter()
