@@ -856,7 +856,7 @@ def infer_main(c, args):
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic,
             "traffic_source": ("live rocprofv3 --pmc passes in this run" if live is not None else "profiles (not measured in this run)")
-                              + ": fabric bytes FETCH_SIZE x2 + WRITE_SIZE of ONE p2 3x3 launch (the 3x3 kernel's largest, 2 of its 22 launches per step) vs 1.10 GB algorithmic",
+                              + ": fabric bytes FETCH_SIZE x2 + WRITE_SIZE of ONE p2 3x3 launch (the dominant kernel's largest: the FPN output conv on p2; the RPN head on p2 is the same shape) vs 1.10 GB algorithmic",
             "mfma_utilisation_pmc": pmc,
             "kernel_ms_per_step": round(ms / max(1, timer.steps_timed()), 3), "launch_avg_ms": round(ms / nlaunch, 4)}
         other = {}
