@@ -188,6 +188,18 @@ int lvc_conv1x1_chain_nhwc_f16s1(const float* x, int ldx, const unsigned short* 
                                  const float* residual, int ldr, float* y1, int ldy1, int relu1, const unsigned short* wb,
                                  int wb_rows, const float* sb, const float* tb, float* y2, int ldy2, int relu2, int M, int K1,
                                  int N1, int N2, void* workspace, void* stream);
+/* A whole bottleneck block in one launch (round 6, csrc/conv_bneck.hip), replacing the three conv + FrozenBN launches and the shortcut
+ * add of detectron2/modeling/backbone/resnet.py:195-211 for the 64-mid / 256-output-channel blocks of res2 (stride 1):
+ *   y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)).
+ * conv1's output lives in LDS (output tile + one-pixel halo, fp16 planes), conv2's in registers; x is read once, y written once.
+ * x [N][H][W][ldx] (cin channels used), y [N][H][W][ldy].  proj = 0: cin = 256, shortcut = x.  proj = 1: cin = 64, the projection
+ * shortcut's weights are the last 64 contraction columns of the third layer.  w: stage images built by
+ * lvc_amd.kernels.pack_bottleneck (row-scaled fp16 planes of lvc_split_weights_rowscaled in fragment order: (cin/32) x 8 KB,
+ * 12 x 12 KB, 8 or 16 x 8 KB); s1/t1, s2/t2 (64 entries), s3/t3 (256): epilogue scales (x row factors) and shifts, never NULL.
+ * |x|, |conv1 out| or |conv2 out| > 4094 (or non-finite) sets bit 1 / 2 of the launch's range word. */
+int lvc_bottleneck_nhwc_f16s1(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int cin, int proj,
+                              const unsigned short* w, const float* s1, const float* t1, const float* s2, const float* t2,
+                              const float* s3, const float* t3, void* workspace, void* stream);
 /* wp [rows][Kg] fp32 (lvc_pack_conv_weights) -> planes_out [2][rows][Kg] fp16: w1 = fp16(wp 2^e), w2 = fp16(wp 2^e - w1) with
  * e = 13 - floor(log2(max |wp[row][:]|)) per row (0 for an all-zero row); row_factor[row] = 2^-(e + 4). */
 int lvc_split_weights_rowscaled(const float* wp, int rows, int Kg, void* planes_out, float* row_factor, void* stream);

@@ -430,6 +430,11 @@ def check_conv_error_word(device):
                         o.state["off"] = True
                         moved.append("chained pair %dx%d->%d->%d: two launches" % (o.K1, o.N1, o.N1, o.N2))
                     continue
+                if isinstance(o, PackedBneck):
+                    if not o.state.get("off"):
+                        o.state["off"] = True
+                        moved.append("fused bottleneck %d->64->256: separate launches" % o.cin)
+                    continue
                 tier = o.state["tier"]
                 t_launch, one = o.state.get("at", {}).get(ws_key, (tier, o.last_one))
                 new = 1 if (one and t_launch < 1) else 2
@@ -1037,6 +1042,107 @@ def conv1x1_chain(x, ch, residual=None, relu1=True, relu2=True, out1=None, out2=
         nbytes = 4.0 * (M * (ch.K1 + ch.N1 + ch.N2 + (ch.N1 if residual is not None else 0)) + ch.K1 * ch.N1 + ch.N1 * ch.N2)
         timer.records.append((2.0 * M * (ch.K1 * ch.N1 + ch.N1 * ch.N2), e0, e1, "f16s1_chain", nbytes))
     return out1, out2
+
+
+class PackedBneck:
+    """One bottleneck block's weights as the stage images of lvc_bottleneck_nhwc_f16s1 (csrc/conv_bneck.hip)."""
+
+    __slots__ = ("w", "s1", "t1", "s2", "t2", "s3", "t3", "cin", "proj", "slot", "state", "__weakref__")
+
+
+BNECK = _os.environ.get("LVC_BNECK", "1") != "0"      # whole res2 blocks (64 mid, 256 out channels, stride 1) as one launch
+BNECK_SHAPES = {(256, 64, 256, False), (64, 64, 256, True)}      # (in, mid, out channels, projection shortcut)
+_BNECK_IDX = {}
+
+
+def _bneck_index(cin, proj, device):
+    """Gather indices (plane, row, column) into the three layers' [2][rows][Kg] split planes for every fp16 of the stage images:
+    a stage is a run of 1 KB fragments in lane order -- lane l holds row l % 32 of the fragment's 32-row block and the 8
+    contraction entries of k half l // 32 in the permuted order of csrc/conv_pw_chain.hip (`_PERM16`)."""
+    key = (cin, proj, str(device))
+    if key in _BNECK_IDX:
+        return _BNECK_IDX[key]
+    import numpy as np
+
+    lane = np.arange(64)
+    rowl = (lane % 32)[:, None].repeat(8, 1)                                    # [64, 8]
+    kpos = np.asarray(_PERM16)[(lane // 32)[:, None] * 8 + np.arange(8)[None]]   # natural k16 offset held at (lane, slot)
+
+    def frags(specs):
+        pl = np.stack([np.full((64, 8), s[0]) for s in specs])
+        rows = np.stack([s[1] + rowl for s in specs])
+        cols = np.stack([np.asarray(s[2])[kpos] for s in specs])
+        return pl, rows, cols
+
+    a16 = np.arange(16)
+    p1 = [(pl, 32 * cb, 32 * c + 16 * sp + a16) for c in range(cin // 32) for sp in range(2) for cb in range(2) for pl in range(2)]
+
+    def col2(ch, r, s_):      # pack_conv's contraction order: (c // 32, r, s, c % 32)
+        return (ch // 32) * 288 + (r * 3 + s_) * 32 + ch % 32
+
+    p2 = [(pl, 32 * cb, col2(16 * s + a16, dy, dx)) for s in range(4) for dx in range(3) for dy in range(3) for cb in range(2)
+          for pl in range(2)]
+    p3 = [(pl, 32 * j, 64 * half + 16 * s + a16) for j in range(8) for half in range(2 if proj else 1) for s in range(4)
+          for pl in range(2)]
+    out = tuple(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in frags(sp)) for sp in (p1, p2, p3))
+    _BNECK_IDX[key] = out
+    return out
+
+
+def pack_bottleneck(pc1, pc2, pc3, proj, state=None):
+    """pc1 / pc2 / pc3: `pack_conv` results of a bottleneck's conv1 (1x1), conv2 (3x3, pad 1) and conv3 (1x1; with proj the fused
+    [conv3 | projection shortcut] pack of BottleneckBlock._fused_projection, 128 contraction channels), FrozenBN folded."""
+    assert pc1.R == 1 and pc2.R == 3 and pc2.S == 3 and pc2.pad == 1 and pc2.stride == 1 and pc3.R == 1 and pc1.stride == 1
+    cin = pc1.C
+    assert (cin, pc1.K, pc3.K, bool(proj)) in BNECK_SHAPES and pc2.C == 64 and pc2.K == 64 and pc3.C == (128 if proj else 64)
+    dev = pc1.w.device
+    bk = PackedBneck()
+    bk.slot = _new_range_slot(bk)
+    bk.state = state if state is not None else {"off": False}
+    bk.cin, bk.proj = cin, bool(proj)
+    parts = []
+    affine = []
+    for pc, (pl, rows, cols) in zip((pc1, pc2, pc3), _bneck_index(cin, bool(proj), dev)):
+        nrows, Kg = pc.w.shape
+        planes = torch.empty((2, nrows, Kg), device=dev, dtype=torch.float16)
+        fac = torch.empty(nrows, device=dev, dtype=torch.float32)
+        check(_lib.lib().lvc_split_weights_rowscaled(ptr(pc.w), c_int(nrows), c_int(Kg), ptr(planes), ptr(fac), _stream(pc.w)),
+              "lvc_split_weights_rowscaled")
+        parts.append(planes[pl, rows, cols].reshape(-1))
+        fac = fac[: pc.K]
+        affine.append(((fac * pc.scale) if pc.scale is not None else fac).contiguous())
+        affine.append(pc.shift.contiguous() if pc.shift is not None else torch.zeros(pc.K, device=dev, dtype=torch.float32))
+    bk.w = torch.cat(parts).contiguous()
+    bk.s1, bk.t1, bk.s2, bk.t2, bk.s3, bk.t3 = affine
+    return bk
+
+
+def bottleneck_fused(x, bk, out=None):
+    """relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)) in ONE launch (reference resnet.py:195-211);
+    x [N,H,W,ldx] NHWC fp32 whose first bk.cin channels are the block's input."""
+    _req_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4 and x.shape[-1] >= bk.cin
+    N, H, W, ldx = x.shape
+    if out is None:
+        out = torch.empty(N, H, W, 256, device=x.device, dtype=torch.float32)
+    timer = CONV_TIMER
+    if timer is not None and (not timer.active or (timer.only is not None and "f16s1_bneck" not in timer.only)):
+        timer = None
+    if timer is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.lib().lvc_set_range_slot(c_int(bk.slot))
+    st = _lib.lib().lvc_bottleneck_nhwc_f16s1(ptr(x), c_int(ldx), ptr(out), c_int(out.shape[-1]), c_int(N), c_int(H), c_int(W),
+                                              c_int(bk.cin), c_int(1 if bk.proj else 0), ptr(bk.w), ptr(bk.s1), ptr(bk.t1), ptr(bk.s2),
+                                              ptr(bk.t2), ptr(bk.s3), ptr(bk.t3), ptr(conv_workspace(x.device)), _stream(x))
+    _lib.lib().lvc_set_range_slot(c_int(0))
+    check(st, "lvc_bottleneck_nhwc_f16s1")
+    if timer is not None:
+        e1.record()
+        M = N * H * W
+        kk = bk.cin * 64 + 64 * 64 * 9 + 64 * 256 + (bk.cin * 256 if bk.proj else 0)
+        timer.records.append((2.0 * M * kk, e0, e1, "f16s1_bneck", 4.0 * (M * (bk.cin + 256) + kk)))
+    return out
 
 
 def split_planes_f16x2(w):
