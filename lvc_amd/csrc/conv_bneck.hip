@@ -99,22 +99,33 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& h,
 
 // 64 mid channels, 256 output channels; CIN input channels (64: res2.0 with the projection shortcut folded into conv3's GEMM as 64
 // more contraction channels, PROJ; 256: identity blocks, residual = x).
-constexpr int BN_TH = 4, BN_TW = 32, BN_HW = BN_TW + 2, BN_HH = BN_TH + 2, BN_HPIX = BN_HW * BN_HH;      // 204 halo pixels
-constexpr int BN_NG1 = (BN_HPIX + 31) / 32;                                                                // 7 groups of 32
+constexpr int BN_TH = 8, BN_TW = 32, BN_HW = BN_TW + 2, BN_HH = BN_TH + 2, BN_HPIX = BN_HW * BN_HH;      // 340 halo pixels
+constexpr int BN_NG1 = (BN_HPIX + 31) / 32;                                                                // 11 groups of 32
 constexpr int BN_T1_SUB = BN_HPIX * 16;                 // bytes of one (k16 step, plane, k half) sub-plane of t1
-constexpr int BN_T1_BYTES = 16 * BN_T1_SUB;             // 4 steps x 2 planes x 2 halves = 52 224
-constexpr int BN_SLOT = 12288, BN_RING = 2 * BN_SLOT;
+constexpr int BN_T1_BYTES = 16 * BN_T1_SUB;             // 4 steps x 2 planes x 2 halves = 87 040
+constexpr int BN_NW = 8;                                // waves of a workgroup = rows of its tile
+constexpr int BN_SLOT = 8192, BN_NSLOT = 8, BN_RING = BN_NSLOT * BN_SLOT;      // every stage image is 8 fragments = 8 KB; 7 stages ahead
 constexpr int BN_TAB = (4 * 64 + 2 * 256) * 4;
 
+// Vector-memory operations of a wave in program order, per ring stage t (all counts per wave):
+//     [wait] barrier | D: LDS-DMA of stage t + 2 (2 pieces) | phase loads TWO stages ahead: phase 1 the x rows of chunk c + 2 (8 loads),
+//     phase 3 the residual rows of block j + 2 (4) | fragment reads, MFMAs | (phase 3) 4 stores
+// LOADS retire in order among themselves, stores are acknowledged out of order with them (conv_pw_chain.hip), so a wait names the
+// number of LOADS issued behind its target -- what the previous stage issued -- and drains nothing else.
 template <int CIN, bool PROJ>
-__global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
-  constexpr int NS1 = CIN / 32, NS2 = 12, NS3 = PROJ ? 16 : 8, NST = NS1 + NS2 + NS3;
-  static_assert(NST % 2 == 0, "the ring slot of a stage is its parity inside a tile");
+__global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
+  constexpr int NS1 = CIN / 32, NS2 = 18, NS3 = PROJ ? 16 : 8, NST = NS1 + NS2 + NS3;
   static_assert(!PROJ || CIN == 64, "projection blocks: 64 input channels");
-  constexpr int OFF2 = NS1 * 8192, OFF3 = OFF2 + NS2 * 12288;      // byte offsets of the phases' stage images
+  static_assert(NS1 >= 2, "two chunks of x are in flight at a tile's start");
+#ifdef BN_DIAG_SMALL_LDS      // timing only (wrong results): the tables alias t1
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[BN_RING + BN_T1_BYTES - BN_DIAG_SMALL_LDS];
+  unsigned char* const t1s = smem + BN_RING - BN_DIAG_SMALL_LDS;
+  float* tab_s1 = reinterpret_cast<float*>(smem + BN_RING);
+#else
   __shared__ __attribute__((aligned(1024))) unsigned char smem[BN_RING + BN_T1_BYTES + BN_TAB];
   unsigned char* const t1s = smem + BN_RING;
   float* tab_s1 = reinterpret_cast<float*>(smem + BN_RING + BN_T1_BYTES);
+#endif
   float* tab_t1 = tab_s1 + 64;
   float* tab_s2 = tab_t1 + 64;
   float* tab_t2 = tab_s2 + 64;
@@ -133,26 +144,52 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
   const int tbase = xcd * tq + (xcd < tr ? xcd : tr), tcnt = tq + (xcd < tr ? 1 : 0);
   if (within >= tcnt) return;
 
-  for (int i = tid; i < 64; i += 256) {
+  for (int i = tid; i < 64; i += BN_NW * 64) {
     tab_s1[i] = p.s1[i]; tab_t1[i] = p.t1[i];
     tab_s2[i] = p.s2[i]; tab_t2[i] = p.t2[i];
   }
-  for (int i = tid; i < 256; i += 256) {
+  for (int i = tid; i < 256; i += BN_NW * 64) {
     tab_s3[i] = p.s3[i]; tab_t3[i] = p.t3[i];
   }
   __syncthreads();
 
   // weights by LDS-DMA through a buffer resource: ONE vector register (lane * 16) addresses every piece, the stage offset is scalar
-  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, OFF3 + NS3 * 8192, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, NST * 8192, 0x00020000);
   const int wlane = lane * 16;
-  auto dma = [&](int ts) {      // stage ts of a tile (a constant at every call site) into its ring slot
-    const int off = ts < NS1 ? ts * 8192 : ts < NS1 + NS2 ? OFF2 + (ts - NS1) * 12288 : OFF3 + (ts - NS1 - NS2) * 8192;
-    const bool wide = ts >= NS1 && ts < NS1 + NS2;
-    const int so = off + wave * 1024;
-    unsigned char* dst = smem + (ts & 1) * BN_SLOT + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)dst, 16, wlane, so, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)(dst + 4096), 16, wlane, so + 4096, 0, 0);
-    if (wide) __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)(dst + 8192), 16, wlane, so + 8192, 0, 0);
+  int rs = 0;      // ring slot of the current stage; the stage BN_NSLOT - 1 ahead goes into the slot the previous stage just left
+  auto dma = [&](int ts, int slot) {      // stage ts of a tile (a constant at every call site): one 1 KB piece per wave
+    unsigned char* dst = smem + slot * BN_SLOT + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)dst, 16, wlane, ts * 8192 + wave * 1024, 0, 0);
+  };
+  // top of a stage: its weights (issued BN_NSLOT - 1 stages ago) and the phase's loads have landed, everybody is done with the
+  // previous stage's slot, which takes the stage BN_NSLOT - 1 ahead; returns this stage's fragment base for the lane
+#ifdef BN_DIAG_TIMELINE      // wave 0 of four workgroups stamps every stage of its first tiles into the head of the workspace
+  unsigned long long* const tl_base = reinterpret_cast<unsigned long long*>(p.flags) - (size_t)LVC_MAX_WORKERS * 256 * 128 / 2;
+  const int tl_slot = blockIdx.x == 0 ? 0 : blockIdx.x == (gridDim.x >> 1) ? 1 : blockIdx.x == 8 ? 2 : blockIdx.x == (gridDim.x >> 1) + 8 ? 3 : -1;
+  int tl_iter = 0;
+#endif
+  auto stage_top = [&](auto n_, int ts) -> const unsigned char* {
+#ifdef BN_DIAG_TIMELINE
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    wait_vm<decltype(n_)::value>();
+    const unsigned long long tl1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long tl2 = __builtin_amdgcn_s_memtime();
+    if (tl_slot >= 0 && tl_iter < 6 && tid == 0) {
+      unsigned long long* o = tl_base + ((tl_slot * 6 + tl_iter) * 48 + ts) * 4;
+      o[0] = tl0; o[1] = tl1; o[2] = tl2; o[3] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));
+    }
+#else
+    wait_vm<decltype(n_)::value>();
+    __builtin_amdgcn_s_barrier();
+#endif
+    int tn = ts + BN_NSLOT - 1;
+    if (tn >= NST) tn -= NST;
+    if (tn >= NST) tn -= NST;
+    dma(tn, (rs + BN_NSLOT - 1) & (BN_NSLOT - 1));
+    const unsigned char* S = smem + rs * BN_SLOT + lane * 16;
+    rs = (rs + 1) & (BN_NSLOT - 1);
+    return S;
   };
 
   const unsigned xbytes = (unsigned)p.N * (unsigned)p.H * (unsigned)p.W * (unsigned)p.ldx * 4u;
@@ -161,12 +198,35 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
   const __amdgpu_buffer_rsrc_t yres = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, ybytes, 0x00020000);
 
   float big = 0.f;
-  const int ftab = 4 * fh;
+  // this lane's base into the epilogue tables (beyond the 64 KB an LDS instruction's immediate reaches from a zero base): ONE opaque
+  // register + immediates -- left to itself the compiler kept every table address in a register of its own and spilled them
+  const float* tabl = tab_s1 + 4 * fh;
+  asm volatile("" : "+v"(tabl));
+  constexpr int TS1 = 0, TT1 = 64, TS2 = 128, TT2 = 192, TS3 = 256, TT3 = 512;
   // phase 2's per-lane base inside t1: (row wave, column fi) of the halo tile, k half fh
   const unsigned char* const zb = t1s + fh * BN_T1_SUB + (wave * BN_HW + fi) * 16;
   const int tpi = p.tiles_x * p.tiles_y;
+  // per-wave transposition scratch (8 KB inside t1's space: t1 is dead outside phase 2) and this lane's slots in it: sw[i] in row
+  // order (instruction i: pixel 8 i + lane / 8, run lane % 8), sr[k] in MFMA order (pixel fi, run 2 k + fh)
+  unsigned char* const scr = t1s + wave * 8192;
+  int sw[4], sr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = 8 * i + (lane >> 3);
+    sw[i] = (8 * q + ((lane & 7) ^ ((q >> 1) & 7))) * 16;
+    sr[i] = (8 * fi + ((2 * i + fh) ^ ((fi >> 1) & 7))) * 16;
+  }
 
-  dma(0);
+  static_assert(NST >= BN_NSLOT - 1, "prologue");
+#pragma unroll
+  for (int i = 0; i < BN_NSLOT - 1; ++i) dma(i, i);
+#ifdef BN_STAGGER
+  // the second workgroup of a CU starts part of a tile later: the two would otherwise walk the phases in lockstep
+  if (blockIdx.x >= (gridDim.x >> 1)) {
+#pragma unroll 1
+    for (int i = 0; i < BN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 #pragma unroll 1
   for (int tl = within; tl < tcnt; tl += wgx) {
     const int tile = tbase + tl;
@@ -175,31 +235,44 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
     const int y0 = ty * BN_TH, x0 = tx * BN_TW;
 
     // ---------------------------------------------------------------- phase 1: t1 = relu(bn1(W1 x)) on the tile + halo
-    unsigned xo[2];
+    // x is fetched in ROW order -- lane l of the group's instruction i reads 16 B of pixel 8 i + l / 8, channel run l % 8 of the stage's
+    // 32 channels: 8 lanes per 128 B line, 8 lines an instruction (as lane = pixel it would be 64 lookups of 32 B lines halves: the
+    // texture unit's tag rate, not HBM, bounded the phase) -- and goes through a per-wave LDS scratch into the MFMA layout (below)
+    unsigned xo[2][4];
     float msk[2];
     int hl[2];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
-      const int h = 32 * (wave + 4 * gi) + fi;
-      const int hy = h / BN_HW, hx = h - hy * BN_HW;
-      const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-      const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      xo[gi] = ok ? (unsigned)((n * p.H + yy) * p.W + xx) * (unsigned)p.ldx * 4u + fh * 16u : BN_MARK;
-      msk[gi] = ok ? 1.f : 0.f;
-      hl[gi] = h;
-    }
-    const bool g1 = wave < BN_NG1 - 4;      // this wave's second group exists
-    f32x4 xr[2][2][4];                      // [stage parity][group][2 k16 steps x 2 runs of four channels]
-    auto load_x = [&](int par, int c) {
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi) {
-        xr[par][gi][0] = load_untracked<0>(xres, xo[gi], 128u * c);
-        xr[par][gi][1] = load_untracked<32>(xres, xo[gi], 128u * c);
-        xr[par][gi][2] = load_untracked<64>(xres, xo[gi], 128u * c);
-        xr[par][gi][3] = load_untracked<96>(xres, xo[gi], 128u * c);
+      {
+        const int h = 32 * (wave + BN_NW * gi) + fi;
+        const int hy = h / BN_HW, hx = h - hy * BN_HW;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        msk[gi] = ok ? 1.f : 0.f;
+        hl[gi] = h;
       }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int h = 32 * (wave + BN_NW * gi) + 8 * i + (lane >> 3);
+        const int hy = h / BN_HW, hx = h - hy * BN_HW;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        xo[gi][i] = ok ? (unsigned)((n * p.H + yy) * p.W + xx) * (unsigned)p.ldx * 4u + (lane & 7) * 16u : BN_MARK;
+#ifdef BN_DIAG_NOX
+        xo[gi][i] = BN_MARK;
+#endif
+      }
+    }
+    const bool g1 = wave < BN_NG1 - BN_NW;      // this wave's second group exists
+    f32x4 xr[2][2][4];                      // [chunk % 2][group][instruction]: row order
+    auto load_x = [&](int slot, int c) {
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xr[slot][gi][i] = load_untracked<0>(xres, xo[gi][i], 128u * c);
     };
     load_x(0, 0);
+    load_x(1, 1);
     f32x16 acc1[2][2];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
@@ -210,41 +283,56 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
 
     static_for<0, NS1>([&](auto c_) {
       constexpr int c = decltype(c_)::value;
-      constexpr int PAR = c & 1;
-      wait_vm<0>();
+      constexpr int XS = c & 1;
+      // loads behind x(c): at c = 0 chunk 1's (8); else the previous stage's DMA (1) and, if it issued them, chunk c + 1's rows (8)
+      constexpr int NW = c == 0 ? 8 : 1 + (c + 1 < NS1 ? 8 : 0);
+      const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, c);
 #pragma unroll
-      for (int gi = 0; gi < 2; ++gi) tie4(xr[PAR][gi][0], xr[PAR][gi][1], xr[PAR][gi][2], xr[PAR][gi][3]);
-      __builtin_amdgcn_s_barrier();
-      dma(c + 1);
-      if (c + 1 < NS1) load_x(PAR ^ 1, c + 1);
-      const unsigned char* S = smem + (c & 1) * BN_SLOT + lane * 16;
-      f16x8 wf[2][2][2];      // [k16 step][channel block][plane]
+      for (int gi = 0; gi < 2; ++gi) tie4(xr[XS][gi][0], xr[XS][gi][1], xr[XS][gi][2], xr[XS][gi][3]);
+      // row order -> MFMA order through the wave's scratch: 16 B slot of (pixel q, run r) = 8 q + (r ^ (q / 2 % 8)), conflict-free both
+      // ways; the registers are free once the writes are issued and take the chunk two stages ahead
 #pragma unroll
-      for (int sp = 0; sp < 2; ++sp)
+      for (int gi = 0; gi < 2; ++gi)
+        if (gi == 0 || g1) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) wf[sp][cb][pl] = *reinterpret_cast<const f16x8*>(S + (((sp * 2 + cb) * 2 + pl) << 10));
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(scr + gi * 4096 + sw[i]) = xr[XS][gi][i];
+        }
+      asm volatile("" ::: "memory");
+      if (c + 2 < NS1) load_x(XS, c + 2);
+      f16x8 zh[2][2], zl[2][2];      // [group][k16 step]
 #pragma unroll
       for (int gi = 0; gi < 2; ++gi) {
         if (gi == 0 || g1) {
-          f16x8 zh[2], zl[2];
+          f32x4 xb[4];      // lane (pixel fi, half fh): runs 2 k + fh, k = 0..3 = k16 step k / 2, its first / second four channels
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xb[k] = *reinterpret_cast<const f32x4*>(scr + gi * 4096 + sr[k]);
 #pragma unroll
           for (int sp = 0; sp < 2; ++sp) {
-            split8(xr[PAR][gi][2 * sp], xr[PAR][gi][2 * sp + 1], zh[sp], zl[sp]);
-            track_abs(big, xr[PAR][gi][2 * sp][0], xr[PAR][gi][2 * sp][1]);
-            track_abs(big, xr[PAR][gi][2 * sp][2], xr[PAR][gi][2 * sp][3]);
-            track_abs(big, xr[PAR][gi][2 * sp + 1][0], xr[PAR][gi][2 * sp + 1][1]);
-            track_abs(big, xr[PAR][gi][2 * sp + 1][2], xr[PAR][gi][2 * sp + 1][3]);
+            split8(xb[2 * sp], xb[2 * sp + 1], zh[gi][sp], zl[gi][sp]);
+            track_abs(big, xb[2 * sp][0], xb[2 * sp][1]);
+            track_abs(big, xb[2 * sp][2], xb[2 * sp][3]);
+            track_abs(big, xb[2 * sp + 1][0], xb[2 * sp + 1][1]);
+            track_abs(big, xb[2 * sp + 1][2], xb[2 * sp + 1][3]);
           }
-#pragma unroll
-          for (int sp = 0; sp < 2; ++sp)
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) { MFMA3(acc1[gi][cb], wf[sp][cb][0], wf[sp][cb][1], zh[sp], zl[sp]); }
         }
+      }
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp) {
+        f16x8 wf[2][2];      // [channel block][plane]
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) wf[cb][pl] = *reinterpret_cast<const f16x8*>(S + (((sp * 2 + cb) * 2 + pl) << 10));
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+          if (gi == 0 || g1) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) { MFMA3(acc1[gi][cb], wf[cb][0], wf[cb][1], zh[gi][sp], zl[gi][sp]); }
+          }
       }
     });
     // epilogue of phase 1: FrozenBN + ReLU, zero outside the image (conv2's padding), split, into LDS
+    __builtin_amdgcn_s_barrier();      // the scratch of every wave lies inside t1
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
       if ((gi == 0 || g1) && hl[gi] < BN_HPIX) {
@@ -254,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
           f16x8 yh[2], yl[2];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const f32x4 sc = *reinterpret_cast<const f32x4*>(tab_s1 + 32 * cb + 8 * i + ftab);
-            const f32x4 sh = *reinterpret_cast<const f32x4*>(tab_t1 + 32 * cb + 8 * i + ftab);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + TS1 + 32 * cb + 8 * i);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + TT1 + 32 * cb + 8 * i);
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -280,55 +368,71 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
     }
 
     // ---------------------------------------------------------------- phase 2: t2 = relu(bn2(conv3x3(t1))), one output row per wave
-    const int oy = y0 + wave, ox = x0 + fi;
-    const bool ook = oy < p.H && ox < p.W;
-    const unsigned opix = (unsigned)((n * p.H + oy) * p.W + ox);
-    const unsigned yo = ook ? opix * (unsigned)p.ldy * 4u + fh * 16u : BN_MARK;
-    const unsigned ro = ook ? opix * (unsigned)p.ldx * 4u + fh * 16u : BN_MARK;
-    f32x4 rb[2][4];      // identity blocks: the residual rows of output block j in rb[j & 1]; projection blocks: x of the own pixel
-    f32x4 xi[8];
+    const int oy = y0 + wave;
+    unsigned yo[4], ro[4];      // row order: instruction i covers pixels 8 i .. 8 i + 7 of the wave's row, 128 B each
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ox = x0 + 8 * i + (lane >> 3);
+      const bool ook = oy < p.H && ox < p.W;
+      const unsigned opix = (unsigned)((n * p.H + oy) * p.W + ox);
+      yo[i] = ook ? opix * (unsigned)p.ldy * 4u + (lane & 7) * 16u : BN_MARK;
+      ro[i] = ook ? opix * (unsigned)p.ldx * 4u + (lane & 7) * 16u : BN_MARK;
+#ifdef BN_DIAG_NOSTORE
+      yo[i] = BN_MARK;
+#endif
+#ifdef BN_DIAG_NORES
+      ro[i] = BN_MARK;
+#endif
+    }
+    // projection blocks: x of the lane's own pixel (MFMA order), 64 channels
+    const unsigned rop = (oy < p.H && x0 + fi < p.W) ? (unsigned)((n * p.H + oy) * p.W + x0 + fi) * (unsigned)p.ldx * 4u + fh * 16u : BN_MARK;
+    f32x4 rb[3][4];      // identity blocks: the residual rows of output block j in rb[j % 3]
+    f32x4 xi[8];         // projection blocks: x of the own pixel
+    auto load_r = [&](int slot, int j) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[slot][i] = load_untracked<0>(xres, ro[i], 128u * j);
+    };
     f32x16 acc2[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[cb][e] = 0.f;
 
-    static_for<0, NS2>([&](auto st_) {
-      constexpr int st = decltype(st_)::value;
-      constexpr int s = st / 3, dx = st % 3, ts = NS1 + st;
-      wait_vm<0>();
-      if (st == 0) wait_lgkm0();
-      __builtin_amdgcn_s_barrier();
-      dma(ts + 1);
-      if (st == NS2 - 1) {
-        if (PROJ) {
+    // a stage = two of the 36 (k16 step, tap) pairs: 8 fragments [pair][channel block][plane]
+    static_for<0, NS2>([&](auto q_) {
+      constexpr int q = decltype(q_)::value;
+      constexpr int ts = NS1 + q;
+      // loads behind this stage's weights: the previous stage's DMA (2) and what it issued of phase 3's first operands
+      constexpr int NW = BN_NSLOT - 2 + (PROJ ? (q == NS2 - 1 ? 8 : 0) : (q == NS2 - 1 ? 4 : 0));
+      if (q == 0) wait_lgkm0();      // t1: this wave's writes are done before the barrier lets anybody read
+      const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
+      if (PROJ) {
+        if (q == NS2 - 2) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            xi[2 * q] = load_untracked<0>(xres, ro, 64u * q);
-            xi[2 * q + 1] = load_untracked<32>(xres, ro, 64u * q);
+          for (int u = 0; u < 4; ++u) {
+            xi[2 * u] = load_untracked<0>(xres, rop, 64u * u);
+            xi[2 * u + 1] = load_untracked<32>(xres, rop, 64u * u);
           }
-        } else {
-          rb[0][0] = load_untracked<0>(xres, ro, 0u);
-          rb[0][1] = load_untracked<32>(xres, ro, 0u);
-          rb[0][2] = load_untracked<64>(xres, ro, 0u);
-          rb[0][3] = load_untracked<96>(xres, ro, 0u);
         }
+      } else {
+        if (q == NS2 - 2) load_r(0, 0);
+        if (q == NS2 - 1) load_r(1, 1);
       }
-      const unsigned char* S = smem + (ts & 1) * BN_SLOT + lane * 16;
-      f16x8 zh[3], zl[3];
+#ifndef BN_DIAG_NOP2
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        zh[dy] = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 0) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
-        zl[dy] = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 1) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
-      }
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+      for (int e = 0; e < 2; ++e) {
+        const int u = 2 * q + e;
+        const int s = u / 9, tp = u % 9, dy = tp / 3, dx = tp % 3;
+        const f16x8 zh = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 0) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
+        const f16x8 zl = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 1) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const f16x8 wh = *reinterpret_cast<const f16x8*>(S + (((dy * 2 + cb) * 2 + 0) << 10));
-          const f16x8 wl = *reinterpret_cast<const f16x8*>(S + (((dy * 2 + cb) * 2 + 1) << 10));
-          MFMA3(acc2[cb], wh, wl, zh[dy], zl[dy]);
+          const f16x8 wh = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 0) << 10));
+          const f16x8 wl = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 1) << 10));
+          MFMA3(acc2[cb], wh, wl, zh, zl);
         }
+      }
+#endif
     });
     // epilogue of phase 2: the split accumulators are phase 3's B operand
     f16x8 t2h[4], t2l[4];
@@ -336,8 +440,8 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(tab_s2 + 32 * cb + 8 * i + ftab);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(tab_t2 + 32 * cb + 8 * i + ftab);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + TS2 + 32 * cb + 8 * i);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + TT2 + 32 * cb + 8 * i);
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -358,28 +462,22 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
     static_for<0, NS3>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
       constexpr int j = PROJ ? st / 2 : st, half = PROJ ? st % 2 : 0, ts = NS1 + NS2 + st;
-      constexpr int PAR = j & 1;
-      wait_vm<0>();
+      constexpr int RS = j % 3;
+      // loads behind this stage's operands: the previous stage's DMA (2) and, identity blocks, the residual rows it issued (4)
+      constexpr int NW = PROJ ? (st == 0 ? 1 : BN_NSLOT - 2) : 1 + (j + 1 < 8 ? 4 : 0);      // projection, first stage: x of the own pixel
+      const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
       if (PROJ) {
         if (st == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            asm volatile("" : "+v"(xi[2 * q]), "+v"(xi[2 * q + 1]));
-            split8(xi[2 * q], xi[2 * q + 1], xh[q], xl[q]);
+          for (int u = 0; u < 4; ++u) {
+            asm volatile("" : "+v"(xi[2 * u]), "+v"(xi[2 * u + 1]));
+            split8(xi[2 * u], xi[2 * u + 1], xh[u], xl[u]);
           }
         }
       } else {
-        tie4(rb[PAR][0], rb[PAR][1], rb[PAR][2], rb[PAR][3]);
+        tie4(rb[RS][0], rb[RS][1], rb[RS][2], rb[RS][3]);
+        if (j + 2 < 8) load_r((j + 2) % 3, j + 2);
       }
-      __builtin_amdgcn_s_barrier();
-      dma(ts + 1 < NST ? ts + 1 : 0);
-      if (!PROJ && j + 1 < 8) {
-        rb[PAR ^ 1][0] = load_untracked<0>(xres, ro, 128u * (j + 1));
-        rb[PAR ^ 1][1] = load_untracked<32>(xres, ro, 128u * (j + 1));
-        rb[PAR ^ 1][2] = load_untracked<64>(xres, ro, 128u * (j + 1));
-        rb[PAR ^ 1][3] = load_untracked<96>(xres, ro, 128u * (j + 1));
-      }
-      const unsigned char* S = smem + (ts & 1) * BN_SLOT + lane * 16;
       if (half == 0) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
@@ -392,21 +490,32 @@ __global__ __launch_bounds__(256, 2) void conv_bneck_kernel(BneckArgs p) {
         else { MFMA3(acc3, wh, wl, xh[s], xl[s]); }
       }
       if (!PROJ || half == 1) {
+        // FrozenBN in the accumulator layout, through the wave's scratch into row order, there + residual, ReLU, full-line stores
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(tab_s3 + 32 * j + 8 * i + ftab);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(tab_t3 + 32 * j + 8 * i + ftab);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + TS3 + 32 * j + 8 * i);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + TT3 + 32 * j + 8 * i);
           f32x4 v;
 #pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = acc3[4 * i + e] * sc[e] + sh[e];
+          *reinterpret_cast<f32x4*>(scr + sr[i]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(scr + sw[i]);
+#pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float o = acc3[4 * i + e] * sc[e] + sh[e];
-            if (!PROJ) o += rb[PAR][i][e];
+            float o = v[e];
+            if (!PROJ) o += rb[RS][i][e];
             v[e] = fmaxf(o, 0.f);
           }
-          store_b128(v, yres, yo + 128u * j + 32u * i);
+          store_b128(v, yres, yo[i] + 128u * j);
         }
       }
     });
+#ifdef BN_DIAG_TIMELINE
+    ++tl_iter;
+#endif
   }
   wait_vm<0>();
   if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);
@@ -418,7 +527,7 @@ static int g_cus_bneck = 0;
 // y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + shortcut(x)).  x [N][H][W][ldx] (cin channels used), y [N][H][W][ldy].
 // proj = 0: cin = 256, shortcut = x (ldx >= 256).  proj = 1: cin = 64, the projection shortcut's weights are the last 64 contraction
 // columns of the third layer (kernels.pack_bottleneck over BottleneckBlock._fused_projection).  w: the stage images of
-// kernels.pack_bottleneck ((cin/32) x 8 KB, 12 x 12 KB, 8 or 16 x 8 KB); s1..t3: epilogue scales (x row factors) and shifts, 64 / 64 /
+// kernels.pack_bottleneck ((cin/32) x 8 KB, 18 x 8 KB, 8 or 16 x 8 KB); s1..t3: epilogue scales (x row factors) and shifts, 64 / 64 /
 // 256 entries, never NULL.  |x|, |t1| or |t2| > 4094 (or non-finite) raises bit 1 / 2 of the launch's range word.
 extern "C" int lvc_bottleneck_nhwc_f16s1(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int cin, int proj,
                                           const unsigned short* w, const float* s1, const float* t1, const float* s2, const float* t2,
@@ -445,11 +554,23 @@ extern "C" int lvc_bottleneck_nhwc_f16s1(const float* x, int ldx, float* y, int 
       cus = 256;
     g_cus_bneck = cus;
   }
-  int grid = g_cus_bneck * 2;
+#ifdef BN_DIAG_WGS1
+  int grid = g_cus_bneck;
+#else
+  int grid = g_cus_bneck;
+#endif
   if (grid > a.ntiles) grid = a.ntiles;
   hipStream_t st = (hipStream_t)stream;
-  if (proj) hipLaunchKernelGGL((conv_bneck_kernel<64, true>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((conv_bneck_kernel<256, false>), dim3(grid), dim3(256), 0, st, a);
+#ifdef BN_DIAG_OCC
+  {
+    int nb0 = -1, nb1 = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb0, conv_bneck_kernel<256, false>, BN_NW * 64, 0);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb1, conv_bneck_kernel<64, true>, BN_NW * 64, 0);
+    fprintf(stderr, "conv_bneck occupancy (blocks/CU): identity %d projection %d\n", nb0, nb1);
+  }
+#endif
+  if (proj) hipLaunchKernelGGL((conv_bneck_kernel<64, true>), dim3(grid), dim3(BN_NW * 64), 0, st, a);
+  else hipLaunchKernelGGL((conv_bneck_kernel<256, false>), dim3(grid), dim3(BN_NW * 64), 0, st, a);
   LVC_CHECK_LAUNCH();
   return LVC_OK;
 }

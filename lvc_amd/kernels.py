@@ -1080,8 +1080,8 @@ def _bneck_index(cin, proj, device):
     def col2(ch, r, s_):      # pack_conv's contraction order: (c // 32, r, s, c % 32)
         return (ch // 32) * 288 + (r * 3 + s_) * 32 + ch % 32
 
-    p2 = [(pl, 32 * cb, col2(16 * s + a16, dy, dx)) for s in range(4) for dx in range(3) for dy in range(3) for cb in range(2)
-          for pl in range(2)]
+    # conv2: the 36 (k16 step, tap) pairs in the order the kernel walks them, two a stage
+    p2 = [(pl, 32 * cb, col2(16 * (u // 9) + a16, (u % 9) // 3, (u % 9) % 3)) for u in range(36) for cb in range(2) for pl in range(2)]
     p3 = [(pl, 32 * j, 64 * half + 16 * s + a16) for j in range(8) for half in range(2 if proj else 1) for s in range(4)
           for pl in range(2)]
     out = tuple(tuple(torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in frags(sp)) for sp in (p1, p2, p3))

@@ -49,6 +49,9 @@ def run(name, N, H, W, cin, proj, timed=True):
         return e0.elapsed_time(e1) / 20
 
     tf = ts = float("nan")
+    if timed == "fused":
+        print("%-28s fused %.4f ms" % (name, timeit(fused)), flush=True)
+        return 0.0
     if timed:
         tf, ts = timeit(fused), timeit(separate)
     fused(0); separate(0)
@@ -78,6 +81,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "small":
     for (N, H, W) in [(1, 4, 32), (1, 5, 33), (2, 13, 70), (1, 50, 84), (3, 9, 31)]:
         run("identity %dx%dx%d" % (N, H, W), N, H, W, 256, False, timed=False)
         run("projection %dx%dx%d" % (N, H, W), N, H, W, 64, True, timed=False)
+elif len(sys.argv) > 1 and sys.argv[1] == "time":
+    run("res2.1 / res2.2 (256->64->256)", 8, 200, 336, 256, False, timed="fused")
+    run("res2.0 (64->64->256, proj)", 8, 200, 336, 64, True, timed="fused")
 else:
     run("res2.1 / res2.2 (256->64->256)", 8, 200, 336, 256, False)
     run("res2.0 (64->64->256, proj)", 8, 200, 336, 64, True)
