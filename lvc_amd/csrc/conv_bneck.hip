@@ -136,6 +136,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fi = lane & 31, fh = lane >> 5;
+  const bool late = wave >= BN_NW / 2;      // the second wave of a SIMD: see the software pipelines of phases 1 and 3
 
   // this workgroup's tiles: XCD k (= blockIdx % 8) owns a contiguous range of the row-major tile order, its workgroups walk it
   // together, so that the tiles in flight on one L2 are neighbours (shared halo rows)
@@ -156,13 +157,14 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   // weights by LDS-DMA through a buffer resource: ONE vector register (lane * 16) addresses every piece, the stage offset is scalar
   const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, NST * 8192, 0x00020000);
   const int wlane = lane * 16;
-  int rs = 0;      // ring slot of the current stage; the stage BN_NSLOT - 1 ahead goes into the slot the previous stage just left
+  int rs = 0;      // ring slot of the current stage
   auto dma = [&](int ts, int slot) {      // stage ts of a tile (a constant at every call site): one 1 KB piece per wave
     unsigned char* dst = smem + slot * BN_SLOT + wave * 1024;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(wres, (lds_ptr_t)dst, 16, wlane, ts * 8192 + wave * 1024, 0, 0);
   };
-  // top of a stage: its weights (issued BN_NSLOT - 1 stages ago) and the phase's loads have landed, everybody is done with the
-  // previous stage's slot, which takes the stage BN_NSLOT - 1 ahead; returns this stage's fragment base for the lane
+  // top of a stage: its weights (issued BN_NSLOT - 2 stages ago) and the phase's loads have landed, everybody is done with the slot
+  // TWO stages back (phases 1 and 3 issue a stage's MFMAs one stage late, under the next one's vector work), which takes the stage
+  // BN_NSLOT - 2 ahead; returns this stage's fragment base for the lane
 #ifdef BN_DIAG_TIMELINE      // wave 0 of four workgroups stamps every stage of its first tiles into the head of the workspace
   unsigned long long* const tl_base = reinterpret_cast<unsigned long long*>(p.flags) - (size_t)LVC_MAX_WORKERS * 256 * 128 / 2;
   const int tl_slot = blockIdx.x == 0 ? 0 : blockIdx.x == (gridDim.x >> 1) ? 1 : blockIdx.x == 8 ? 2 : blockIdx.x == (gridDim.x >> 1) + 8 ? 3 : -1;
@@ -183,10 +185,9 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     wait_vm<decltype(n_)::value>();
     __builtin_amdgcn_s_barrier();
 #endif
-    int tn = ts + BN_NSLOT - 1;
+    int tn = ts + BN_NSLOT - 2;
     if (tn >= NST) tn -= NST;
-    if (tn >= NST) tn -= NST;
-    dma(tn, (rs + BN_NSLOT - 1) & (BN_NSLOT - 1));
+    dma(tn, (rs + BN_NSLOT - 2) & (BN_NSLOT - 1));
     const unsigned char* S = smem + rs * BN_SLOT + lane * 16;
     rs = (rs + 1) & (BN_NSLOT - 1);
     return S;
@@ -206,27 +207,29 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   // phase 2's per-lane base inside t1: (row wave, column fi) of the halo tile, k half fh
   const unsigned char* const zb = t1s + fh * BN_T1_SUB + (wave * BN_HW + fi) * 16;
   const int tpi = p.tiles_x * p.tiles_y;
-  // per-wave transposition scratch (8 KB inside t1's space: t1 is dead outside phase 2) and this lane's slots in it: sw[i] in row
-  // order (instruction i: pixel 8 i + lane / 8, run lane % 8), sr[k] in MFMA order (pixel fi, run 2 k + fh)
+  // per-wave transposition scratch (8 KB inside t1's space: t1 is dead outside phase 2) and this lane's slots in it: sw(i) in row
+  // order (instruction i: pixel 8 i + lane / 8, run lane % 8), sr(k) in MFMA order (pixel fi, run 2 k + fh)
   unsigned char* const scr = t1s + wave * 8192;
-  int sw[4], sr[4];
+  // sw(i) = 16 (64 i + 8 (lane / 8) + (lane % 8 ^ (lane / 16 % 4 + 4 (i % 2)))) = (sw0 ^ 64 (i % 2)) + 1024 i;  sr(k) = 16 (8 fi + (2 k + fh ^ fi / 2 % 8)) =
+  // sr0 ^ 32 k: two registers instead of eight (the tile loop has none to spare)
+  const int sw0 = (8 * (lane >> 3) + ((lane & 7) ^ ((lane >> 4) & 3))) * 16;
+  const int sr0 = (8 * fi + (fh ^ ((fi >> 1) & 7))) * 16;
+  auto sw = [&](int i) { return (sw0 ^ ((i & 1) << 6)) + 1024 * i; };
+  auto sr = [&](int k) { return sr0 ^ (k << 5); };
+  static_assert(NST >= BN_NSLOT - 2, "prologue");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = 8 * i + (lane >> 3);
-    sw[i] = (8 * q + ((lane & 7) ^ ((q >> 1) & 7))) * 16;
-    sr[i] = (8 * fi + ((2 * i + fh) ^ ((fi >> 1) & 7))) * 16;
-  }
-
-  static_assert(NST >= BN_NSLOT - 1, "prologue");
-#pragma unroll
-  for (int i = 0; i < BN_NSLOT - 1; ++i) dma(i, i);
+  for (int i = 0; i < BN_NSLOT - 2; ++i) dma(i, i);
 #ifdef BN_STAGGER
-  // the second workgroup of a CU starts part of a tile later: the two would otherwise walk the phases in lockstep
-  if (blockIdx.x >= (gridDim.x >> 1)) {
+  // de-phase the CUs: every workgroup walks load-bound, matrix-bound and store-bound phases of equal length, and all of them start together
+  {
+    const int ph = (blockIdx.x >> 3) & 3;
 #pragma unroll 1
-    for (int i = 0; i < BN_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    for (int i = 0; i < BN_STAGGER * ph; ++i) __builtin_amdgcn_s_sleep(127);
   }
 #endif
+  // two copies of the tile loop: the second wave of every SIMD runs the software-pipelined phases' halves in the opposite order
+  auto tiles = [&](auto late_) {
+  constexpr bool LATE = decltype(late_)::value;
 #pragma unroll 1
   for (int tl = within; tl < tcnt; tl += wgx) {
     const int tile = tbase + tl;
@@ -241,10 +244,13 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     unsigned xo[2][4];
     float msk[2];
     int hl[2];
+    int lane_o = lane;      // opaque: the halo coordinates below are recomputed per tile instead of living in 20 registers across the loop
+    asm volatile("" : "+v"(lane_o));
+    const int fi_o = lane_o & 31;
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
       {
-        const int h = 32 * (wave + BN_NW * gi) + fi;
+        const int h = 32 * (wave + BN_NW * gi) + fi_o;
         const int hy = h / BN_HW, hx = h - hy * BN_HW;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
@@ -253,11 +259,11 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int h = 32 * (wave + BN_NW * gi) + 8 * i + (lane >> 3);
+        const int h = 32 * (wave + BN_NW * gi) + 8 * i + (lane_o >> 3);
         const int hy = h / BN_HW, hx = h - hy * BN_HW;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        xo[gi][i] = ok ? (unsigned)((n * p.H + yy) * p.W + xx) * (unsigned)p.ldx * 4u + (lane & 7) * 16u : BN_MARK;
+        xo[gi][i] = ok ? (unsigned)((n * p.H + yy) * p.W + xx) * (unsigned)p.ldx * 4u + (lane_o & 7) * 16u : BN_MARK;
 #ifdef BN_DIAG_NOX
         xo[gi][i] = BN_MARK;
 #endif
@@ -281,41 +287,10 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc1[gi][cb][e] = 0.f;
 
-    static_for<0, NS1>([&](auto c_) {
-      constexpr int c = decltype(c_)::value;
-      constexpr int XS = c & 1;
-      // loads behind x(c): at c = 0 chunk 1's (8); else the previous stage's DMA (1) and, if it issued them, chunk c + 1's rows (8)
-      constexpr int NW = c == 0 ? 8 : 1 + (c + 1 < NS1 ? 8 : 0);
-      const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, c);
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi) tie4(xr[XS][gi][0], xr[XS][gi][1], xr[XS][gi][2], xr[XS][gi][3]);
-      // row order -> MFMA order through the wave's scratch: 16 B slot of (pixel q, run r) = 8 q + (r ^ (q / 2 % 8)), conflict-free both
-      // ways; the registers are free once the writes are issued and take the chunk two stages ahead
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi)
-        if (gi == 0 || g1) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(scr + gi * 4096 + sw[i]) = xr[XS][gi][i];
-        }
-      asm volatile("" ::: "memory");
-      if (c + 2 < NS1) load_x(XS, c + 2);
-      f16x8 zh[2][2], zl[2][2];      // [group][k16 step]
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi) {
-        if (gi == 0 || g1) {
-          f32x4 xb[4];      // lane (pixel fi, half fh): runs 2 k + fh, k = 0..3 = k16 step k / 2, its first / second four channels
-#pragma unroll
-          for (int k = 0; k < 4; ++k) xb[k] = *reinterpret_cast<const f32x4*>(scr + gi * 4096 + sr[k]);
-#pragma unroll
-          for (int sp = 0; sp < 2; ++sp) {
-            split8(xb[2 * sp], xb[2 * sp + 1], zh[gi][sp], zl[gi][sp]);
-            track_abs(big, xb[2 * sp][0], xb[2 * sp][1]);
-            track_abs(big, xb[2 * sp][2], xb[2 * sp][3]);
-            track_abs(big, xb[2 * sp + 1][0], xb[2 * sp + 1][1]);
-            track_abs(big, xb[2 * sp + 1][2], xb[2 * sp + 1][3]);
-          }
-        }
-      }
+    // software pipeline: stage c converts chunk c (scratch round trip, fp16 split: vector work) while the matrix pipe runs chunk c - 1
+    f16x8 zh[2][2][2], zl[2][2][2];      // [chunk % 2][group][k16 step]
+    const unsigned char* Sp = nullptr;   // the previous stage's fragments
+    auto mfma1 = [&](int par, const unsigned char* S) {
 #pragma unroll
       for (int sp = 0; sp < 2; ++sp) {
         f16x8 wf[2][2];      // [channel block][plane]
@@ -327,10 +302,79 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         for (int gi = 0; gi < 2; ++gi)
           if (gi == 0 || g1) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) { MFMA3(acc1[gi][cb], wf[cb][0], wf[cb][1], zh[gi][sp], zl[gi][sp]); }
+#ifdef BN_DIAG_NOMFMA1
+            for (int cb = 0; cb < 2; ++cb) { asm volatile("" : "+v"(acc1[gi][cb]) : "v"(wf[cb][0]), "v"(wf[cb][1]), "v"(zh[par][gi][sp]), "v"(zl[par][gi][sp])); }
+#else
+            for (int cb = 0; cb < 2; ++cb) { MFMA3(acc1[gi][cb], wf[cb][0], wf[cb][1], zh[par][gi][sp], zl[par][gi][sp]); }
+#endif
           }
       }
+    };
+    static_for<0, NS1>([&](auto c_) {
+      constexpr int c = decltype(c_)::value;
+      constexpr int XS = c & 1;
+      // loads behind x(c): at c = 0 chunk 1's (8); else the previous stage's DMA (1) and, if it issued them, chunk c + 1's rows (8)
+      constexpr int NW = c == 0 ? 8 : 1 + (c + 1 < NS1 ? 8 : 0);
+      const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, c);
+#ifdef BN_DIAG_NOSCR
+      f32x4 xbk[2][4];
+#endif
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) tie4(xr[XS][gi][0], xr[XS][gi][1], xr[XS][gi][2], xr[XS][gi][3]);
+      // row order -> MFMA order through the wave's scratch: 16 B slot of (pixel q, run r) = 8 q + (r ^ (q / 2 % 8)), conflict-free both
+      // ways; the registers are free once the writes are issued and take the chunk two stages ahead
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi)
+        if (gi == 0 || g1) {
+#pragma unroll
+#ifdef BN_DIAG_NOSCR
+          for (int i = 0; i < 4; ++i) xbk[gi][i] = xr[XS][gi][i];
+#else
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(scr + gi * 4096 + sw(i)) = xr[XS][gi][i];
+#endif
+        }
+      asm volatile("" ::: "memory");
+      if (c + 2 < NS1) load_x(XS, c + 2);
+      // the two waves of a SIMD (w, w + 4) take the halves in opposite order: one's MFMAs run under the other's vector and LDS work
+      auto prep = [&]() {
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          if (gi == 0 || g1) {
+            f32x4 xb[4];      // lane (pixel fi, half fh): runs 2 k + fh, k = 0..3 = k16 step k / 2, its first / second four channels
+#pragma unroll
+#ifdef BN_DIAG_NOSCR
+            for (int k = 0; k < 4; ++k) xb[k] = xbk[gi][k];
+#else
+            for (int k = 0; k < 4; ++k) xb[k] = *reinterpret_cast<const f32x4*>(scr + gi * 4096 + sr(k));
+#endif
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+#ifdef BN_DIAG_NOSPLIT
+              zh[XS][gi][sp] = __builtin_bit_cast(f16x8, xb[2 * sp]);
+              zl[XS][gi][sp] = __builtin_bit_cast(f16x8, xb[2 * sp + 1]);
+#else
+              split8(xb[2 * sp], xb[2 * sp + 1], zh[XS][gi][sp], zl[XS][gi][sp]);
+              track_abs(big, xb[2 * sp][0], xb[2 * sp][1]);
+              track_abs(big, xb[2 * sp][2], xb[2 * sp][3]);
+              track_abs(big, xb[2 * sp + 1][0], xb[2 * sp + 1][1]);
+              track_abs(big, xb[2 * sp + 1][2], xb[2 * sp + 1][3]);
+#endif
+            }
+          }
+        }
+      };
+      if (LATE) {
+        prep();
+        __builtin_amdgcn_sched_barrier(0);
+        if (c > 0) mfma1(XS ^ 1, Sp);
+      } else {
+        if (c > 0) mfma1(XS ^ 1, Sp);
+        __builtin_amdgcn_sched_barrier(0);
+        prep();
+      }
+      Sp = S;
     });
+    mfma1((NS1 - 1) & 1, Sp);
     // epilogue of phase 1: FrozenBN + ReLU, zero outside the image (conv2's padding), split, into LDS
     __builtin_amdgcn_s_barrier();      // the scratch of every wave lies inside t1
 #pragma unroll
@@ -403,7 +447,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       constexpr int q = decltype(q_)::value;
       constexpr int ts = NS1 + q;
       // loads behind this stage's weights: the previous stage's DMA (2) and what it issued of phase 3's first operands
-      constexpr int NW = BN_NSLOT - 2 + (PROJ ? (q == NS2 - 1 ? 8 : 0) : (q == NS2 - 1 ? 4 : 0));
+      constexpr int NW = BN_NSLOT - 3 + (PROJ ? (q == NS2 - 1 ? 8 : 0) : (q == NS2 - 1 ? 4 : 0));
       if (q == 0) wait_lgkm0();      // t1: this wave's writes are done before the barrier lets anybody read
       const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
       if (PROJ) {
@@ -457,14 +501,44 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       }
 
     // ---------------------------------------------------------------- phase 3: y = relu(bn3(W3 t2) + shortcut), 32 channels a stage
+    // software pipeline: a stage issues its block's MFMAs and, under them, the epilogue of the block the previous stage completed
     f16x8 xh[4], xl[4];
-    f32x16 acc3;
+    f32x16 acc3[2];
+    auto epi3 = [&](auto j_) {
+      constexpr int j = decltype(j_)::value;
+      constexpr int RS = j % 3;
+#ifdef BN_DIAG_NOEPI3
+      asm volatile("" :: "v"(acc3[j & 1]), "v"(rb[RS][0]), "v"(rb[RS][1]), "v"(rb[RS][2]), "v"(rb[RS][3]));
+      return;
+#endif
+      // FrozenBN in the accumulator layout, through the wave's scratch into row order, there + residual, ReLU, full-line stores
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + TS3 + 32 * j + 8 * i);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + TT3 + 32 * j + 8 * i);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc3[j & 1][4 * i + e] * sc[e] + sh[e];
+        *reinterpret_cast<f32x4*>(scr + sr(i)) = v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(scr + sw(i));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float o = v[e];
+          if (!PROJ) o += rb[RS][i][e];
+          v[e] = fmaxf(o, 0.f);
+        }
+        store_b128(v, yres, yo[i] + 128u * j);
+      }
+    };
     static_for<0, NS3>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
       constexpr int j = PROJ ? st / 2 : st, half = PROJ ? st % 2 : 0, ts = NS1 + NS2 + st;
       constexpr int RS = j % 3;
-      // loads behind this stage's operands: the previous stage's DMA (2) and, identity blocks, the residual rows it issued (4)
-      constexpr int NW = PROJ ? (st == 0 ? 1 : BN_NSLOT - 2) : 1 + (j + 1 < 8 ? 4 : 0);      // projection, first stage: x of the own pixel
+      // loads behind this stage's operands: the previous stage's DMA (1) and, identity blocks, the residual rows it issued (4)
+      constexpr int NW = PROJ ? (st == 0 ? 1 : BN_NSLOT - 3) : 1 + (j + 1 < 8 ? 4 : 0);      // projection, first stage: x of the own pixel
       const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
       if (PROJ) {
         if (st == 0) {
@@ -476,47 +550,43 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         }
       } else {
         tie4(rb[RS][0], rb[RS][1], rb[RS][2], rb[RS][3]);
-        if (j + 2 < 8) load_r((j + 2) % 3, j + 2);
       }
       if (half == 0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc3[e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc3[j & 1][e] = 0.f;
       }
+      auto mfma3 = [&]() {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const f16x8 wh = *reinterpret_cast<const f16x8*>(S + ((s * 2 + 0) << 10));
-        const f16x8 wl = *reinterpret_cast<const f16x8*>(S + ((s * 2 + 1) << 10));
-        if (half == 0) { MFMA3(acc3, wh, wl, t2h[s], t2l[s]); }
-        else { MFMA3(acc3, wh, wl, xh[s], xl[s]); }
-      }
-      if (!PROJ || half == 1) {
-        // FrozenBN in the accumulator layout, through the wave's scratch into row order, there + residual, ReLU, full-line stores
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + TS3 + 32 * j + 8 * i);
-          const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + TT3 + 32 * j + 8 * i);
-          f32x4 v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc3[4 * i + e] * sc[e] + sh[e];
-          *reinterpret_cast<f32x4*>(scr + sr[i]) = v;
+        for (int s = 0; s < 4; ++s) {
+          const f16x8 wh = *reinterpret_cast<const f16x8*>(S + ((s * 2 + 0) << 10));
+          const f16x8 wl = *reinterpret_cast<const f16x8*>(S + ((s * 2 + 1) << 10));
+#ifdef BN_DIAG_NOMFMA3
+          asm volatile("" : "+v"(acc3[j & 1]) : "v"(wh), "v"(wl));
+#else
+          if (half == 0) { MFMA3(acc3[j & 1], wh, wl, t2h[s], t2l[s]); }
+          else { MFMA3(acc3[j & 1], wh, wl, xh[s], xl[s]); }
+#endif
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(scr + sw[i]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float o = v[e];
-            if (!PROJ) o += rb[RS][i][e];
-            v[e] = fmaxf(o, 0.f);
-          }
-          store_b128(v, yres, yo[i] + 128u * j);
-        }
+      };
+      if (LATE) {
+        if (j > 0 && half == 0) epi3(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3();
+      } else {
+        mfma3();
+        __builtin_amdgcn_sched_barrier(0);
+        if (j > 0 && half == 0) epi3(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
       }
+      // the residual rows two blocks ahead go where block j - 1's just were read
+      if (!PROJ && j + 2 < 8) load_r((j + 2) % 3, j + 2);
     });
+    epi3(std::integral_constant<int, 7>{});
 #ifdef BN_DIAG_TIMELINE
     ++tl_iter;
 #endif
   }
+  };
+  if (late) tiles(std::true_type{}); else tiles(std::false_type{});
   wait_vm<0>();
   if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);
 }
@@ -558,6 +628,9 @@ extern "C" int lvc_bottleneck_nhwc_f16s1(const float* x, int ldx, float* y, int 
   int grid = g_cus_bneck;
 #else
   int grid = g_cus_bneck;
+#endif
+#ifdef BN_DIAG_GRID
+  grid = BN_DIAG_GRID;
 #endif
   if (grid > a.ntiles) grid = a.ntiles;
   hipStream_t st = (hipStream_t)stream;
