@@ -116,6 +116,20 @@ template <int CIN, bool PROJ>
 __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   constexpr int NS1 = CIN / 32, NS2 = 18, NS3 = PROJ ? 16 : 8, NST = NS1 + NS2 + NS3;
   static_assert(!PROJ || CIN == 64, "projection blocks: 64 input channels");
+  // pl(ts): loads stage ts of a tile issues BEHIND its own DMA piece; pl_sum(ts): over the six stages before ts (never reaching into
+  // the previous tile: phase 2 starts at stage NS1 >= 2 ... see the static_assert) -- the wait counts of the weights-only stages
+  struct Issue {
+    static constexpr int pl(int ts) {
+      if (ts < 0) ts += NST;                                                       // the previous tile
+      if (ts < NS1) return ts + 2 < NS1 ? 8 : 0;                                   // x(c + 2)
+      if (ts < NS1 + NS2) {
+        const int q = ts - NS1;
+        return (q == 2 || q == 10 ? 8 : 0) + (q == NS2 - 2 ? (PROJ ? 8 : 0) : q == NS2 - 1 ? (PROJ ? 0 : 4) : 0);
+      }
+      return PROJ ? 0 : (ts - NS1 - NS2 + 1 < 8 ? 4 : 0);                          // identity blocks: block j + 1's residual rows
+    }
+  };
+  auto pl_sum = [](int ts) constexpr { int n = 0; for (int d = 1; d <= 6; ++d) n += Issue::pl(ts - d); return n; };
   static_assert(NS1 >= 2, "two chunks of x are in flight at a tile's start");
 #ifdef BN_DIAG_SMALL_LDS      // timing only (wrong results): the tables alias t1
   __shared__ __attribute__((aligned(1024))) unsigned char smem[BN_RING + BN_T1_BYTES - BN_DIAG_SMALL_LDS];
@@ -230,6 +244,40 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   // two copies of the tile loop: the second wave of every SIMD runs the software-pipelined phases' halves in the opposite order
   auto tiles = [&](auto late_) {
   constexpr bool LATE = decltype(late_)::value;
+  // x offsets (row order) of a tile's halo pixels for this lane; tile < 0: none (loads return zeros)
+  unsigned xo[2][4];
+  f32x4 xr[2][2][4];                      // [chunk % 2][group][instruction]: row order
+  auto set_xo = [&](int tile) {
+    int lane_o = lane;      // opaque: the halo coordinates are recomputed per tile instead of living in registers across the loop
+    asm volatile("" : "+v"(lane_o));
+    const int n = tile / tpi, trem = tile - n * tpi;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * BN_TH, x0 = tx * BN_TW;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int h = 32 * (wave + BN_NW * gi) + 8 * i + (lane_o >> 3);
+        const int hy = h / BN_HW, hx = h - hy * BN_HW;
+        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+        const bool ok = tile >= 0 && h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        xo[gi][i] = ok ? (unsigned)((n * p.H + yy) * p.W + xx) * (unsigned)p.ldx * 4u + (lane_o & 7) * 16u : BN_MARK;
+#ifdef BN_DIAG_NOX
+        xo[gi][i] = BN_MARK;
+#endif
+      }
+  };
+  auto load_x = [&](int slot, int c) {
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[slot][gi][i] = load_untracked<0>(xres, xo[gi][i], 128u * c);
+  };
+  // the first tile's first two chunks; later tiles' are issued under the previous tile's phase 2
+  set_xo(tbase + within);
+  load_x(0, 0);
+  load_x(1, 1);
+  wait_vm<0>();
 #pragma unroll 1
   for (int tl = within; tl < tcnt; tl += wgx) {
     const int tile = tbase + tl;
@@ -241,44 +289,23 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     // x is fetched in ROW order -- lane l of the group's instruction i reads 16 B of pixel 8 i + l / 8, channel run l % 8 of the stage's
     // 32 channels: 8 lanes per 128 B line, 8 lines an instruction (as lane = pixel it would be 64 lookups of 32 B lines halves: the
     // texture unit's tag rate, not HBM, bounded the phase) -- and goes through a per-wave LDS scratch into the MFMA layout (below)
-    unsigned xo[2][4];
+    set_xo(tile);      // again: not kept across phase 3 (registers)
     float msk[2];
     int hl[2];
-    int lane_o = lane;      // opaque: the halo coordinates below are recomputed per tile instead of living in 20 registers across the loop
-    asm volatile("" : "+v"(lane_o));
-    const int fi_o = lane_o & 31;
+    {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      {
-        const int h = 32 * (wave + BN_NW * gi) + fi_o;
+      for (int gi = 0; gi < 2; ++gi) {
+        const int h = 32 * (wave + BN_NW * gi) + (lane_o & 31);
         const int hy = h / BN_HW, hx = h - hy * BN_HW;
         const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
         const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
         msk[gi] = ok ? 1.f : 0.f;
         hl[gi] = h;
       }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int h = 32 * (wave + BN_NW * gi) + 8 * i + (lane_o >> 3);
-        const int hy = h / BN_HW, hx = h - hy * BN_HW;
-        const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-        const bool ok = h < BN_HPIX && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        xo[gi][i] = ok ? (unsigned)((n * p.H + yy) * p.W + xx) * (unsigned)p.ldx * 4u + (lane_o & 7) * 16u : BN_MARK;
-#ifdef BN_DIAG_NOX
-        xo[gi][i] = BN_MARK;
-#endif
-      }
     }
     const bool g1 = wave < BN_NG1 - BN_NW;      // this wave's second group exists
-    f32x4 xr[2][2][4];                      // [chunk % 2][group][instruction]: row order
-    auto load_x = [&](int slot, int c) {
-#pragma unroll
-      for (int gi = 0; gi < 2; ++gi)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xr[slot][gi][i] = load_untracked<0>(xres, xo[gi][i], 128u * c);
-    };
-    load_x(0, 0);
-    load_x(1, 1);
     f32x16 acc1[2][2];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
@@ -314,7 +341,10 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       constexpr int c = decltype(c_)::value;
       constexpr int XS = c & 1;
       // loads behind x(c): at c = 0 chunk 1's (8); else the previous stage's DMA (1) and, if it issued them, chunk c + 1's rows (8)
-      constexpr int NW = c == 0 ? 8 : 1 + (c + 1 < NS1 ? 8 : 0);
+      // chunks 0 and 1 were fetched under the previous tile's phase 2 and are older than every load its phase 3 waited for: stages 0
+      // and 1 wait for their weights (issued six stages back) -- behind those: five DMA pieces, the residual rows of the last phase-3
+      // stages (identity blocks: 4 each up to block 5's stage) and chunk 2's rows (stage 0); from stage 2 on: x(c), issued two stages back
+      constexpr int NW = c < 2 ? BN_NSLOT - 3 + pl_sum(c) : 1 + (c + 1 < NS1 ? 8 : 0);
       const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, c);
 #ifdef BN_DIAG_NOSCR
       f32x4 xbk[2][4];
@@ -430,7 +460,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     }
     // projection blocks: x of the lane's own pixel (MFMA order), 64 channels
     const unsigned rop = (oy < p.H && x0 + fi < p.W) ? (unsigned)((n * p.H + oy) * p.W + x0 + fi) * (unsigned)p.ldx * 4u + fh * 16u : BN_MARK;
-    f32x4 rb[3][4];      // identity blocks: the residual rows of output block j in rb[j % 3]
+    f32x4 rb[2][4];      // identity blocks: the residual rows of output block j in rb[j % 2]
     f32x4 xi[8];         // projection blocks: x of the own pixel
     auto load_r = [&](int slot, int j) {
 #pragma unroll
@@ -447,9 +477,17 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       constexpr int q = decltype(q_)::value;
       constexpr int ts = NS1 + q;
       // loads behind this stage's weights: the previous stage's DMA (2) and what it issued of phase 3's first operands
-      constexpr int NW = BN_NSLOT - 3 + (PROJ ? (q == NS2 - 1 ? 8 : 0) : (q == NS2 - 1 ? 4 : 0));
+      // loads behind this stage's weights (issued six stages back): five DMA pieces and whatever stages ts - 6 .. ts - 1 issued after
+      // their own piece -- phase 1's rows two chunks ahead, the next tile's chunks 0 / 1 (stages 2 and 10 of this phase), phase 3's first operands
+      constexpr int NW = BN_NSLOT - 3 + pl_sum(ts);
       if (q == 0) wait_lgkm0();      // t1: this wave's writes are done before the barrier lets anybody read
       const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
+      if (q == 2) {
+        const int tn = tl + wgx;
+        set_xo(tn < tcnt ? tbase + tn : -1);
+        load_x(0, 0);
+      }
+      if (q == 10) load_x(1, 1);
       if (PROJ) {
         if (q == NS2 - 2) {
 #pragma unroll
@@ -459,8 +497,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
           }
         }
       } else {
-        if (q == NS2 - 2) load_r(0, 0);
-        if (q == NS2 - 1) load_r(1, 1);
+        if (q == NS2 - 1) load_r(0, 0);
       }
 #ifndef BN_DIAG_NOP2
 #pragma unroll
@@ -506,7 +543,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     f32x16 acc3[2];
     auto epi3 = [&](auto j_) {
       constexpr int j = decltype(j_)::value;
-      constexpr int RS = j % 3;
+      constexpr int RS = j % 2;
 #ifdef BN_DIAG_NOEPI3
       asm volatile("" :: "v"(acc3[j & 1]), "v"(rb[RS][0]), "v"(rb[RS][1]), "v"(rb[RS][2]), "v"(rb[RS][3]));
       return;
@@ -536,9 +573,9 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     static_for<0, NS3>([&](auto st_) {
       constexpr int st = decltype(st_)::value;
       constexpr int j = PROJ ? st / 2 : st, half = PROJ ? st % 2 : 0, ts = NS1 + NS2 + st;
-      constexpr int RS = j % 3;
-      // loads behind this stage's operands: the previous stage's DMA (1) and, identity blocks, the residual rows it issued (4)
-      constexpr int NW = PROJ ? (st == 0 ? 1 : BN_NSLOT - 3) : 1 + (j + 1 < 8 ? 4 : 0);      // projection, first stage: x of the own pixel
+      // identity blocks: the stage runs the epilogue of block j - 1, whose residual rows were issued two stages back; behind them the
+      // previous stage's DMA piece and block j's rows.  Otherwise the weights only (six stages back).
+      constexpr int NW = PROJ ? (st == 0 ? 1 : BN_NSLOT - 3) : j == 0 ? BN_NSLOT - 3 + pl_sum(ts) : 5;
       const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
       if (PROJ) {
         if (st == 0) {
@@ -548,8 +585,8 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
             split8(xi[2 * u], xi[2 * u + 1], xh[u], xl[u]);
           }
         }
-      } else {
-        tie4(rb[RS][0], rb[RS][1], rb[RS][2], rb[RS][3]);
+      } else if (j > 0) {
+        tie4(rb[(j - 1) & 1][0], rb[(j - 1) & 1][1], rb[(j - 1) & 1][2], rb[(j - 1) & 1][3]);
       }
       if (half == 0) {
 #pragma unroll
@@ -577,9 +614,13 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         if (j > 0 && half == 0) epi3(std::integral_constant<int, (j > 0 ? j - 1 : 0)>{});
       }
-      // the residual rows two blocks ahead go where block j - 1's just were read
-      if (!PROJ && j + 2 < 8) load_r((j + 2) % 3, j + 2);
+      // the next block's residual rows go where block j - 1's just were read
+      if (!PROJ && j + 1 < 8) load_r((j + 1) & 1, j + 1);
     });
+    if (!PROJ) {
+      wait_vm<1>();      // block 7's rows (issued in stage 6; behind them stage 7's DMA piece)
+      tie4(rb[1][0], rb[1][1], rb[1][2], rb[1][3]);
+    }
     epi3(std::integral_constant<int, 7>{});
 #ifdef BN_DIAG_TIMELINE
     ++tl_iter;
