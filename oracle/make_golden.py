@@ -187,6 +187,22 @@ def gen_blocks():
         y = blk(x)
     save("bottleneck", x=x, y=y, **{"sd." + k: v for k, v in blk.state_dict().items()})
 
+    # the res2 shapes that run as ONE launch (lvc_amd/csrc/conv_bneck.hip): the stage head with its stride-1 projection shortcut
+    # (64 -> 64 -> 256) and an identity block (256 -> 64 -> 256), on a map with ragged tile edges (13 x 37: not multiples of 8 / 32)
+    for name, cin in (("bottleneck_res2_proj", 64), ("bottleneck_res2_identity", 256)):
+        torch.manual_seed(40 + cin)
+        blk = BottleneckBlock(cin, 256, bottleneck_channels=64, stride=1, norm="FrozenBN", stride_in_1x1=True).eval()
+        for m in blk.modules():
+            if isinstance(m, FrozenBatchNorm2d):
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.1)
+                m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
+                m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
+        x = torch.randn(2, cin, 13, 37).relu_()
+        with torch.no_grad():
+            y = blk(x)
+        save(name, x=x, y=y, **{"sd." + k: v for k, v in blk.state_dict().items()})
+
 
 def gen_e2e():
     from detectron2.layers import FrozenBatchNorm2d

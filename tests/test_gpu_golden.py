@@ -65,3 +65,36 @@ def test_bottleneck_block_on_the_reference_output():
     err = float((y - ref).abs().max())
     print("bottleneck block: max |hip - reference| = %.2e of output scale %.2f" % (err / scale, scale))
     assert y.shape == ref.shape and err <= 2e-6 * scale     # two fp32 evaluations of three chained convolutions
+
+
+@pytest.mark.parametrize("name,cin", [("bottleneck_res2_proj", 64), ("bottleneck_res2_identity", 256)])
+def test_fused_bottleneck_block_on_the_reference_output(name, cin):
+    """A res2 block as ONE launch (csrc/conv_bneck.hip: conv1 -> 3x3 -> conv3 + shortcut; reference resnet.py:195-211) against the
+    reference module's own output on a map with ragged tile edges; and the same block with the fused form switched off."""
+    from lvc_amd import kernels as K
+    from lvc_amd.modeling.backbone.resnet import BottleneckBlock
+
+    g = gold(name)
+    blk = BottleneckBlock(cin, 256, bottleneck_channels=64, stride=1, norm="FrozenBN", stride_in_1x1=True).eval()
+    blk.load_state_dict({key[3:]: v for key, v in g.items() if key.startswith("sd.")}, strict=True)
+    blk = blk.to("cuda:0")
+    ref = g["y"]
+    scale = float(ref.abs().max())
+    errs = {}
+    for on in (True, False):
+        K.BNECK = on
+        timer = K.LaunchTimer()
+        K.CONV_TIMER = timer
+        try:
+            with torch.no_grad():
+                y = blk(g["x"].to("cuda:0")).cpu()
+        finally:
+            K.CONV_TIMER = None
+            K.BNECK = True
+        tags = [r[3] for r in timer.records]
+        assert (tags == ["f16s1_bneck"]) if on else ("f16s1_bneck" not in tags and len(tags) >= 3), tags
+        errs[on] = float((y - ref).abs().max()) / scale
+        assert y.shape == ref.shape
+    print("%s: max |hip - reference| / scale: one launch %.2e, separate launches %.2e" % (name, errs[True], errs[False]))
+    assert errs[True] <= 2e-6 and errs[True] <= 2.0 * errs[False] + 2e-7, errs
+    assert K.conv_error_word(torch.device("cuda:0")) == 0

@@ -993,6 +993,62 @@ def test_chained_conv3_conv1_matches_two_launches_and_fp64(shape):
     assert ch.state["off"] and k.conv_error_word(d) == 0
 
 
+@pytest.mark.parametrize("proj", [False, True])
+@pytest.mark.parametrize("shape", [(1, 8, 32), (2, 13, 70), (1, 50, 84), (3, 9, 31), (1, 1, 1)])
+def test_fused_bottleneck_matches_separate_launches_and_fp64(shape, proj):
+    """csrc/conv_bneck.hip (kernels.BNECK / LVC_BNECK): conv1 -> conv2 -> conv3 + shortcut + ReLU of a res2 block (reference
+    resnet.py:195-211) as one launch against the separate launches and an fp64 evaluation: whole tiles, ragged tile edges in both
+    directions, more tiles than one workgroup's share, a single pixel; then the range word for an input beyond 4094."""
+    import torch.nn.functional as F
+    from lvc_amd import kernels as k
+
+    N, H, W = shape
+    cin = 64 if proj else 256
+    g = torch.Generator().manual_seed(N * 1000 + H * 10 + W + cin)
+
+    def bn(c):
+        return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5)
+
+    w1 = torch.randn(64, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    w2 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5
+    w3 = torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    ws = torch.randn(256, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5
+    b1, b2, b3, bs = bn(64), bn(64), bn(256), bn(256)
+    x = torch.randn(N, H, W, cin, generator=g).relu_()
+    d = _dev()
+    dv = lambda ts: [t.to(d) for t in ts]
+    p1, p2, p3 = k.pack_conv(w1.to(d), bn=dv(b1)), k.pack_conv(w2.to(d), bn=dv(b2), pad=1), k.pack_conv(w3.to(d), bn=dv(b3))
+    a3, asc = k.conv_affine(None, b3), k.conv_affine(None, bs)
+    if proj:
+        wf = torch.cat([w3 * a3[0].view(-1, 1, 1, 1), ws * asc[0].view(-1, 1, 1, 1)], 1).contiguous()
+        pf = k.pack_conv(wf.to(d), affine=(None, (a3[1] + asc[1]).to(d)))
+        pss = k.pack_conv(ws.to(d), bn=dv(bs))
+    bk = k.pack_bottleneck(p1, p2, pf if proj else p3, proj)
+    xd = x.to(d)
+    y = k.bottleneck_fused(xd, bk)
+    t = k.conv2d_nhwc(k.conv2d_nhwc(xd, p1, relu=True), p2, relu=True)
+    z = k.conv2d_nhwc(t, p3, relu=True, residual=k.conv2d_nhwc(xd, pss) if proj else xd, res_mode=1)
+
+    def cb(v, w, b, pad=0):
+        s_, t_ = k.conv_affine(None, b)
+        return F.conv2d(v, w.double(), padding=pad) * s_.double().view(1, -1, 1, 1) + t_.double().view(1, -1, 1, 1)
+
+    x0 = x.permute(0, 3, 1, 2).double()
+    ref = (cb(cb(cb(x0, w1, b1).relu(), w2, b2, 1).relu(), w3, b3) + (cb(x0, ws, bs) if proj else x0)).relu().permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    e_one = float((y.cpu().double() - ref).abs().max()) / scale
+    e_sep = float((z.cpu().double() - ref).abs().max()) / scale
+    assert y.shape == (N, H, W, 256) and e_one <= 2e-6 and e_one <= 2.0 * e_sep + 3e-7, (e_one, e_sep)
+    assert k.conv_error_word(d) == 0
+    if shape == (2, 13, 70):
+        x2 = xd.clone()
+        x2[1, 12, 69, 5] = 5000.0      # the last pixel of the last (ragged) tile: a legal fp32 activation beyond the form's range
+        k.bottleneck_fused(x2, bk)
+        with pytest.raises(k.Fp16RangeError):
+            k.check_conv_error_word(d)
+        assert bk.state["off"] and k.conv_error_word(d) == 0
+
+
 @pytest.mark.parametrize("jitter,nidx,thr,max_keep", [(4.0, 80, 0.5, 100), (0.02, 3, 0.5, 100), (4.0, 80, 0.5, 1000), (0.5, 1, 0.3, 64)])
 def test_batched_nms_head_block_form_bit_exact(jitter, nidx, thr, max_keep):
     """lvc_batched_nms with max_keep << Nmax (the detection stage: 100 of ~10 000 candidates): the greedy pass runs on a head block of

@@ -1,6 +1,7 @@
 """Every surviving LVC_* switch is exercised on the device: the ones without a test of their own elsewhere.
   LVC_CONV_ENGINE=f32  -> kernels.CONV_ENGINE  (every conv / GEMM on the exact fp32 MFMA kernel)
   LVC_CHAIN=0          -> kernels.CHAIN        (conv3 -> next conv1 as two launches)
+  LVC_BNECK=0          -> kernels.BNECK        (res2's bottleneck blocks as separate layers instead of one launch each)
   resnet.FUSE_STRIDED_PROJECTION, fpn.MERGE_OUTPUT_CONVS, rpn.MERGE_LEVELS / MERGE_LEVELS_CONV / FUSE_PREDICTOR (module constants)  (the RPN head's predictor / 3x3 conv over all levels as one launch each, then both as one)
 and the attention's range report (kernels.mha -> the shared error word)."""
 import pytest
@@ -49,6 +50,7 @@ def test_chain_switch_two_launches_equal_one(monkeypatch):
     x = torch.randn(2, 3, 416, 608, generator=torch.Generator().manual_seed(1)).cuda() * 40
     res, tags = {}, {}
     monkeypatch.setattr(R, "FUSE_STRIDED_PROJECTION", False)      # (without the chain res3.0 would take that form: one launch fewer)
+    monkeypatch.setattr(K, "BNECK", False)                        # (res2's blocks as separate layers: the chains this test counts)
     for chain in (True, False):
         monkeypatch.setattr(K, "CHAIN", chain)
         timer = K.LaunchTimer()
@@ -214,3 +216,31 @@ def test_mha_reports_operands_beyond_fp16():
     with pytest.raises(K.Fp16RangeError) as e:
         K.check_conv_error_word(d)
     assert not e.value.rerouted and K.conv_error_word(d) == 0
+
+
+def test_bneck_switch_one_launch_per_res2_block(monkeypatch):
+    """The trunk with res2's three blocks as ONE launch each (csrc/conv_bneck.hip, default) against the layer-by-layer form: the same
+    features to a valid fp32 re-association, three `f16s1_bneck` launches, no res2 chain, and the block falling back (and staying
+    there) once an activation leaves the fused kernel's range."""
+    from lvc_amd import kernels as K
+    from test_gpu_e2e import _model
+
+    model = _model()
+    x = torch.randn(2, 3, 416, 608, generator=torch.Generator().manual_seed(2)).cuda() * 40
+    res, tags = {}, {}
+    for on in (True, False):
+        monkeypatch.setattr(K, "BNECK", on)
+        timer = K.LaunchTimer()
+        monkeypatch.setattr(K, "CONV_TIMER", timer)
+        with torch.no_grad():
+            res[on] = {k: v.clone() for k, v in model.backbone.bottom_up(x).items()}
+        monkeypatch.setattr(K, "CONV_TIMER", None)
+        tags[on] = [r[3] for r in timer.records]
+    assert tags[True].count("f16s1_bneck") == 3 and "f16s1_bneck" not in tags[False], tags[True]
+    assert tags[True].count("f16s1_chain") == 3 and tags[False].count("f16s1_chain") == 5      # res3's pairs / res2's + res3's
+    assert len(tags[True]) < len(tags[False])
+    for name in res[True]:
+        a, b = res[True][name], res[False][name]
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 3e-5 * scale, (name, float((a - b).abs().max()) / scale)
+    K.check_conv_error_word(x.device)

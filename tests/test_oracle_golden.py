@@ -96,6 +96,15 @@ def test_bottleneck_block():
     assert torch.allclose(y, g["y"], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("name", ["bottleneck_res2_proj", "bottleneck_res2_identity"])
+def test_bottleneck_block_res2_shapes(name):
+    """The res2 blocks the HIP path runs as one launch (lvc_amd/csrc/conv_bneck.hip), reference outputs on a 13 x 37 map."""
+    g = gold(name)
+    sd = {"b." + k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    y = orc._bottleneck(sd, "b", g["x"], stride=1)
+    assert torch.allclose(y, g["y"], rtol=0, atol=2e-6)
+
+
 def _check_e2e(name, inputs, depth=50):
     g = gold(name)
     sd = r50_state_dict() if depth == 50 else r101_state_dict()
