@@ -149,7 +149,29 @@ def _setup():
         c.rccl = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                   "allreduce_of_ones": float(one.item()), "devices_shared": bool(shared), "cpu_affinity_rank0": pin}
         assert dist.get_world_size() == c.world and float(one.item()) == c.world
+        # who runs where (VERDICT r5 #9: the first real N > 1 run explains itself): one entry per rank
+        import socket
+
+        props = torch.cuda.get_device_properties(c.dev)
+        mine = {"rank": c.rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "device": c.local_rank, "device_name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")), "host": socket.gethostname(), "pid": os.getpid(),
+                "cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+                "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES")), "devices_on_node": ndev}
+        every = [None] * c.world
+        dist.all_gather_object(every, mine)
+        c.rccl["device_map"] = every
     return c
+
+
+def _gather_obj(c, obj):
+    """[obj of rank 0, ..] on every rank."""
+    if not c.use_dist:
+        return [obj]
+    import torch.distributed as dist
+
+    every = [None] * c.world
+    dist.all_gather_object(every, obj)
+    return every
 
 
 def _barrier(c):
@@ -360,6 +382,8 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
     buckets = D.GradientBuckets(params) if which != "cfg3" else None
     nbytes = 0
 
+    exch = None      # a list: (event after backward() returned, event after the exchange finished) per step, on the compute stream
+
     def step(sync=None):
         nonlocal nbytes
         t = [time.perf_counter()]
@@ -368,10 +392,16 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
             torch.cuda.synchronize(); t.append(time.perf_counter())
         opt.zero_grad()      # set_to_none: the deferred weight gradients are written straight into the bucket slices
         sum(losses.values()).backward()
+        if exch is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         if buckets is not None:
             nbytes = buckets.finish()
         else:
             nbytes = D.allreduce_gradients_(params)
+        if exch is not None:
+            e1.record()
+            exch.append((e0, e1))
         if sync is not None:
             torch.cuda.synchronize(); t.append(time.perf_counter())
         opt.step()
@@ -389,6 +419,27 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
             losses = step()
         _barrier(c)
         dt, every = _max_and_all(c, time.perf_counter() - t0)
+        # gradient exchange: how much of it the backward hides.  exposed = compute-stream time between the end of
+        # backward() and the end of the exchange (what the step pays); alone = the same collectives back to back on idle GPUs;
+        # hidden = alone - exposed (cfg 5's buckets start under the backward; cfg 3's one flat all-reduce has nothing to hide under)
+        exch = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        exposed_ms = sum(a.elapsed_time(b) for a, b in exch) / len(exch)
+        exch = None
+        _barrier(c)
+        t1 = time.perf_counter()
+        if buckets is not None:
+            for b in buckets.buckets:
+                b["pending"] = 0
+            buckets.finish()
+        else:
+            D.allreduce_gradients_(params)
+        torch.cuda.synchronize()
+        alone_ms = 1e3 * (time.perf_counter() - t1)
+        exchange = _gather_obj(c, {"exposed_ms": round(exposed_ms, 3), "alone_ms": round(alone_ms, 3),
+                                   "hidden_ms": round(max(0.0, alone_ms - exposed_ms), 3)})
         ph = []
         if phases:
             for _ in range(3):
@@ -437,6 +488,11 @@ def train_leg(c, steps, warmup, batch_per_gpu=8, which="cfg3", phases=True):
     out = {"workload": "%s, %d x 800x1333 per GPU" % (name, batch_per_gpu), "trainable_tensors": len(params),
            "value": round(c.world * batch_per_gpu * steps / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
            "global_batch": batch_per_gpu * c.world, "gradient_bytes_allreduced": nbytes,
+           "gradient_exchange": {"per_rank": exchange, "mode": "one flattened all-reduce after backward()" if buckets is None else
+                                 "64 MB buckets, all-reduce launched as each bucket's last gradient arrives (GradientBuckets)",
+                                 "note": "exposed = compute-stream ms from the end of backward() to the end of the exchange; alone = the same "
+                                         "collectives with nothing else running; hidden = alone - exposed.  World size 1: no collective runs"},
+           "per_rank_img_per_s": [round(batch_per_gpu * steps / t, 2) for t in every],
            "parameters_identical_across_ranks": same, "losses": {k: round(float(v.detach()), 5) for k, v in losses.items()}}
     if ph:
         out["ms_forward_backward_optimizer"] = [round(1e3 * sum(p[i] for p in ph) / len(ph), 2) for i in range(3)]
@@ -549,15 +605,16 @@ def r101_leg(c, steps=10, warmup=3, parity_images=2):
         t1 = time.perf_counter()
         with torch.no_grad():
             ref = orc.generalized_rcnn_inference(sd, spec, cpu_in)
-            nz = onoise.fp32_vs_fp64(sd, spec, cpu_in, res32=ref, box_tol=0.5, score_tol=1e-2)
-        dev = onoise.deviation(hip, [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in ref], 0.5, 1e-2)
+            nz = onoise.fp32_vs_fp64(sd, spec, cpu_in, res32=ref, derive_identity=True)
+        dev = onoise.deviation(hip, [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in ref], nz["box_tol"], nz["score_tol"])
         ok, bars, msg = onoise.gate(dev, nz)
         parity = {"images_checked": idx, "deviation_among_matched": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev.items()},
                   "cpu_path_fp32_vs_fp64_noise": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in nz.items()},
                   "bars": {k: round(v, 6) for k, v in bars.items()}, "gate": msg, "gate_ok": bool(ok), "seconds": round(time.perf_counter() - t1, 1),
-                  "pass_bar": "as timed_batch_parity: equal counts, >= 90 %% of the oracle's detections found within the identity bars (0.5 px / 1e-2: R101's "
-                              "conditioned weights carry 6x R50's fp32 noise, tests/test_gpu_e2e.py), median / p90 of "
-                              "the matched differences <= %g x the CPU path's own fp32-vs-fp64 noise on these images; else the run exits non-zero" % onoise.K_NOISE}
+                  "pass_bar": "as timed_batch_parity, with the identity bars themselves derived from the noise run (%g x its medians of a first, generous "
+                              "matching: R101's conditioned weights carry ~6x R50's fp32 noise): equal counts, found fraction >= the CPU path's own - %g, "
+                              "median / p90 <= %g x and the largest <= %g x its fp32-vs-fp64 noise on these images; else the run exits non-zero"
+                              % (onoise.IDENT_K, onoise.IDENT_MARGIN, onoise.K_NOISE, onoise.K_MAX)}
     del model
     torch.cuda.empty_cache()
     return {"workload": "R101-FPN GeneralizedRCNN inference, bs=%d synthetic 3x800x1333 per GPU" % BATCH_PER_GPU,
@@ -716,6 +773,7 @@ def infer_main(c, args):
              "f16x2_wino": "conv3x3_wino_kernel (Winograd F(2,3) along x: the 3x3 layers on the large maps, 6 products per output instead of 9)",
              "f16x2_pws1": "conv_pw_s1_kernel (pipelined pointwise / FC: every layer with >= 64 input and output channels)", "bf16x3_halo": "conv3x3_halo_kernel",
              "f16s1_chain": "conv_pw_chain_kernel (conv3 + shortcut add + ReLU -> the next block's conv1 in one launch: res2 / res3)",
+             "f16s1_bneck": "conv_bneck_kernel (a whole res2 bottleneck block -- conv1, 3x3, conv3 + shortcut + ReLU -- in one launch)",
              "bf16x3": "conv_bf16x3_kernel (+ bf16 pointwise shapes)", "f32": "conv_igemm_f32_kernel"}
     if not args.no_launch_timer:
         probe = K.LaunchTimer()
@@ -728,15 +786,18 @@ def infer_main(c, args):
         timer = K.LaunchTimer(only={dom}, every=4)
         _barrier(c)
     K.CONV_TIMER = timer
+    cpu0 = time.thread_time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if timer is not None:
             timer.next_step()
         res = step_forward()
+    host_cpu = time.thread_time() - cpu0      # this rank's launching thread, CPU time (not the wait for the step's one device->host read)
     _barrier(c)
     dt = time.perf_counter() - t0
     K.CONV_TIMER = None
     dt_max, dt_all = _max_and_all(c, dt)
+    host_us_all = [round(h, 1) for h in _gather_obj(c, 1e6 * host_cpu / args.steps)]
     if timer is not None:
         full = K.LaunchTimer()
         K.CONV_TIMER = full
@@ -830,7 +891,7 @@ def infer_main(c, args):
     if timer is not None:
         fl, ms, nlaunch = timer.flops_and_ms(dom)
         achieved = fl / (ms * 1e-3) / 1e12
-        peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_F16X2_TFLOPS if dom.startswith("f16x2") else PEAK_BF16X3_TFLOPS
+        peak = PEAK_F32_MFMA_TFLOPS if dom == "f32" else PEAK_F16X2_TFLOPS if dom.startswith("f16") else PEAK_BF16X3_TFLOPS
         traffic = pmc = None
         live = step_pmc = None
         if c.rank == 0 and c.world == 1 and not args.no_live_pmc:
@@ -852,7 +913,11 @@ def infer_main(c, args):
         roofline = {
             "kernel": "%s (%d launches/step; HIP-event brackets in %d of the %d timed steps)" % (NAMES[dom], nlaunch // max(1, timer.steps_timed()), timer.steps_timed(), args.steps),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split, a1 b1 + a1 b2 + a2 b1 in fp32 accumulators)" if dom.startswith("f16x2") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once (2 M K C 9 for a 3x3 layer -- also for the Winograd F(2,3) kernel, which issues two thirds of the direct form's MFMAs for them: its ceiling in this unit is 1.5 x 833); under the socket power cap a bare loop of these MFMAs on random data sustains 1.66 PFLOP/s = 552 TFLOP/s fp32-equivalent (profiles/r03_mfma_ceiling.txt)",
+            "peak_note": ("2500 TFLOP/s dense fp16 MFMA / 3 MFMAs per fp32-accurate product (two-way fp16 operand split, a1 b1 + a1 b2 + a2 b1 in fp32 accumulators)" if dom.startswith("f16") else "2500 TFLOP/s dense bf16 MFMA / 6 MFMAs per fp32-accurate product (exact 3-way bf16 operand split, fp32 accumulate)") + "; achieved counts algorithmic fp32 flops once (2 M K C 9 for a 3x3 layer -- also for the Winograd F(2,3) kernel, which issues two thirds of the direct form's MFMAs for them: its ceiling in this unit is 1.5 x 833); under the socket power cap a bare loop of these MFMAs on random data sustains 1.66 PFLOP/s = 552 TFLOP/s fp32-equivalent (profiles/r03_mfma_ceiling.txt)",
+            "frac_convention": "frac = algorithmic fp32 flops (direct form, counted once) / (2500 / 3): the fp32-accurate ceiling of the two-way fp16 split; the two "
+                               "readings against the guide's raw 2500 TFLOP/s follow",
+            "frac_issued_mfma_of_2500": round(achieved * (3.0 if dom.startswith("f16") else 6.0) * (2.0 / 3.0 if dom == "f16x2_wino" else 1.0) / 2500.0, 4),
+            "frac_algorithmic_of_2500": round(achieved / 2500.0, 4),
             "frac_of_fp32_mfma_peak_157.3": round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
             "traffic": traffic,
             "traffic_source": ("live rocprofv3 --pmc passes in this run" if live is not None else "profiles (not measured in this run)")
@@ -863,7 +928,7 @@ def infer_main(c, args):
         for e in NAMES:
             f2, m2, n2 = full.flops_and_ms(e)
             if n2:
-                pk = PEAK_F32_MFMA_TFLOPS if e == "f32" else PEAK_F16X2_TFLOPS if e.startswith("f16x2") else PEAK_BF16X3_TFLOPS
+                pk = PEAK_F32_MFMA_TFLOPS if e == "f32" else PEAK_F16X2_TFLOPS if e.startswith("f16") else PEAK_BF16X3_TFLOPS
                 tf = f2 / (m2 * 1e-3) / 1e12
                 other[NAMES[e]] = {"launches_per_step": n2 // 2, "ms_per_step": round(m2 / 2, 3), "tflops": round(tf, 2),
                                    "frac_of_engine_peak": round(tf / pk, 4)}
@@ -877,6 +942,7 @@ def infer_main(c, args):
         alg_conv = full.algorithmic_bytes() / 2
         alg_other = BATCH_PER_GPU * (3 * 800 * 1333 * 4 + 800 * 1344 * 16) + BATCH_PER_GPU * (1000 * 49 * 256 * 4 + 91.4e6)   # preprocess in / out; ROIAlign out + pyramid once
         roofline["step_algorithmic_bytes"] = int(alg_conv + alg_other)
+        roofline["backbone_mfma_busy_target"] = 0.70      # north_star's figure; `backbone_mfma_busy` below is the measured one
         if step_pmc is not None:
             roofline["backbone_mfma_busy"] = step_pmc["backbone_mfma_busy"]
             roofline["step_traffic"] = step_pmc["step_hbm_bytes"]
@@ -892,6 +958,11 @@ def infer_main(c, args):
             extras["bandwidth_kernels"] = bandwidth_kernels(c, model, batch)
         except Exception as e:   # an extra must never cost the headline line
             extras["bandwidth_kernels"] = {"error": repr(e)}
+    if c.rank == 0 and c.world == 1 and not args.no_extras:
+        try:
+            extras["range_reroutes"] = range_rehearsal(c, max(5, args.steps // 2), 3)
+        except Exception as e:
+            extras["range_reroutes"] = {"error": repr(e)}
     if not args.no_extras:
         try:
             if c.world == 1:
@@ -932,14 +1003,17 @@ def infer_main(c, args):
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": BATCH_PER_GPU * c.world, "parallelism": "dp%d" % c.world,
                        "detections_per_image": n_det},
             "rccl": c.rccl, "per_rank": {"img_per_s": [round(BATCH_PER_GPU * args.steps / t, 2) for t in dt_all],
-                                         "seconds": [round(t, 4) for t in dt_all], "max_over_ranks_s": round(dt_max, 4)},
+                                         "seconds": [round(t, 4) for t in dt_all], "max_over_ranks_s": round(dt_max, 4),
+                                         "host_cpu_us_per_step": host_us_all,
+                                         "host_note": "CPU time of each rank's launching thread per step (time.thread_time): what the host must supply per "
+                                                      "rank; a step is host-bound when this approaches ms_per_step"},
             "roofline": roofline, "value_inference_batched": through_forward, "pipelined": pipelined, "graphed": graphed,
             "eval_loop_host_inputs": eval_loop, "value_inputs": "device-resident (the 8 fp32 images are in HBM before the timed region, as the bench contract asks; `eval_loop_host_inputs` is the PCIe-inclusive loop)",
             "cpu_baseline": cpu_baseline, "timed_batch_parity": parity,
         }
         line.update(extras)
         print(json.dumps(line))
-        if parity is not None and not (parity["matched_fraction_0.1px_2e-3"] >= 0.9 and parity["detection_counts_equal"] and parity["gate_ok"]):
+        if parity is not None and not (parity["detection_counts_equal"] and parity["gate_ok"]):
             sys.stdout.flush()
             sys.stderr.write("bench.py: the timed batch's detections do not match the CPU oracle: %s\n" % json.dumps(parity))
             os._exit(4)
@@ -1147,6 +1221,67 @@ def _match(boxes, scores, classes, gboxes, gscores, gclasses, box_tol, score_tol
     return matched, wb, ws
 
 
+def range_rehearsal(c, steps, warmup):
+    """a checkpoint-shaped rehearsal of the fp16 forms' range envelope.  No trained weights exist in this environment; the
+    detector is built with an MSRA-initialised trunk behind identity FrozenBN, loaded through the pre-v3 path (no running statistics:
+    lvc_amd.utils.synthetic.msra_checkpoint_rehearsal_), so that activations reach O(1e3..1e4) in the deep stages.  Reported: how many
+    layers leave the one-accumulator forms (|a| <= 4094), where they go, how many passes that takes, and the steady-state rate with
+    them re-routed (the bench batch: 8 x 800x1333)."""
+    import torch
+
+    from lvc_amd import kernels as K
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.layers.wrappers import Conv2d, Linear
+    from lvc_amd.modeling import build_model
+    from lvc_amd.modeling.backbone.resnet import BottleneckBlock
+    from lvc_amd.utils import synthetic as syn
+
+    model = build_model(base_rcnn_fpn(device="cuda:%d" % c.local_rank)).eval()
+    syn.msra_checkpoint_rehearsal_(model)
+    batch = [{"image": syn.synthetic_image(1 + i).to(c.dev), "height": 800, "width": 1333} for i in range(BATCH_PER_GPU)]
+    epoch0, split0 = K.RANGE_EPOCH, K.CONV_SPLIT
+    with torch.no_grad():
+        feats = model.backbone.bottom_up(model.preprocess_image(batch).tensor)      # (re-routes nothing by itself: the words are read by forward())
+        scales = {k: round(float(v.abs().max()), 1) for k, v in feats.items()}
+        del feats
+        K.clear_conv_error_word(c.dev)
+        passes = 0
+        while passes < 64:      # forward() repeats a flagged pass itself (8 tries); the loop covers a longer cascade
+            try:
+                model(batch)
+                break
+            except K.Fp16RangeError:
+                passes += 1
+        for _ in range(warmup):
+            model(batch)
+        epoch1 = K.RANGE_EPOCH
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = model(batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    tiers = {n: m._range_state["tier"] for n, m in model.named_modules() if isinstance(m, (Conv2d, Linear)) and m._range_state["tier"]}
+    layers = sum(1 for _n, m in model.named_modules() if isinstance(m, (Conv2d, Linear)))
+    blocks = [m for m in model.modules() if isinstance(m, BottleneckBlock)]
+    res = {"workload": "R50-FPN inference, bs=%d synthetic 3x800x1333, MSRA-initialised trunk behind identity FrozenBN loaded through the pre-v3 "
+                       "state_dict path (no trained checkpoint exists here)" % BATCH_PER_GPU,
+           "activation_scale_max": scales,
+           "layers_total": layers, "layers_off_the_one_accumulator_form": len(tiers),
+           "to_two_accumulators": sum(1 for t in tiers.values() if t == 1), "to_bf16x3": sum(1 for t in tiers.values() if t == 2),
+           "fused_blocks_off": sum(1 for b in blocks if getattr(b, "_bneck_state", {}).get("off")),
+           "chained_pairs_off": sum(1 for b in blocks if getattr(b, "_chain_state", {}).get("off")),
+           "rerouting_passes": K.RANGE_EPOCH - epoch0, "settled": K.RANGE_EPOCH == epoch1,
+           "value": round(BATCH_PER_GPU * steps / dt, 2), "unit": "img/s", "ms_per_step": round(1e3 * dt / steps, 3),
+           "detections_per_image": [len(o["instances"]) for o in out],
+           "rerouted_layers": {k: ("two accumulators" if t == 1 else "bf16x3") for k, t in sorted(tiers.items())}}
+    res["process_wide_split_after"] = K.CONV_SPLIT      # "f16x2" unless an operand without a per-layer range word overflowed (stem, weights)
+    K.CONV_SPLIT = split0                                 # the legs after this one run as configured
+    del model
+    torch.cuda.empty_cache()
+    return res
+
+
 def _cpu_baseline(model, imgs, gpu_dets):
     """the CPU restatement (oracle/) on this host, 5 warm-up + 20 timed single-image forwards
     (bounded to ~60 s of CPU time: fewer timed iterations are taken, and reported, on a slower host).  The forwards cycle
@@ -1187,7 +1322,8 @@ def _cpu_baseline(model, imgs, gpu_dets):
         nz = onoise.fp32_vs_fp64(sd, spec, [cpu_in[i][0] for i in nz_imgs], res32=[ref[i] for i in nz_imgs])
         nz_s = time.perf_counter() - t2
     dev = onoise.deviation([gpu_dets[i] for i in sorted(ref)], [(ref[i]["pred_boxes"], ref[i]["scores"], ref[i]["pred_classes"]) for i in sorted(ref)])
-    gate_ok, bars, gate_msg = onoise.gate(dev, nz)
+    dev_same = onoise.deviation([gpu_dets[i] for i in nz_imgs], [(ref[i]["pred_boxes"], ref[i]["scores"], ref[i]["pred_classes"]) for i in nz_imgs])
+    gate_ok, bars, gate_msg = onoise.gate(dev, nz, dev_same=dev_same)
     # parity of the timed batch: every image the oracle saw
     tot = loose = tight = 0
     wb = ws = 0.0
@@ -1206,8 +1342,14 @@ def _cpu_baseline(model, imgs, gpu_dets):
               "cpu_path_fp32_vs_fp64_noise": dict({k: (round(v, 6) if isinstance(v, float) else v) for k, v in nz.items()},
                                                   images=nz_imgs, seconds=round(nz_s, 1)),
               "bars": {k: round(v, 6) for k, v in bars.items()}, "gate": gate_msg, "gate_ok": bool(gate_ok),
-              "pass_bar": "equal counts, matched_fraction_0.1px_2e-3 >= 0.9 (identity) AND median / p90 of the matched |box|, |score| differences "
-                          "<= 2 x the CPU path's own fp32-vs-fp64 noise on this batch (`bars`), else the run exits non-zero",
+              "deviation_on_the_noise_images": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev_same.items()},
+              "pass_bar": "every bar is measured in this run on the CPU path itself (oracle/noise.py; `bars`): equal counts; matched_fraction >= the fraction "
+                          "the CPU path finds of its OWN fp64 detections - %g (identity); median / p90 of the matched |box|, |score| differences <= %g x its "
+                          "fp32-vs-fp64 noise; the largest matched difference on the noise images <= %g x its largest; else the run exits non-zero"
+                          % (onoise.IDENT_MARGIN, onoise.K_NOISE, onoise.K_MAX),
+              "oracle_pinning": "oracle/rcnn.py is pinned against the imported reference's outputs (tests/golden, tests/test_oracle_golden.py) -- except "
+                                "torchvision's NMS (absent from the reference tree; independent witness: the reference's rotated-NMS kernel) and the DINO "
+                                "ViT of the descriptor leg (weights are network-only): those two oracles are unpinned",
               "note": "GPU detections of the LAST TIMED step vs oracle/rcnn.py (fp32 CPU) on the same images; both are fp32 evaluations "
                       "of a 53-layer trunk, each ~2e-3 px (median) from the fp64 answer (tests/test_gpu_chain.py), so the literal 1e-3 "
                       "fraction is what two valid fp32 paths share"}

@@ -164,7 +164,7 @@ class GradientBuckets:
         from . import kernels as K
 
         for p in self.params:
-            K.register_wgrad_sink(p, self._slot, self._hook)
+            K.register_wgrad_sink(p, self._slot, self._hook, owner=self)
         self._next = 0
         self.bytes_reduced = 0
 
@@ -186,6 +186,10 @@ class GradientBuckets:
 
     def _hook(self, p):
         if p.grad is None:      # AccumulateGrad ran on an undefined gradient (a deferred weight gradient: it arrives through the sink)
+            return
+        from . import kernels as K
+
+        if K.wgrad_queued(p):   # more of this parameter's gradient is still to come (another use's deferred job): not final yet
             return
         bi, off = self._where[id(p)]
         b = self.buckets[bi]

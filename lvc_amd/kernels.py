@@ -63,7 +63,12 @@ class PackedConv:
         self._last_one = bool(one)
         dev = self.w.device
         if dev.type == "cuda":
-            self.state.setdefault("at", {})[(dev.index, torch.cuda.current_stream(dev).cuda_stream)] = (self.state["tier"], bool(one))
+            # one layer may launch several forms in a pass (the RPN head: single-accumulator Winograd on p2 / p3, two accumulators on
+            # p4 - p6, all on this slot): the narrowest form seen at this tier decides the reaction, not the last launch
+            at = self.state.setdefault("at", {})
+            key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+            prev = at.get(key)
+            at[key] = (self.state["tier"], bool(one) or (prev is not None and prev[0] == self.state["tier"] and prev[1]))
 
     def _split(self, planes):
         n = self.w.numel()
@@ -1991,20 +1996,73 @@ _WGRAD_SIDE = {}             # device index -> the stream the grouped launches r
 _WGRAD_PENDING = []          # (event, deliveries, operands kept alive) of groups in flight on the side stream
 
 
-def register_wgrad_sink(param, destination, ready):
+_WGRAD_USES = {}             # id(param) -> differentiable forward uses whose backward node has not run yet (layers.wrappers._ConvFn)
+
+
+def register_wgrad_sink(param, destination, ready, owner=None):
     """A gradient exchange that owns flat buckets hands out the bucket slice as the place the deferred weight gradient is written
-    to (no copy into the bucket afterwards) and is told when it is there (`lvc_amd.distributed.GradientBuckets`)."""
-    _WGRAD_SINKS[id(param)] = (destination, ready)
+    to (no copy into the bucket afterwards) and is told when it is there (`lvc_amd.distributed.GradientBuckets`).  The sink dies with
+    the exchange: bound methods are held through weak references (and `owner`, if given, through another) -- a dropped exchange must
+    not keep receiving gradients into its dead buckets, nor be kept alive by this table.  One live sink per parameter."""
+    import weakref
+
+    def weak(fn):
+        try:
+            return weakref.WeakMethod(fn)
+        except TypeError:          # a plain function: nothing to die with
+            return lambda: fn
+
+    if _wgrad_sink(param) is not None:
+        raise RuntimeError("lvc_amd: parameter already has a deferred-gradient sink (a second GradientBuckets over the same parameters? "
+                           "call remove() on the first)")
+    _WGRAD_SINKS[id(param)] = (weak(destination), weak(ready), weakref.ref(param), weakref.ref(owner) if owner is not None else None)
 
 
 def unregister_wgrad_sink(param):
     _WGRAD_SINKS.pop(id(param), None)
 
 
+def _wgrad_sink(param):
+    """(destination, ready) of the live sink of `param`, or None (and the entry is dropped) when its parameter, its owner or its
+    callables are gone -- ids are reused."""
+    sink = _WGRAD_SINKS.get(id(param))
+    if sink is None:
+        return None
+    dst, rdy = sink[0](), sink[1]()
+    if sink[2]() is not param or (sink[3] is not None and sink[3]() is None) or dst is None or rdy is None:
+        del _WGRAD_SINKS[id(param)]
+        return None
+    return dst, rdy
+
+
 def reset_wgrad_queue():
     del _WGRAD_Q[:]
     del _WGRAD_PENDING[:]
+    _WGRAD_USES.clear()
     _WGRAD_ARMED[0] = False
+
+
+def in_backward():
+    """True while the autograd engine is executing a graph task on this thread."""
+    return torch._C._current_graph_task_id() != -1
+
+
+def note_wgrad_use(param):
+    """A differentiable forward use of `param` (layers.wrappers._ConvFn.forward): its backward node will deliver one weight gradient."""
+    _WGRAD_USES[id(param)] = _WGRAD_USES.get(id(param), 0) + 1
+
+
+def wgrad_use_done(param):
+    """That use's backward node ran (it queued a deferred job or handed its gradient to AccumulateGrad)."""
+    n = _WGRAD_USES.get(id(param), 0)
+    if n > 0:
+        _WGRAD_USES[id(param)] = n - 1
+
+
+def wgrad_queued(param):
+    """True while a deferred weight gradient of `param` waits in the queue or more uses of it have yet to run their backward:
+    its gradient is not final (lvc_amd.distributed.GradientBuckets._hook)."""
+    return _WGRAD_USES.get(id(param), 0) > 0 or any(j[0] is param for j in _WGRAD_Q)
 
 
 def can_defer_wgrad(x, g):
@@ -2020,7 +2078,7 @@ def defer_wgrad(param, x, g, scale, R, stride, pad):
     if not _WGRAD_ARMED[0]:
         _WGRAD_ARMED[0] = True
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad_end)
-    if len(_WGRAD_Q) >= _WGRAD_GROUP:
+    if sum(1 for j in _WGRAD_Q if _WGRAD_USES.get(id(j[0]), 0) == 0) >= _WGRAD_GROUP:
         flush_wgrad()
 
 
@@ -2031,8 +2089,27 @@ def _flush_wgrad_end():
 
 def flush_wgrad(final=False):
     """Launch the queued weight gradients: one zeroing, one grouped wgrad launch, one grouped layout / accumulate launch."""
-    q = list(_WGRAD_Q)
-    del _WGRAD_Q[:]
+    if final:
+        q = list(_WGRAD_Q)
+        del _WGRAD_Q[:]
+        # uses counted by a forward whose backward never ran (two forwards, one backward) made `wgrad_queued` hold back parameters that
+        # got their whole gradient through AccumulateGrad: report those now, the pass is over
+        stale = [i for i, n in _WGRAD_USES.items() if n > 0]
+        _WGRAD_USES.clear()
+        queued = {id(j[0]) for j in q}
+        for i in stale:
+            entry = _WGRAD_SINKS.get(i)
+            if entry is not None and i not in queued:
+                prm = entry[2]()
+                sink = _wgrad_sink(prm) if prm is not None else None
+                if sink is not None and prm.grad is not None:
+                    sink[1](prm)
+    else:
+        # a flush DELIVERS its parameters (p.grad is set, a bucketed exchange may start reducing them): only parameters whose every use
+        # of this pass has run its backward node go out -- the RPN head's convolutions are used once per pyramid level, and a weight
+        # whose uses straddled two flushes was accumulated into a bucket slice that was already being reduced (ADVICE r5)
+        q = [j for j in _WGRAD_Q if _WGRAD_USES.get(id(j[0]), 0) == 0]
+        _WGRAD_Q[:] = [j for j in _WGRAD_Q if _WGRAD_USES.get(id(j[0]), 0) != 0]
     if not q:
         if final:
             _retire_wgrad()
@@ -2071,7 +2148,7 @@ def flush_wgrad(final=False):
         nbytes += 4.0 * (x.numel() + g.numel() + p.numel())
         if first[id(p)] != j:
             continue
-        sink = _WGRAD_SINKS.get(id(p))
+        sink = _wgrad_sink(p)
         if p.grad is not None:
             dst, beta = p.grad, 1
             assert dst.is_contiguous() and dst.dtype == torch.float32

@@ -92,7 +92,7 @@ class Conv2d(nn.Module):
         may be written to `weight.grad` in its place; False under `torch.autograd.grad(...)` / `backward(inputs=...)`, where the node must
         hand its gradient back to the engine."""
         w = self.weight
-        if id(w) not in K._WGRAD_SINKS:
+        if K._wgrad_sink(w) is None:
             # no registered taker for the deferred gradient (GradientBuckets registers one per parameter): anything that listens to the
             # autograd path of this parameter -- tensor hooks, or a data-parallel wrapper's hooks on the AccumulateGrad node
             # (torch DistributedDataParallel, which the reference's DefaultTrainer uses) -- must see the gradient arrive there
@@ -189,8 +189,12 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, residual, conv, res_mode, relu):
         if conv.in_channels == 3:
             raise NotImplementedError("training the 7x7 stem is not implemented (every shipped config has FREEZE_AT >= 1)")
-        if K._WGRAD_ARMED[0]:
-            K.reset_wgrad_queue()     # a backward() that raised left queued weight gradients behind
+        if K._WGRAD_ARMED[0] and not K.in_backward():
+            # a backward() that raised left queued weight gradients behind.  (A forward INSIDE a live backward -- checkpoint
+            # recomputation, a hook -- keeps the queue: those gradients are still to be delivered.)
+            K.reset_wgrad_queue()
+        if weight.requires_grad:
+            K.note_wgrad_use(weight)
         y = K.conv2d_nhwc(x, conv.packed(), relu=relu, residual=residual, res_mode=res_mode)
         ctx.save_for_backward(x, y if relu else None)
         ctx.conv, ctx.res_mode, ctx.relu = conv, res_mode, relu
@@ -207,6 +211,7 @@ class _ConvFn(torch.autograd.Function):
         if need_r:
             dres = g if ctx.res_mode == 1 else K.downsum2x2(g)
         if need_w:
+            K.wgrad_use_done(conv.weight)
             R = conv.kernel_size[0]
             scale = conv.packed().scale if conv.norm is not None else None
             if K.can_defer_wgrad(x, g) and conv._grad_lands_in_weight():

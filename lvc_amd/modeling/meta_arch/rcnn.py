@@ -229,6 +229,7 @@ class GeneralizedRCNN(_RCNNBase):
                 inst.objectness_logits = logits[i, : pc[i]]
                 proposals.append(inst)
             _, detector_losses = heads(images, features, proposals, gt_instances)
+            K.check_conv_error_word(self.device)      # this second heads pass raised its own range words: judged in THIS step
         losses = {}
         losses.update(detector_losses)
         losses.update(proposal_losses)

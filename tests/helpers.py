@@ -44,6 +44,13 @@ def r101_state_dict():
     return syn.conditioned_state_dict(template, seed=0, bn_calibration=gold("r101_bn_calibration"))
 
 
+def found_bar(p0, n, margin=0.02):
+    """Lower bar of a found fraction over n items when a valid fp32 evaluation of the same path (the oracle, fp32 vs fp64) finds the
+    fraction p0 of its own exact answers: p0 - margin (oracle/noise.py IDENT_MARGIN) - two standard deviations of a count of n."""
+    n = max(1, n)
+    return p0 - margin - 2.0 * (max(p0 * (1.0 - p0), 1.0 / n) / n) ** 0.5
+
+
 def match_detections(boxes, scores, classes, gboxes, gscores, gclasses, tol=1e-3):
     """Set-equality of detections within `tol` (order may differ where scores are closer than tol).
     Returns (ok, message)."""

@@ -455,6 +455,95 @@ def test_deferred_wgrad_queue_survives_a_failed_backward_and_buckets_take_the_gr
         buckets.remove()
 
 
+def test_shared_deferred_weight_is_delivered_once_after_its_last_use(monkeypatch):
+    """a flush of the deferred weight gradients (every 24 jobs) DELIVERS its parameters -- `p.grad` is set and a bucketed
+    exchange may start reducing the slice.  A weight used several times in one pass (the RPN head over the pyramid levels) whose uses
+    straddle two flushes must wait for its last use: one delivery, carrying the whole gradient.  Also a forward inside a live backward
+    (checkpoint recomputation) must not drop the queue, and a dead exchange's sinks must not receive gradients."""
+    import gc
+    from lvc_amd import kernels as K
+    from lvc_amd.layers import Conv2d
+
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    shared = Conv2d(32, 32, 3, padding=1, bias=False).to(dev)
+    others = [Conv2d(32, 32, 1, bias=False).to(dev) for _ in range(30)]
+    params = [shared.weight] + [c.weight for c in others]
+    x = torch.randn(1, 12, 20, 32, device=dev)
+
+    def loss():
+        h = x
+        for k in range(5):
+            h = shared.forward_nhwc(h)
+            for c in others[6 * k: 6 * k + 6]:
+                h = c.forward_nhwc(h) * 0.5
+        return h.square().sum()
+
+    monkeypatch.setattr(K, "DEFER_WGRAD", False)
+    loss().backward()
+    ref = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    monkeypatch.setattr(K, "DEFER_WGRAD", True)
+
+    class Exchange:      # what GradientBuckets does with its slices: hand them out, act when told a parameter is there
+        def __init__(self):
+            self.slots = {id(p): torch.zeros_like(p) for p in params}
+            self.seen = {}
+            for p in params:
+                K.register_wgrad_sink(p, self.slot, self.ready, owner=self)
+
+        def slot(self, q):
+            return self.slots[id(q)]
+
+        def ready(self, q):
+            self.seen.setdefault(id(q), []).append(self.slots[id(q)].clone())
+
+    ex = Exchange()
+    with pytest.raises(RuntimeError, match="already has a deferred-gradient sink"):
+        K.register_wgrad_sink(params[0], lambda q: None, lambda q: None, owner=ex)
+    flushes = []
+    real_flush = K.flush_wgrad
+    monkeypatch.setattr(K, "flush_wgrad", lambda final=False: (flushes.append((final, len(K._WGRAD_Q))), real_flush(final))[1])
+    loss().backward()
+    torch.cuda.synchronize()
+    assert len(flushes) >= 2 and not flushes[0][0] and flushes[-1][0], flushes      # at least one flush before the final one
+    for p, r in zip(params, ref):
+        assert len(ex.seen[id(p)]) == 1, "delivered %d times" % len(ex.seen[id(p)])
+        assert _rel(ex.seen[id(p)][0], r) < 1e-5 and _rel(p.grad, r) < 1e-5       # complete when reported, and final
+    assert not K._WGRAD_Q and not K._WGRAD_USES
+    # a forward inside a live backward keeps the queue
+    for p in params:
+        p.grad = None
+    ex.seen.clear()
+
+    class Recompute(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t.clone()
+
+        @staticmethod
+        def backward(ctx, gr):
+            assert K.in_backward() and K._WGRAD_Q          # the outer layers' gradients are queued
+            n = len(K._WGRAD_Q)
+            with torch.enable_grad():
+                others[0].forward_nhwc(x.detach())         # a differentiable forward (recomputation) while the pass is running
+            assert len(K._WGRAD_Q) == n
+            return gr
+
+    (others[2].forward_nhwc(Recompute.apply(others[1].forward_nhwc(x)))).sum().backward()
+    assert others[2].weight.grad is not None and others[1].weight.grad is not None and not K._WGRAD_Q
+    # a dropped exchange: its sinks die with it
+    for p in params:
+        p.grad = None
+    del ex
+    gc.collect()
+    loss().backward()
+    assert all(p.grad is not None for p in params) and K._wgrad_sink(params[0]) is None
+    for p, r in zip(params, ref):
+        assert _rel(p.grad, r) < 1e-5
+
+
 def test_weight_gradient_takes_the_autograd_path_when_a_hook_listens():
     """A tensor hook or a post-accumulate hook on the weight (what a data-parallel wrapper other than GradientBuckets relies on) must see the
     gradient: such a parameter is not deferred."""

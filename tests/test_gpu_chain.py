@@ -269,8 +269,8 @@ def _fp64_compare(model, sd, spec, inputs, tag, loose=(0.1, 2e-3)):
         assert np.median(e_gs) <= 1.25 * np.median(e_cs) + 1e-8
         assert np.percentile(e_gs, 90) <= 1.5 * np.percentile(e_cs, 90) + 1e-8
         # The literal 1e-3 of north_star, end to end, against the EXACT answer: the HIP path must sit within 1e-3 (box px and
-        # score, same class) of the fp64 detections at least as often as the reference's own fp32 CPU path does, minus 2 points
-        # of matching noise.  (HIP-vs-reference distances contain BOTH paths' rounding errors, so the fraction of reference
+        # score, same class) of the fp64 detections at least as often as the reference's own fp32 CPU path does, minus the
+        # sampling noise of that count.  (HIP-vs-reference distances contain BOTH paths' rounding errors, so the fraction of reference
         # detections the HIP path hits within 1e-3 is reported, not asserted: two evaluations that are each ~3e-3 px from the
         # truth are rarely within 1e-3 of each other.)
         b64, s64, c64 = r64[i]["pred_boxes"].float(), r64[i]["scores"].float(), r64[i]["pred_classes"]
@@ -283,8 +283,12 @@ def _fp64_compare(model, sd, spec, inputs, tag, loose=(0.1, 2e-3)):
         print("   fp64 detections within 1e-3 of: the HIP path %.1f%%, the reference cpu-fp32 path %.1f%%; reference detections within 1e-3 "
               "of the HIP path %.1f%%, within %g px / %g %.1f%% (worst %.2e px, %.2e)"
               % (100 * tight_g, 100 * tight_c, 100 * tight_gc, loose[0], loose[1], 100 * loose_g, wb, ws))
-        assert tight_g >= tight_c - 0.02
-        assert loose_g >= 0.9
+        # (a count of n64 detections with hit probability ~tight_c: two standard deviations of that count, at least the 2 points)
+        assert tight_g >= tight_c - max(0.02, 2.0 * (tight_c * (1.0 - tight_c) / max(n64, 1)) ** 0.5), (tight_g, tight_c, n64)
+        # identity: the fraction the reference's fp32 path finds of the EXACT detections within the same bars, minus IDENT_MARGIN + sampling noise
+        from helpers import found_bar
+        loose_c, _, _ = match_fraction(r32[i]["pred_boxes"], r32[i]["scores"], r32[i]["pred_classes"], b64, s64, c64, box_tol=loose[0], score_tol=loose[1])
+        assert loose_g >= found_bar(loose_c, n64), (loose_g, loose_c)
 
 
 def test_final_outputs_vs_fp64_r50():
@@ -311,7 +315,8 @@ def test_final_outputs_vs_fp64_r101():
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     inputs = [{"image": syn.synthetic_image(3, 240, 320), "height": 480, "width": 640},
               {"image": syn.synthetic_image(4, 200, 352), "height": 200, "width": 352}]
-    # R101's conditioned weights have a 5-6x higher fp32 noise floor than R50's: 0.5 px / 1e-2 as in test_gpu_e2e
+    # R101's conditioned weights have a 5-6x higher fp32 noise floor than R50's: identity bars 5 x R50's (the found fraction is held to what the
+    # reference's own fp32 path reaches within the SAME bars, so their size only decides which pairs count as the same detection)
     _fp64_compare(model, sd, orc.RCNNSpec(depth=101), inputs, "R101 small", loose=(0.5, 1e-2))
 
 

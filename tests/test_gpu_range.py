@@ -189,3 +189,44 @@ def test_hidden_overflow_of_the_fused_predictor_moves_the_predictor_only():
                                          wp.double(), bp.double()).permute(0, 2, 3, 1)
         assert float((y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
     assert K.conv_error_word(dev) == 0
+
+
+def test_msra_scale_checkpoint_rehearsal():
+    """no trained checkpoint exists here, so the |a| <= 4094 envelope of the one-accumulator forms is rehearsed on
+    checkpoint-SHAPED weights (lvc_amd.utils.synthetic.msra_checkpoint_rehearsal_: MSRA-initialised trunk behind identity FrozenBN,
+    loaded through the pre-v3 path without running statistics): activations reach O(1e3..1e4) in res4 / res5.  The layers whose
+    operands leave their form's range re-route (and only move wider), the passes settle, the second settled pass re-routes nothing,
+    and the re-routed trunk agrees with the CPU oracle (fp32) on the same weights to the usual conv tolerance."""
+    from lvc_amd import kernels as K
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+
+    model = build_model(base_rcnn_fpn()).eval()
+    syn.msra_checkpoint_rehearsal_(model)
+    bn = model.backbone.bottom_up.res4[0].conv1.norm
+    assert float(bn.running_mean.abs().max()) == 0.0 and abs(float(bn.running_var[0]) - 1.0) < 1e-6     # supplied by the loader
+    inputs = [{"image": syn.synthetic_image(1), "height": 800, "width": 1333}]
+    epoch0 = K.RANGE_EPOCH
+    with torch.no_grad():
+        model(inputs)                  # re-routes internally (run_with_fallbacks) until the pass is clean
+        tiers = _tiers(model)
+        epoch1 = K.RANGE_EPOCH
+        model(inputs)
+    assert K.RANGE_EPOCH == epoch1 and _tiers(model) == tiers, "a settled model must not move again"
+    trunk = {n: t for n, t in tiers.items() if n.startswith("backbone.bottom_up")}
+    print("re-routed: %d layers (%d of the trunk) in %d re-routing passes: %s" % (len(tiers), len(trunk), epoch1 - epoch0, tiers))
+    assert trunk, "MSRA-scale activations must push some trunk layer beyond |a| <= 4094"
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        images = model.preprocess_image(inputs)
+        feats = model.backbone.bottom_up(images.tensor)
+        imgs, _ = orc.preprocess([inputs[0]["image"]], orc.RCNNSpec().pixel_mean, orc.RCNNSpec().pixel_std, 32)
+        ref = orc.resnet(sd, imgs, 50)
+    for name in ("res2", "res3", "res4", "res5"):
+        scale = float(ref[name].abs().max())
+        err = float((feats[name].cpu() - ref[name]).abs().max()) / scale
+        print("   %s: scale %.3g, max |hip - oracle| / scale %.2e" % (name, scale, err))
+        assert err <= 1e-4, (name, err)
+    K.check_conv_error_word(torch.device("cuda:0"))
