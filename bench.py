@@ -990,7 +990,7 @@ def infer_main(c, args):
     if c.rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         ob, osc, ocl, cnt = out[0].cpu(), out[1].cpu(), out[2].cpu(), n_det
         gpu_dets = [(ob[i, :cnt[i]], osc[i, :cnt[i]], ocl[i, :cnt[i]].long()) for i in range(BATCH_PER_GPU)]
-        cpu_baseline, parity = _cpu_baseline(model, imgs, gpu_dets)
+        cpu_baseline, parity = _cpu_baseline(model, imgs, gpu_dets, _gpu_proposals(model, batch))
 
     if c.rank == 0:
         line = {
@@ -1282,7 +1282,21 @@ def range_rehearsal(c, steps, warmup):
     return res
 
 
-def _cpu_baseline(model, imgs, gpu_dets):
+def _gpu_proposals(model, batch):
+    """The proposal stage's output for `batch` (what inference_batched hands to the heads), per image [n,4] on the CPU."""
+    import torch
+
+    with torch.no_grad():
+        images = model.preprocess_image(batch)
+        sizes_dev = model._dev_const(images.image_sizes, torch.int32)
+        N, _, Hp, Wp = images.tensor.shape
+        x4 = images.tensor.as_strided((N, Hp, Wp, 4), (Hp * Wp * 4, Wp * 4, 4, 1), images.tensor.storage_offset())
+        pb, _pl, pc = model.proposal_generator.predict_proposals_batched(model.backbone.forward_nhwc(x4), sizes_dev)
+    pc = pc.tolist()
+    return [pb[i, : pc[i]].cpu() for i in range(len(pc))]
+
+
+def _cpu_baseline(model, imgs, gpu_dets, gpu_props=None):
     """the CPU restatement (oracle/) on this host, 5 warm-up + 20 timed single-image forwards
     (bounded to ~60 s of CPU time: fewer timed iterations are taken, and reported, on a slower host).  The forwards cycle
     through the images of the TIMED GPU batch and their detections are kept: `timed_batch_parity` compares them with what the
@@ -1319,11 +1333,15 @@ def _cpu_baseline(model, imgs, gpu_dets):
     with torch.no_grad():
         t2 = time.perf_counter()
         nz_imgs = sorted(ref)[:2]
-        nz = onoise.fp32_vs_fp64(sd, spec, [cpu_in[i][0] for i in nz_imgs], res32=[ref[i] for i in nz_imgs])
+        props32 = None
+        if gpu_props is not None:      # the fp32 oracle's proposals on the noise images (one more fp32 pass each: outside the timed loop)
+            props32 = [orc.generalized_rcnn_inference(sd, spec, cpu_in[i], return_intermediates=True)[1]["proposals"][0][0] for i in nz_imgs]
+        nz = onoise.fp32_vs_fp64(sd, spec, [cpu_in[i][0] for i in nz_imgs], res32=[ref[i] for i in nz_imgs], props32=props32)
         nz_s = time.perf_counter() - t2
     dev = onoise.deviation([gpu_dets[i] for i in sorted(ref)], [(ref[i]["pred_boxes"], ref[i]["scores"], ref[i]["pred_classes"]) for i in sorted(ref)])
     dev_same = onoise.deviation([gpu_dets[i] for i in nz_imgs], [(ref[i]["pred_boxes"], ref[i]["scores"], ref[i]["pred_classes"]) for i in nz_imgs])
-    gate_ok, bars, gate_msg = onoise.gate(dev, nz, dev_same=dev_same)
+    prop_dev = onoise.proposal_deviation([gpu_props[i] for i in nz_imgs], props32) if props32 is not None else None
+    gate_ok, bars, gate_msg = onoise.gate(dev, nz, dev_same=dev_same, prop_dev=prop_dev)
     # parity of the timed batch: every image the oracle saw
     tot = loose = tight = 0
     wb = ws = 0.0
@@ -1343,10 +1361,13 @@ def _cpu_baseline(model, imgs, gpu_dets):
                                                   images=nz_imgs, seconds=round(nz_s, 1)),
               "bars": {k: round(v, 6) for k, v in bars.items()}, "gate": gate_msg, "gate_ok": bool(gate_ok),
               "deviation_on_the_noise_images": {k: (round(v, 6) if isinstance(v, float) else v) for k, v in dev_same.items()},
+              "proposal_stage_on_the_noise_images": prop_dev,
               "pass_bar": "every bar is measured in this run on the CPU path itself (oracle/noise.py; `bars`): equal counts; matched_fraction >= the fraction "
                           "the CPU path finds of its OWN fp64 detections - %g (identity); median / p90 of the matched |box|, |score| differences <= %g x its "
-                          "fp32-vs-fp64 noise; the largest matched difference on the noise images <= %g x its largest; else the run exits non-zero"
-                          % (onoise.IDENT_MARGIN, onoise.K_NOISE, onoise.K_MAX),
+                          "fp32-vs-fp64 noise; the largest matched difference on the noise images <= %g x its largest; one stage earlier, the fraction of "
+                          "the CPU path's PROPOSALS found within 0.1 px >= its own fp32-vs-fp64 fraction - %g and the proposal counts no further apart than "
+                          "2 x its own + 2; else the run exits non-zero"
+                          % (onoise.IDENT_MARGIN, onoise.K_NOISE, onoise.K_MAX, onoise.IDENT_MARGIN),
               "oracle_pinning": "oracle/rcnn.py is pinned against the imported reference's outputs (tests/golden, tests/test_oracle_golden.py) -- except "
                                 "torchvision's NMS (absent from the reference tree; independent witness: the reference's rotated-NMS kernel) and the DINO "
                                 "ViT of the descriptor leg (weights are network-only): those two oracles are unpinned",

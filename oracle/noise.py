@@ -62,7 +62,22 @@ def _dets(results):
     return [(r["pred_boxes"], r["scores"], r["pred_classes"]) for r in results]
 
 
-def fp32_vs_fp64(sd, spec, inputs, res32=None, box_tol=LOOSE_BOX, score_tol=LOOSE_SCORE, derive_identity=False):
+def proposal_deviation(props_a, props_b, tol=LOOSE_BOX):
+    """props_*: per image [n,4] proposal boxes (find_top_rpn_proposals' output).  -> the fraction of b's boxes that a holds within
+    `tol` px, and the largest per-image difference of the counts: what the stage BEFORE the heads hands over (a few percent of the
+    proposals lost barely move the 100 final detections of a full-size image, so the detections alone do not see it)."""
+    found = total = 0
+    dcount = 0
+    for a, b in zip(props_a, props_b):
+        dcount = max(dcount, abs(len(a) - len(b)))
+        total += len(b)
+        if len(a) and len(b):
+            d = (b.double()[:, None, :] - a.double()[None, :, :]).abs().max(dim=2)[0].min(dim=1)[0]
+            found += int((d <= tol).sum())
+    return {"proposals": total, "found_fraction": found / max(1, total), "count_diff_max": dcount}
+
+
+def fp32_vs_fp64(sd, spec, inputs, res32=None, box_tol=LOOSE_BOX, score_tol=LOOSE_SCORE, derive_identity=False, props32=None):
     """The oracle in fp32 (or `res32`, its precomputed fp32 results) against the oracle in fp64 on `inputs`.
     derive_identity: the identity bars are not given but MEASURED -- IDENT_K x the medians of a first matching with generous bars
     (never below LOOSE_*); returned as `box_tol` / `score_tol` of the result.  For weights whose noise floor is not R50's (R101)."""
@@ -72,17 +87,24 @@ def fp32_vs_fp64(sd, spec, inputs, res32=None, box_tol=LOOSE_BOX, score_tol=LOOS
         if res32 is None:
             res32 = orc.generalized_rcnn_inference(sd, spec, inputs)
         sd64 = {k: v.double() for k, v in sd.items()}      # the oracle computes in the state_dict's dtype
-        res64 = orc.generalized_rcnn_inference(sd64, spec, inputs)
+        if props32 is not None:      # per image [n,4]: the fp32 run's proposals -> the same statistics one stage earlier
+            res64, mid64 = orc.generalized_rcnn_inference(sd64, spec, inputs, return_intermediates=True)
+            props64 = [p[0] for p in mid64["proposals"]]
+            del mid64
+        else:
+            res64 = orc.generalized_rcnn_inference(sd64, spec, inputs)
     if derive_identity:
         wide = deviation(_dets(res32), _dets(res64), WIDE_BOX, WIDE_SCORE)
         box_tol = max(LOOSE_BOX, IDENT_K * wide["box_median"])
         score_tol = max(LOOSE_SCORE, IDENT_K * wide["score_median"])
     out = deviation(_dets(res32), _dets(res64), box_tol, score_tol)
     out["box_tol"], out["score_tol"] = box_tol, score_tol
+    if props32 is not None:
+        out["proposal_stage"] = proposal_deviation(props32, props64)
     return out
 
 
-def gate(dev, noise, k=K_NOISE, dev_same=None):
+def gate(dev, noise, k=K_NOISE, dev_same=None, prop_dev=None):
     """dev = deviation(hip, reference fp32), noise = fp32_vs_fp64 on the same (or representative) inputs; dev_same: the deviation
     restricted to the images the noise was measured on (default: dev) -- the extremes of two samples compare only at equal size.
     -> (ok, bars, message).  Identity: equal counts, and the fraction of the reference's detections found within the identity bars
@@ -108,4 +130,14 @@ def gate(dev, noise, k=K_NOISE, dev_same=None):
         if val > bar:
             mult = K_MAX if key.endswith("_max") else k
             bad.append("%s %.2e > %.2e (= %.0f x the reference path's own fp32-vs-fp64 %s %.2e)" % (key, val, bar, mult, key, noise[key]))
+    if prop_dev is not None and "proposal_stage" in noise:
+        # prop_dev = proposal_deviation(hip proposals, reference fp32 proposals) on the images the noise was measured on
+        pn = noise["proposal_stage"]
+        bars["proposals_found_fraction"] = pn["found_fraction"] - IDENT_MARGIN
+        bars["proposals_count_diff_max"] = 2 * pn["count_diff_max"] + 2
+        if prop_dev["found_fraction"] < bars["proposals_found_fraction"]:
+            bad.append("only %.1f %% of the reference's proposals found within %.2g px (the reference path finds %.1f %% of its own fp64 proposals)"
+                       % (100 * prop_dev["found_fraction"], LOOSE_BOX, 100 * pn["found_fraction"]))
+        if prop_dev["count_diff_max"] > bars["proposals_count_diff_max"]:
+            bad.append("proposal counts differ by %d (the reference path's fp32 and fp64 runs: by %d)" % (prop_dev["count_diff_max"], pn["count_diff_max"]))
     return not bad, bars, "; ".join(bad) if bad else "ok"
