@@ -150,7 +150,6 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fi = lane & 31, fh = lane >> 5;
-  const bool late = wave >= BN_NW / 2;      // the second wave of a SIMD: see the software pipelines of phases 1 and 3
 
   // this workgroup's tiles: XCD k (= blockIdx % 8) owns a contiguous range of the row-major tile order, its workgroups walk it
   // together, so that the tiles in flight on one L2 are neighbours (shared halo rows)
@@ -241,9 +240,11 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     for (int i = 0; i < BN_STAGGER * ph; ++i) __builtin_amdgcn_s_sleep(127);
   }
 #endif
-  // two copies of the tile loop: the second wave of every SIMD runs the software-pipelined phases' halves in the opposite order
-  auto tiles = [&](auto late_) {
-  constexpr bool LATE = decltype(late_)::value;
+  // two copies of the tile loop: waves with two groups of halo pixels in phase 1 (11 groups over 8 waves) and waves with one -- no
+  // branches inside a stage, so that its MFMAs and its vector work are ONE scheduling region
+  auto tiles = [&](auto g2_) {
+  constexpr bool G2 = decltype(g2_)::value;      // this wave has a second group of halo pixels in phase 1
+  constexpr bool LATE = false;
   // x offsets (row order) of a tile's halo pixels for this lane; tile < 0: none (loads return zeros)
   unsigned xo[2][4];
   f32x4 xr[2][2][4];                      // [chunk % 2][group][instruction]: row order
@@ -305,7 +306,6 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         hl[gi] = h;
       }
     }
-    const bool g1 = wave < BN_NG1 - BN_NW;      // this wave's second group exists
     f32x16 acc1[2][2];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
           for (int pl = 0; pl < 2; ++pl) wf[cb][pl] = *reinterpret_cast<const f16x8*>(S + (((sp * 2 + cb) * 2 + pl) << 10));
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi)
-          if (gi == 0 || g1) {
+          if (gi == 0 || G2) {
 #pragma unroll
 #ifdef BN_DIAG_NOMFMA1
             for (int cb = 0; cb < 2; ++cb) { asm volatile("" : "+v"(acc1[gi][cb]) : "v"(wf[cb][0]), "v"(wf[cb][1]), "v"(zh[par][gi][sp]), "v"(zl[par][gi][sp])); }
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       // ways; the registers are free once the writes are issued and take the chunk two stages ahead
 #pragma unroll
       for (int gi = 0; gi < 2; ++gi)
-        if (gi == 0 || g1) {
+        if (gi == 0 || G2) {
 #pragma unroll
 #ifdef BN_DIAG_NOSCR
           for (int i = 0; i < 4; ++i) xbk[gi][i] = xr[XS][gi][i];
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       auto prep = [&]() {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-          if (gi == 0 || g1) {
+          if (gi == 0 || G2) {
             f32x4 xb[4];      // lane (pixel fi, half fh): runs 2 k + fh, k = 0..3 = k16 step k / 2, its first / second four channels
 #pragma unroll
 #ifdef BN_DIAG_NOSCR
@@ -393,6 +393,17 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
           }
         }
       };
+#ifdef BN_INTERLEAVE      // experiment: one instruction stream, the conversion's vector work between the MFMAs (scripts/probe_bneck_variants.sh)
+      if (c > 0) mfma1(XS ^ 1, Sp);
+      prep();
+      if (c > 0) {
+#pragma unroll
+        for (int i = 0; i < (G2 ? 24 : 12); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, BN_INTERLEAVE, 0);
+        }
+      }
+#else
       if (LATE) {
         prep();
         __builtin_amdgcn_sched_barrier(0);
@@ -402,6 +413,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         prep();
       }
+#endif
       Sp = S;
     });
     mfma1((NS1 - 1) & 1, Sp);
@@ -409,7 +421,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
     __builtin_amdgcn_s_barrier();      // the scratch of every wave lies inside t1
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
-      if ((gi == 0 || g1) && hl[gi] < BN_HPIX) {
+      if ((gi == 0 || G2) && hl[gi] < BN_HPIX) {
         unsigned char* dst = t1s + fh * BN_T1_SUB + hl[gi] * 16;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -627,7 +639,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
 #endif
   }
   };
-  if (late) tiles(std::true_type{}); else tiles(std::false_type{});
+  if (wave < BN_NG1 - BN_NW) tiles(std::true_type{}); else tiles(std::false_type{});
   wait_vm<0>();
   if (!(big <= ACT_MAX)) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);
 }
