@@ -216,6 +216,8 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
   // register + immediates -- left to itself the compiler kept every table address in a register of its own and spilled them
   const float* tabl = tab_s1 + 4 * fh;
   asm volatile("" : "+v"(tabl));
+  const float* tabr = tab_s1 + 4 * (lane & 7);      // the same for the row-order epilogue of phase 3 (channel run lane % 8 of a block)
+  asm volatile("" : "+v"(tabr));
   constexpr int TS1 = 0, TT1 = 64, TS2 = 128, TT2 = 192, TS3 = 256, TT3 = 512;
   // phase 2's per-lane base inside t1: (row wave, column fi) of the halo tile, k half fh
   const unsigned char* const zb = t1s + fh * BN_T1_SUB + (wave * BN_HW + fi) * 16;
@@ -365,6 +367,9 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         }
       asm volatile("" ::: "memory");
       if (c + 2 < NS1) load_x(XS, c + 2);
+#ifdef BN_DIAG_PF0      // experiment: expose the load latency of every stage (how long is it under the kernel's own traffic?)
+      wait_vm<0>();
+#endif
       // the two waves of a SIMD (w, w + 4) take the halves in opposite order: one's MFMAs run under the other's vector and LDS work
       auto prep = [&]() {
 #pragma unroll
@@ -560,22 +565,23 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       asm volatile("" :: "v"(acc3[j & 1]), "v"(rb[RS][0]), "v"(rb[RS][1]), "v"(rb[RS][2]), "v"(rb[RS][3]));
       return;
 #endif
-      // FrozenBN in the accumulator layout, through the wave's scratch into row order, there + residual, ReLU, full-line stores
+      // the accumulators through the wave's scratch into row order; there FrozenBN (a lane's four channels are the same in all four
+      // instructions: two table reads a stage instead of eight in the accumulator layout), + residual, ReLU, full-line stores
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(tabl + TS3 + 32 * j + 8 * i);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(tabl + TT3 + 32 * j + 8 * i);
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc3[j & 1][4 * i + e] * sc[e] + sh[e];
+        for (int e = 0; e < 4; ++e) v[e] = acc3[j & 1][4 * i + e];
         *reinterpret_cast<f32x4*>(scr + sr(i)) = v;
       }
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(tabr + TS3 + 32 * j);
+      const f32x4 sh = *reinterpret_cast<const f32x4*>(tabr + TT3 + 32 * j);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = *reinterpret_cast<const f32x4*>(scr + sw(i));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          float o = v[e];
+          float o = v[e] * sc[e] + sh[e];
           if (!PROJ) o += rb[RS][i][e];
           v[e] = fmaxf(o, 0.f);
         }

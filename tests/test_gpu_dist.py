@@ -109,7 +109,7 @@ def test_bench_gpus_8_rehearsal_on_this_box():
     # the line explains itself: who ran where, what the host spent per rank, how much of the gradient exchange was hidden
     dm = line["rccl"]["device_map"]
     assert [d["rank"] for d in dm] == list(range(8)) and all(d["pid"] > 0 and d["device_name"] for d in dm) and len({d["pid"] for d in dm}) == 8
-    assert len(line["per_rank"]["host_cpu_us_per_step"]) == 8 and all(h > 0 for h in line["per_rank"]["host_cpu_us_per_step"])
+    assert len(line["per_rank"]["host_enqueue_us_per_step"]) == 8 and all(h > 0 for h in line["per_rank"]["host_enqueue_us_per_step"])
     ex = legs["train_cfg3"]["gradient_exchange"]["per_rank"]
     assert len(ex) == 8 and all(set(e) == {"exposed_ms", "alone_ms", "hidden_ms"} and e["alone_ms"] > 0 for e in ex)
     assert len(legs["train_cfg3"]["per_rank_img_per_s"]) == 8
