@@ -9,19 +9,24 @@
 // block at batch 8 of 800x1333 on layers that already run at the rate of a copy.  Here a block reads x once (plus the halo ring of
 // its tiles, served by L2 / the memory-side cache) and writes y once: 1.1 GB.
 //
-// Work decomposition.  A workgroup (4 waves) owns an output tile of TH x 32 pixels of one image (TH = 4 at 64 mid channels, 2 at
-// 128: the tile's t1 planes must leave room for TWO workgroups per CU, so that one tile's 3x3 phase, which touches no HBM, runs
-// under the other's loads and stores).  Everything is computed TRANSPOSED as in conv_pw_chain.hip: out^T [channels x pixels] =
-// W [channels x k] . act^T [k x pixels]; the MFMA's A operand is a weight fragment from LDS, its B operand the activations, an
-// accumulator lane owns ONE pixel (lane % 32) and sixteen channels of a 32-channel block (c = 8 i + 4 (lane / 32) + {0..3}).
-//   phase 1 (conv1): a wave takes groups of 32 halo pixels; x goes from HBM straight into the B-operand layout (two dwordx4 per k16
-//     step and lane), is split in registers, contracted against W1 streamed through the LDS ring in 32-channel chunks; the epilogue
-//     (FrozenBN, ReLU, zero outside the image = conv2's padding, x 2^4, fp16 split) writes t1 into LDS as
-//     [k16 step][plane][k half][halo pixel][16 B]: conflict-free for these writes and for phase 2's tap-shifted reads.
-//   phase 2 (conv2): a wave owns one output row (two at TH = 2 ... see below) for ALL mid channels; per ring stage = (k16 step, dx)
-//     it reads the three t1 rows at that column shift and the 3 dy x {channel blocks} x 2 planes weight fragments.
-//   phase 3 (conv3): per ring stage = 32 output channels; B operand = t2 from the wave's own registers; the residual is read in the
-//     accumulator layout (the rows were fetched by phase 1 moments ago: L2 / memory-side cache hits) and y is stored from it.
+// Work decomposition.  A workgroup of 8 waves owns an output tile of 8 x 32 pixels of one image, ONE workgroup per CU (the first form
+// -- 4 waves on 4 x 32 tiles, two workgroups per CU -- streamed twice the weight bytes per pixel through LDS-DMA, ~8 B/clk/CU, and its
+// two workgroups walked the phases in lockstep: profiles/README.md).  Everything is computed TRANSPOSED as in conv_pw_chain.hip:
+// out^T [channels x pixels] = W [channels x k] . act^T [k x pixels]; the MFMA's A operand is a weight fragment from LDS, its B operand
+// the activations, an accumulator lane owns ONE pixel (lane % 32) and sixteen channels of a 32-channel block (c = 8 i + 4 (lane / 32)
+// + {0..3}).
+//   phase 1 (conv1): the 340 halo pixels are 11 groups of 32 over the 8 waves (three waves take two: the tile loop exists in two
+//     copies, by group count, so that a stage is one scheduling region).  x is fetched in ROW order (8 lanes per 128 B line; lane =
+//     pixel cost 64 tag look-ups per instruction), 32 channels a stage two stages ahead, goes through a per-wave LDS scratch into the
+//     B-operand layout, is split in registers and contracted against W1 from the ring; the stage's MFMAs are issued one stage late,
+//     under the next chunk's conversion.  Epilogue (FrozenBN, ReLU, zero outside the image = conv2's padding, x 2^4, fp16 split):
+//     t1 into LDS as [k16 step][plane][k half][halo pixel][16 B] -- conflict-free for these writes and phase 2's tap-shifted reads.
+//   phase 2 (conv2): a wave owns one output row for all 64 mid channels; a ring stage = two of the 36 (k16 step, tap) pairs; under it
+//     the next tile's first two x chunks are fetched.
+//   phase 3 (conv3): a ring stage = 32 output channels; B operand = t2 from the wave's own registers; the accumulators go through
+//     the wave's scratch into row order, there FrozenBN, + residual (x rows again: L2 / memory-side cache) and ReLU, full-line stores;
+//     a block's epilogue runs under the next block's MFMAs.
+// The weights of all three layers come through ONE ring of 8 x 8 KB slots, six stages ahead; wait counts from a compile-time table.
 // All weights come as ONE pre-swizzled image (lvc_amd.kernels.pack_bottleneck): a sequence of stages, each a sequence of 1 KB
 // fragments in lane order (lane l: row l % 32, k half l / 32, 8 fp16), so a stage is a straight LDS-DMA copy and a fragment read is
 // conflict-free; the contraction index is permuted within every 16 (0-3, 8-11, 4-7, 12-15) as in conv_pw_chain.hip.
