@@ -426,12 +426,13 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
 #endif
       Sp = S;
     });
-    mfma1((NS1 - 1) & 1, Sp);
+    __builtin_amdgcn_s_barrier();      // the scratch of every wave lies inside t1: nobody writes t1 before everybody has read its last chunk
+    mfma1((NS1 - 1) & 1, Sp);          // (behind the barrier: the last chunk's MFMAs and the epilogue's vector work are one region)
     // epilogue of phase 1: FrozenBN + ReLU, zero outside the image (conv2's padding), split, into LDS
-    __builtin_amdgcn_s_barrier();      // the scratch of every wave lies inside t1
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
-      if ((gi == 0 || G2) && hl[gi] < BN_HPIX) {
+      if (gi == 0 || G2) {
+        const bool live = hl[gi] < BN_HPIX;      // only the stores are predicated (the group's tail lanes have no halo pixel)
         unsigned char* dst = t1s + fh * BN_T1_SUB + hl[gi] * 16;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -456,8 +457,10 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
 #pragma unroll
           for (int sp = 0; sp < 2; ++sp) {
             const int s = 2 * cb + sp;
-            *reinterpret_cast<f16x8*>(dst + ((s * 2 + 0) * 2) * BN_T1_SUB) = yh[sp];
-            *reinterpret_cast<f16x8*>(dst + ((s * 2 + 1) * 2) * BN_T1_SUB) = yl[sp];
+            if (live) {
+              *reinterpret_cast<f16x8*>(dst + ((s * 2 + 0) * 2) * BN_T1_SUB) = yh[sp];
+              *reinterpret_cast<f16x8*>(dst + ((s * 2 + 1) * 2) * BN_T1_SUB) = yl[sp];
+            }
           }
         }
       }
@@ -537,8 +540,9 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       }
 #endif
     });
-    // epilogue of phase 2: the split accumulators are phase 3's B operand
+    // epilogue of phase 2: the split accumulators are phase 3's B operand (run behind phase 3's first stage top: one region with its MFMAs)
     f16x8 t2h[4], t2l[4];
+    auto epi2 = [&]() {
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -558,6 +562,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         track_abs(big, v[0], v[1]);
         track_abs(big, v[2], v[3]);
       }
+    };
 
     // ---------------------------------------------------------------- phase 3: y = relu(bn3(W3 t2) + shortcut), 32 channels a stage
     // software pipeline: a stage issues its block's MFMAs and, under them, the epilogue of the block the previous stage completed
@@ -600,6 +605,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
       // previous stage's DMA piece and block j's rows.  Otherwise the weights only (six stages back).
       constexpr int NW = PROJ ? (st == 0 ? 1 : BN_NSLOT - 3) : j == 0 ? BN_NSLOT - 3 + pl_sum(ts) : 5;
       const unsigned char* S = stage_top(std::integral_constant<int, NW>{}, ts);
+      if (st == 0) epi2();
       if (PROJ) {
         if (st == 0) {
 #pragma unroll
