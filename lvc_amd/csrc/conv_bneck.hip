@@ -530,11 +530,19 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         const int u = 2 * q + e;
         const int s = u / 9, tp = u % 9, dy = tp / 3, dx = tp % 3;
         const f16x8 zh = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 0) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
+#ifdef BN_DIAG_HALFZ      // timing only: half of phase 2's activation reads
+        const f16x8 zl = zh;
+#else
         const f16x8 zl = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 1) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
+#endif
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
           const f16x8 wh = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 0) << 10));
+#ifdef BN_DIAG_HALFW      // timing only (wrong results): half of phase 2's weight-fragment reads
+          const f16x8 wl = wh;
+#else
           const f16x8 wl = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 1) << 10));
+#endif
           MFMA3(acc2[cb], wh, wl, zh, zl);
         }
       }
