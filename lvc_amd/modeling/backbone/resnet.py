@@ -99,7 +99,7 @@ class BottleneckBlock(CNNBlockBase):
         4x-wide block output is written once and never read back by conv1.  Returns the packed pair, or None when the pair is
         outside that kernel's range (gradient passes, a strided conv1, channel counts it has no instance for, a layer that must
         keep two accumulators, the range-free split)."""
-        if nxt is not None and nxt.fused() is not None:
+        if nxt is not None and nxt.fused_eligible():
             return None     # the next block is one launch of its own: it reads this block's output, not a conv1 result
         if not (K.CHAIN and K.CONV_ENGINE == "bf16x3" and K.CONV_SPLIT == "f16x2" and K.PW_S1 == 2 and nxt is not None
                 and self._grad_free() and nxt._grad_free() and nxt.conv1.stride == 1 and self.conv2.stride == 1
@@ -118,27 +118,36 @@ class BottleneckBlock(CNNBlockBase):
         pb = nxt.conv1.packed()
         return self._cache_chain.get([pa.w, pa.scale, pa.shift, pb.w, pb.scale, pb.shift], lambda: K.pack_chain(pa, pb, self._chain_state))
 
+    def fused_eligible(self):
+        """The cheap half of `fused`: everything but the packing (flags, shapes, gradient-free pass, range state).  `ResNet.forward_nhwc`
+        decides with it whether the stem writes a second copy of its output BEFORE the stem is launched -- at the top of a step the GPU
+        queue is empty and every host microsecond in front of the first launches is exposed."""
+        if not (K.BNECK and K.CONV_ENGINE == "bf16x3" and K.CONV_SPLIT == "f16x2" and self.conv1.stride == 1 and self.conv2.stride == 1
+                and self.conv2.out_channels == 64):
+            return False
+        proj = self.shortcut is not None
+        if (self.in_channels, self.conv2.in_channels, self.out_channels, proj) not in K.BNECK_SHAPES:
+            return False
+        if getattr(self, "_bneck_state", None) is not None and self._bneck_state["off"]:
+            return False     # an operand left the kernel's range once (|a| > 4094): the block's layers run on their own tiers from then on
+        if not self._grad_free():
+            return False
+        if proj and (self.shortcut.stride != 1 or not self.can_fuse_projection()):
+            return False
+        layers = (self.conv1, self.conv2, self.conv3, self.shortcut) if proj else (self.conv1, self.conv2, self.conv3)
+        return not any(l.norm is None or getattr(l, "two_acc", False) or l._range_state["tier"] for l in layers)
+
     def fused(self):
         """The whole block as ONE launch (csrc/conv_bneck.hip: conv1's output in LDS, conv2's in registers) -- the packed weights, or None
         when the block is outside that kernel's range: gradient passes, strides, channel counts other than res2's (64 mid / 256 out,
         256 in with the identity shortcut or 64 in with a stride-1 projection), a layer off the one-accumulator tier, `K.BNECK` off."""
-        if not (K.BNECK and K.CONV_ENGINE == "bf16x3" and K.CONV_SPLIT == "f16x2" and self._grad_free()
-                and self.conv1.stride == 1 and self.conv2.stride == 1):
+        if not self.fused_eligible():
             return None
         proj = self.shortcut is not None
-        if (self.in_channels, self.conv2.in_channels, self.out_channels, proj) not in K.BNECK_SHAPES or self.conv2.out_channels != 64:
-            return None
-        if proj and (self.shortcut.stride != 1 or not self.can_fuse_projection()):
-            return None
-        layers = [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if proj else [])
-        if any(l.norm is None or getattr(l, "two_acc", False) or l._range_state["tier"] for l in layers):
-            return None
         if not hasattr(self, "_cache_bneck"):
             from ...layers.wrappers import _PackedCache
             self._cache_bneck = _PackedCache()
             self._bneck_state = {"off": False}
-        if self._bneck_state["off"]:
-            return None     # an operand left the kernel's range once (|a| > 4094): the block's layers run on their own tiers from then on
         p1, p2 = self.conv1.packed(), self.conv2.packed()
         p3 = self._fused_projection() if proj else self.conv3.packed()
         return self._cache_bneck.get([p1.w, p1.scale, p1.shift, p2.w, p2.scale, p2.shift, p3.w, p3.scale, p3.shift],
@@ -251,7 +260,7 @@ class ResNet(Backbone):
         first = self.stages_and_names[0][0][0] if self.stages_and_names else None
         concat = []
         if (isinstance(first, BottleneckBlock) and first.shortcut is not None and first.shortcut.stride == 1 and first.can_fuse_projection()
-                and first.fused() is None):   # the stem writes into a concat buffer at ITS resolution: stride-1 projections only
+                and not first.fused_eligible()):   # the stem writes into a concat buffer at ITS resolution: stride-1 projections only
             # the stem writes its output a second time, into the tail channels of res2.0's [conv2 output | x] buffer
             def second(shape):
                 n, h, w, c = shape
