@@ -403,6 +403,61 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
           }
         }
       };
+#ifdef BN_HANDMIX
+      // ONE instruction stream, interleaved by hand and pinned: an MFMA, then a two-value slice of the next chunk's conversion in its shadow
+      // (left to the scheduler the stage is a block of MFMAs followed by a block of vector work: the wave stalls at every MFMA issue
+      // for the pipe and then runs the conversion with the pipe idle -- removing either block saved its full time).  Consecutive MFMAs
+      // alternate between the two channel blocks' accumulators.
+      {
+        constexpr int NGR = G2 ? 2 : 1;
+        constexpr int NM = c > 0 ? 12 * NGR : 0, NH = 8 * NGR;      // MFMAs / two-value slices of this stage
+        f32x4 xb[4];            // the scratch rows of the group being converted (group 1's replace group 0's at the stage's midpoint)
+        f16x8 wf[2][2];         // [channel block][plane] of the k16 step being multiplied (step 1's replace step 0's at the midpoint)
+        auto load_xb = [&](int gi) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xb[k] = *reinterpret_cast<const f32x4*>(scr + gi * 4096 + sr(k));
+        };
+        auto load_wf = [&](int sp) {
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wf[cb][pl] = *reinterpret_cast<const f16x8*>(Sp + (((sp * 2 + cb) * 2 + pl) << 10));
+        };
+        load_xb(0);
+        if (c > 0) load_wf(0);
+        auto slice = [&](auto h_) {      // slice h: group h / 8, register (h / 2) % 4, values 2 (h % 2) + {0, 1}
+          constexpr int h = decltype(h_)::value;
+          constexpr int gi = h / 8, k = (h / 2) % 4, e0 = 2 * (h % 2);
+          if (NGR == 2 && h == 8 && NM == 0) load_xb(1);
+          const float a = xb[k][e0], b2 = xb[k][e0 + 1];
+          const float u = a * ACT_SCALE, v = b2 * ACT_SCALE;
+          const f16 uh = (f16)u, vh = (f16)v;
+          constexpr int d0 = 4 * (k & 1) + e0;
+          zh[XS][gi][k >> 1][d0] = uh; zh[XS][gi][k >> 1][d0 + 1] = vh;
+          zl[XS][gi][k >> 1][d0] = (f16)(u - (float)uh); zl[XS][gi][k >> 1][d0 + 1] = (f16)(v - (float)vh);
+          track_abs(big, a, b2);
+        };
+        if constexpr (NM == 0) {
+          static_for<0, NH>([&](auto h_) { slice(h_); });
+        } else {
+          static_for<0, NM>([&](auto m_) {
+            constexpr int m = decltype(m_)::value;
+            // order: k16 step, group, then the triple's three products with the channel block alternating
+            constexpr int sp = m / (6 * NGR), r = m % (6 * NGR), gi = r / 6, t = (r % 6) / 2, cb = r % 2;
+            if (m == NM / 2) {      // the midpoint: every step-0 MFMA is issued (it read its operands), group 0 is converted
+              load_wf(1);
+              if (NGR == 2) load_xb(1);
+            }
+            const f16x8 wa = t == 1 ? wf[cb][1] : wf[cb][0];
+            const f16x8 zb2 = t == 0 ? zl[XS ^ 1][gi][sp] : zh[XS ^ 1][gi][sp];
+            acc1[gi][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa, zb2, acc1[gi][cb], 0, 0, 0);
+            constexpr int h0 = m * NH / NM, h1 = (m + 1) * NH / NM;
+            static_for<h0, h1>([&](auto h_) { slice(h_); });
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+      }
+#else
 #ifdef BN_INTERLEAVE      // experiment: one instruction stream, the conversion's vector work between the MFMAs (scripts/probe_bneck_variants.sh)
       if (c > 0) mfma1(XS ^ 1, Sp);
       prep();
@@ -423,6 +478,7 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         prep();
       }
+#endif
 #endif
       Sp = S;
     });
