@@ -591,16 +591,24 @@ __global__ __launch_bounds__(BN_NW * 64) void conv_bneck_kernel(BneckArgs p) {
 #else
         const f16x8 zl = *reinterpret_cast<const f16x8*>(zb + ((s * 2 + 1) * 2) * BN_T1_SUB + (dy * BN_HW + dx) * 16);
 #endif
+        f16x8 wh[2], wl[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const f16x8 wh = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 0) << 10));
+          wh[cb] = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 0) << 10));
 #ifdef BN_DIAG_HALFW      // timing only (wrong results): half of phase 2's weight-fragment reads
-          const f16x8 wl = wh;
+          wl[cb] = wh[cb];
 #else
-          const f16x8 wl = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 1) << 10));
+          wl[cb] = *reinterpret_cast<const f16x8*>(S + (((e * 2 + cb) * 2 + 1) << 10));
 #endif
-          MFMA3(acc2[cb], wh, wl, zh, zl);
         }
+        // the two channel blocks' accumulators alternate: no MFMA waits for the result of the one before it (each block's own
+        // order -- wh zl, wl zh, wh zh -- is unchanged: same sums)
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], zl, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[1], zl, acc2[1], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0], zh, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[1], zh, acc2[1], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0], zh, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[1], zh, acc2[1], 0, 0, 0);
       }
 #endif
     });
