@@ -195,7 +195,7 @@ int lvc_conv1x1_chain_nhwc_f16s1(const float* x, int ldx, const unsigned short* 
  * x [N][H][W][ldx] (cin channels used), y [N][H][W][ldy].  proj = 0: cin = 256, shortcut = x.  proj = 1: cin = 64, the projection
  * shortcut's weights are the last 64 contraction columns of the third layer.  w: stage images built by
  * lvc_amd.kernels.pack_bottleneck (row-scaled fp16 planes of lvc_split_weights_rowscaled in fragment order: (cin/32) x 8 KB,
- * 12 x 12 KB, 8 or 16 x 8 KB); s1/t1, s2/t2 (64 entries), s3/t3 (256): epilogue scales (x row factors) and shifts, never NULL.
+ * 18 x 8 KB, 8 or 16 x 8 KB: 34 or 36 stages of eight 1 KB fragments); s1/t1, s2/t2 (64 entries), s3/t3 (256): epilogue scales (x row factors) and shifts, never NULL.
  * |x|, |conv1 out| or |conv2 out| > 4094 (or non-finite) sets bit 1 / 2 of the launch's range word. */
 int lvc_bottleneck_nhwc_f16s1(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int cin, int proj,
                               const unsigned short* w, const float* s1, const float* t1, const float* s2, const float* t2,
