@@ -167,6 +167,17 @@ int lvc_conv1x1_nhwc_f16x2_pipe(const float* x, const unsigned short* w_split, c
 int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                            const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu,
                            int res_mode, int ldy, int ldr, void* workspace, void* stream);
+/* A bottleneck's conv2 -> conv3 hand-over without the consumer's operand split (round 6; reference resnet.py:200-212).
+ * lvc_conv3x3_nhwc_f16s1_presplit = lvc_conv3x3_nhwc_f16s1 with ReLU and no residual whose output y [N,H,W,K] (K % 32 == 0; same bytes as
+ * the fp32 tensor) holds, per pixel and 32-channel chunk, the 32 hi halves then the 32 lo halves of the two-way fp16 split of the result
+ * x 2^4 -- the planes lvc_conv1x1_nhwc_f16s1's own split would form; a value beyond |a| <= 4094 raises range word `next_slot` (the
+ * consumer's).  lvc_conv1x1_nhwc_f16s1_presplit = lvc_conv1x1_nhwc_f16s1 (stride 1, K > 64) reading such planes: the same products in
+ * the same order, results bit-identical to the fp32 hand-over. */
+int lvc_conv3x3_nhwc_f16s1_presplit(const float* x, const unsigned short* w_split, const float* scale, const float* shift, void* y,
+                                    int N, int H, int W, int C, int K, int Kg, int next_slot, void* workspace, void* stream);
+int lvc_conv1x1_nhwc_f16s1_presplit(const void* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                    const float* residual, float* y, int N, int H, int W, int C, int K, int relu,
+                                    int res_mode, int ldy, int ldr, void* workspace, void* stream);
 /* _f16s1_w2 (round 5, csrc/conv_pw_w2.hip): the single-accumulator form on a 256-row x 256-channel workgroup tile (wave tile 64 x
  * 128, 16-deep stages) for layers with >= 256 input and output channels -- res4 / res5 conv1 and conv3, the FPN laterals
  * (detectron2/modeling/backbone/fpn.py:128-140), box-head fc1 / fc2: 0.67 x the operand bytes per MFMA of the 256 x 128 tile.  Same

@@ -54,6 +54,8 @@ struct HaloArgsS {
   float* partials;
   int* flags;
   int N, H, W, C, K, relu, res_mode, ldy, ldr;
+  int next_err_index;        // presplit: the consumer's range word (a value beyond its |a| <= 4094 is raised THERE, as its own split would)
+  int presplit;              // 1: y is written as the fp16 planes its ONE consumer multiplies (see lvc_conv3x3_nhwc_f16s1_presplit)
   int PH, PW, HW, HP, MP;
   int inv_pw;                // ceil(2^16 / PW): (r * inv_pw) >> 16 == r / PW for the tile rows r < 256
   int tiles_x, tiles_y, tiles_n, nk, total_units, units_per_worker, nworkers, err_index;
@@ -675,9 +677,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
       // one copy of the loop per (residual mode, ReLU): with the modes tested inside, every iteration ended in the compiler's
       // vmcnt(0) lgkmcnt(0) -- the LDS read of a row and the acknowledgement of the previous row's store, one after the other,
       // sixteen times per tile (the "output rows" share of scripts/probe_halo_timeline.py)
-      auto rows = [&](auto rm_tag, auto relu_tag) {
+      float bigq = 0.f;      // presplit: the largest value handed to the consumer
+      auto rows = [&](auto rm_tag, auto relu_tag, auto ps_tag) {
         constexpr int RM = decltype(rm_tag)::value;
         constexpr bool RELU = decltype(relu_tag)::value;
+        constexpr bool PS = decltype(ps_tag)::value;
 #pragma unroll 4
         for (int it = 0; it < HM / RPI; ++it) {
           const int r = it * RPI + rsub;
@@ -697,14 +701,37 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_halo_s1_kernel(HaloArgsS p) {
               v[0] = v[0] > 0.f ? v[0] : 0.f; v[1] = v[1] > 0.f ? v[1] : 0.f;
               v[2] = v[2] > 0.f ? v[2] : 0.f; v[3] = v[3] > 0.f ? v[3] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(ybase + (size_t)pix * p.ldy) = v;
+            if (PS) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bigq = (v[e] > bigq || v[e] != v[e]) ? v[e] : bigq;
+              // the row's 32-channel chunk as [32 hi halves | 32 lo halves] (128 B, where the fp32 values would lie): exactly the
+              // planes the consumer's own split would form (x 2^4, hi = fp16, lo = fp16 of the remainder) -- it skips the split
+              typedef _Float16 f16x4s __attribute__((ext_vector_type(4)));
+              f16x4s h, l;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float a = v[e] * ACT_SCALE;
+                const f16 hh = (f16)a;
+                h[e] = hh;
+                l[e] = (f16)(a - (float)hh);
+              }
+              char* yc = reinterpret_cast<char*>(yl + (origin + pix) * p.ldy + (col & ~31)) + (col & 31) * 2;
+              *reinterpret_cast<f16x4s*>(yc) = h;
+              *reinterpret_cast<f16x4s*>(yc + 64) = l;
+            } else {
+              *reinterpret_cast<f32x4*>(ybase + (size_t)pix * p.ldy) = v;
+            }
           }
         }
       };
       using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
-      if (p.res_mode == 0) { if (p.relu) rows(T0{}, std::true_type{}); else rows(T0{}, std::false_type{}); }
-      else if (p.res_mode == 1) { if (p.relu) rows(T1{}, std::true_type{}); else rows(T1{}, std::false_type{}); }
-      else { if (p.relu) rows(T2{}, std::true_type{}); else rows(T2{}, std::false_type{}); }
+      if (p.presplit) {      // (the entry point admits it without residual, with ReLU)
+        rows(T0{}, std::true_type{}, std::true_type{});
+        if (!(bigq * ACT_SCALE <= ACT_MAX)) atomicOr(p.flags + p.next_err_index, bigq < INFINITY ? 2 : 4);
+      }
+      else if (p.res_mode == 0) { if (p.relu) rows(T0{}, std::true_type{}, std::false_type{}); else rows(T0{}, std::false_type{}, std::false_type{}); }
+      else if (p.res_mode == 1) { if (p.relu) rows(T1{}, std::true_type{}, std::false_type{}); else rows(T1{}, std::false_type{}, std::false_type{}); }
+      else { if (p.relu) rows(T2{}, std::true_type{}, std::false_type{}); else rows(T2{}, std::false_type{}, std::false_type{}); }
     }
     __syncthreads();
 #ifdef HALO_TIMELINE
@@ -811,7 +838,7 @@ static void halo_s1_patch(HaloArgsS& a, int H, int W) {
 
 static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                           const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu, int res_mode,
-                          int ldy, int ldr, void* workspace, void* stream) {
+                          int ldy, int ldr, void* workspace, void* stream, int presplit = 0, int next_slot = 0) {
   LVC_CHECK_ARG(x && w_split && workspace && y, "null pointer");
   LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0, "non-positive dimension");
@@ -826,6 +853,9 @@ static int halo_s1_launch(bool oneacc, const float* x, const unsigned short* w_s
   LVC_CHECK_ARG((K & 3) == 0 && (a.ldy & 3) == 0 && (res_mode == 0 || (a.ldr & 3) == 0), "K, ldy, ldr must be multiples of 4");
   LVC_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w_split & 15) == 0 && ((uintptr_t)y & 15) == 0 &&
                     ((uintptr_t)workspace & 15) == 0 && ((uintptr_t)scale & 15) == 0, "pointers must be 16-byte aligned");
+  if (presplit) LVC_CHECK_ARG(oneacc && relu == 1 && res_mode == 0 && K % 32 == 0 && a.ldy == K, "pre-split output: single accumulator, ReLU, no residual, K % 32 == 0, dense rows");
+  if (presplit) LVC_CHECK_ARG(next_slot > 0 && next_slot < lvc_range_slots(), "pre-split output: the consumer's range slot");
+  a.presplit = presplit; a.next_err_index = LVC_MAX_WORKERS + next_slot;
   halo_s1_patch(a, H, W);
   a.tiles_x = lvc_cdiv(W, a.PW); a.tiles_y = lvc_cdiv(H, a.PH);
   const long long xb = (long long)N * H * W * C * 4;
@@ -928,6 +958,16 @@ extern "C" int lvc_conv3x3_nhwc_f16s1(const float* x, const unsigned short* w_sp
                                        const float* residual, float* y, int N, int H, int W, int C, int K, int Kg, int relu,
                                        int res_mode, int ldy, int ldr, void* workspace, void* stream) {
   return halo_s1_launch(true, x, w_split, scale, shift, residual, y, N, H, W, C, K, Kg, relu, res_mode, ldy, ldr, workspace, stream);
+}
+
+// lvc_conv3x3_nhwc_f16s1 whose output goes to ONE consumer, lvc_conv1x1_nhwc_f16s1_presplit (a bottleneck's conv2 -> conv3, reference
+// resnet.py:200-205): y [N,H,W,K] holds, per pixel and 32-channel chunk, the 32 hi halves then the 32 lo halves of the two-way fp16
+// split of relu(conv * scale + shift) x 2^4 (128 B, the chunk's place in a row of K floats) -- bit for bit the planes the consumer's own
+// split forms, which it then skips (six vector instructions per MFMA in its chunk loop).  ReLU is applied; no residual; K % 32 == 0.
+// A value whose x 2^4 leaves the consumer's range (|a| > 4094) raises range word `next_slot` (the CONSUMER's), as its split would have.
+extern "C" int lvc_conv3x3_nhwc_f16s1_presplit(const float* x, const unsigned short* w_split, const float* scale, const float* shift, void* y,
+                                                int N, int H, int W, int C, int K, int Kg, int next_slot, void* workspace, void* stream) {
+  return halo_s1_launch(true, x, w_split, scale, shift, nullptr, (float*)y, N, H, W, C, K, Kg, 1, 0, K, 0, workspace, stream, 1, next_slot);
 }
 
 // lvc_conv3x3_nhwc_f16x2 (arguments, weight planes, numerics: main + cross accumulators, |a| <= 65504) on this file's pipeline.

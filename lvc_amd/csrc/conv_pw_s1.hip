@@ -74,7 +74,8 @@ template <int N> __device__ __forceinline__ void wait_tied(f32x4& a, f32x4& b, f
 }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int NI, bool ONEACC, bool PLANES = false>
+// PRE: x holds the pre-split planes of lvc_conv3x3_nhwc_f16s1_presplit (per row and 32-channel chunk 64 B of hi halves, 64 B of lo halves)
+template <int NI, bool ONEACC, bool PLANES = false, bool PRE = false>
 __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
   constexpr int HN = 64 * NI;
   constexpr int PLANE_A = PM * AROW;               // bytes
@@ -97,8 +98,10 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int fi = lane & 31, fh = lane >> 5;
-  const int q = tid & 7;
-  const int arid = tid >> 3;
+  // PRE: the 16 lanes of a ds_write_b128 pass take ONE plane of four consecutive rows (4 x 64 B = the 64 banks once); with the split
+  // path's lane order a row's two planes (16 KB apart: the same banks) would meet in one pass
+  const int q = PRE ? ((tid >> 4) & 1) * 4 + (tid & 3) : tid & 7;
+  const int arid = PRE ? (tid >> 5) * 4 + ((tid >> 2) & 3) : tid >> 3;
   const int hrow = arid;    // tile rows hrow + 64 j: 32 lanes of a ds_write_b64 cover four consecutive 64-byte rows = the 64 banks once
                             // (the 3x3 kernel's row order, made for its 80-byte pitch, put rows r and r + 4 -- the same banks -- into one pass:
                             // SQ_LDS_BANK_CONFLICT was 25 % of the LDS-active cycles on fc1)
@@ -124,6 +127,13 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     a_lds[j] = row * AROW + (((q >> 1) ^ ((row >> 2) & 3)) << 4) + (q & 1) * 8;     // bytes
   }
   float big = 0.f;
+  // PRE: this thread's 16 B piece q of a row's chunk is granule q % 4 of plane q / 4 -- stored as it comes
+  int a_pre[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = hrow + 64 * j;
+    a_pre[j] = (q >> 2) * (PM * AROW) + row * AROW + (((q & 3) ^ ((row >> 2) & 3)) << 4);
+  }
 #ifdef PW_TIMELINE
   // diagnostics build only (scripts/probe_pw_s1_timeline.py): cycles of this wave in a tile's prologue, chunk loop, hand-off, epilogue
   unsigned long long tl_pro = 0, tl_loop = 0, tl_hand = 0, tl_cs = 0, tl_rows = 0, tl_t0 = __builtin_readcyclecounter();
@@ -174,6 +184,13 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
       for (int j = 0; j < NJ; ++j) ar[set][j] = load_untracked(xres, a_off[j], (unsigned)cc * 128u);
     };
     auto store_A = [&](int set, unsigned char* dstA) {
+      if (PRE) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          *reinterpret_cast<f32x4*>(dstA + a_pre[j]) = ar[set][j];
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         f16x4 h, m;
@@ -664,6 +681,7 @@ __global__ __launch_bounds__(NT, 2) void conv_pw_s1_kernel(PwArgsS p) {
     d[0] = tl_pro; d[1] = tl_loop; d[2] = tl_hand; d[3] = tl_cs; d[4] = tl_rows; d[5] = tl_tiles; d[6] = tl_chunks; d[7] = __builtin_readcyclecounter() - tl_t0; d[8] = 1; d[9] = tl_wa; d[10] = tl_wv; d[11] = tl_wb;
   }
 #endif
+  if (PRE) return;      // the producer raised this layer's range word where its output x 2^4 left fp16's range
   if (!(big <= (ONEACC ? ACT_MAX : 65504.f))) atomicOr(p.flags + p.err_index, big < INFINITY ? 2 : 4);      // finite / non-finite: see conv3x3_halo_s1.hip
 }
 
@@ -674,7 +692,7 @@ struct PwPlanes { unsigned short* planes; int* err; long long PS; int N, Npad, H
 
 static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_split, const float* scale, const float* shift,
                         const float* residual, float* y, int N, int H, int W, int C, int K, int stride, int relu, int res_mode,
-                        int ldy, int ldr, void* workspace, void* stream, const PwPlanes* pl = nullptr) {
+                        int ldy, int ldr, void* workspace, void* stream, const PwPlanes* pl = nullptr, bool pre = false) {
   LVC_CHECK_ARG(x && w_split && y && workspace, "null pointer");
   LVC_CHECK_ARG(!oneacc || scale, "the single-accumulator form needs the row factors in `scale`");
   LVC_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && stride >= 1, "non-positive dimension");
@@ -738,6 +756,12 @@ static int pw_s1_launch(bool oneacc, const float* x, const unsigned short* w_spl
     LVC_CHECK_LAUNCH();
     return LVC_OK;
   }
+  if (pre) {
+    LVC_CHECK_ARG(oneacc && ni == 2 && stride == 1, "pre-split input: the single-accumulator 128-column tile, stride 1");
+    hipLaunchKernelGGL((conv_pw_s1_kernel<2, true, false, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
+    LVC_CHECK_LAUNCH();
+    return LVC_OK;
+  }
   if (oneacc) {
     if (ni == 1) hipLaunchKernelGGL((conv_pw_s1_kernel<1, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
     else hipLaunchKernelGGL((conv_pw_s1_kernel<2, true>), dim3(a.nworkers), dim3(NT), 0, st, a);
@@ -765,6 +789,14 @@ extern "C" int lvc_conv1x1_nhwc_f16s1(const float* x, const unsigned short* w_sp
   return pw_s1_launch(true, x, w_split, scale, shift, residual, y, N, H, W, C, K, stride, relu, res_mode, ldy, ldr, workspace, stream);
 }
 
+// lvc_conv1x1_nhwc_f16s1 on the pre-split planes lvc_conv3x3_nhwc_f16s1_presplit wrote (x [N,H,W,C]: per pixel and 32-channel chunk 32 hi
+// halves, 32 lo halves; C % 32 == 0, K > 64, stride 1): the same products in the same order -- results bit-identical to the fp32 hand-over.
+// The layer's range word is raised by the PRODUCER (its `next_slot`).  Reference: resnet.py:200-212 (conv2 -> conv3 of a bottleneck).
+extern "C" int lvc_conv1x1_nhwc_f16s1_presplit(const void* x, const unsigned short* w_split, const float* scale, const float* shift,
+                                                const float* residual, float* y, int N, int H, int W, int C, int K, int relu,
+                                                int res_mode, int ldy, int ldr, void* workspace, void* stream) {
+  return pw_s1_launch(true, (const float*)x, w_split, scale, shift, residual, y, N, H, W, C, K, 1, relu, res_mode, ldy, ldr, workspace, stream, nullptr, true);
+}
 
 // The qkv layer of a ViT block straight into the attention kernel's operand planes (round 5): lvc_conv1x1_nhwc_f16s1 on x [B*N][C] with
 // K = 3 * H * 64 output columns (q | k | v, head, d) whose epilogue writes what lvc_mha_mfma's first pass would make of the fp32 result --

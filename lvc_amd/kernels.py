@@ -548,6 +548,79 @@ CHAIN = _os.environ.get("LVC_CHAIN", "1") != "0"
 _HALO_H2_MIN_TILES = 64    # smaller 3x3 layers (p6; p5 of fewer than seven images) use the bf16 kernels (tests set 0): scripts/probe_small_maps.py -- p5 of the batch of eight (80 tiles) 0.052 / 0.056 ms on the fp16-split kernel against 0.077 / 0.069, p6 (32 tiles) 0.041 / 0.050 against 0.040
 
 
+# inference: a bottleneck's conv2 (3x3, direct single-accumulator kernel) hands its output to conv3 (pointwise, single accumulator) as the
+# two fp16 planes conv3 multiplies -- conv3 skips the split (csrc/conv3x3_halo_s1.hip / conv_pw_s1.hip `_presplit`); bit-identical results.
+# OFF by default: measured (scripts/probe_presplit.py, profiles/r06_presplit.txt) the pair of launches gets 2.2 % (res4) / 2.8 % (res5)
+# shorter -- conv3 there moves 2.6 TB/s of fp32 rows, the split it skips was not what bounds it -- which is +0.15 % on the step
+# (same-box A/B, four alternations, inside the noise): not worth a second hand-over format in the default path.  LVC_PRESPLIT=1 enables it.
+PRESPLIT = _os.environ.get("LVC_PRESPLIT", "0") == "1"
+
+
+def presplit_pair_ok(x, pc2, pc3, residual=None):
+    """True where `conv2d_nhwc` would run pc2 on lvc_conv3x3_nhwc_f16s1 and pc3 on lvc_conv1x1_nhwc_f16s1 (both on tier 0): the pair
+    `conv3x3_conv1x1_presplit` replaces launch for launch.  (The routing conditions of conv2d_nhwc, restated; the bit-identity test
+    in tests/test_gpu_kernels.py fails if the two ever disagree.)"""
+    if not (PRESPLIT and CONV_ENGINE == "bf16x3" and CONV_SPLIT == "f16x2" and CONV_HALO and HALO_S1 == 2 and PW_S1 == 2):
+        return False
+    N, H, W, C = x.shape
+    rows = N * H * W
+    return (pc2.mode == 0 and pc3.mode == 0 and C == pc2.C
+            and pc2.R == 3 and pc2.S == 3 and pc2.stride == 1 and pc2.pad == 1 and pc2.C % 32 == 0 and pc2.K % 32 == 0 and pc2.K >= 64
+            and pc3.R == 1 and pc3.S == 1 and pc3.stride == 1 and pc3.pad == 0 and pc3.C == pc2.K and pc3.K > 64 and pc3.K % 4 == 0
+            and pc3.C >= max(_H2_PW_MIN_C, _PW_S1_MIN_C, _PW_S1_ONE_MIN_C)
+            and pc2.state["tier"] == 0 and pc3.state["tier"] == 0 and not pc2.two_acc and not pc3.two_acc
+            and N * ((H * W + 255) // 256) * ((pc2.K + 127) // 128) >= _HALO_H2_MIN_TILES
+            and not (CONV_WINO and pc2.K >= 128 and wino_tiles(N, H, W, pc2.K) >= _WINO_MIN_TILES)
+            and rows >= 2048 and rows * pc3.K < (1 << 29) and x.numel() < (1 << 29) and rows * pc2.K < (1 << 29)
+            and (residual is None or (_PW_S1_RES and residual.shape[-1] % 4 == 0))
+            and not (PW_W2 and pc3.C >= _PW_W2_MIN_C and pc3.K >= 256 and pc3.K % 256 == 0 and rows >= _PW_W2_MIN_ROWS))
+
+
+def conv3x3_conv1x1_presplit(x, pc2, pc3, residual=None, relu=True):
+    """relu(conv3x3(x) * s2 + t2) -> act(conv1x1(.) * s3 + t3 (+ residual)) where `presplit_pair_ok`: two launches, the tensor between
+    them written as the second one's operand planes (include/lvc_amd.h, `_presplit`).  Reference resnet.py:200-212."""
+    _req_cuda(x, residual)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    N, H, W, C = x.shape
+    mid = torch.empty(N, H, W, pc2.K, device=x.device, dtype=torch.float32)      # (planes: same bytes, not fp32 values)
+    out = torch.empty(N, H, W, pc3.K, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.dtype == torch.float32 and residual.shape[:3] == out.shape[:3]
+    ldr = residual.shape[-1] if residual is not None else 0
+    ws = ptr(conv_workspace(x.device))
+
+    def timed(engine, flops, nbytes, launch):
+        timer = CONV_TIMER
+        if timer is not None and (not timer.active or (timer.only is not None and engine not in timer.only)):
+            timer = None
+        if timer is None:
+            return launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        timer.records.append((flops, e0, e1, engine, nbytes))
+
+    planes2, scale2 = pc2.split2s()
+    planes3, scale3 = pc3.split2s()
+    rows = N * H * W
+    pc2.last_one = True
+    pc3.last_one = True
+    _lib.lib().lvc_set_range_slot(c_int(pc2.slot))
+    timed("f16x2_halo", 2.0 * rows * pc2.K * C * 9, 4.0 * (rows * C + rows * pc2.K + pc2.K * C * 9),
+          lambda: check(_lib.lib().lvc_conv3x3_nhwc_f16s1_presplit(
+              ptr(x), ptr(planes2), ptr(scale2), ptr(pc2.shift), ptr(mid), c_int(N), c_int(H), c_int(W), c_int(C), c_int(pc2.K),
+              c_int(pc2.Kg), c_int(pc3.slot), ws, _stream(x)), "lvc_conv3x3_nhwc_f16s1_presplit"))
+    _lib.lib().lvc_set_range_slot(c_int(pc3.slot))
+    timed("f16x2_pws1", 2.0 * rows * pc3.K * pc3.C, 4.0 * (rows * pc3.C + rows * pc3.K + (residual.numel() if residual is not None else 0) + pc3.K * pc3.C),
+          lambda: check(_lib.lib().lvc_conv1x1_nhwc_f16s1_presplit(
+              ptr(mid), ptr(planes3), ptr(scale3), ptr(pc3.shift), ptr(residual), ptr(out), c_int(N), c_int(H), c_int(W), c_int(pc3.C),
+              c_int(pc3.K), c_int(1 if relu else 0), c_int(1 if residual is not None else 0), c_int(pc3.K), c_int(ldr), ws, _stream(x)),
+              "lvc_conv1x1_nhwc_f16s1_presplit"))
+    _lib.lib().lvc_set_range_slot(c_int(0))
+    return out
+
+
 def conv2d_nhwc(x, pc, relu=False, residual=None, res_mode=0, out=None, split=None, act=None):
     """x: [N,H,W,C] fp32 contiguous (NHWC).  Returns [N,Ho,Wo,K].
     act="gelu": torch.nn.GELU() (erf form) on the result -- in the epilogue of the LDS-DMA pointwise kernel where the layer

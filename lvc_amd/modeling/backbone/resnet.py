@@ -175,9 +175,18 @@ class BottleneckBlock(CNNBlockBase):
             if ch is not None and concat.numel() < (1 << 29):
                 return K.conv1x1_chain(concat, ch)
             return K.conv2d_nhwc(concat, self._fused_projection(), relu=True), None
+        ch = self.chain_to(nxt, False)
+        if (ch is None and self.conv2.activation is not None and self._grad_free()
+                and not (torch.is_grad_enabled() and (t.requires_grad or x.requires_grad))):
+            p2, p3 = self.conv2.packed(), self.conv3.packed()
+            shortcut = self.shortcut.forward_nhwc(x) if self.shortcut is not None else x
+            if K.presplit_pair_ok(t, p2, p3, shortcut):
+                # conv2's output goes to conv3 as the two fp16 planes conv3 multiplies (res4 / res5: conv3 skips its operand split)
+                return K.conv3x3_conv1x1_presplit(t, p2, p3, residual=shortcut, relu=True), None
+            z = self.conv2.forward_nhwc(t)
+            return self.conv3.forward_nhwc(z, residual=shortcut, res_mode=1, relu=True), None
         z = self.conv2.forward_nhwc(t)
         shortcut = self.shortcut.forward_nhwc(x) if self.shortcut is not None else x
-        ch = self.chain_to(nxt, False)
         if ch is not None and shortcut.numel() < (1 << 29):
             return K.conv1x1_chain(z, ch, residual=shortcut)
         # conv3 + FrozenBN + residual add + ReLU in one epilogue (reference resnet.py:205-211)

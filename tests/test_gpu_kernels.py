@@ -1049,6 +1049,51 @@ def test_fused_bottleneck_matches_separate_launches_and_fp64(shape, proj):
         assert bk.state["off"] and k.conv_error_word(d) == 0
 
 
+@pytest.mark.parametrize("shape", [(2, 50, 84, 256, 1024), (8, 25, 42, 512, 2048), (7, 37, 29, 256, 1024), (1, 46, 45, 64, 128)])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_presplit_handover_bit_identical(shape, with_res, monkeypatch):
+    """kernels.conv3x3_conv1x1_presplit (LVC_PRESPLIT; csrc `_presplit` entry points): a bottleneck's conv2 writes the two fp16 planes
+    conv3 multiplies instead of the fp32 tensor conv3 would split (reference resnet.py:200-212).  Same products, same order: the
+    result must equal the two ordinary launches BIT FOR BIT -- on res4's and res5's shapes, ragged tiles, and (pair forced) a narrow
+    layer; `presplit_pair_ok` must agree with conv2d_nhwc's routing wherever it says yes.  Then the consumer's range word, raised by
+    the producer."""
+    from lvc_amd import kernels as k
+
+    monkeypatch.setattr(k, "PRESPLIT", True)       # (off by default: kernels.PRESPLIT says why)
+    N, H, W, cb, cout = shape
+    g = torch.Generator().manual_seed(H * 100 + W + cb)
+    d = _dev()
+
+    def bn(c):
+        return [t.to(d) for t in (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1,
+                                  torch.rand(c, generator=g) + 0.5)]
+
+    p2 = k.pack_conv((torch.randn(cb, cb, 3, 3, generator=g) * (2.0 / (9 * cb)) ** 0.5).to(d), bn=bn(cb), pad=1)
+    p3 = k.pack_conv((torch.randn(cout, cb, 1, 1, generator=g) * (2.0 / cb) ** 0.5).to(d), bn=bn(cout))
+    t = torch.randn(N, H, W, cb, generator=g).relu_().to(d)
+    res = torch.randn(N, H, W, cout, generator=g).relu_().to(d) if with_res else None
+    ok = k.presplit_pair_ok(t, p2, p3, res)
+    assert ok == (cb >= 256), "presplit_pair_ok: res4 / res5 shapes qualify, a 64-channel pair does not"
+    z = k.conv2d_nhwc(k.conv2d_nhwc(t, p2, relu=True), p3, relu=True, residual=res, res_mode=1 if with_res else 0)
+    if not ok:
+        return
+    y = k.conv3x3_conv1x1_presplit(t, p2, p3, residual=res, relu=True)
+    assert torch.equal(y, z)
+    y2 = k.conv3x3_conv1x1_presplit(t, p2, p3, residual=res, relu=False)
+    assert torch.equal(y2, k.conv2d_nhwc(k.conv2d_nhwc(t, p2, relu=True), p3, relu=False, residual=res, res_mode=1 if with_res else 0))
+    assert k.conv_error_word(d) == 0
+    if shape[1:3] == (37, 29):
+        # conv2 output beyond conv3's single-accumulator range (|a| <= 4094): the PRODUCER raises conv3's word; conv3 moves a tier up and
+        # the pair stops qualifying
+        big = k.pack_conv((torch.randn(cb, cb, 3, 3, generator=g) * (2.0 / (9 * cb)) ** 0.5).to(d),
+                          affine=(torch.full((cb,), 1.0, device=d), torch.full((cb,), 5000.0, device=d)), pad=1)
+        k.conv3x3_conv1x1_presplit(t, big, p3, residual=res)
+        with pytest.raises(k.Fp16RangeError):
+            k.check_conv_error_word(d)
+        assert p3.state["tier"] >= 1 and big.state["tier"] == 0 and not k.presplit_pair_ok(t, big, p3, res)
+        assert k.conv_error_word(d) == 0
+
+
 @pytest.mark.parametrize("jitter,nidx,thr,max_keep", [(4.0, 80, 0.5, 100), (0.02, 3, 0.5, 100), (4.0, 80, 0.5, 1000), (0.5, 1, 0.3, 64)])
 def test_batched_nms_head_block_form_bit_exact(jitter, nidx, thr, max_keep):
     """lvc_batched_nms with max_keep << Nmax (the detection stage: 100 of ~10 000 candidates): the greedy pass runs on a head block of
