@@ -301,7 +301,7 @@ def gen_knn():
          q_classes=torch.cat(dcls), **res)
 
 
-def gen_train():
+def gen_train(name="train_novel_ft", sizes=((240, 320, 3), (200, 352, 4))):
     """BASELINE config 3 (novel fine-tune): loss dict + the 4 trainable gradients for a fixed 2-image batch.
     torch.randperm is patched to the identity permutation so that the sampled anchors / proposals are the FIRST
     num_pos positives and num_neg negatives (the product test applies the same patch)."""
@@ -316,12 +316,13 @@ def gen_train():
     g = torch.Generator().manual_seed(11)
     batch = []
     gts = {}
-    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+    for i, (h, w, seed) in enumerate(sizes):
         n = 5 + i
-        x1 = torch.rand(n, generator=g) * (w - 80)
-        y1 = torch.rand(n, generator=g) * (h - 80)
-        bw = 30 + torch.rand(n, generator=g) * 120
-        bh = 30 + torch.rand(n, generator=g) * 100
+        k = h / 240.0 if h > 400 else 1.0       # (the full-size batch: boxes over all pyramid levels, 100 .. 500 px)
+        x1 = torch.rand(n, generator=g) * (w - 80 * k)
+        y1 = torch.rand(n, generator=g) * (h - 80 * k)
+        bw = (30 + torch.rand(n, generator=g) * 120) * k
+        bh = (30 + torch.rand(n, generator=g) * 100) * k
         boxes = torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
         classes = torch.randint(0, 20, (n,), generator=g)
         inst = Instances((h, w))
@@ -343,8 +344,14 @@ def gen_train():
     grads = {"grad." + n: p.grad for n, p in model.named_parameters() if p.requires_grad}
     assert len(grads) == 4
     print("  losses", {k: float(v) for k, v in losses.items()}, scalars)
-    save("train_novel_ft", **gts, **{"loss." + k: v.detach() for k, v in losses.items()}, **grads,
+    save(name, **gts, **{"loss." + k: v.detach() for k, v in losses.items()}, **grads,
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
+
+
+def gen_train_full():
+    """Config 3 at the size it is quoted on (two 800 x 1333 images; BASELINE.json configs[2] uses eight per GPU): the same step
+    as gen_train on the full pyramid -- 268 569 anchors per image, all four ROIAlign levels in use."""
+    gen_train("train_novel_ft_800x1333", ((800, 1333, 5), (800, 1333, 6)))
 
 
 def gen_train_base():
@@ -796,6 +803,79 @@ def gen_r101():
     save("box_corrector_train_r101", **d, **{"loss." + k: v.detach() for k, v in losses.items()})
 
 
+def gen_box_corrector_train_r101_full():
+    """BASELINE config 5 at the size and batch it is quoted on (box-corrector training, R101-FPN, two 3 x 800 x 1333 images per
+    GPU): one reference CPU step of cascade_ubbr base yaml with DEPTH 101 -- 133 trainable tensors, the full pyramid under
+    ROIAlign's backward.  Stored as in gen_r101: GT, loaded proposals, RBG's output, the three stage losses, per tensor the
+    gradient's sum / norm / strided sample (<= 1024 entries)."""
+    from detectron2.structures import Boxes, Instances
+    from detectron2.utils.events import EventStorage
+
+    cfg, model = build_ref_model("COCO-detection/cascade_ubbr_R_50_FPN_base.yaml", ["MODEL.RESNETS.DEPTH", 101])
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r101_bn_calibration.npz")).items()}
+    model.load_state_dict(syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib), strict=True)
+    model.train()
+    g = torch.Generator().manual_seed(47)
+    batch, d = [], {}
+    for i, (h, w, seed) in enumerate([(800, 1333, 5), (800, 1333, 6)]):
+        n = 6 + i
+        # boxes of 40 .. 600 px: every pooler level (canonical size 224) is used
+        side = 40.0 * (15.0 ** torch.rand(n, generator=g))
+        bw = side * (0.7 + 0.6 * torch.rand(n, generator=g))
+        bh = side * (0.7 + 0.6 * torch.rand(n, generator=g))
+        x1 = torch.rand(n, generator=g) * (w - bw).clamp(min=1)
+        y1 = torch.rand(n, generator=g) * (h - bh).clamp(min=1)
+        boxes = torch.stack([x1, y1, (x1 + bw).clamp(max=w), (y1 + bh).clamp(max=h)], 1)
+        classes = torch.randint(0, 60, (n,), generator=g)
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(boxes)
+        inst.gt_classes = classes
+        # loaded proposals: noisy copies of the GT (noise in proportion to the box: some pass RBG's IoU filter, some do not) + far boxes
+        noisy = boxes.repeat(3, 1) + torch.randn(3 * n, 4, generator=g) * 0.12 * side.repeat(3)[:, None]
+        far = torch.stack([torch.rand(4, generator=g) * 100, torch.rand(4, generator=g) * 100,
+                           150 + torch.rand(4, generator=g) * 80, 150 + torch.rand(4, generator=g) * 80], 1)
+        pb = torch.cat([noisy, far])
+        pb[:, 2:] = torch.max(pb[:, 2:], pb[:, :2] + 4)
+        props = Instances((h, w))
+        props.proposal_boxes = Boxes(pb)
+        props.objectness_logits = torch.randn(len(pb), generator=g)
+        batch.append({"image": syn.synthetic_image(seed, h, w), "instances": inst, "proposals": props, "height": h, "width": w})
+        d["gt_boxes%d" % i], d["gt_classes%d" % i] = boxes, classes
+        d["loaded_boxes%d" % i], d["loaded_logits%d" % i] = pb, props.objectness_logits
+    rbg_out = []
+    orig = model.proposal_generator.forward
+
+    def recording(proposals, targets):
+        out, extra = orig(proposals, targets)
+        rbg_out.extend(out)
+        return out, extra
+
+    model.proposal_generator.forward = recording
+    real = torch.randperm
+    torch.randperm = lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")})
+    torch.manual_seed(5)
+    try:
+        with EventStorage(0):
+            losses = model(batch)
+            sum(losses.values()).backward()
+    finally:
+        torch.randperm = real
+    for i, p in enumerate(rbg_out):
+        d["rbg_boxes%d" % i] = p.proposal_boxes.tensor
+        d["rbg_logits%d" % i] = p.objectness_logits
+    ntrain = 0
+    for n_, p_ in model.named_parameters():
+        if p_.requires_grad:
+            ntrain += 1
+            gflat = p_.grad.flatten()
+            stride = max(1, gflat.numel() // 1024) | 1
+            d["grad_sample." + n_] = gflat[::stride][:1024].clone()
+            d["grad_stats." + n_] = torch.tensor([float(gflat.double().sum()), float(gflat.double().norm()), float(stride)], dtype=torch.float64)
+    print("  R101 corrector, 2 x 800 x 1333: losses", {k: float(v.detach()) for k, v in losses.items()}, "trainable tensors", ntrain,
+          "rbg proposals", [len(p) for p in rbg_out])
+    save("box_corrector_train_r101_800x1333", **d, **{"loss." + k: v.detach() for k, v in losses.items()})
+
+
 def gen_r101_full():
     """R101-FPN at the headline's image size (VERDICT r4 missing #5): detections, proposals and sampled pyramid features of
     two 3x800x1333 images through the reference's CPU path, same weights as gen_r101 (seed-0 conditioned, its FrozenBN
@@ -1014,7 +1094,7 @@ def gen_wire():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "r101_full", "wire"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_full", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "r101_full", "box_corrector_train_r101_full", "wire"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -272,21 +272,24 @@ def test_box_corrector_training_step_with_trunk_matches_reference(monkeypatch, r
     assert not bad, bad
 
 
+@pytest.mark.parametrize("fixture,sizes", [("box_corrector_train_r101", ((240, 320, 3), (200, 352, 4))),
+                                           ("box_corrector_train_r101_800x1333", ((800, 1333, 5), (800, 1333, 6)))])
 @pytest.mark.parametrize("rows", ["lists", "batched"])
-def test_box_corrector_training_step_r101_matches_reference(monkeypatch, rows):
+def test_box_corrector_training_step_r101_matches_reference(monkeypatch, rows, fixture, sizes):
     """BASELINE config 5 as named: box-corrector training on R101-FPN (cascade_ubbr base yaml with RESNETS.DEPTH 101):
     133 trainable tensors (res4 has 23 blocks) against the reference's CPU step
-    (tests/golden/box_corrector_train_r101.npz); same robust metrics as the R50 step."""
+    (tests/golden/box_corrector_train_r101.npz); same robust metrics as the R50 step.  _800x1333: the size and per-GPU batch the
+    config is quoted on (two 3 x 800 x 1333 images; oracle/make_golden.py gen_box_corrector_train_r101_full), same bars."""
     from lvc_amd.structures import Boxes, Instances
     from lvc_amd.utils import synthetic as syn
     from lvc_amd.utils.events import EventStorage
 
-    g = gold("box_corrector_train_r101")
+    g = gold(fixture)
     model = _train_model(num_classes=60, freeze_backbone=False, depth=101)
     assert sum(1 for p in model.parameters() if p.requires_grad) == 133
     dev = torch.device("cuda:0")
     batch = []
-    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+    for i, (h, w, seed) in enumerate(sizes):
         inst = Instances((h, w))
         inst.gt_boxes = Boxes(g["gt_boxes%d" % i])
         inst.gt_classes = g["gt_classes%d" % i]

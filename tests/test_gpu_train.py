@@ -23,12 +23,16 @@ def _train_model():
     return model.train()
 
 
-def _batch(g):
+_SMALL = ((240, 320, 3), (200, 352, 4))
+_FULL = ((800, 1333, 5), (800, 1333, 6))      # the size config 3 is quoted on (oracle/make_golden.py gen_train_full)
+
+
+def _batch(g, sizes=_SMALL):
     from lvc_amd.structures import Boxes, Instances
     from lvc_amd.utils import synthetic as syn
 
     batch = []
-    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+    for i, (h, w, seed) in enumerate(sizes):
         inst = Instances((h, w))
         inst.gt_boxes = Boxes(g["gt_boxes%d" % i])
         inst.gt_classes = g["gt_classes%d" % i]
@@ -36,15 +40,17 @@ def _batch(g):
     return batch
 
 
-def test_novel_finetune_step_matches_reference(monkeypatch):
+@pytest.mark.parametrize("fixture,sizes", [("train_novel_ft", _SMALL), ("train_novel_ft_800x1333", _FULL)])
+def test_novel_finetune_step_matches_reference(monkeypatch, fixture, sizes):
+    """Small images, and the full 800 x 1333 pyramid (268 569 anchors per image, every ROIAlign level): same bars."""
     from lvc_amd.utils.events import EventStorage
 
-    g = gold("train_novel_ft")
+    g = gold(fixture)
     model = _train_model()
     assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 103525
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0) as storage:
-        losses = model(_batch(g))
+        losses = model(_batch(g, sizes))
         sum(losses.values()).backward()
     for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
         ref = float(g["loss." + k])
@@ -113,7 +119,7 @@ def test_base_detector_training_step_matches_reference(monkeypatch):
     assert frozen == g["frozen_names"].tolist()
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0) as storage:
-        losses = model(_batch(g))
+        losses = model(_batch(g, sizes))
         sum(losses.values()).backward()
     for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
         ref, got = float(g["loss." + k]), float(losses[k].detach())
