@@ -119,7 +119,7 @@ def test_base_detector_training_step_matches_reference(monkeypatch):
     assert frozen == g["frozen_names"].tolist()
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0) as storage:
-        losses = model(_batch(g, sizes))
+        losses = model(_batch(g))
         sum(losses.values()).backward()
     for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
         ref, got = float(g["loss." + k]), float(losses[k].detach())
