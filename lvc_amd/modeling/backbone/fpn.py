@@ -58,8 +58,9 @@ class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
         assert isinstance(bottom_up, Backbone)
-        if fuse_type != "sum":
-            raise NotImplementedError("FPN.FUSE_TYPE 'avg' is not used by the shipped configs")
+        assert fuse_type in {"avg", "sum"}       # reference fpn.py:63
+        # "avg" (reference fpn.py:133-134; no shipped config selects it): the fused lateral + upsample-add launch, then an exact halving
+        self._fuse_type = fuse_type
         input_shapes = bottom_up.output_shape()
         strides = [input_shapes[f].stride for f in in_features]
         in_channels_per_feature = [input_shapes[f].channels for f in in_features]
@@ -96,6 +97,9 @@ class FPN(Backbone):
     def size_divisibility(self):
         return self._size_divisibility
 
+    def _fuse(self, summed):
+        return summed * 0.5 if self._fuse_type == "avg" else summed
+
     def forward_nhwc(self, x4):
         bottom_up = self.bottom_up.forward_nhwc(x4)
         x = [bottom_up[f] for f in self.in_features[::-1]]
@@ -106,7 +110,7 @@ class FPN(Backbone):
             # (kernels.conv3x3_levels: a layer per map; the small levels no longer pay a launch each that cannot fill the chip)
             prevs = [self.lateral_convs[0].forward_nhwc(x[0])]
             for feat, lateral in zip(x[1:], self.lateral_convs[1:]):
-                prevs.append(lateral.forward_nhwc(feat, residual=prevs[-1], res_mode=2))
+                prevs.append(self._fuse(lateral.forward_nhwc(feat, residual=prevs[-1], res_mode=2)))
             order = list(range(len(prevs)))[::-1]          # finest (largest) map first
             outs = K.conv3x3_levels([prevs[i] for i in order], [self.output_convs[i].packed() for i in order], relu=False)
             results = list(outs)                           # fine to coarse, the order of self._out_features
@@ -114,7 +118,7 @@ class FPN(Backbone):
             prev = self.lateral_convs[0].forward_nhwc(x[0])
             results.append(self.output_convs[0].forward_nhwc(prev))
             for feat, lateral, output in zip(x[1:], self.lateral_convs[1:], self.output_convs[1:]):
-                prev = lateral.forward_nhwc(feat, residual=prev, res_mode=2)  # lateral + upsample(prev)
+                prev = self._fuse(lateral.forward_nhwc(feat, residual=prev, res_mode=2))  # lateral + upsample(prev)
                 results.insert(0, output.forward_nhwc(prev))
         if self.top_block is not None:
             src = bottom_up.get(self.top_block.in_feature, None)

@@ -265,6 +265,23 @@ def gen_e2e():
         print("  small image", i, "proposals", len(props[i]), "detections", len(out[i]["instances"]))
 
 
+def gen_fpn_avg():
+    """MODEL.FPN.FUSE_TYPE "avg" (reference fpn.py:133-134; no shipped yaml selects it): the pyramid of the small two-image batch of
+    gen_e2e through the reference backbone with averaged top-down fusion, same weights and FrozenBN calibration."""
+    cfg, model = build_ref_model("COCO-detection/faster_rcnn_R_50_FPN_base.yaml", ["MODEL.ROI_HEADS.NUM_CLASSES", 80, "MODEL.FPN.FUSE_TYPE", "avg"])
+    calib = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "r50_bn_calibration.npz")).items()}
+    model.load_state_dict(syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib), strict=True)
+    inputs = [{"image": syn.synthetic_image(3, 240, 320), "height": 480, "width": 640},
+              {"image": syn.synthetic_image(4, 200, 352), "height": 200, "width": 352}]
+    with torch.no_grad():
+        feats = model.backbone(model.preprocess_image(inputs).tensor)
+    d = {}
+    for k, v in feats.items():
+        d["feat_" + k] = v[:, ::16, ::2, ::2].contiguous()
+        d["featstat_" + k] = torch.stack([v.mean(), v.std(), v.abs().max()])
+    save("fpn_avg_small", **d)
+
+
 def gen_knn():
     from detectron2.structures import Instances
     from tools.run_nearest_neighbours import get_nn_class_confirmatory, run_nearest_neighbours
@@ -1094,7 +1111,7 @@ def gen_wire():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_full", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "r101_full", "box_corrector_train_r101_full", "wire"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_full", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "r101_full", "box_corrector_train_r101_full", "fpn_avg", "wire"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

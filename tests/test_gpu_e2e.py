@@ -26,11 +26,12 @@ pytestmark = pytest.mark.gpu
 # of the matched differences <= K_NOISE x the noise, the largest <= K_MAX x its largest, found fraction >= the noise run's own - IDENT_MARGIN.
 
 
-def _model():
+def _model(fuse_type="sum"):
     from lvc_amd.config import get_cfg
     from lvc_amd.modeling import build_model
 
     cfg = get_cfg()
+    cfg.MODEL.FPN.FUSE_TYPE = fuse_type
     cfg.MODEL.DEVICE = "cuda"
     cfg.MODEL.BACKBONE.NAME = "build_resnet_fpn_backbone"
     cfg.MODEL.RESNETS.OUT_FEATURES = ["res2", "res3", "res4", "res5"]
@@ -103,6 +104,31 @@ def test_e2e_small_matches_reference_cpu():
     inputs = [{"image": syn.synthetic_image(3, 240, 320), "height": 480, "width": 640},
               {"image": syn.synthetic_image(4, 200, 352), "height": 200, "width": 352}]
     _check("e2e_r50_fpn_small", inputs, model)
+
+
+@pytest.mark.parametrize("merged", [True, False])
+def test_fpn_avg_fusion_matches_reference(merged, monkeypatch):
+    """MODEL.FPN.FUSE_TYPE "avg" (reference fpn.py:133-134; no shipped config selects it): p2..p6 of the small batch against the reference
+    backbone's (tests/golden/fpn_avg_small.npz), at the bar of the sum pyramid (1e-4 of the level's largest value), on both top-down walks
+    (output convs merged into one launch / level by level)."""
+    from lvc_amd.modeling.backbone import fpn as F
+    from lvc_amd.utils import synthetic as syn
+
+    monkeypatch.setattr(F, "MERGE_OUTPUT_CONVS", merged)
+    g = gold("fpn_avg_small")
+    model = _model("avg")
+    inputs = [{"image": syn.synthetic_image(3, 240, 320), "height": 480, "width": 640},
+              {"image": syn.synthetic_image(4, 200, 352), "height": 200, "width": 352}]
+    with torch.no_grad():
+        feats = model.backbone(model.preprocess_image(inputs).tensor)
+        summed = _model("sum").backbone(model.preprocess_image(inputs).tensor)
+    for k in ("p2", "p3", "p4", "p5", "p6"):
+        got = feats[k][:, ::16, ::2, ::2].cpu()
+        assert got.shape == g["feat_" + k].shape
+        err = float((got - g["feat_" + k]).abs().max()) / float(g["featstat_" + k][2])
+        print(k, "relative error", err)
+        assert err <= 1e-4, k
+    assert not torch.equal(feats["p2"], summed["p2"]) and torch.equal(feats["p5"], summed["p5"])      # (the coarsest level has no top-down term)
 
 
 def test_e2e_800x1333_matches_reference_cpu():
