@@ -371,7 +371,7 @@ def gen_train_full():
     gen_train("train_novel_ft_800x1333", ((800, 1333, 5), (800, 1333, 6)))
 
 
-def gen_train_base():
+def gen_train_base(name="train_base", source="train_novel_ft", sizes=((240, 320, 3), (200, 352, 4))):
     """faster_rcnn_R_50_FPN_base.yaml (the base detector training of BASELINE config 3's first stage: 60 classes,
     FREEZE_AT 2, RPN + box head + predictor + FPN + res3..res5 all train): one training step on the same 2-image
     batch as gen_train (read back from its fixture).  Stored: the four losses, event scalars, and per trainable
@@ -384,9 +384,9 @@ def gen_train_base():
     sd = syn.conditioned_state_dict(model.state_dict(), seed=0, bn_calibration=calib)
     model.load_state_dict(sd, strict=True)
     model.train()
-    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, "train_novel_ft.npz")).items()}
+    t = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, source + ".npz")).items()}
     batch, d = [], {}
-    for i, (h, w, seed) in enumerate([(240, 320, 3), (200, 352, 4)]):
+    for i, (h, w, seed) in enumerate(sizes):
         inst = Instances((h, w))
         inst.gt_boxes = Boxes(t["gt_boxes%d" % i])
         inst.gt_classes = t["gt_classes%d" % i]      # < 20 < 60
@@ -413,8 +413,14 @@ def gen_train_base():
             frozen.append(n_)
     print("  losses", {k: float(v.detach()) for k, v in losses.items()}, "trainable tensors", ntrain, "frozen", len(frozen), scalars)
     d["frozen_names"] = np.array(frozen)
-    save("train_base", **d, **{"loss." + k: v.detach() for k, v in losses.items()},
+    save(name, **d, **{"loss." + k: v.detach() for k, v in losses.items()},
          **{"scalar." + k.replace("/", "."): np.float64(v) for k, v in scalars.items()})
+
+
+def gen_train_base_full():
+    """The base detector's training step on two 3 x 800 x 1333 images (GT of gen_train_full): 72 trainable tensors under the full
+    pyramid -- the size the reference trains at."""
+    gen_train_base("train_base_800x1333", "train_novel_ft_800x1333", ((800, 1333, 5), (800, 1333, 6)))
 
 
 def gen_train_base_steps():
@@ -1111,7 +1117,7 @@ def gen_wire():
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_full", "train_base", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "r101_full", "box_corrector_train_r101_full", "fpn_avg", "wire"]
+    which = sys.argv[1:] or ["roi_align", "nms", "box_ops", "rpn_and_det_ops", "blocks", "e2e", "knn", "train", "train_full", "train_base", "train_base_full", "train_base_steps", "train_ft_all", "box_corrector", "box_corrector_train", "box_corrector_eval", "box_corrector_train_base", "crops", "resize", "solver", "r101", "r101_full", "box_corrector_train_r101_full", "fpn_avg", "wire"]
     for w in which:
         print("== ", w)
         globals()["gen_" + w]()

@@ -105,21 +105,23 @@ def _base_model():
     return model.train()
 
 
-def test_base_detector_training_step_matches_reference(monkeypatch):
-    """The whole detector training (faster_rcnn_R_50_FPN_base.yaml): RPN losses -> fused predictor / 3x3 conv of the
+@pytest.mark.parametrize("fixture,sizes", [("train_base", _SMALL), ("train_base_800x1333", _FULL)])
+def test_base_detector_training_step_matches_reference(monkeypatch, fixture, sizes):
+    """(_800x1333: the same step on two full-size images, oracle/make_golden.py gen_train_base_full; same bars.)
+    The whole detector training (faster_rcnn_R_50_FPN_base.yaml): RPN losses -> fused predictor / 3x3 conv of the
     RPN head -> p2..p6 (p6 through LastLevelMaxPool's scatter); CE + smooth-L1 -> predictor -> 2-FC box head ->
     ROIAlign backward -> p2..p5; FPN; res5..res3.  72 trainable tensors against the reference's CPU step
     (tests/golden/train_base.npz).  Losses to 1e-4; gradients through robust metrics (direction and size): the same
     ReLU-flip noise as in test_gpu_box_corrector.py, plus proposals that the RPN's own fp32 noise reorders."""
     from lvc_amd.utils.events import EventStorage
 
-    g = gold("train_base")
+    g = gold(fixture)
     model = _base_model()
     frozen = [n for n, p in model.named_parameters() if not p.requires_grad]
     assert frozen == g["frozen_names"].tolist()
     monkeypatch.setattr(torch, "randperm", lambda n, **kw: torch.arange(n, **{k: v for k, v in kw.items() if k in ("device", "dtype")}))
     with EventStorage(0) as storage:
-        losses = model(_batch(g))
+        losses = model(_batch(g, sizes))
         sum(losses.values()).backward()
     for k in ("loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"):
         ref, got = float(g["loss." + k]), float(losses[k].detach())
