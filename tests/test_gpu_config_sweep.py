@@ -62,3 +62,36 @@ def test_detector_configuration_sweep_matches_oracle(case):
     # found fraction minus IDENT_MARGIN and the sampling noise of the count -- not a hand-set 90 %
     print("case %d: %d of %d reproduced; the oracle's fp32 run finds %.1f%% of its fp64 detections" % (case, found, total, 100 * nz["matched_fraction"]))
     assert total == 0 or found / total >= found_bar(nz["matched_fraction"], total), (case, found, total, nz["matched_fraction"])
+
+
+def test_no_detection_passes_the_score_threshold():
+    """SCORE_THRESH_TEST above every score: the candidate stage, the detection NMS and `detector_postprocess` run on zero rows per
+    image (reference fast_rcnn.py:117-160 returns empty `Instances`); the next batch through the same model is unaffected."""
+    from lvc_amd.config.presets import base_rcnn_fpn
+    from lvc_amd.modeling import build_model
+    from lvc_amd.utils import synthetic as syn
+    from oracle import rcnn as orc
+
+    cfg = base_rcnn_fpn(num_classes=80)
+    model = build_model(cfg).eval()
+    syn.conditioned_r50_fpn_(model)
+    inputs = [{"image": syn.synthetic_image(61, 128, 160), "height": 256, "width": 320},
+              {"image": syn.synthetic_image(62, 97, 131), "height": 97, "width": 131}]
+    with torch.no_grad():
+        before = model(inputs)
+        model.roi_heads.test_score_thresh = 0.999
+        out = model(inputs)
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ref = orc.generalized_rcnn_inference(sd, orc.RCNNSpec(score_thresh=0.999), inputs)
+        model.roi_heads.test_score_thresh = 0.05
+        after = model(inputs)
+    for o, r, inp in zip(out, ref, inputs):
+        inst = o["instances"]
+        assert len(r["scores"]) == 0 and len(inst) == 0
+        assert inst.image_size == (inp["height"], inp["width"])
+        assert inst.pred_boxes.tensor.shape == (0, 4) and inst.scores.shape == (0,) and inst.pred_classes.shape == (0,)
+        assert inst.pred_classes.dtype == torch.int64
+    for a, b in zip(before, after):
+        assert len(a["instances"]) > 0
+        assert torch.equal(a["instances"].pred_boxes.tensor, b["instances"].pred_boxes.tensor)
+        assert torch.equal(a["instances"].scores, b["instances"].scores)
