@@ -435,6 +435,8 @@ def run_with_fallbacks(model, fn):
 
 def instances_from_batched(boxes, scores, classes, count, image_sizes, status=None):
     """One device->host read (counts + status), then per-image `Instances` of device tensors."""
+    classes64 = classes.to(torch.int64)     # one conversion for the batch (queued BEFORE the blocking read: it runs in the step's tail,
+                                            # not in the gap behind it); the per-image fields below are views
     if status is not None:
         # ONE read: counts, the status word and whether any of the conv kernels' error / range words is set
         meta = torch.cat([count, status, K.range_summary(count.device)]).tolist()
@@ -445,7 +447,6 @@ def instances_from_batched(boxes, scores, classes, count, image_sizes, status=No
     else:
         counts = count.tolist()
     out = []
-    classes64 = classes.to(torch.int64)     # one conversion for the batch; the per-image fields below are views
     # The host builds these while the GPU idles (forward() returns the batch's results before the next batch can be enqueued): the
     # three fields of an image are rows [0, n) of device tensors of one shape -- the objects are filled directly instead of through
     # Boxes.__init__ (as_tensor, reshape of empties, asserts) and Instances.set (a length check per field); 90 -> 45 us per batch.
